@@ -1,0 +1,80 @@
+"""Synthetic LJSpeech-shaped batches: no corpus is shipped with the
+reference (only metadata + stats.json), so measurement and parity both run on seeded
+synthetic inputs of the shapes dataset.py:166-227 would produce.
+
+The positional layout of `as_model_args` is what train.py:106 passes: `model(*batch[2:])`.
+"""
+import torch
+
+CANONICAL_SRC_LENS = [128, 123, 117, 115, 113, 112, 111, 96, 83, 82, 82, 81, 78, 63, 60, 55]
+C1_SRC_LENS = [128, 113, 78, 60]
+
+
+def _mel2ph_from_durations(d, src_lens):
+    B, Ts = d.shape
+    cum = torch.cumsum(d, 1)
+    total = cum[:, -1]
+    Tm = int(total.max())
+    t = torch.arange(Tm)[None, :].expand(B, -1).contiguous()
+    idx = torch.searchsorted(cum, t, right=True) + 1
+    return torch.where(t < total[:, None], idx, torch.zeros_like(idx))
+
+
+def make_batch(src_lens=None, frames_per_phone=8, seed=1234, n_mels=80, multi_speaker=False, speaker_dim=512,
+               max_mel_cap=None):
+    """Seeded CPU batch.  Returns a dict of CPU tensors; see `as_model_args`."""
+    src_lens = list(CANONICAL_SRC_LENS if src_lens is None else src_lens)
+    g = torch.Generator().manual_seed(seed)
+    B = len(src_lens)
+    src = torch.tensor(src_lens, dtype=torch.long)
+    mel = src * frames_per_phone
+    if max_mel_cap is not None:
+        mel = torch.clamp(mel, max=max_mel_cap)
+    Ts, Tm = int(src.max()), int(mel.max())
+    texts = torch.randint(1, 360, (B, Ts), generator=g)
+    texts[:, 5::6] = 357  # '@sp' so the word-duration loss is finite (loss.py:153-160)
+    d = torch.zeros(B, Ts, dtype=torch.long)
+    for b in range(B):
+        n, extra = src_lens[b], int(mel[b]) - src_lens[b]
+        d[b, :n] = 1
+        if extra > 0:
+            pick = torch.multinomial(torch.ones(n), extra, replacement=True, generator=g)
+            d[b, :n] += torch.bincount(pick, minlength=n)
+        texts[b, n:] = 0
+    mels = torch.randn(B, Tm, n_mels, generator=g) * 1.5 - 5.0
+    frame_valid = (torch.arange(Tm)[None, :] < mel[:, None])
+    mels = mels * frame_valid[..., None]
+    f0 = (torch.randn(B, Tm, generator=g) * 0.3 + 7.5) * frame_valid
+    uv = (torch.rand(B, Tm, generator=g) < 0.3).float() * frame_valid
+    cwt_spec = torch.randn(B, Tm, 10, generator=g) * frame_valid[..., None]
+    energy = torch.randn(B, Ts, generator=g) * (torch.arange(Ts)[None, :] < src[:, None])
+    batch = {
+        "speakers": torch.zeros(B, dtype=torch.long),
+        "texts": texts, "src_lens": src, "max_src_len": Ts,
+        "mels": mels, "mel_lens": mel, "max_mel_len": Tm,
+        "p_targets": {
+            "pitch": f0.clone(), "f0": f0, "uv": uv, "cwt_spec": cwt_spec,
+            "f0_mean": torch.full((B,), 5.3), "f0_std": torch.full((B,), 0.3),
+            "mel2ph": _mel2ph_from_durations(d, src_lens),
+        },
+        "e_targets": energy, "d_targets": d,
+        "spker_embeds": torch.randn(B, speaker_dim, generator=g) if multi_speaker else None,
+    }
+    return batch
+
+
+def to_device(batch, device):
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, dict):
+            out[k] = {kk: (vv.to(device) if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+        else:
+            out[k] = v.to(device) if torch.is_tensor(v) else v
+    return out
+
+
+def as_model_args(batch):
+    """Positional args in the order of CompTransTTS.forward (model/CompTransTTS.py:64-82)."""
+    return (batch["speakers"], batch["texts"], batch["src_lens"], batch["max_src_len"], batch["mels"],
+            batch["mel_lens"], batch["max_mel_len"], batch["p_targets"], batch["e_targets"], batch["d_targets"],
+            None, batch["spker_embeds"])

@@ -1,0 +1,348 @@
+"""TEST INFRASTRUCTURE - CPU restatement (oracle) of the reference hot path.
+
+This module is the *checker*, never the product: only tests/, __graft_entry__.smoke()
+and bench.py's `cpu_baseline` leg may import it.  The product package
+(comprehensive-transformer-tts_amd/) must never import anything under oracle/.
+
+It restates, as plain functional torch-CPU fp32 code driven by a reference-keyed
+state dict, what the reference computes on the path SURVEY.md section 8(a) lists:
+
+  a1  CompTransTTS.forward                 model/CompTransTTS.py:64-152
+  a2  get_mask_from_lengths                utils/tools.py:188-196
+  a3  embedding + sinusoid positions       model/transformers/transformer_fs2.py:113-119,
+                                           model/transformers/blocks.py:49-108, utils/tools.py:640-652
+  a4  FFTBlocks.forward                    model/transformers/transformer_fs2.py:47-72
+  a5  EncSALayer / MultiheadAttention      model/transformers/transformer_fs2.py:176-200,348-394
+  a6  TransformerFFNLayer                  model/transformers/transformer_fs2.py:220-239
+  a7  DurationPredictor                    model/modules.py:1299-1310
+  a8  LengthRegulator + pad                model/modules.py:1216-1249, utils/tools.py:577-595
+  a9  dur_to_mel2ph                        utils/tools.py:598-628
+  a10 pitch (cwt) embedding                model/modules.py:890-948,1313-1356, utils/pitch_tools.py:27-82,258-294
+  a11 energy embedding                     model/modules.py:950-960
+  a12 VarianceAdaptor.forward              model/modules.py:962-1114
+  a13 mel_linear                           model/CompTransTTS.py:133
+  a14 PostNet                              model/modules.py:140-148
+
+Parity pinning: the reference has no tests / golden vectors, so this
+restatement is pinned against the reference itself imported in the build container
+(oracle/ref_import.py -> tests/golden/make_goldens.py -> tests/golden/*.npz).
+The layout is [B, T, C] end to end (the reference flips between T,B,C / B,C,T).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+F0_BIN = 256
+F0_MEL_MIN = 1127 * math.log(1 + 50.0 / 700)
+F0_MEL_MAX = 1127 * math.log(1 + 1100.0 / 700)
+
+
+# ----------------------------------------------------------------------------- helpers
+def mask_from_lengths(lengths, max_len=None):
+    """True = padding.  utils/tools.py:188-196"""
+    if max_len is None:
+        max_len = int(lengths.max())
+    ids = torch.arange(max_len, device=lengths.device)[None, :]
+    return ids >= lengths[:, None]
+
+
+def sinusoid_table(n_pos, dim):
+    """fs2 table: [sin | cos] halves, row 0 (padding) zero.  blocks.py:66-83"""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    freq = torch.exp(torch.arange(half, dtype=torch.float) * -e)
+    ang = torch.arange(n_pos, dtype=torch.float)[:, None] * freq[None, :]
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    tab[0] = 0
+    return tab
+
+
+def positions_from_nonpad(nonpad):
+    """make_positions with padding_idx=0.  utils/tools.py:640-652"""
+    m = nonpad.int()
+    return (torch.cumsum(m, dim=1) * m).long()
+
+
+def pos_embed(x_first_channel_or_tokens, dim):
+    nonpad = x_first_channel_or_tokens.ne(0)
+    pos = positions_from_nonpad(nonpad)
+    tab = sinusoid_table(pos.shape[1] + 1, dim)
+    return tab[pos]
+
+
+def layer_norm(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def conv1d_btc(x, w, b, pad):
+    """x [B,T,Cin], w [Cout,Cin,K] (reference layout) -> [B,T,Cout]"""
+    return F.conv1d(x.transpose(1, 2), w, b, padding=pad).transpose(1, 2)
+
+
+def _drop(x, p, on):
+    return F.dropout(x, p, True) if (on and p > 0) else x
+
+
+# ----------------------------------------------------------------------------- a8 / a9
+def length_regulate_indices(dur, max_len=None):
+    """Integer core of LengthRegulator (modules.py:1222-1245) + pad/crop (tools.py:577-595).
+
+    dur [B,Ts] (any numeric dtype; truncated toward zero like int(), clamped at 0).
+    Returns (idx [B,Tm] int64 = source phoneme index or -1 for zero rows,
+             mel_len [B] int64 = UN-cropped sum of durations)."""
+    d = dur.to(torch.float64).trunc().clamp(min=0).long()
+    cum = torch.cumsum(d, dim=1)
+    mel_len = cum[:, -1].clone()
+    Tm = int(max_len) if max_len else int(mel_len.max())
+    t = torch.arange(Tm, device=dur.device)[None, :].expand(dur.shape[0], -1).contiguous()
+    idx = torch.searchsorted(cum, t, right=True)
+    idx = torch.where(t < mel_len[:, None], idx, torch.full_like(idx, -1))
+    return idx, mel_len
+
+
+def length_regulate(x, dur, max_len=None):
+    idx, mel_len = length_regulate_indices(dur, max_len)
+    g = torch.gather(x, 1, idx.clamp(min=0)[..., None].expand(-1, -1, x.shape[-1]))
+    out = g * (idx >= 0)[..., None].to(x.dtype)
+    return out, mel_len
+
+
+def dur_to_mel2ph(dur, dur_padding=None):
+    """utils/tools.py:598-628 - 1-based phoneme index per frame, 0 for pad; width = max sum."""
+    d = torch.round(dur.float()).long()
+    if dur_padding is not None:
+        d = d * (1 - dur_padding.long())
+    cum = torch.cumsum(d, 1)
+    total = cum[:, -1]
+    Tm = int(total.max())
+    t = torch.arange(Tm, device=dur.device)[None, :].expand(dur.shape[0], -1).contiguous()
+    idx = torch.searchsorted(cum, t, right=True) + 1
+    return torch.where(t < total[:, None], idx, torch.zeros_like(idx))
+
+
+# ----------------------------------------------------------------------------- pitch helpers
+def cwt2f0_norm(cwt_spec, mean, std, width, eps=1e-9):
+    """utils/pitch_tools.py:258-294 (pitch_norm == 'log')."""
+    b = (torch.arange(cwt_spec.shape[-1], dtype=torch.float, device=cwt_spec.device) + 3.5) ** (-2.5)
+    rec = (cwt_spec * b[None, None, :]).sum(-1)
+    rec = (rec - rec.mean(-1, keepdim=True)) / rec.std(-1, keepdim=True)
+    f0 = (rec * std[:, None] + mean[:, None]).exp()
+    if width > f0.shape[1]:
+        f0 = torch.cat([f0] + [f0[:, -1:]] * (width - f0.shape[1]), 1)
+    return torch.log2(f0 + eps)
+
+
+def f0_to_coarse(f0):
+    """utils/pitch_tools.py:27-36"""
+    f0_mel = 1127 * (1 + f0 / 700).log()
+    scaled = (f0_mel - F0_MEL_MIN) * (F0_BIN - 2) / (F0_MEL_MAX - F0_MEL_MIN) + 1
+    f0_mel = torch.where(f0_mel > 0, scaled, f0_mel)
+    f0_mel = torch.where(f0_mel <= 1, torch.ones_like(f0_mel), f0_mel)
+    f0_mel = torch.where(f0_mel > F0_BIN - 1, torch.full_like(f0_mel, F0_BIN - 1), f0_mel)
+    return (f0_mel + 0.5).long()
+
+
+# ----------------------------------------------------------------------------- a4-a6
+def fft_blocks(sd, pre, x, pad_mask, n_layers, n_heads, ksize, p_drop, use_pos, train_dropout=False, taps=None):
+    B, T, C = x.shape
+    nonpad = (~pad_mask).to(x.dtype)[..., None]
+    if use_pos:
+        x = x + sd[pre + "pos_embed_alpha"] * pos_embed(x[..., 0], C)
+        x = _drop(x, p_drop, train_dropout)
+    x = x * nonpad
+    dh = C // n_heads
+    for l in range(n_layers):
+        p = f"{pre}layers.{l}.op."
+        res = x
+        h = layer_norm(x, sd[p + "layer_norm1.weight"], sd[p + "layer_norm1.bias"], 1e-12)
+        qkv = h @ sd[p + "self_attn.in_proj_weight"].t()
+        q, k, v = qkv.split(C, dim=-1)
+        q = q.reshape(B, T, n_heads, dh).transpose(1, 2) * dh ** -0.5
+        k = k.reshape(B, T, n_heads, dh).transpose(1, 2)
+        v = v.reshape(B, T, n_heads, dh).transpose(1, 2)
+        s = q @ k.transpose(-1, -2)
+        s = s.masked_fill(pad_mask[:, None, None, :], float("-inf"))
+        a = torch.softmax(s, dim=-1) @ v
+        a = a.transpose(1, 2).reshape(B, T, C) @ sd[p + "self_attn.out_proj.weight"].t()
+        x = (res + _drop(a, p_drop, train_dropout)) * nonpad
+        res = x
+        h = layer_norm(x, sd[p + "layer_norm2.weight"], sd[p + "layer_norm2.bias"], 1e-12)
+        z = conv1d_btc(h, sd[p + "ffn.ffn_1.weight"], sd[p + "ffn.ffn_1.bias"], ksize // 2) * ksize ** -0.5
+        g = _drop(F.gelu(z), p_drop, train_dropout)
+        y = g @ sd[p + "ffn.ffn_2.weight"].t() + sd[p + "ffn.ffn_2.bias"]
+        x = (res + _drop(y, p_drop, train_dropout)) * nonpad
+        if taps is not None:
+            taps[f"{pre}layer{l}"] = x
+    x = layer_norm(x, sd[pre + "layer_norm.weight"], sd[pre + "layer_norm.bias"], 1e-5) * nonpad
+    return x
+
+
+def text_encoder(sd, cfg, tokens, pad_mask, train_dropout=False, taps=None):
+    c = cfg["transformer_fs2"]
+    H = c["encoder_hidden"]
+    emb = math.sqrt(H) * F.embedding(tokens, sd["encoder.embed_tokens.weight"], padding_idx=0)
+    x = emb + pos_embed(tokens, H)
+    x = _drop(x, c["encoder_dropout"], train_dropout)
+    x = fft_blocks(sd, "encoder.", x, pad_mask, c["encoder_layer"], c["encoder_head"], c["ffn_kernel_size"],
+                   c["encoder_dropout"], False, train_dropout, taps)
+    return x, emb
+
+
+# ----------------------------------------------------------------------------- a7, a10, a11 predictors
+def _predictor_convs(sd, pre, x, n_layers, ksize, p_drop, mask_nonpad, train_dropout):
+    for i in range(n_layers):
+        x = conv1d_btc(x, sd[f"{pre}conv.{i}.1.weight"], sd[f"{pre}conv.{i}.1.bias"], (ksize - 1) // 2)
+        x = torch.relu(x)
+        x = layer_norm(x, sd[f"{pre}conv.{i}.3.weight"], sd[f"{pre}conv.{i}.3.bias"], 1e-12)
+        x = _drop(x, p_drop, train_dropout)
+        if mask_nonpad is not None:
+            x = x * mask_nonpad
+    return x
+
+
+def duration_predictor(sd, cfg, x, src_pad, train_dropout=False):
+    vp = cfg["variance_predictor"]
+    nonpad = (~src_pad).to(x.dtype)[..., None]
+    pre = "variance_adaptor.duration_predictor."
+    h = _predictor_convs(sd, pre, x, vp["dur_predictor_layers"], vp["dur_predictor_kernel"], vp["dropout"], nonpad,
+                         train_dropout)
+    out = h @ sd[pre + "linear.weight"].t() + sd[pre + "linear.bias"]
+    return (out * nonpad).squeeze(-1)
+
+
+def pitch_like_predictor(sd, pre, cfg, x, train_dropout=False):
+    vp = cfg["variance_predictor"]
+    x = x + sd[pre + "pos_embed_alpha"] * pos_embed(x[..., 0], x.shape[-1])
+    h = _predictor_convs(sd, pre, x, vp["predictor_layers"], vp["predictor_kernel"], vp["dropout"], None, train_dropout)
+    return h @ sd[pre + "linear.weight"].t() + sd[pre + "linear.bias"]
+
+
+def _grad_scale(x, g):
+    return x.detach() + g * (x - x.detach())
+
+
+# ----------------------------------------------------------------------------- a12
+def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pad, max_mel_len,
+                     p_targets, e_targets, d_targets, speaker_embedding=None,
+                     p_control=1.0, e_control=1.0, d_control=1.0, train_dropout=False, taps=None):
+    vp = cfg["variance_predictor"]
+    va = "variance_adaptor."
+    pitch_cfg = pre_cfg["preprocessing"]["pitch"]
+    assert pitch_cfg["pitch_type"] == "cwt" and pitch_cfg["pitch_norm"] == "log" and pitch_cfg["use_uv"]
+    x = text.clone()
+    if speaker_embedding is not None:
+        x = x + speaker_embedding[:, None, :]
+    log_d = duration_predictor(sd, cfg, _grad_scale(x, vp["predictor_grad"]), src_pad, train_dropout)
+    x_org = x
+    mel2ph_inf = None
+    if d_targets is not None:
+        x, mel_len = length_regulate(x, d_targets, max_mel_len)
+        d_rounded = d_targets
+    else:
+        d_rounded = torch.clamp(torch.round(torch.exp(log_d) - 1) * d_control, min=0)
+        x, mel_len = length_regulate(x, d_rounded, max_mel_len)
+        mel_pad = mask_from_lengths(mel_len)
+        mel2ph_inf = dur_to_mel2ph(d_rounded, src_pad)
+    if taps is not None:
+        taps["lr_out"] = x
+
+    # pitch (cwt)
+    dec_inp = _grad_scale(x, vp["predictor_grad"])
+    h = dec_inp @ sd[va + "cwt_predictor.0.weight"].t() + sd[va + "cwt_predictor.0.bias"]
+    cwt = pitch_like_predictor(sd, va + "cwt_predictor.1.", cfg, h, train_dropout) * p_control
+    s = x_org[:, 0, :]
+    s = torch.relu(s @ sd[va + "cwt_stats_layers.0.weight"].t() + sd[va + "cwt_stats_layers.0.bias"])
+    s = torch.relu(s @ sd[va + "cwt_stats_layers.2.weight"].t() + sd[va + "cwt_stats_layers.2.bias"])
+    stats = s @ sd[va + "cwt_stats_layers.4.weight"].t() + sd[va + "cwt_stats_layers.4.bias"]
+    f0_mean, f0_std = stats[:, 0], stats[:, 1]
+    if p_targets is not None:
+        p_targets = dict(p_targets)
+        mel2ph = p_targets["mel2ph"]
+        p_targets["f0"] = cwt2f0_norm(p_targets["cwt_spec"], p_targets["f0_mean"], p_targets["f0_std"],
+                                      mel2ph.shape[1], pitch_cfg["pitch_norm_eps"])
+        p_targets["f0_cwt"] = p_targets["f0"]
+        f0, uv = p_targets["f0"], p_targets["uv"]
+    else:
+        f0 = cwt2f0_norm(cwt[:, :, :10], f0_mean, f0_std * vp["cwt_std_scale"], mel2ph_inf.shape[1],
+                         pitch_cfg["pitch_norm_eps"])
+        uv = cwt[:, :, -1] > 0
+    f0_denorm = 2 ** f0
+    f0_denorm = torch.where(uv > 0, torch.zeros_like(f0_denorm), f0_denorm)
+    pitch_emb = F.embedding(f0_to_coarse(f0_denorm), sd[va + "pitch_embed.weight"], padding_idx=0)
+    p_pred = {"pitch_pred": None, "f0_denorm": f0_denorm, "cwt": cwt, "f0_mean": f0_mean, "f0_std": f0_std}
+
+    # energy (phoneme level; NOTE modules.py:951 discards the grad-scaled tensor -> full gradient)
+    e_pred = pitch_like_predictor(sd, va + "energy_predictor.", cfg, x_org, train_dropout).squeeze(-1)
+    bins = sd[va + "energy_bins"]
+    if e_targets is not None:
+        e_idx = torch.bucketize(e_targets, bins)
+    else:
+        e_pred = e_pred * e_control
+        e_idx = torch.bucketize(e_pred, bins)
+    e_emb = F.embedding(e_idx, sd[va + "energy_embedding.weight"], padding_idx=0)
+    e_emb_frames, _ = length_regulate(e_emb, d_rounded, max_mel_len)
+    out = x + pitch_emb + e_emb_frames
+    if taps is not None:
+        taps["va_out"] = out
+    return out, p_targets, p_pred, e_targets, e_pred, log_d, d_rounded, mel_len, mel_pad
+
+
+# ----------------------------------------------------------------------------- a14
+def postnet(sd, x, training_bn, train_dropout=False, new_stats=None):
+    """x [B,T,80] -> [B,T,80]; BN over all B*T positions incl. pads (modules.py:140-148)."""
+    n = 5
+    for i in range(n):
+        p = f"postnet.convolutions.{i}."
+        x = conv1d_btc(x, sd[p + "0.conv.weight"], sd[p + "0.conv.bias"], 2)
+        C = x.shape[-1]
+        if training_bn:
+            flat = x.reshape(-1, C)
+            mean = flat.mean(0)
+            var = flat.var(0, unbiased=False)
+            if new_stats is not None:
+                m = 0.1
+                nrow = flat.shape[0]
+                new_stats[p + "1.running_mean"] = (1 - m) * sd[p + "1.running_mean"] + m * mean.detach()
+                new_stats[p + "1.running_var"] = (1 - m) * sd[p + "1.running_var"] + m * var.detach() * nrow / (nrow - 1)
+        else:
+            mean, var = sd[p + "1.running_mean"], sd[p + "1.running_var"]
+        x = (x - mean) / torch.sqrt(var + 1e-5) * sd[p + "1.weight"] + sd[p + "1.bias"]
+        if i < n - 1:
+            x = torch.tanh(x)
+        x = _drop(x, 0.5, train_dropout)
+    return x
+
+
+# ----------------------------------------------------------------------------- a1
+def comp_trans_tts_forward(sd, model_cfg, pre_cfg, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None,
+                           max_mel_len=None, p_targets=None, e_targets=None, d_targets=None, attn_priors=None,
+                           spker_embeds=None, p_control=1.0, e_control=1.0, d_control=1.0, step=None,
+                           training=False, train_dropout=False, taps=None, new_stats=None):
+    """Restates model/CompTransTTS.py:64-152 for block_type == transformer_fs2,
+    learn_alignment == False.  `training` selects BatchNorm batch statistics;
+    `train_dropout` additionally turns the dropouts on (for CPU-baseline timing)."""
+    assert model_cfg["block_type"] == "transformer_fs2" and attn_priors is None
+    src_pad = mask_from_lengths(src_lens, max_src_len)
+    mel_pad = mask_from_lengths(mel_lens, max_mel_len) if mel_lens is not None else None
+    enc, _ = text_encoder(sd, model_cfg, texts, src_pad, train_dropout, taps)
+    if taps is not None:
+        taps["encoder_out"] = enc
+    spk = None
+    if model_cfg["multi_speaker"]:
+        if "speaker_emb.bias" in sd:
+            spk = spker_embeds @ sd["speaker_emb.weight"].t() + sd["speaker_emb.bias"]
+        else:
+            spk = F.embedding(speakers, sd["speaker_emb.weight"])
+    (x, p_targets, p_pred, e_targets, e_pred, log_d, d_rounded, mel_lens, mel_pad) = variance_adaptor(
+        sd, model_cfg, pre_cfg, enc, src_lens, src_pad, mel_lens, mel_pad, max_mel_len, p_targets, e_targets,
+        d_targets, spk, p_control, e_control, d_control, train_dropout, taps)
+    c = model_cfg["transformer_fs2"]
+    dec = fft_blocks(sd, "decoder.", x, mel_pad, c["decoder_layer"], c["decoder_head"], c["ffn_kernel_size"],
+                     c["decoder_dropout"], True, train_dropout, taps)
+    if taps is not None:
+        taps["decoder_out"] = dec
+    mel = dec @ sd["mel_linear.weight"].t() + sd["mel_linear.bias"]
+    post = postnet(sd, mel, training, train_dropout, new_stats) + mel
+    return (mel, post, p_pred, e_pred, log_d, d_rounded, src_pad, mel_pad, src_lens, mel_lens,
+            (None, None, None, None), None, p_targets, e_targets)

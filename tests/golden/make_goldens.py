@@ -1,0 +1,253 @@
+"""Golden-vector generator - runs ONLY in the build container (needs /root/reference).
+
+Imports the live reference (oracle/ref_import.py), loads closed-form weights
+(oracle/weights.py), runs it on seeded synthetic inputs (ctts_amd.synthetic) and writes
+small .npz fixtures next to this file.  Fixtures are data (inputs + expected outputs);
+no reference source travels.  Re-run:  python tests/golden/make_goldens.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+import ctts_amd  # noqa: E402
+from ctts_amd.synthetic import make_batch, as_model_args  # noqa: E402
+from oracle import ref_import  # noqa: E402
+from oracle.weights import closed_form_state_dict, _hash_uniform  # noqa: E402
+
+ref_import.install()
+import torch.nn.functional as F  # noqa: E402
+
+_real_dropout = F.dropout
+
+
+def _np(v):
+    if v is None:
+        return None
+    return v.detach().cpu().clone().numpy()
+
+
+def pseudo(name, shape):
+    return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float()
+
+
+def build(dataset="LJSpeech", block_type="transformer_fs2"):
+    from model import CompTransTTS
+
+    pre, mc, tc = ref_import.load_configs(dataset)
+    mc["duration_modeling"]["learn_alignment"] = False
+    mc["block_type"] = block_type
+    model = CompTransTTS(pre, mc, tc)
+    sd = closed_form_state_dict(model.state_dict())
+    model.load_state_dict(sd)
+    import json
+    tag = f"{dataset}_{block_type}"
+    with open(os.path.join(OUT, f"state_dict_schema_{tag}.json"), "w") as f:
+        json.dump({k: [list(v.shape), str(v.dtype).replace("torch.", ""), bool(k in dict(model.named_parameters()))]
+                   for k, v in model.state_dict().items()}, f, indent=0)
+    return model, (pre, mc, tc)
+
+
+def flatten_outputs(out, prefix="out."):
+    (mel, post, p_pred, e_pred, log_d, d_rounded, src_mask, mel_mask, src_lens, mel_lens, attn, pros, p_t, e_t) = out
+    d = {
+        "mel": _np(mel), "postnet_mel": _np(post), "e_pred": _np(e_pred), "log_d": _np(log_d),
+        "d_rounded": _np(d_rounded), "src_mask": _np(src_mask), "mel_mask": _np(mel_mask),
+        "src_lens": _np(src_lens), "mel_lens": _np(mel_lens),
+        "cwt": _np(p_pred["cwt"]), "f0_denorm": _np(p_pred["f0_denorm"]), "f0_mean": _np(p_pred["f0_mean"]),
+        "f0_std": _np(p_pred["f0_std"]),
+    }
+    if p_t is not None:
+        d["pt_f0"] = _np(p_t["f0"])
+        d["pt_mel2ph"] = _np(p_t["mel2ph"])
+    return {prefix + k: v for k, v in d.items() if v is not None}
+
+
+def batch_arrays(batch):
+    d = {}
+    for k, v in batch.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                d[f"in.p_targets.{kk}"] = _np(vv)
+        elif torch.is_tensor(v):
+            d["in." + k] = _np(v)
+        elif v is not None:
+            d["in." + k] = np.asarray(v)
+    return d
+
+
+def run_case(model, batch, mode, name, with_grads=False, extra_kwargs=None):
+    taps = {}
+    hooks = [
+        model.encoder.register_forward_hook(lambda m, i, o: taps.__setitem__("encoder_out", o[0])),
+        model.variance_adaptor.register_forward_hook(lambda m, i, o: taps.__setitem__("va_out", o[0])),
+        model.decoder.register_forward_hook(lambda m, i, o: taps.__setitem__("decoder_out", o[0])),
+    ]
+    if mode == "eval":
+        model.eval()
+    else:
+        model.train()
+        F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+    args = list(as_model_args(batch))
+    # the reference mutates p_targets in place: hand it a copy
+    if args[7] is not None:
+        args[7] = {k: v.clone() for k, v in args[7].items()}
+    kw = dict(extra_kwargs or {})
+    sd_before = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.set_grad_enabled(with_grads):
+        out = model(*args, **kw)
+    F.dropout = _real_dropout
+    for h in hooks:
+        h.remove()
+    arrs = batch_arrays(batch)
+    arrs.update(flatten_outputs(out))
+    for k, v in taps.items():
+        arrs["tap." + k] = _np(v)
+    if mode == "train":
+        for k, v in model.state_dict().items():
+            if "running_" in k:
+                arrs["bn." + k] = _np(v)
+    if with_grads:
+        mel, post, p_pred, e_pred, log_d = out[0], out[1], out[2], out[3], out[4]
+        loss = ((post * pseudo("post", post.shape)).sum() + (mel * pseudo("mel", mel.shape)).sum()
+                + (log_d * pseudo("logd", log_d.shape)).sum() + (e_pred * pseudo("e", e_pred.shape)).sum()
+                + (p_pred["cwt"] * pseudo("cwt", p_pred["cwt"].shape)).sum()
+                + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum())
+        model.zero_grad()
+        loss.backward()
+        arrs["grad.loss"] = _np(loss)
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.detach().flatten()
+            arrs["grad.head." + k] = _np(g[:64])
+            arrs["grad.stat." + k] = np.array([g.double().sum().item(), g.double().pow(2).sum().sqrt().item()])
+    model.load_state_dict(sd_before)  # undo BN running-stat updates
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, f"{os.path.getsize(path)/1024:.0f} KB", "mel absmax", np.abs(arrs['out.mel']).max())
+    return out
+
+
+def golden_loss(model_out, batch, cfgs, name):
+    """G9: CompTransTTSLoss 9-tuple (model/loss.py:266-347) on a train-mode output."""
+    from model import CompTransTTSLoss
+
+    pre, mc, tc = cfgs
+    L = CompTransTTSLoss(pre, mc, tc)
+    L.train()
+    b = [None, None] + list(as_model_args(batch))
+    out = model_out
+    b[9:11], output = out[-2:], out[:-2]
+    step = tc["step"]["var_start_steps"] + 1
+    losses = L(b, output, step=step)
+    arrs = {}
+    names = ["total", "mel", "postnet_mel", "pitch", "energy", "duration", "ctc", "bin", "prosody"]
+    for n, l in zip(names, losses):
+        if isinstance(l, dict):
+            for k, v in l.items():
+                arrs[f"loss.{n}.{k}"] = _np(v)
+        else:
+            arrs[f"loss.{n}"] = _np(l)
+    arrs["step"] = np.asarray(step)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, {k: float(np.asarray(v).reshape(-1)[0]) for k, v in arrs.items()})
+
+
+def golden_integer_vectors():
+    """G7: integer kernels - LengthRegulator indices, dur_to_mel2ph, make_positions,
+    f0_to_coarse, bucketize.  Includes zero durations, cropping and padded phonemes."""
+    from model.modules import LengthRegulator
+    from utils.tools import dur_to_mel2ph, make_positions, get_mask_from_lengths
+    from utils.pitch_tools import f0_to_coarse
+
+    g = torch.Generator().manual_seed(7)
+    arrs = {}
+    B, Ts, H = 5, 23, 8
+    d = torch.randint(0, 9, (B, Ts), generator=g)
+    d[1, 10:] = 0          # padded phonemes have zero duration
+    d[2, :] = 0            # an all-zero row
+    d[3, 3] = 40           # one long phoneme
+    x = torch.arange(B * Ts * H, dtype=torch.float32).reshape(B, Ts, H) + 1
+    lr = LengthRegulator()
+    for tag, max_len in (("none", None), ("crop", 50), ("pad", 200)):
+        if tag == "none":
+            dd = d.clone()
+        else:
+            dd = d
+        out, mel_len = lr(x, dd, max_len)
+        # phoneme index per frame recovered from the gathered data (x rows are unique, >0)
+        idx = torch.where(out[..., 0] > 0, ((out[..., 0] - 1) / H).long() % Ts, torch.full_like(out[..., 0], -1).long())
+        arrs[f"lr.{tag}.idx"] = _np(idx)
+        arrs[f"lr.{tag}.mel_len"] = _np(mel_len)
+        arrs[f"lr.{tag}.out"] = _np(out)
+    arrs["lr.dur"] = _np(d)
+    arrs["lr.x"] = _np(x)
+    # float durations (inference branch: clamp(round(exp(logd)-1)*ctrl, 0) is float32)
+    df = torch.tensor([[0.0, 1.0, 2.0, 3.0, 0.0, 5.0], [2.0, 0.0, 0.0, 1.0, 1.0, 0.0]])
+    xf = torch.arange(2 * 6 * 4, dtype=torch.float32).reshape(2, 6, 4) + 1
+    outf, mlf = lr(xf, df, None)
+    arrs["lrf.dur"], arrs["lrf.x"], arrs["lrf.out"], arrs["lrf.mel_len"] = _np(df), _np(xf), _np(outf), _np(mlf)
+    src_lens = torch.tensor([23, 10, 23, 23, 15])
+    pad = get_mask_from_lengths(src_lens, Ts)
+    arrs["m2p.dur"] = _np(d)
+    arrs["m2p.pad"] = _np(pad)
+    arrs["m2p.out"] = _np(dur_to_mel2ph(d, pad))
+    arrs["m2p.out_nopad"] = _np(dur_to_mel2ph(d, None))
+    tok = torch.randint(0, 5, (4, 19), generator=g)
+    arrs["pos.in"] = _np(tok)
+    arrs["pos.out"] = _np(make_positions(tok, 0))
+    f0 = torch.cat([torch.zeros(8), torch.rand(500, generator=g) * 1300, torch.tensor([50.0, 1100.0, 49.9, 1100.1])])
+    arrs["f0c.in"] = _np(f0)
+    arrs["f0c.out"] = _np(f0_to_coarse(f0.clone()))
+    bins = torch.linspace(-1.431044578552246, 8.184337615966797, 255)
+    ev = torch.cat([torch.randn(300, generator=g) * 3 + 2, bins[::17], torch.tensor([-5.0, 20.0])])
+    arrs["bkt.bins"], arrs["bkt.in"], arrs["bkt.out"] = _np(bins), _np(ev), _np(torch.bucketize(ev, bins))
+    path = os.path.join(OUT, "g7_integer.npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path)
+
+
+def golden_stft():
+    """G8: TacotronSTFT.mel_spectrogram (audio/stft.py:166-185) on a seeded waveform."""
+    from audio.stft import TacotronSTFT
+
+    st = TacotronSTFT(1024, 256, 1024, 80, 22050, 0, 8000)
+    g = torch.Generator().manual_seed(11)
+    y = (torch.rand(2, 22050, generator=g) - 0.5)
+    t = torch.arange(22050) / 22050.0
+    y[1] = 0.4 * torch.sin(2 * np.pi * 440 * t) + 0.1 * torch.sin(2 * np.pi * 3000 * t)
+    mag, _ = st.stft_fn.transform(y)
+    mel, energy = st.mel_spectrogram(y)
+    arrs = {"y": _np(y), "mag": _np(mag), "mel": _np(mel), "energy": _np(energy), "mel_basis": _np(st.mel_basis),
+            "window": _np(st.stft_fn.forward_basis[0, 0, :] * 0) }
+    path = os.path.join(OUT, "g8_stft.npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, mel.shape, energy.shape)
+
+
+def main():
+    torch.manual_seed(0)
+    model, cfgs = build("LJSpeech")
+    small = make_batch([24, 17], 6, seed=1234)
+    run_case(model, small, "eval", "g1_fs2_eval")
+    out = run_case(model, small, "train", "g2_fs2_train_nodrop", with_grads=True)
+    golden_loss(out, small, cfgs, "g9_loss")
+    inf = {k: v for k, v in small.items()}
+    inf.update(mels=None, mel_lens=None, max_mel_len=None, p_targets=None, e_targets=None, d_targets=None)
+    run_case(model, inf, "eval", "g3_fs2_infer", extra_kwargs=dict(p_control=1.1, e_control=0.9, d_control=2.0))
+    model_v, cfgs_v = build("VCTK")
+    vb = make_batch([21, 24, 9], 5, seed=77, multi_speaker=True)
+    run_case(model_v, vb, "eval", "g5_vctk_eval")
+    golden_integer_vectors()
+    golden_stft()
+
+
+if __name__ == "__main__":
+    main()

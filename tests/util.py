@@ -1,0 +1,52 @@
+"""Shared helpers for tests: golden loading, closed-form state dicts, batch rebuild."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import ctts_amd  # noqa: F401  (root shim)
+from ctts_amd.configs import get_configs
+from oracle.weights import fill_tensor, SKIP
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def schema(dataset="LJSpeech", block="transformer_fs2"):
+    with open(os.path.join(GOLDEN, f"state_dict_schema_{dataset}_{block}.json")) as f:
+        return json.load(f)
+
+
+def closed_form_sd(dataset="LJSpeech", block="transformer_fs2"):
+    """Closed-form weights for every schema key (energy_bins from stats.json like modules.py:795-818)."""
+    pre, mc, tc = get_configs(dataset)
+    sd = {}
+    for k, (shape, dtype, is_param) in schema(dataset, block).items():
+        if k.endswith("energy_bins"):
+            with open(os.path.join(pre["path"]["preprocessed_path"], "stats.json")) as f:
+                emin, emax = json.load(f)["energy_sup_phone"][:2]
+            sd[k] = torch.linspace(emin, emax, shape[0])
+        elif any(s in k for s in SKIP):
+            sd[k] = torch.zeros(shape)
+        else:
+            sd[k] = fill_tensor(k, tuple(shape))
+    return sd
+
+
+def batch_from_golden(g):
+    """Rebuild the positional model args from the 'in.*' arrays of a golden."""
+    def t(k):
+        return torch.from_numpy(g[k]) if k in g else None
+    p_targets = {k[len("in.p_targets."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("in.p_targets.")}
+    return dict(
+        speakers=t("in.speakers"), texts=t("in.texts"), src_lens=t("in.src_lens"),
+        max_src_len=int(g["in.max_src_len"]), mels=t("in.mels"), mel_lens=t("in.mel_lens"),
+        max_mel_len=int(g["in.max_mel_len"]) if "in.max_mel_len" in g else None,
+        p_targets=p_targets or None, e_targets=t("in.e_targets"), d_targets=t("in.d_targets"),
+        spker_embeds=t("in.spker_embeds"),
+    )
