@@ -1,0 +1,98 @@
+"""ctypes binding of libctts_hip.so (the C ABI declared in include/ctts.h).
+
+cffi is not available in the image; ctypes is the binding.  The library is
+built in-tree by csrc/build.sh (hipcc --offload-arch=gfx950).  There is NO fallback: if the
+shared object is missing or a kernel reports an error, the call raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libctts_hip.so")
+
+_c_f32p = C.c_void_p
+_i32, _i64, _f32, _u32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("B", _vp), ("C", _vp),
+        ("M", _i32), ("N", _i32), ("K", _i32),
+        ("lda", _i64), ("ldb", _i64), ("ldc", _i64),
+        ("a_kc", _i32), ("b_kc", _i32),
+        ("nb0", _i32), ("nb1", _i32),
+        ("sA0", _i64), ("sA1", _i64), ("sB0", _i64), ("sB1", _i64), ("sC0", _i64), ("sC1", _i64),
+        ("lens", _vp),
+        ("lim_m", _i32), ("lim_n", _i32), ("lim_k", _i32),
+        ("conv_T", _i32), ("conv_pad", _i32), ("conv_cin", _i32), ("conv_on_b", _i32),
+        ("split_k", _i32),
+        ("alpha", _f32),
+        ("bias", _vp),
+        ("Z", _vp), ("ldz", _i64),
+        ("act", _i32),
+        ("p_drop", _f32), ("seed", _vp), ("drop_offset", _u32),
+        ("R", _vp), ("ldr", _i64),
+        ("rowscale", _vp),
+    ]
+
+
+# name -> argtypes (every function returns int status except the two listed below)
+_SIGNATURES = {
+    "ctts_gemm": [C.POINTER(GemmDesc), _vp],
+    "ctts_conv_weight_repack": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_lr_index": [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
+    "ctts_lr_gather_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_lr_gather_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_positions": [_vp, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp],
+    "ctts_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp, _vp],
+    "ctts_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _u32, _vp, _vp],
+    "ctts_colstats": [_vp, _vp, C.c_int, C.c_int, _vp],
+    "ctts_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp],
+    "ctts_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp],
+    "ctts_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp,
+                          _u32, C.c_int, _vp],
+    "ctts_softmax_fwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
+    "ctts_softmax_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
+    "ctts_act_dropout_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
+    "ctts_rowscale_dropout": [_vp, _vp, _i64, C.c_int, _vp, _f32, _vp, _u32, _vp],
+    "ctts_colsum": [_vp, _vp, _i64, C.c_int, _i64, _vp],
+    "ctts_reflect_pad": [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
+    "ctts_stft_magnitude": [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _vp],
+    "ctts_log_clamp_transpose": [_vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version"])
+
+_lib = None
+
+
+class CttsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CttsError(
+            f"{LIB_PATH} not found - build it with comprehensive-transformer-tts_amd/csrc/build.sh "
+            "(or __graft_entry__.build()).  There is no CPU / PyTorch fallback for the hot path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.ctts_last_error.restype = C.c_char_p
+    lib.ctts_last_error.argtypes = []
+    lib.ctts_version.restype = C.c_int
+    lib.ctts_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().ctts_last_error().decode(errors="replace")
+        raise CttsError(f"{what} failed with status {status}: {msg}")

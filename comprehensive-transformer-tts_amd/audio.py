@@ -1,0 +1,93 @@
+"""Drop-in `TacotronSTFT` (reference: audio/stft.py:137-185) on the gfx950 kernels.
+
+mel_spectrogram(y[B,N] in [-1,1]) -> (mel[B,80,F], energy[B,F]),  F = 1 + N // hop.
+The windowed real-DFT basis [2*(n_fft/2+1), n_fft] is the same matrix the reference feeds to
+F.conv1d (stft.py:32-56: rows = real parts then imaginary parts, periodic hann window); the mel
+filterbank restates librosa==0.7.2 `filters.mel` (Slaney scale, area normalisation, htk=False),
+which the reference pulls from a third-party dependency (requirements.txt:9) - parity of that
+basis is pinned by the golden `tests/golden/g8_stft.npz` captured from the reference run.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _hz_to_mel(f):
+    f = np.asanyarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, f / f_sp)
+
+
+def _mel_to_hz(m):
+    m = np.asanyarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax):
+    if fmax is None:
+        fmax = sr / 2.0
+    nb = 1 + n_fft // 2
+    fftfreqs = np.linspace(0, sr / 2.0, nb)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    w = np.zeros((n_mels, nb))
+    for i in range(n_mels):
+        w[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def windowed_dft_basis(n_fft, win_length):
+    """[2*(n_fft/2+1), n_fft]: rows [0,nb) = cos, [nb,2nb) = -sin, times the periodic hann window
+    zero-padded (centred) to n_fft - the matrix of audio/stft.py:32-56."""
+    nb = n_fft // 2 + 1
+    four = np.fft.fft(np.eye(n_fft))
+    basis = np.vstack([np.real(four[:nb, :]), np.imag(four[:nb, :])])
+    n = np.arange(win_length)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)       # scipy get_window('hann', fftbins=True)
+    lpad = (n_fft - win_length) // 2
+    win = np.pad(win, (lpad, n_fft - win_length - lpad))
+    return (basis.astype(np.float32) * win.astype(np.float32)[None, :]).astype(np.float32)
+
+
+class TacotronSTFT(nn.Module):
+    def __init__(self, filter_length, hop_length, win_length, n_mel_channels, sampling_rate, mel_fmin, mel_fmax):
+        super().__init__()
+        self.n_fft, self.hop, self.n_mel_channels, self.sampling_rate = filter_length, hop_length, n_mel_channels, sampling_rate
+        self.nbins = filter_length // 2 + 1
+        mel = slaney_mel_basis(sampling_rate, filter_length, n_mel_channels, mel_fmin, mel_fmax)
+        self.register_buffer("mel_basis", torch.from_numpy(mel))
+        ld = (self.nbins + 3) // 4 * 4
+        padded = np.zeros((n_mel_channels, ld), dtype=np.float32)
+        padded[:, :self.nbins] = mel
+        self.register_buffer("_mel_basis_padded", torch.from_numpy(padded), persistent=False)
+        self.register_buffer("_dft_basis", torch.from_numpy(windowed_dft_basis(filter_length, win_length)), persistent=False)
+
+    def mel_spectrogram(self, y):
+        """y [B,N] float32 on the HIP device, values in [-1, 1] (asserted like stft.py:177-178)."""
+        if not y.is_cuda:
+            raise RuntimeError("TacotronSTFT (ctts_amd) computes on the MI355X: pass a device tensor")
+        assert torch.min(y.data) >= -1 and torch.max(y.data) <= 1
+        if self._dft_basis.device != y.device:
+            self.to(y.device)
+        mel, energy, _ = ops.mel_spectrogram(y.float(), self._dft_basis, self._mel_basis_padded, self.n_fft, self.hop,
+                                             self.n_mel_channels, self.nbins)
+        return mel, energy
+
+    def magnitudes(self, y):
+        if self._dft_basis.device != y.device:
+            self.to(y.device)
+        _, _, mag = ops.mel_spectrogram(y.float(), self._dft_basis, self._mel_basis_padded, self.n_fft, self.hop,
+                                        self.n_mel_channels, self.nbins)
+        B = y.shape[0]
+        return mag.view(B, -1, mag.shape[-1])[:, :, :self.nbins].transpose(1, 2)

@@ -1,0 +1,81 @@
+// Shared device/host helpers for libctts_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ctts.h"
+
+#define CTTS_WAVE 64
+
+void ctts_set_error(const char* fmt, ...);
+
+#define CTTS_CHECK_LAUNCH(name)                                                     \
+  do {                                                                              \
+    hipError_t _e = hipGetLastError();                                              \
+    if (_e != hipSuccess) {                                                         \
+      ctts_set_error("%s: launch failed: %s", name, hipGetErrorString(_e));         \
+      return -2;                                                                    \
+    }                                                                               \
+  } while (0)
+
+#define CTTS_REQUIRE(cond, ...)                                                     \
+  do {                                                                              \
+    if (!(cond)) {                                                                  \
+      ctts_set_error(__VA_ARGS__);                                                  \
+      return -1;                                                                    \
+    }                                                                               \
+  } while (0)
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// keep(idx) is a pure function of (seed, call-site offset, element index): the backward pass
+// regenerates the forward mask instead of storing it.  seed lives in device memory so that a
+// captured hipGraph sees a fresh value on every replay.
+__device__ __forceinline__ uint32_t ctts_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t ctts_drop_key(const uint64_t* seed, uint32_t offset) {
+  uint64_t s = seed ? *seed : 0x9E3779B97F4A7C15ULL;
+  uint32_t k = ctts_mix32((uint32_t)s ^ (offset * 0x9E3779B1U));
+  return ctts_mix32(k + (uint32_t)(s >> 32));
+}
+// returns the multiplicative factor: 0 or 1/(1-p)
+__device__ __forceinline__ float ctts_drop_scale(uint32_t key, uint32_t idx, float p, float inv_keep) {
+  uint32_t h = ctts_mix32(idx * 0x9E3779B1U + key);
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float ctts_act(float v, int act) {
+  switch (act) {
+    case 1: return v > 0.f ? v : 0.f;
+    case 2: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case 3: return tanhf(v);
+    default: return v;
+  }
+}
+// derivative w.r.t. the pre-activation z
+__device__ __forceinline__ float ctts_act_grad(float z, int act) {
+  switch (act) {
+    case 1: return z > 0.f ? 1.f : 0.f;
+    case 2: {
+      float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+      float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+      return cdf + z * pdf;
+    }
+    case 3: { float t = tanhf(z); return 1.f - t * t; }
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float ctts_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float ctts_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,208 @@
+// Backward-pass elementwise helpers, bias-gradient column sums, Conv1d weight repacks and the
+// small kernels of the mel front end.  All HBM-bound streaming kernels (float4 where the shape allows).
+#include "ctts_common.h"
+
+namespace {
+
+__global__ void act_dropout_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ z, float* __restrict__ dz,
+                                       long total, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset) {
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  const long n4 = total >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 g = reinterpret_cast<const float4*>(dg)[i];
+    const float4 zz = reinterpret_cast<const float4*>(z)[i];
+    float ga[4] = {g.x, g.y, g.z, g.w};
+    const float za[4] = {zz.x, zz.y, zz.z, zz.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (do_drop) ga[e] *= ctts_drop_scale(dkey, (uint32_t)(i * 4 + e), p_drop, inv_keep);
+      ga[e] *= ctts_act_grad(za[e], act);
+    }
+    reinterpret_cast<float4*>(dz)[i] = make_float4(ga[0], ga[1], ga[2], ga[3]);
+  }
+}
+
+__global__ void rowscale_dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C,
+                                        const float* __restrict__ rowscale, float p_drop, const uint64_t* seed,
+                                        uint32_t drop_offset) {
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  const long n4 = total >> 2;
+  const int C4 = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float a[4] = {v.x, v.y, v.z, v.w};
+    const float sc = rowscale ? rowscale[i / C4] : 1.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (do_drop) a[e] *= ctts_drop_scale(dkey, (uint32_t)(i * 4 + e), p_drop, inv_keep);
+      a[e] *= sc;
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(a[0], a[1], a[2], a[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C,
+                                                      long ld) {
+  __shared__ float s[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+  const long stripe = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = blockIdx.y * stripe, r1 = min(rows, r0 + stripe);
+  float a = 0.f;
+  if (c < C)
+    for (long r = r0 + ty; r < r1; r += 4) a += x[r * ld + c];
+  s[ty][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    const int l = threadIdx.x;
+    atomicAdd(out + c, s[0][l] + s[1][l] + s[2][l] + s[3][l]);
+  }
+}
+
+// w[Cout][Cin][K] <-> GEMM-friendly layouts
+__global__ void conv_weight_repack_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k,
+                                          int mode, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    if (mode == 0) {         // dst[co][kk][ci] = src[co][ci][kk]
+      const int ci = (int)(e % cin); const long t = e / cin; const int kk = (int)(t % k); const int co = (int)(t / k);
+      dst[e] = src[((long)co * cin + ci) * k + kk];
+    } else if (mode == 1) {  // dst[ci][kk][co] = src[co][ci][k-1-kk]
+      const int co = (int)(e % cout); const long t = e / cout; const int kk = (int)(t % k); const int ci = (int)(t / k);
+      dst[e] = src[((long)co * cin + ci) * k + (k - 1 - kk)];
+    } else {                 // dst[co][ci][kk] = src[co][kk][ci]
+      const int kk = (int)(e % k); const long t = e / k; const int ci = (int)(t % cin); const int co = (int)(t / cin);
+      dst[e] = src[((long)co * k + kk) * cin + ci];
+    }
+  }
+}
+
+__global__ void reflect_pad_kernel(const float* __restrict__ y, float* __restrict__ ypad, int N, int pad, long ld_out,
+                                   long total) {
+  const int W = N + 2 * pad;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / ld_out;
+    const int j = (int)(e - b * ld_out);
+    float v = 0.f;
+    if (j < W) {
+      int i = j - pad;
+      if (i < 0) i = -i;
+      if (i >= N) i = 2 * (N - 1) - i;
+      v = y[b * N + i];
+    }
+    ypad[e] = v;
+  }
+}
+
+// reim [frames, 2*nbins] (cols [0,nbins) real, [nbins,2nbins) imag) -> mag [frames, ld_mag], energy[frames]
+__global__ __launch_bounds__(256) void stft_magnitude_kernel(const float* __restrict__ reim, long ld_reim,
+                                                              float* __restrict__ mag, long ld_mag,
+                                                              float* __restrict__ energy, long frames, int nbins) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long f = (long)blockIdx.x * 4 + wave; f < frames; f += (long)gridDim.x * 4) {
+    const float* r = reim + f * ld_reim;
+    float acc = 0.f;
+    for (int k = lane; k < ld_mag; k += 64) {
+      float m = 0.f;
+      if (k < nbins) {
+        const float re = r[k], im = r[nbins + k];
+        const float p = re * re + im * im;
+        acc += p;
+        m = sqrtf(p);
+      }
+      mag[f * ld_mag + k] = m;
+    }
+    acc = ctts_wave_sum(acc);
+    if (lane == 0) energy[f] = sqrtf(acc);
+  }
+}
+
+// mel_fm [B*F, n_mel] -> out [B, n_mel, F] = log(max(v, clip))
+__global__ void log_clamp_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int F, int n_mel,
+                                           float clip, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int f = (int)(e % F); const long t = e / F; const int m = (int)(t % n_mel); const long b = t / n_mel;
+    out[e] = logf(fmaxf(in[(b * F + f) * n_mel + m], clip));
+  }
+}
+
+inline int grid_for(long n, int cap = 4096) { return (int)min((n + 255) / 256, (long)cap); }
+
+}  // namespace
+
+extern "C" int ctts_act_dropout_bwd(const float* dg, const float* z, float* dz, int64_t rows, int C, int act,
+                                    float alpha_unused, float p_drop, const uint64_t* seed, uint32_t drop_offset,
+                                    void* stream) {
+  (void)alpha_unused;
+  CTTS_REQUIRE(dg && z && dz && (C % 4) == 0, "ctts_act_dropout_bwd: bad arguments (C %% 4 must be 0)");
+  const long total = (long)rows * C;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(grid_for(total >> 2)), dim3(256), 0, (hipStream_t)stream, dg, z, dz, total,
+                     act, p_drop, seed, drop_offset);
+  CTTS_CHECK_LAUNCH("ctts_act_dropout_bwd");
+  return 0;
+}
+
+extern "C" int ctts_rowscale_dropout(const float* x, float* y, int64_t rows, int C, const float* rowscale, float p_drop,
+                                     const uint64_t* seed, uint32_t drop_offset, void* stream) {
+  CTTS_REQUIRE(x && y && (C % 4) == 0, "ctts_rowscale_dropout: bad arguments (C %% 4 must be 0)");
+  const long total = (long)rows * C;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(rowscale_dropout_kernel, dim3(grid_for(total >> 2)), dim3(256), 0, (hipStream_t)stream, x, y, total, C,
+                     rowscale, p_drop, seed, drop_offset);
+  CTTS_CHECK_LAUNCH("ctts_rowscale_dropout");
+  return 0;
+}
+
+extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, void* stream) {
+  CTTS_REQUIRE(x && out && C > 0, "ctts_colsum: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { ctts_set_error("ctts_colsum: memset failed"); return -2; }
+  if (rows == 0) return 0;
+  const int gy = (int)max((long)1, min((long)64, (long)rows / 64));
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, st, x, out, (long)rows, C, (long)ld);
+  CTTS_CHECK_LAUNCH("ctts_colsum");
+  return 0;
+}
+
+extern "C" int ctts_conv_weight_repack(const float* src, float* dst, int cout, int cin, int k, int mode, void* stream) {
+  CTTS_REQUIRE(src && dst && mode >= 0 && mode <= 2, "ctts_conv_weight_repack: bad arguments");
+  const long total = (long)cout * cin * k;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(conv_weight_repack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, cout, cin, k,
+                     mode, total);
+  CTTS_CHECK_LAUNCH("ctts_conv_weight_repack");
+  return 0;
+}
+
+extern "C" int ctts_reflect_pad(const float* y, float* ypad, int B, int N, int pad, int64_t ld_out, void* stream) {
+  CTTS_REQUIRE(y && ypad && N > pad && ld_out >= N + 2 * pad, "ctts_reflect_pad: need N > pad and ld_out >= N + 2*pad");
+  const long total = (long)B * ld_out;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, ypad, N, pad, (long)ld_out, total);
+  CTTS_CHECK_LAUNCH("ctts_reflect_pad");
+  return 0;
+}
+
+extern "C" int ctts_stft_magnitude(const float* reim, int64_t ld_reim, float* mag, int64_t ld_mag, float* energy,
+                                   int64_t frames, int nbins, void* stream) {
+  CTTS_REQUIRE(reim && mag && energy && ld_mag >= nbins, "ctts_stft_magnitude: bad arguments");
+  if (frames == 0) return 0;
+  const int blocks = (int)min((frames + 3) / 4, (int64_t)4096);
+  hipLaunchKernelGGL(stft_magnitude_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reim, (long)ld_reim, mag,
+                     (long)ld_mag, energy, (long)frames, nbins);
+  CTTS_CHECK_LAUNCH("ctts_stft_magnitude");
+  return 0;
+}
+
+extern "C" int ctts_log_clamp_transpose(const float* mel_fm, float* out, int B, int F, int n_mel, float clip, void* stream) {
+  CTTS_REQUIRE(mel_fm && out, "ctts_log_clamp_transpose: null pointer");
+  const long total = (long)B * F * n_mel;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(log_clamp_transpose_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mel_fm, out, F, n_mel,
+                     clip, total);
+  CTTS_CHECK_LAUNCH("ctts_log_clamp_transpose");
+  return 0;
+}

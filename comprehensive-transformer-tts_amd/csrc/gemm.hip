@@ -1,0 +1,344 @@
+// fp32 MFMA GEMM for gfx950 with implicit-im2col operand views and a fused epilogue.
+//
+// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN x 32, wave tile (BM/2) x (BN/2) as
+// (BM/64) x (BN/64) MFMA tiles of v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = the
+// fp32 roofline on CDNA4).  K is consumed 32 at a time; inside a K-block the MFMA's two
+// k-lanes (lane>>5) take k = h*16 + j so that a K-contiguous operand is fetched from LDS as four
+// ds_read_b128 per 32-row tile (row stride 36 floats -> conflict-free 16-lane groups).
+// Global->LDS staging goes through registers (prefetch of K-block i+1 is issued before the
+// MFMAs of block i), which lets the loader apply the conv time-boundary predicate and the
+// batch/length limits for free.  blockIdx.x is remapped so that each XCD owns a contiguous
+// run of tiles (tiles that share an A panel hit the same L2).
+#include "ctts_common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int KC_LD = BK + 4;  // 36 floats = 144 B row stride for K-contiguous operand tiles
+
+struct ConvView {
+  int T, pad, cin;
+};
+
+// ---- K-contiguous operand tile: ROWS x BK, element (r,k) = P[r*ld + k]
+template <int ROWS, bool CONV>
+struct LoaderKC {
+  static constexpr int NV = ROWS * BK / 4 / 256;
+  const float* base;
+  long ld;
+  int row0, row_lim, kq;
+  bool vec;
+  ConvView cv;
+  int trow[NV];
+  __device__ void init(const float* p, long ld_, int row0_, int row_lim_, bool vec_, ConvView cv_) {
+    base = p; ld = ld_; row0 = row0_; row_lim = row_lim_; vec = vec_; cv = cv_;
+    kq = (threadIdx.x & 7) << 2;
+    if (CONV) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int gr = row0 + ((threadIdx.x + i * 256) >> 3);
+        trow[i] = gr % cv.T;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(int k0, int k_end, float4 (&r)[NV]) const {
+    const int gk = k0 + kq;
+    int tap = 0;
+    if (CONV) tap = gk / cv.cin - cv.pad;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int gr = row0 + ((threadIdx.x + i * 256) >> 3);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < row_lim && gk < k_end) {
+        const float* p = base + (long)gr * ld + gk;
+        bool ok = true;
+        if (CONV) { int tt = trow[i] + tap; ok = (tt >= 0) && (tt < cv.T); }
+        if (vec && gk + 3 < k_end) {
+          if (ok) v = *reinterpret_cast<const float4*>(p);
+        } else {
+          float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bool okq = (gk + q < k_end);
+            if (CONV && okq) { int tt = trow[i] + (gk + q) / cv.cin - cv.pad; okq = (tt >= 0) && (tt < cv.T); }
+            if (okq) e[q] = p[q];
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      r[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* s, const float4 (&r)[NV]) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = (threadIdx.x + i * 256) >> 3;
+      *reinterpret_cast<float4*>(s + row * KC_LD + kq) = r[i];
+    }
+  }
+};
+
+// ---- row-contiguous operand tile: BK x COLS, element (k,c) = P[k*ld + c]
+template <int COLS, bool CONV>
+struct LoaderRC {
+  static constexpr int NV = COLS * BK / 4 / 256;
+  static constexpr int LD = COLS + 4;
+  const float* base;
+  long ld;
+  int col0, col_lim;
+  bool vec;
+  ConvView cv;
+  int tap[1];
+  __device__ void init(const float* p, long ld_, int col0_, int col_lim_, bool vec_, ConvView cv_) {
+    base = p; ld = ld_; col0 = col0_; col_lim = col_lim_; vec = vec_; cv = cv_;
+    tap[0] = 0;
+  }
+  __device__ __forceinline__ void load(int k0, int k_end, float4 (&r)[NV]) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = threadIdx.x + i * 256;
+      const int k = f / (COLS / 4);
+      const int cq = (f % (COLS / 4)) << 2;
+      const int gk = k0 + k, gc = col0 + cq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gk < k_end && gc < col_lim) {
+        const float* p = base + (long)gk * ld + gc;
+        int trow = 0;
+        if (CONV) trow = gk % cv.T;
+        if (vec && gc + 3 < col_lim) {
+          bool ok = true;
+          if (CONV) { int tt = trow + gc / cv.cin - cv.pad; ok = (tt >= 0) && (tt < cv.T); }
+          if (ok) v = *reinterpret_cast<const float4*>(p);
+        } else {
+          float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bool okq = (gc + q < col_lim);
+            if (CONV && okq) { int tt = trow + (gc + q) / cv.cin - cv.pad; okq = (tt >= 0) && (tt < cv.T); }
+            if (okq) e[q] = p[q];
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      r[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* s, const float4 (&r)[NV]) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = threadIdx.x + i * 256;
+      const int k = f / (COLS / 4);
+      const int cq = (f % (COLS / 4)) << 2;
+      *reinterpret_cast<float4*>(s + k * LD + cq) = r[i];
+    }
+  }
+};
+
+template <bool KC, int EXT, bool CONV>
+struct LoaderSel { using type = LoaderKC<EXT, CONV>; };
+template <int EXT, bool CONV>
+struct LoaderSel<false, EXT, CONV> { using type = LoaderRC<EXT, CONV>; };
+
+// fragment fetch for one 32-wide MFMA tile: 16 k-steps, lane (l31, h) gets element k = h*16 + j
+template <bool KC, int LD>
+__device__ __forceinline__ void fetch_frag(const float* s, int ext0, int l31, int h, float (&f)[16]) {
+  if (KC) {
+    const float4* p = reinterpret_cast<const float4*>(s + (ext0 + l31) * LD + h * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = p[q];
+      f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+  } else {
+    const float* p = s + (h * 16) * LD + ext0 + l31;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = p[j * LD];
+  }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
+__global__ __launch_bounds__(256) void gemm_kernel(const ctts_gemm_desc d) {
+  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+  constexpr int A_LD = A_KC ? KC_LD : BM + 4;
+  constexpr int B_LD = B_KC ? KC_LD : BN + 4;
+  constexpr int A_SZ = A_KC ? BM * KC_LD : BK * (BM + 4);
+  constexpr int B_SZ = B_KC ? BN * KC_LD : BK * (BN + 4);
+  __shared__ __attribute__((aligned(16))) float smem[A_SZ + B_SZ];
+  float* sA = smem;
+  float* sB = smem + A_SZ;
+
+  // ---- batch / split decode
+  const int z = blockIdx.z;
+  int z0 = 0, z1 = 0, split = 0;
+  if (d.split_k > 1) split = z; else { z0 = z / d.nb1; z1 = z - z0 * d.nb1; }
+  int Mv = d.M, Nv = d.N, Kv = d.K;
+  if (d.lens) {
+    const int L = d.lens[z0];
+    if (d.lim_m) Mv = min(Mv, L);
+    if (d.lim_n) Nv = min(Nv, L);
+    if (d.lim_k) Kv = min(Kv, L);
+  }
+  // ---- XCD-aware tile mapping (bijective for any grid size)
+  const int tiles_n = (d.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int row0 = (wg / tiles_n) * BM, col0 = (wg % tiles_n) * BN;
+  if (row0 >= Mv || col0 >= Nv) return;
+
+  int k_begin = 0, k_end = Kv;
+  if (d.split_k > 1) {
+    int chunk = ((Kv + d.split_k - 1) / d.split_k + BK - 1) / BK * BK;
+    k_begin = split * chunk;
+    k_end = min(Kv, k_begin + chunk);
+    if (k_begin >= k_end) return;
+  }
+
+  const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
+  const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
+  float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
+  ConvView cv{d.conv_T, d.conv_pad, d.conv_cin};
+  ConvView nocv{1, 0, 1};
+  constexpr bool CONV_A = CONV && A_KC;
+  constexpr bool CONV_B = CONV && !A_KC && !B_KC;
+  if (CONV_A) Ab -= (long)d.conv_pad * d.conv_cin;
+  if (CONV_B) Bb -= (long)d.conv_pad * d.conv_cin;
+
+  using LA = typename LoaderSel<A_KC, BM, CONV_A>::type;
+  using LB = typename LoaderSel<B_KC, BN, CONV_B>::type;
+  LA la; LB lb;
+  const bool a_vec = ((d.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(Ab) & 15) == 0);
+  const bool b_vec = ((d.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bb) & 15) == 0);
+  la.init(Ab, d.lda, row0, Mv, a_vec, CONV_A ? cv : nocv);
+  lb.init(Bb, d.ldb, col0, Nv, b_vec, CONV_B ? cv : nocv);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[LA::NV], rb[LB::NV];
+  la.load(k_begin, k_end, ra);
+  lb.load(k_begin, k_end, rb);
+  la.store(sA, ra);
+  lb.store(sB, rb);
+  __syncthreads();
+
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool has_next = (k0 + BK) < k_end;
+    if (has_next) {
+      la.load(k0 + BK, k_end, ra);
+      lb.load(k0 + BK, k_end, rb);
+    }
+    float fa[MT][16], fb[NT][16];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fetch_frag<A_KC, A_LD>(sA, wm0 + i * 32, l31, h, fa[i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sB, wn0 + j * 32, l31, h, fb[j]);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+    __syncthreads();
+    if (has_next) {
+      la.store(sA, ra);
+      lb.store(sB, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const float alpha = d.alpha;
+  if (d.split_k > 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int n = col0 + wn0 + j * 32 + l31;
+          if (m < Mv && n < Nv) atomicAdd(Cb + (long)m * d.ldc + n, alpha * acc[i][j][r]);
+        }
+    return;
+  }
+  const bool do_drop = d.p_drop > 0.f;
+  uint32_t dkey = 0;
+  float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
+  const uint32_t zoff = (uint32_t)z * (uint32_t)d.M * (uint32_t)d.N;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = col0 + wn0 + j * 32 + l31;
+      const float bv = (d.bias && n < Nv) ? d.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < Mv && n < Nv) {
+          float v = alpha * (acc[i][j][r] + bv);
+          if (d.Z) d.Z[(long)m * d.ldz + n] = v;
+          v = ctts_act(v, d.act);
+          if (do_drop) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
+          if (d.R) v += d.R[(long)m * d.ldr + n];
+          if (d.rowscale) v *= d.rowscale[m];
+          Cb[(long)m * d.ldc + n] = v;
+        }
+      }
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
+int launch(const ctts_gemm_desc& d, hipStream_t st) {
+  const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  const int nz = d.split_k > 1 ? d.split_k : d.nb0 * d.nb1;
+  dim3 grid(tiles, 1, nz);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, CONV>), grid, dim3(256), 0, st, d);
+  CTTS_CHECK_LAUNCH("ctts_gemm");
+  return 0;
+}
+
+template <int BM, int BN>
+int dispatch_layout(const ctts_gemm_desc& d, hipStream_t st) {
+  const bool conv = d.conv_T > 0;
+  if (d.a_kc && d.b_kc) return conv ? launch<BM, BN, true, true, true>(d, st) : launch<BM, BN, true, true, false>(d, st);
+  if (d.a_kc && !d.b_kc) return conv ? launch<BM, BN, true, false, true>(d, st) : launch<BM, BN, true, false, false>(d, st);
+  if (!d.a_kc && !d.b_kc) return conv ? launch<BM, BN, false, false, true>(d, st) : launch<BM, BN, false, false, false>(d, st);
+  ctts_set_error("ctts_gemm: layout a_kc=0,b_kc=1 is not instantiated");
+  return -1;
+}
+
+}  // namespace
+
+extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
+  CTTS_REQUIRE(dp != nullptr, "ctts_gemm: null descriptor");
+  ctts_gemm_desc d = *dp;
+  CTTS_REQUIRE(d.A && d.B && d.C, "ctts_gemm: null operand pointer");
+  CTTS_REQUIRE(d.M >= 0 && d.N >= 0 && d.K >= 0, "ctts_gemm: negative dimension");
+  if (d.M == 0 || d.N == 0) return 0;
+  if (d.nb0 < 1) d.nb0 = 1;
+  if (d.nb1 < 1) d.nb1 = 1;
+  CTTS_REQUIRE(!(d.split_k > 1 && d.nb0 * d.nb1 > 1), "ctts_gemm: split_k and batching are exclusive");
+  if (d.conv_T > 0) {
+    CTTS_REQUIRE(d.conv_cin > 0 && (d.conv_cin % 4) == 0, "ctts_gemm: conv view needs cin %% 4 == 0 (got %d)", d.conv_cin);
+    CTTS_REQUIRE(d.conv_on_b ? (!d.a_kc && !d.b_kc) : (d.a_kc != 0), "ctts_gemm: conv view on an unsupported operand layout");
+  }
+  CTTS_REQUIRE(d.p_drop >= 0.f && d.p_drop < 1.f, "ctts_gemm: p_drop out of range");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : d.nb0 * d.nb1);
+  if (tiles128 >= 256 && d.N > 64) return dispatch_layout<128, 128>(d, st);
+  return dispatch_layout<64, 64>(d, st);
+}

@@ -1,0 +1,173 @@
+// LengthRegulator / dur_to_mel2ph / make_positions: wavefront prefix scans + coalesced gathers.
+// All index arithmetic is integer and bit-exact against the reference
+// (model/modules.py:1216-1249, utils/tools.py:577-652).  HBM-bound: 4*C*(Ts+Tm) bytes per sample.
+#include "ctts_common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+void ctts_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ctts_last_error(void) { return g_err; }
+extern "C" int ctts_version(void) { return 1; }
+
+namespace {
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// one block per batch row.  Phase 1 (wave 0): scan durations -> cum (LDS + global).
+// Phase 2 (all threads): upper-bound search of t in cum -> mel2ph.
+__global__ __launch_bounds__(256) void lr_index_kernel(const void* dur, int dur_is_float, int round_mode,
+                                                        const uint8_t* pad, int Ts, int Tm, int32_t* mel2ph,
+                                                        int64_t* mel_len, int32_t* cum_out) {
+  extern __shared__ int s_cum[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  __shared__ int s_total;
+  if (tid < 64) {
+    int carry = 0;
+    for (int i0 = 0; i0 < Ts; i0 += 64) {
+      const int i = i0 + lane;
+      int dv = 0;
+      if (i < Ts) {
+        if (dur_is_float) {
+          float f = reinterpret_cast<const float*>(dur)[(long)b * Ts + i];
+          f = round_mode ? rintf(f) : truncf(f);
+          dv = f > 0.f ? (f < 2.0e9f ? (int)f : 2000000000) : 0;
+        } else {
+          long long v = reinterpret_cast<const long long*>(dur)[(long)b * Ts + i];
+          dv = v > 0 ? (v < 2000000000LL ? (int)v : 2000000000) : 0;
+        }
+        if (pad && pad[(long)b * Ts + i]) dv = 0;
+      }
+      int inc = wave_incl_scan(dv, lane) + carry;
+      if (i < Ts) {
+        s_cum[i] = inc;
+        if (cum_out) cum_out[(long)b * Ts + i] = inc;
+      }
+      carry = __shfl(inc, 63, 64);
+    }
+    if (lane == 0) {
+      s_total = carry;
+      if (mel_len) mel_len[b] = carry;
+    }
+  }
+  __syncthreads();
+  if (!mel2ph) return;
+  const int total = s_total;
+  for (int t = tid; t < Tm; t += 256) {
+    int v = 0;
+    if (t < total) {
+      int lo = 0, hi = Ts;  // first i with cum[i] > t
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (s_cum[mid] > t) hi = mid; else lo = mid + 1;
+      }
+      v = lo + 1;
+    }
+    mel2ph[(long)b * Tm + t] = v;
+  }
+}
+
+__global__ void lr_gather_fwd_kernel(const float4* __restrict__ x, const int32_t* __restrict__ mel2ph,
+                                     float4* __restrict__ out, int Ts, int Tm, int C4, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / C4;
+    const int c = (int)(e - row * C4);
+    const int b = (int)(row / Tm);
+    const int ph = mel2ph[row];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ph > 0) v = x[((long)b * Ts + (ph - 1)) * C4 + c];
+    out[e] = v;
+  }
+}
+
+__global__ void lr_gather_bwd_kernel(const float4* __restrict__ dy, const int32_t* __restrict__ cum,
+                                     float4* __restrict__ dx, int Ts, int Tm, int C4, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / C4;  // (b, i)
+    const int c = (int)(e - row * C4);
+    const int b = (int)(row / Ts), i = (int)(row - (long)b * Ts);
+    const int start = i > 0 ? cum[row - 1] : 0;
+    const int end = min(cum[row], Tm);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = start; t < end; ++t) {
+      float4 v = dy[((long)b * Tm + t) * C4 + c];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    dx[e] = s;
+  }
+}
+
+__global__ __launch_bounds__(64) void positions_kernel(const void* src, int src_is_float, long stride, int T,
+                                                        int32_t* pos) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int carry = 0;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    int nz = 0;
+    if (t < T) {
+      if (src_is_float) nz = reinterpret_cast<const float*>(src)[((long)b * T + t) * stride] != 0.f;
+      else nz = reinterpret_cast<const long long*>(src)[((long)b * T + t) * stride] != 0;
+    }
+    int inc = wave_incl_scan(nz, lane) + carry;
+    if (t < T) pos[(long)b * T + t] = nz ? inc : 0;
+    carry = __shfl(inc, 63, 64);
+  }
+}
+
+}  // namespace
+
+extern "C" int ctts_lr_index(const void* dur, int dur_is_float, int round_mode, const uint8_t* pad, int B, int Ts,
+                             int Tm, int32_t* mel2ph, int64_t* mel_len, int32_t* cum, void* stream) {
+  CTTS_REQUIRE(dur && B >= 0 && Ts > 0 && Tm >= 0, "ctts_lr_index: bad arguments");
+  CTTS_REQUIRE((size_t)Ts * 4 <= 60000, "ctts_lr_index: Ts=%d too large for the LDS scan buffer", Ts);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(lr_index_kernel, dim3(B), dim3(256), (size_t)Ts * sizeof(int), (hipStream_t)stream, dur,
+                     dur_is_float, round_mode, pad, Ts, Tm, mel2ph, mel_len, cum);
+  CTTS_CHECK_LAUNCH("ctts_lr_index");
+  return 0;
+}
+
+extern "C" int ctts_lr_gather_fwd(const float* x, const int32_t* mel2ph, float* out, int B, int Ts, int Tm, int C,
+                                  void* stream) {
+  CTTS_REQUIRE(x && mel2ph && out && (C % 4) == 0, "ctts_lr_gather_fwd: bad arguments (C %% 4 must be 0)");
+  const long total = (long)B * Tm * (C / 4);
+  if (total == 0) return 0;
+  const int blocks = (int)min((total + 255) / 256, (long)2048);
+  hipLaunchKernelGGL(lr_gather_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), mel2ph, reinterpret_cast<float4*>(out), Ts, Tm, C / 4, total);
+  CTTS_CHECK_LAUNCH("ctts_lr_gather_fwd");
+  return 0;
+}
+
+extern "C" int ctts_lr_gather_bwd(const float* dy, const int32_t* cum, float* dx, int B, int Ts, int Tm, int C,
+                                  void* stream) {
+  CTTS_REQUIRE(dy && cum && dx && (C % 4) == 0, "ctts_lr_gather_bwd: bad arguments (C %% 4 must be 0)");
+  const long total = (long)B * Ts * (C / 4);
+  if (total == 0) return 0;
+  const int blocks = (int)min((total + 255) / 256, (long)2048);
+  hipLaunchKernelGGL(lr_gather_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(dy), cum, reinterpret_cast<float4*>(dx), Ts, Tm, C / 4, total);
+  CTTS_CHECK_LAUNCH("ctts_lr_gather_bwd");
+  return 0;
+}
+
+extern "C" int ctts_positions(const void* src, int src_is_float, int64_t stride, int B, int T, int32_t* pos,
+                              void* stream) {
+  CTTS_REQUIRE(src && pos && T > 0, "ctts_positions: bad arguments");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(positions_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, src, src_is_float, (long)stride, T,
+                     pos);
+  CTTS_CHECK_LAUNCH("ctts_positions");
+  return 0;
+}

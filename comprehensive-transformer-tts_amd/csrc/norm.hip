@@ -1,0 +1,375 @@
+// LayerNorm / BatchNorm1d (channel-last) / masked softmax kernels.  All HBM-bound: one pass over
+// the activation per direction, row statistics in registers (one wavefront per row).
+#include "ctts_common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
+
+// y = rowscale * drop(LN(x)); one wave per row, 4 rows in flight per block
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                             int rows, int C, float eps, float p_drop,
+                                                             const uint64_t* seed, uint32_t drop_offset,
+                                                             const float* __restrict__ rowscale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = C >> 2;
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  const float invC = 1.f / (float)C;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < nvec ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mu = ctts_wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      if (lane + 64 * i < nvec) {
+        float a = v[i].x - mu, b = v[i].y - mu, c2 = v[i].z - mu, d2 = v[i].w - mu;
+        q += a * a + b * b + c2 * c2 + d2 * d2;
+      }
+    }
+    const float rs = rsqrtf(ctts_wave_sum(q) * invC + eps);
+    if (lane == 0) { mean_o[row] = mu; rstd_o[row] = rs; }
+    const float sc = rowscale ? rowscale[row] : 1.f;
+    float4* yr = reinterpret_cast<float4*>(y + (long)row * C);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+        const float4 bb = reinterpret_cast<const float4*>(beta)[c];
+        float o[4] = {(v[i].x - mu) * rs * g.x + bb.x, (v[i].y - mu) * rs * g.y + bb.y,
+                      (v[i].z - mu) * rs * g.z + bb.z, (v[i].w - mu) * rs * g.w + bb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (do_drop) o[e] *= ctts_drop_scale(dkey, (uint32_t)row * (uint32_t)C + (uint32_t)(c * 4 + e), p_drop, inv_keep);
+          o[e] *= sc;
+        }
+        yr[c] = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int rows, int C, float p_drop,
+                                                             const uint64_t* seed, uint32_t drop_offset,
+                                                             const float* __restrict__ rowscale) {
+  __shared__ float s_red[2][4][LN_MAXV * 64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = C >> 2;
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  const float invC = 1.f / (float)C;
+  float ag[LN_MAXV][4], ab[LN_MAXV][4];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
+    const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * C);
+    const float mu = mean[row], rs = rstd[row];
+    const float sc = rowscale ? rowscale[row] : 1.f;
+    float xh[LN_MAXV][4], g[LN_MAXV][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        const float4 xv = xr[c], dv = dr[c], gv = reinterpret_cast<const float4*>(gamma)[c];
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, da[4] = {dv.x, dv.y, dv.z, dv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float d = da[e] * sc;
+          if (do_drop) d *= ctts_drop_scale(dkey, (uint32_t)row * (uint32_t)C + (uint32_t)(c * 4 + e), p_drop, inv_keep);
+          xh[i][e] = (xa[e] - mu) * rs;
+          ag[i][e] += d * xh[i][e];
+          ab[i][e] += d;
+          g[i][e] = d * ga[e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xh[i][e] = 0.f; g[i][e] = 0.f; }
+      }
+    }
+    const float c1 = ctts_wave_sum(s1) * invC, c2 = ctts_wave_sum(s2) * invC;
+    float4* dxr = reinterpret_cast<float4*>(dx + (long)row * C);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec)
+        dxr[c] = make_float4(rs * (g[i][0] - c1 - xh[i][0] * c2), rs * (g[i][1] - c1 - xh[i][1] * c2),
+                             rs * (g[i][2] - c1 - xh[i][2] * c2), rs * (g[i][3] - c1 - xh[i][3] * c2));
+    }
+  }
+  // block reduce of the per-wave dgamma/dbeta partials, then one atomic per channel per block
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s_red[0][wave][(i * 64 + lane) * 4 + e] = ag[i][e];
+      s_red[1][wave][(i * 64 + lane) * 4 + e] = ab[i][e];
+    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < LN_MAXV * 64 * 4; idx += 256) {
+    const int v = idx >> 2, e = idx & 3;  // v = i*64 + lane -> channel vector index = lane + 64*i
+    const int cvec = (v & 63) + 64 * (v >> 6);
+    if (cvec < nvec) {
+      const float sg = s_red[0][0][idx] + s_red[0][1][idx] + s_red[0][2][idx] + s_red[0][3][idx];
+      const float sb = s_red[1][0][idx] + s_red[1][1][idx] + s_red[1][2][idx] + s_red[1][3][idx];
+      atomicAdd(dgamma + cvec * 4 + e, sg);
+      atomicAdd(dbeta + cvec * 4 + e, sb);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- BatchNorm1d (channel-last)
+// column sums: block = 64 columns x a stripe of rows; thread (c = tid & 63, ty = tid >> 6)
+template <int MODE>  // 0: sum x, sum x^2   1: BN-bwd sums (dt, dt*xhat)
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         double* __restrict__ sums, int rows, int C, int act, float p_drop,
+                                                         const uint64_t* seed, uint32_t drop_offset) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+  const int stripe = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * stripe, r1 = min(rows, r0 + stripe);
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+    float mu = 0.f, rs = 1.f, g = 1.f, be = 0.f, inv_keep = 1.f;
+    uint32_t dkey = 0;
+    const bool do_drop = (MODE == 1) && p_drop > 0.f;
+    if (MODE == 1) { mu = mean[c]; rs = rstd[c]; g = gamma[c]; be = beta[c]; }
+    if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+    for (int r = r0 + ty; r < r1; r += 4) {
+      const float xv = x[(long)r * C + c];
+      if (MODE == 0) { a += xv; b += xv * xv; }
+      else {
+        float d = dy[(long)r * C + c];
+        if (do_drop) d *= ctts_drop_scale(dkey, (uint32_t)r * (uint32_t)C + (uint32_t)c, p_drop, inv_keep);
+        const float xh = (xv - mu) * rs;
+        d *= ctts_act_grad(xh * g + be, act);
+        a += d; b += d * xh;
+      }
+    }
+  }
+  s1[ty][threadIdx.x & 63] = a; s2[ty][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    const int l = threadIdx.x;
+    const double A = (double)s1[0][l] + s1[1][l] + s1[2][l] + s1[3][l];
+    const double Bv = (double)s2[0][l] + s2[1][l] + s2[2][l] + s2[3][l];
+    atomicAdd(sums + c, A);
+    atomicAdd(sums + C + c, Bv);
+  }
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                long total, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset) {
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    float v = ctts_act((x[e] - mean[c]) * rstd[c] * gamma[c] + beta[c], act);
+    if (do_drop) v *= ctts_drop_scale(dkey, (uint32_t)e, p_drop, inv_keep);
+    y[e] = v;
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const double* __restrict__ sums, float* __restrict__ dx,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, long total, int rows, int C, int act,
+                                    float p_drop, const uint64_t* seed, uint32_t drop_offset, int batch_stats) {
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  const float invR = 1.f / (float)rows;
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    float d = dy[e];
+    if (do_drop) d *= ctts_drop_scale(dkey, (uint32_t)e, p_drop, inv_keep);
+    const float xh = (x[e] - mean[c]) * rstd[c];
+    d *= ctts_act_grad(xh * gamma[c] + beta[c], act);
+    float v = d;
+    if (batch_stats) v = d - (float)sums[c] * invR - xh * (float)sums[C + c] * invR;
+    dx[e] = gamma[c] * rstd[c] * v;
+  }
+}
+
+// ---------------------------------------------------------------- masked softmax over keys
+constexpr int SM_MAXV = 16;  // 64 * 16 = 1024 keys held in registers
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ S, const float* __restrict__ P,
+                                                       const int32_t* __restrict__ lens, int nb1, int T, long ld, long nrows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < nrows; row += (long)gridDim.x * 4) {
+    const long z = row / T;
+    const int q = (int)(row - z * T);
+    const int L = lens ? min(lens[z / nb1], T) : T;
+    if (q >= L) continue;
+    float* s = S + (z * T + q) * ld;
+    if (!BWD) {
+      if (L <= 64 * SM_MAXV) {
+        float v[SM_MAXV];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < SM_MAXV; ++i) {
+          const int k = lane + 64 * i;
+          v[i] = k < L ? s[k] : -INFINITY;
+          mx = fmaxf(mx, v[i]);
+        }
+        mx = ctts_wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < SM_MAXV; ++i) { v[i] = (lane + 64 * i) < L ? __expf(v[i] - mx) : 0.f; sum += v[i]; }
+        const float inv = 1.f / ctts_wave_sum(sum);
+#pragma unroll
+        for (int i = 0; i < SM_MAXV; ++i) { const int k = lane + 64 * i; if (k < L) s[k] = v[i] * inv; }
+      } else {
+        float mx = -INFINITY;
+        for (int k = lane; k < L; k += 64) mx = fmaxf(mx, s[k]);
+        mx = ctts_wave_max(mx);
+        float sum = 0.f;
+        for (int k = lane; k < L; k += 64) sum += __expf(s[k] - mx);
+        const float inv = 1.f / ctts_wave_sum(sum);
+        for (int k = lane; k < L; k += 64) s[k] = __expf(s[k] - mx) * inv;
+      }
+    } else {
+      const float* p = P + (z * T + q) * ld;
+      float dot = 0.f;
+      for (int k = lane; k < L; k += 64) dot += s[k] * p[k];
+      dot = ctts_wave_sum(dot);
+      for (int k = lane; k < L; k += 64) s[k] = p[k] * (s[k] - dot);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ctts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                  float* rstd, int rows, int C, float eps, float p_drop, const uint64_t* seed,
+                                  uint32_t drop_offset, const float* rowscale, void* stream) {
+  CTTS_REQUIRE(x && gamma && beta && y && mean && rstd, "ctts_layernorm_fwd: null pointer");
+  CTTS_REQUIRE((C % 4) == 0 && C <= 1024 && C > 0, "ctts_layernorm_fwd: C=%d must be a multiple of 4 and <= 1024", C);
+  if (rows == 0) return 0;
+  const int blocks = min((rows + 3) / 4, 2048);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd,
+                     rows, C, eps, p_drop, seed, drop_offset, rowscale);
+  CTTS_CHECK_LAUNCH("ctts_layernorm_fwd");
+  return 0;
+}
+
+extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                  const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
+                                  float p_drop, const uint64_t* seed, uint32_t drop_offset, const float* rowscale,
+                                  void* stream) {
+  CTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "ctts_layernorm_bwd: null pointer");
+  CTTS_REQUIRE((C % 4) == 0 && C <= 1024 && C > 0, "ctts_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess) {
+    ctts_set_error("ctts_layernorm_bwd: memset failed");
+    return -2;
+  }
+  if (rows == 0) return 0;
+  const int blocks = min((rows + 3) / 4, 256);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
+                     C, p_drop, seed, drop_offset, rowscale);
+  CTTS_CHECK_LAUNCH("ctts_layernorm_bwd");
+  return 0;
+}
+
+static int colreduce_grid_y(int rows) { return max(1, min(64, rows / 64)); }
+
+extern "C" int ctts_colstats(const float* x, double* sums, int rows, int C, void* stream) {
+  CTTS_REQUIRE(x && sums && rows > 0 && C > 0, "ctts_colstats: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { ctts_set_error("ctts_colstats: memset failed"); return -2; }
+  hipLaunchKernelGGL((colreduce_kernel<0>), dim3((C + 63) / 64, colreduce_grid_y(rows)), dim3(256), 0, st, x, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, sums, rows, C, 0, 0.f, nullptr, 0u);
+  CTTS_CHECK_LAUNCH("ctts_colstats");
+  return 0;
+}
+
+extern "C" int ctts_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                             float* y, int rows, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset,
+                             void* stream) {
+  CTTS_REQUIRE(x && mean && rstd && gamma && beta && y, "ctts_bn_apply: null pointer");
+  const long total = (long)rows * C;
+  if (total == 0) return 0;
+  const int blocks = (int)min((total + 255) / 256, (long)4096);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, total, C,
+                     act, p_drop, seed, drop_offset);
+  CTTS_CHECK_LAUNCH("ctts_bn_apply");
+  return 0;
+}
+
+extern "C" int ctts_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, double* sums, int rows, int C, int act, float p_drop,
+                                  const uint64_t* seed, uint32_t drop_offset, void* stream) {
+  CTTS_REQUIRE(dy && x && mean && rstd && gamma && beta && sums && rows > 0, "ctts_bn_bwd_reduce: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { ctts_set_error("ctts_bn_bwd_reduce: memset failed"); return -2; }
+  hipLaunchKernelGGL((colreduce_kernel<1>), dim3((C + 63) / 64, colreduce_grid_y(rows)), dim3(256), 0, st, x, dy, mean, rstd,
+                     gamma, beta, sums, rows, C, act, p_drop, seed, drop_offset);
+  CTTS_CHECK_LAUNCH("ctts_bn_bwd_reduce");
+  return 0;
+}
+
+extern "C" int ctts_bn_bwd_apply(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, const double* sums, float* dx, float* dgamma, float* dbeta, int rows,
+                                 int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, int batch_stats,
+                                 void* stream) {
+  CTTS_REQUIRE(dy && x && mean && rstd && gamma && beta && sums && dx && dgamma && dbeta, "ctts_bn_bwd_apply: null pointer");
+  const long total = (long)rows * C;
+  if (total == 0) return 0;
+  const int blocks = (int)min((total + 255) / 256, (long)4096);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, sums,
+                     dx, dgamma, dbeta, total, rows, C, act, p_drop, seed, drop_offset, batch_stats);
+  CTTS_CHECK_LAUNCH("ctts_bn_bwd_apply");
+  return 0;
+}
+
+extern "C" int ctts_softmax_fwd(float* S, const int32_t* lens, int nb0, int nb1, int T, int64_t ld, void* stream) {
+  CTTS_REQUIRE(S && nb0 > 0 && nb1 > 0 && T > 0, "ctts_softmax_fwd: bad arguments");
+  const long nrows = (long)nb0 * nb1 * T;
+  const int blocks = (int)min((nrows + 3) / 4, (long)8192);
+  hipLaunchKernelGGL((softmax_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, (const float*)nullptr, lens,
+                     nb1, T, (long)ld, nrows);
+  CTTS_CHECK_LAUNCH("ctts_softmax_fwd");
+  return 0;
+}
+
+extern "C" int ctts_softmax_bwd(const float* P, float* dP, const int32_t* lens, int nb0, int nb1, int T, int64_t ld,
+                                void* stream) {
+  CTTS_REQUIRE(P && dP && nb0 > 0 && nb1 > 0 && T > 0, "ctts_softmax_bwd: bad arguments");
+  const long nrows = (long)nb0 * nb1 * T;
+  const int blocks = (int)min((nrows + 3) / 4, (long)8192);
+  hipLaunchKernelGGL((softmax_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dP, P, lens, nb1, T, (long)ld,
+                     nrows);
+  CTTS_CHECK_LAUNCH("ctts_softmax_bwd");
+  return 0;
+}

@@ -1,0 +1,264 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per exported kernel).
+
+Tensors are only used for device memory + the current stream; every call goes through
+libctts_hip.so.  Inputs must live on a HIP device ("cuda" in PyTorch-ROCm) - a CPU tensor
+raises: there is no CPU path in the product.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, offset=0):
+    """device pointer of tensor `t` advanced by `offset` elements (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.CttsError("ctts kernels need device (HIP) tensors; got a CPU tensor - no CPU fallback exists")
+    return t.data_ptr() + offset * t.element_size()
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.CttsError(f"{name}: expected contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+class DropCtx:
+    """Dropout bookkeeping: device-resident 64-bit seed + per-call-site offsets.
+
+    The seed tensor is bumped once per step *on the device* (`advance`), so a captured
+    hipGraph draws fresh masks on every replay; offsets are plain host constants assigned
+    in program order, identical between eager and captured runs."""
+
+    def __init__(self, device, seed=1234):
+        self.seed = torch.tensor([seed * 0x9E3779B1 + 0x7F4A7C15], dtype=torch.int64, device=device)
+        self.counter = 0
+
+    def next_offset(self):
+        self.counter = (self.counter + 1) & 0x7FFFFFFF
+        return self.counter
+
+    def begin_step(self):
+        self.counter = 0
+
+    def advance(self):
+        self.seed.add_(0x632BE5AB)
+
+
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_off=0, c_off=0, nb0=1, nb1=1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), lens=None, lim=(0, 0, 0), conv=None, conv_on_b=False, split_k=1, alpha=1.0,
+         bias=None, Z=None, ldz=0, act=ACT_NONE, p_drop=0.0, seed=None, drop_offset=0, R=None, ldr=0, rowscale=None):
+    """C = epi(alpha * (opA @ opB + bias)); see include/ctts.h ctts_gemm_desc."""
+    d = GemmDesc()
+    d.A, d.B, d.C = _p(A, a_off), _p(B, b_off), _p(Cout, c_off)
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.lda, d.ldb, d.ldc = int(lda), int(ldb), int(ldc)
+    d.a_kc, d.b_kc = int(a_kc), int(b_kc)
+    d.nb0, d.nb1 = int(nb0), int(nb1)
+    d.sA0, d.sA1 = int(sA[0]), int(sA[1])
+    d.sB0, d.sB1 = int(sB[0]), int(sB[1])
+    d.sC0, d.sC1 = int(sC[0]), int(sC[1])
+    d.lens = _p(lens)
+    d.lim_m, d.lim_n, d.lim_k = int(lim[0]), int(lim[1]), int(lim[2])
+    if conv is not None:
+        d.conv_T, d.conv_pad, d.conv_cin = int(conv[0]), int(conv[1]), int(conv[2])
+        d.conv_on_b = int(conv_on_b)
+    d.split_k = int(split_k)
+    d.alpha = float(alpha)
+    d.bias = _p(bias)
+    d.Z, d.ldz = _p(Z), int(ldz)
+    d.act = int(act)
+    d.p_drop = float(p_drop)
+    d.seed = _p(seed)
+    d.drop_offset = int(drop_offset)
+    d.R, d.ldr = _p(R), int(ldr)
+    d.rowscale = _p(rowscale)
+    lib = _lib.load()
+    _lib.check(lib.ctts_gemm(C.byref(d), _stream()), "ctts_gemm")
+    return Cout
+
+
+def conv_weight_repack(src, dst, cout, cin, k, mode):
+    lib = _lib.load()
+    _lib.check(lib.ctts_conv_weight_repack(_p(src), _p(dst), cout, cin, k, mode, _stream()), "ctts_conv_weight_repack")
+    return dst
+
+
+def lr_index(dur, Tm, pad=None, round_mode=0, want_mel2ph=True):
+    """-> (mel2ph int32 [B,Tm] or None, mel_len int64 [B], cum int32 [B,Ts])"""
+    B, Ts = dur.shape
+    is_float = dur.dtype == torch.float32
+    if not is_float and dur.dtype != torch.int64:
+        raise _lib.CttsError(f"lr_index: durations must be int64 or float32, got {dur.dtype}")
+    dur = dur.contiguous()
+    mel2ph = torch.empty(B, Tm, dtype=torch.int32, device=dur.device) if want_mel2ph else None
+    mel_len = torch.empty(B, dtype=torch.int64, device=dur.device)
+    cum = torch.empty(B, Ts, dtype=torch.int32, device=dur.device)
+    padp = None
+    if pad is not None:
+        pad = pad.to(torch.uint8).contiguous()
+        padp = _p(pad)
+    lib = _lib.load()
+    _lib.check(lib.ctts_lr_index(_p(dur), int(is_float), int(round_mode), padp, B, Ts, int(Tm), _p(mel2ph), _p(mel_len),
+                                 _p(cum), _stream()), "ctts_lr_index")
+    return mel2ph, mel_len, cum
+
+
+def lr_gather_fwd(x, mel2ph):
+    B, Ts, Cc = x.shape
+    Tm = mel2ph.shape[1]
+    out = torch.empty(B, Tm, Cc, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_lr_gather_fwd(_p(_f32c(x, "x")), _p(mel2ph), _p(out), B, Ts, Tm, Cc, _stream()), "ctts_lr_gather_fwd")
+    return out
+
+
+def lr_gather_bwd(dy, cum, Ts):
+    B, Tm, Cc = dy.shape
+    dx = torch.empty(B, Ts, Cc, dtype=torch.float32, device=dy.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_lr_gather_bwd(_p(_f32c(dy, "dy")), _p(cum), _p(dx), B, Ts, Tm, Cc, _stream()), "ctts_lr_gather_bwd")
+    return dx
+
+
+def positions(src, stride=1):
+    """src: int64 tokens [B,T] or float32 [B,T,C] (channel 0 is tested, stride=C)."""
+    B, T = src.shape[0], src.shape[1]
+    pos = torch.empty(B, T, dtype=torch.int32, device=src.device)
+    is_float = src.dtype == torch.float32
+    lib = _lib.load()
+    _lib.check(lib.ctts_positions(_p(src), int(is_float), int(stride), B, T, _p(pos), _stream()), "ctts_positions")
+    return pos
+
+
+def layernorm_fwd(x, gamma, beta, eps, p_drop=0.0, seed=None, drop_offset=0, rowscale=None):
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_layernorm_fwd(_p(_f32c(x, "x")), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, Cc, eps,
+                                      p_drop, _p(seed), drop_offset, _p(rowscale), _stream()), "ctts_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, p_drop=0.0, seed=None, drop_offset=0, rowscale=None):
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_layernorm_bwd(_p(_f32c(dy, "dy")), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
+                                      _p(dbeta), rows, Cc, p_drop, _p(seed), drop_offset, _p(rowscale), _stream()),
+               "ctts_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def colstats(x2d):
+    rows, Cc = x2d.shape
+    sums = torch.empty(2 * Cc, dtype=torch.float64, device=x2d.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_colstats(_p(_f32c(x2d, "x")), _p(sums), rows, Cc, _stream()), "ctts_colstats")
+    return sums
+
+
+def bn_apply(x2d, mean, rstd, gamma, beta, act, p_drop=0.0, seed=None, drop_offset=0):
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    lib = _lib.load()
+    _lib.check(lib.ctts_bn_apply(_p(_f32c(x2d, "x")), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), rows, Cc, act, p_drop,
+                                 _p(seed), drop_offset, _stream()), "ctts_bn_apply")
+    return y
+
+
+def bn_bwd(dy, x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats):
+    rows, Cc = x2d.shape
+    sums = torch.empty(2 * Cc, dtype=torch.float64, device=x2d.device)
+    dx = torch.empty_like(x2d)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_bn_bwd_reduce(_p(_f32c(dy, "dy")), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), rows,
+                                      Cc, act, p_drop, _p(seed), drop_offset, _stream()), "ctts_bn_bwd_reduce")
+    _lib.check(lib.ctts_bn_bwd_apply(_p(dy), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), _p(dx), _p(dgamma),
+                                     _p(dbeta), rows, Cc, act, p_drop, _p(seed), drop_offset, int(batch_stats), _stream()),
+               "ctts_bn_bwd_apply")
+    return dx, dgamma, dbeta
+
+
+def softmax_fwd(S, lens, nb0, nb1, T):
+    lib = _lib.load()
+    _lib.check(lib.ctts_softmax_fwd(_p(S), _p(lens), nb0, nb1, T, T, _stream()), "ctts_softmax_fwd")
+    return S
+
+
+def softmax_bwd(P, dP, lens, nb0, nb1, T):
+    lib = _lib.load()
+    _lib.check(lib.ctts_softmax_bwd(_p(P), _p(dP), _p(lens), nb0, nb1, T, T, _stream()), "ctts_softmax_bwd")
+    return dP
+
+
+def act_dropout_bwd(dg, z, act, p_drop=0.0, seed=None, drop_offset=0):
+    Cc = z.shape[-1]
+    rows = z.numel() // Cc
+    dz = torch.empty_like(z)
+    lib = _lib.load()
+    _lib.check(lib.ctts_act_dropout_bwd(_p(_f32c(dg, "dg")), _p(z), _p(dz), rows, Cc, act, 1.0, p_drop, _p(seed),
+                                        drop_offset, _stream()), "ctts_act_dropout_bwd")
+    return dz
+
+
+def rowscale_dropout(x, rowscale=None, p_drop=0.0, seed=None, drop_offset=0):
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.ctts_rowscale_dropout(_p(_f32c(x, "x")), _p(y), rows, Cc, _p(rowscale), p_drop, _p(seed), drop_offset,
+                                         _stream()), "ctts_rowscale_dropout")
+    return y
+
+
+def colsum(x2d, ld=None):
+    rows, Cc = x2d.shape
+    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_colsum(_p(x2d), _p(out), rows, Cc, ld if ld is not None else Cc, _stream()), "ctts_colsum")
+    return out
+
+
+def reflect_pad(y, pad):
+    """-> [B, ld] with ld = N + 2*pad rounded up to a multiple of 4 (16-B aligned rows), tail zero."""
+    B, N = y.shape
+    ld = (N + 2 * pad + 3) // 4 * 4
+    out = torch.empty(B, ld, dtype=torch.float32, device=y.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_reflect_pad(_p(_f32c(y, "y")), _p(out), B, N, pad, ld, _stream()), "ctts_reflect_pad")
+    return out
+
+
+def stft_magnitude(reim, frames, nbins, ld_mag):
+    mag = torch.empty(frames, ld_mag, dtype=torch.float32, device=reim.device)
+    energy = torch.empty(frames, dtype=torch.float32, device=reim.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_stft_magnitude(_p(reim), reim.shape[-1], _p(mag), ld_mag, _p(energy), frames, nbins, _stream()),
+               "ctts_stft_magnitude")
+    return mag, energy
+
+
+def log_clamp_transpose(mel_fm, B, F, n_mel, clip):
+    out = torch.empty(B, n_mel, F, dtype=torch.float32, device=mel_fm.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_log_clamp_transpose(_p(mel_fm), _p(out), B, F, n_mel, clip, _stream()), "ctts_log_clamp_transpose")
+    return out

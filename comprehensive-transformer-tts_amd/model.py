@@ -1,0 +1,520 @@
+"""Drop-in `CompTransTTS` (reference: model/CompTransTTS.py:12-152) and the `transformer_fs2`
+block plugin (`TextEncoder` / `Decoder`, reference: model/transformers/transformer_fs2.py)
+re-built on the gfx950 kernels of libctts_hip.so.
+
+Contract kept from the reference:
+  * constructor `(preprocess_config, model_config, train_config)` and the positional
+    `forward(speakers, texts, src_lens, max_src_len, mels, mel_lens, max_mel_len, p_targets,
+    e_targets, d_targets, attn_priors, spker_embeds, p_control, e_control, d_control, step)`
+    returning the same 14-tuple (CompTransTTS.py:64-82,137-152);
+  * `state_dict()` key names / shapes so released checkpoints load;
+  * the `block_type` plugin surface: `TextEncoder(config)`, `Decoder(config)`, `.d_model`.
+
+Not a module-tree translation: activations stay [B,T,C]; each reference sub-layer maps to one
+or two fused kernel launches (see ops.py).  Supported here: block_type transformer_fs2,
+learn_alignment False, pitch_type cwt, phoneme-level energy, prosody model "none"
+(BASELINE.json configs 1, 2 and 4); anything else raises NotImplementedError loudly.
+"""
+import json
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import kernels as K
+from . import ops
+from .configs import N_SYMBOLS
+
+F0_BIN = 256
+F0_MEL_MIN = 1127 * math.log(1 + 50.0 / 700)
+F0_MEL_MAX = 1127 * math.log(1 + 1100.0 / 700)
+
+
+# --------------------------------------------------------------------------- parameter holders
+class _Linear(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+
+
+class _Norm(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _BatchNorm(_Norm):
+    def __init__(self, c):
+        super().__init__(c)
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _PosEmbed(nn.Module):
+    """fs2 SinusoidalPositionalEmbedding (blocks.py:49-108): only the `_float_tensor` buffer is
+    state; the table itself is regenerated (and grown on demand) on the module's device."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.register_buffer("_float_tensor", torch.zeros(1))
+        self._table = None
+
+    def table(self, n_pos):
+        dev = self._float_tensor.device
+        if self._table is None or self._table.shape[0] < n_pos or self._table.device != dev:
+            self._table = ops.sinusoid_table(max(n_pos, 1025), self.dim, dev)
+        return self._table
+
+    def lookup(self, src, stride):
+        """src: tokens [B,T] int64 or activations [B,T,C] float32 (channel 0 != 0 marks non-pad)."""
+        pos = K.positions(src, stride)
+        tab = self.table(src.shape[1] + 1)
+        return F.embedding(pos.long(), tab)
+
+
+class _SelfAttn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * c, c))
+        self.out_proj = _Linear(c, c, bias=False)
+
+
+class _FFN(nn.Module):
+    def __init__(self, c, k):
+        super().__init__()
+        self.ffn_1 = _Conv(c, 4 * c, k)
+        self.ffn_2 = _Linear(4 * c, c)
+
+
+class _EncSALayer(nn.Module):
+    def __init__(self, c, k):
+        super().__init__()
+        self.layer_norm1 = _Norm(c)
+        self.self_attn = _SelfAttn(c)
+        self.layer_norm2 = _Norm(c)
+        self.ffn = _FFN(c, k)
+
+
+class _Layer(nn.Module):
+    def __init__(self, c, k):
+        super().__init__()
+        self.op = _EncSALayer(c, k)
+
+
+def _runtime(module):
+    """dropout context shared by the whole model (device-resident seed, see kernels.DropCtx)."""
+    ctx = getattr(module, "_drop_ctx", None)
+    dev = next(module.parameters()).device
+    if ctx is None or ctx.seed.device != dev:
+        ctx = K.DropCtx(dev)
+        module._drop_ctx = ctx
+    return ctx
+
+
+class FFTBlocks(nn.Module):
+    """reference: transformer_fs2.py:16-72 (FFTBlocks), :154-200 (EncSALayer), :203-239 (FFN)."""
+
+    def __init__(self, hidden, n_layers, ksize, dropout, n_heads, use_pos_embed):
+        super().__init__()
+        self.hidden_size, self.num_layers, self.ksize = hidden, n_layers, ksize
+        self.dropout, self.num_heads, self.use_pos_embed = dropout, n_heads, use_pos_embed
+        if use_pos_embed:
+            self.pos_embed_alpha = nn.Parameter(torch.ones(1))
+            self.embed_positions = _PosEmbed(hidden)
+        self.layers = nn.ModuleList([_Layer(hidden, ksize) for _ in range(n_layers)])
+        self.layer_norm = _Norm(hidden)
+        self.drop_ctx = None  # set by the owning model
+
+    def run(self, x, pad_mask):
+        """x [B,T,C] float32, pad_mask [B,T] bool (True = pad) -> [B,T,C]"""
+        B, T, C = x.shape
+        p = self.dropout if self.training else 0.0
+        drop = self.drop_ctx if p > 0 else None
+        nonpad = (~pad_mask).to(torch.float32).reshape(-1).contiguous()
+        lens = (~pad_mask).sum(1).to(torch.int32).contiguous()
+        if self.use_pos_embed:
+            x = x + self.pos_embed_alpha * self.embed_positions.lookup(x, C)
+            x = ops.rowscale_dropout(x, nonpad, p, drop)
+        else:
+            x = ops.rowscale_dropout(x, nonpad, 0.0, None)
+        alpha = self.ksize ** -0.5
+        for layer in self.layers:
+            op = layer.op
+            h = ops.layer_norm(x, op.layer_norm1.weight, op.layer_norm1.bias, 1e-12)
+            qkv = ops.linear(h, op.self_attn.in_proj_weight)
+            a = ops.self_attention(qkv, lens, self.num_heads)
+            x = ops.linear(a, op.self_attn.out_proj.weight, None, residual=x, rowscale=nonpad, p_drop=p, drop=drop)
+            h = ops.layer_norm(x, op.layer_norm2.weight, op.layer_norm2.bias, 1e-12)
+            g = ops.conv1d(h, op.ffn.ffn_1.weight, op.ffn.ffn_1.bias, act=ops.ACT_GELU, alpha=alpha, p_drop=p, drop=drop)
+            x = ops.linear(g, op.ffn.ffn_2.weight, op.ffn.ffn_2.bias, residual=x, rowscale=nonpad, p_drop=p, drop=drop)
+        return ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, 1e-5, rowscale=nonpad)
+
+    def forward(self, x, padding_mask=None):
+        if padding_mask is None:
+            padding_mask = x.abs().sum(-1).eq(0)
+        return self.run(x, padding_mask), padding_mask
+
+
+class TextEncoder(FFTBlocks):
+    """plugin contract: TextEncoder(config).forward(tokens[B,Ts], pad_mask[B,Ts]) -> (enc, word_emb)."""
+
+    def __init__(self, config):
+        c = config["transformer_fs2"]
+        super().__init__(c["encoder_hidden"], c["encoder_layer"], c["ffn_kernel_size"], c["encoder_dropout"],
+                         c["encoder_head"], use_pos_embed=False)
+        self.embed_tokens = nn.Embedding(N_SYMBOLS + 1, c["encoder_hidden"], padding_idx=0)
+        self.embed_positions = _PosEmbed(c["encoder_hidden"])
+        self.embed_scale = math.sqrt(c["encoder_hidden"])
+        self.d_model = c["encoder_hidden"]
+
+    def forward(self, txt_tokens, encoder_padding_mask):
+        emb = self.embed_scale * self.embed_tokens(txt_tokens)
+        x = emb + self.embed_positions.lookup(txt_tokens.contiguous(), 1)
+        p = self.dropout if self.training else 0.0
+        x = ops.rowscale_dropout(x, None, p, self.drop_ctx if p > 0 else None)
+        return self.run(x, encoder_padding_mask), emb
+
+
+class Decoder(FFTBlocks):
+    """plugin contract: Decoder(config).forward(x[B,Tm,H], pad_mask[B,Tm]) -> (dec, mask)."""
+
+    def __init__(self, config):
+        c = config["transformer_fs2"]
+        super().__init__(c["decoder_hidden"], c["decoder_layer"], c["ffn_kernel_size"], c["decoder_dropout"],
+                         c["decoder_head"], use_pos_embed=True)
+        self.d_model = c["decoder_hidden"]
+
+
+# --------------------------------------------------------------------------- variance adaptor
+class _PredictorConvs(nn.Module):
+    """ModuleList of {1: Conv1d, 3: LayerNorm} so that keys read conv.{i}.1.weight / conv.{i}.3.weight."""
+
+    def __init__(self, idim, n_layers, n_chans, ksize):
+        super().__init__()
+        self.conv = nn.ModuleList([
+            nn.ModuleDict({"1": _Conv(idim if i == 0 else n_chans, n_chans, ksize), "3": _Norm(n_chans)})
+            for i in range(n_layers)])
+
+    def run_convs(self, x, p, drop, nonpad):
+        for blk in self.conv:
+            x = ops.conv1d(x, blk["1"].weight, blk["1"].bias, act=ops.ACT_RELU)
+            x = ops.layer_norm(x, blk["3"].weight, blk["3"].bias, 1e-12, rowscale=nonpad, p_drop=p, drop=drop)
+        return x
+
+
+class DurationPredictor(_PredictorConvs):
+    """reference: modules.py:1252-1310"""
+
+    def __init__(self, idim, n_layers, n_chans, ksize, dropout):
+        super().__init__(idim, n_layers, n_chans, ksize)
+        self.linear = _Linear(n_chans, 1)
+        self.dropout = dropout
+        self.drop_ctx = None
+
+    def forward(self, x, src_pad):
+        p = self.dropout if self.training else 0.0
+        nonpad = (~src_pad).to(torch.float32).reshape(-1).contiguous()
+        h = self.run_convs(x, p, self.drop_ctx if p > 0 else None, nonpad)
+        return ops.linear(h, self.linear.weight, self.linear.bias, rowscale=nonpad).squeeze(-1)
+
+
+class PitchPredictor(_PredictorConvs):
+    """reference: modules.py:1313-1356 (also EnergyPredictor, :1359)"""
+
+    def __init__(self, idim, n_layers, n_chans, odim, ksize, dropout):
+        super().__init__(idim, n_layers, n_chans, ksize)
+        self.linear = _Linear(n_chans, odim)
+        self.embed_positions = _PosEmbed(idim)
+        self.pos_embed_alpha = nn.Parameter(torch.ones(1))
+        self.dropout = dropout
+        self.drop_ctx = None
+
+    def forward(self, x, squeeze=False):
+        p = self.dropout if self.training else 0.0
+        x = x.contiguous()
+        x = x + self.pos_embed_alpha * self.embed_positions.lookup(x, x.shape[-1])
+        h = self.run_convs(x, p, self.drop_ctx if p > 0 else None, None)
+        out = ops.linear(h, self.linear.weight, self.linear.bias)
+        return out.squeeze(-1) if squeeze else out
+
+
+class _CwtPredictor(nn.Module):
+    """nn.Sequential(Linear, PitchPredictor) of modules.py:765-772 with keys '0' / '1'."""
+
+    def __init__(self, hidden, h, filt, layers, odim, ksize, dropout):
+        super().__init__()
+        self.add_module("0", _Linear(hidden, h))
+        self.add_module("1", PitchPredictor(h, layers, filt, odim, ksize, dropout))
+
+    def forward(self, x):
+        lin, pp = getattr(self, "0"), getattr(self, "1")
+        return pp(ops.linear(x, lin.weight, lin.bias))
+
+
+class _StatsMLP(nn.Module):
+    """nn.Sequential(Linear, ReLU, Linear, ReLU, Linear) of modules.py:773-776 (keys 0, 2, 4)."""
+
+    def __init__(self, hidden, h):
+        super().__init__()
+        self.add_module("0", _Linear(hidden, h))
+        self.add_module("2", _Linear(h, h))
+        self.add_module("4", _Linear(h, 2))
+
+    def forward(self, x):
+        a, b, c = getattr(self, "0"), getattr(self, "2"), getattr(self, "4")
+        x = ops.linear(x, a.weight, a.bias, act=ops.ACT_RELU)
+        x = ops.linear(x, b.weight, b.bias, act=ops.ACT_RELU)
+        return ops.linear(x, c.weight, c.bias)
+
+
+def cwt2f0_norm(cwt_spec, mean, std, width, eps):
+    """utils/pitch_tools.py:258-294 with pitch_norm == 'log' (tiny [B,Tm] elementwise math)."""
+    b = (torch.arange(cwt_spec.shape[-1], dtype=torch.float32, device=cwt_spec.device) + 3.5) ** (-2.5)
+    rec = (cwt_spec * b).sum(-1)
+    rec = (rec - rec.mean(-1, keepdim=True)) / rec.std(-1, keepdim=True)
+    f0 = (rec * std[:, None] + mean[:, None]).exp()
+    if width > f0.shape[1]:
+        f0 = torch.cat([f0] + [f0[:, -1:]] * (width - f0.shape[1]), 1)
+    return torch.log2(f0 + eps)
+
+
+def f0_to_coarse(f0):
+    """utils/pitch_tools.py:27-36"""
+    f0_mel = 1127 * (1 + f0 / 700).log()
+    scaled = (f0_mel - F0_MEL_MIN) * (F0_BIN - 2) / (F0_MEL_MAX - F0_MEL_MIN) + 1
+    f0_mel = torch.where(f0_mel > 0, scaled, f0_mel)
+    f0_mel = f0_mel.clamp(min=1.0, max=float(F0_BIN - 1))
+    return (f0_mel + 0.5).long()
+
+
+class VarianceAdaptor(nn.Module):
+    """reference: modules.py:726-1114 (supervised and inference branches)."""
+
+    def __init__(self, preprocess_config, model_config, train_config, d_model):
+        super().__init__()
+        if model_config["duration_modeling"]["learn_alignment"]:
+            raise NotImplementedError("learn_alignment=True (AlignmentEncoder/MAS, SURVEY section 8 row a16) is a next-round row")
+        if model_config["prosody_modeling"]["model_type"] != "none":
+            raise NotImplementedError("prosody_modeling other than 'none' is not on the round-1 hot path")
+        pitch = preprocess_config["preprocessing"]["pitch"]
+        if pitch["pitch_type"] != "cwt" or pitch["pitch_norm"] != "log" or not pitch["use_uv"]:
+            raise NotImplementedError("only pitch_type=cwt / pitch_norm=log / use_uv=True (the shipped configs)")
+        if preprocess_config["preprocessing"]["energy"]["feature"] != "phoneme_level":
+            raise NotImplementedError("only phoneme_level energy (the shipped configs)")
+        self.pitch_cfg = pitch
+        vp = model_config["variance_predictor"]
+        self.predictor_grad = vp["predictor_grad"]
+        self.cwt_std_scale = vp["cwt_std_scale"]
+        hidden = model_config["transformer"]["encoder_hidden"]  # sic: modules.py:739 reads the 'transformer' section
+        filt, drop = vp["filter_size"], vp["dropout"]
+        with open(os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")) as f:
+            emin, emax = json.load(f)["energy_sup_phone"][:2]
+        n_ebins = model_config["variance_embedding"]["energy_n_bins"]
+        if model_config["variance_embedding"]["energy_quantization"] == "log":
+            bins = torch.exp(torch.linspace(math.log(emin), math.log(emax), n_ebins - 1))
+        else:
+            bins = torch.linspace(emin, emax, n_ebins - 1)
+        self.energy_bins = nn.Parameter(bins, requires_grad=False)
+        self.duration_predictor = DurationPredictor(hidden, vp["dur_predictor_layers"], filt, vp["dur_predictor_kernel"], drop)
+        self.cwt_predictor = _CwtPredictor(hidden, vp["cwt_hidden_size"], filt, vp["predictor_layers"], 11,
+                                           vp["predictor_kernel"], drop)
+        self.cwt_stats_layers = _StatsMLP(hidden, vp["cwt_hidden_size"])
+        self.pitch_embed = nn.Embedding(model_config["variance_embedding"]["pitch_n_bins"], hidden, padding_idx=0)
+        self.energy_predictor = PitchPredictor(hidden, vp["predictor_layers"], filt, 1, vp["predictor_kernel"], drop)
+        self.energy_embedding = nn.Embedding(n_ebins, hidden, padding_idx=0)
+
+    def forward(self, speaker_embedding, text, text_embedding, src_len, src_mask, mel, mel_len, mel_mask=None,
+                max_len=None, pitch_target=None, energy_target=None, duration_target=None, attn_prior=None,
+                p_control=1.0, e_control=1.0, d_control=1.0, step=None):
+        if attn_prior is not None:
+            raise NotImplementedError("unsupervised duration modeling (attn_prior) is a next-round row")
+        x = text
+        if speaker_embedding is not None:
+            x = x + speaker_embedding.unsqueeze(1)
+        log_d = self.duration_predictor(ops.grad_scale(x, self.predictor_grad), src_mask)
+        x_org = x
+        if duration_target is not None:
+            x, mel_len, _ = ops.length_regulate(x_org, duration_target, max_len)
+            d_rounded = duration_target
+            mel2ph = None
+        else:
+            d_rounded = torch.clamp(torch.round(torch.exp(log_d.detach()) - 1) * d_control, min=0)
+            x, mel_len, _ = ops.length_regulate(x_org, d_rounded, max_len)
+            ids = torch.arange(x.shape[1], device=x.device)[None, :]
+            mel_mask = ids >= mel_len[:, None]
+            mel2ph = ops.dur_to_mel2ph(d_rounded, src_mask)
+        # ---- pitch (cwt)   modules.py:890-948
+        cwt = self.cwt_predictor(ops.grad_scale(x, self.predictor_grad)) * p_control
+        stats = self.cwt_stats_layers(x_org[:, 0, :].contiguous())
+        f0_mean, f0_std = stats[:, 0], stats[:, 1]
+        eps = self.pitch_cfg["pitch_norm_eps"]
+        with torch.no_grad():
+            if pitch_target is not None:
+                mel2ph = pitch_target["mel2ph"]
+                pitch_target["f0"] = cwt2f0_norm(pitch_target["cwt_spec"], pitch_target["f0_mean"], pitch_target["f0_std"],
+                                                 mel2ph.shape[1], eps)
+                pitch_target.update({"f0_cwt": pitch_target["f0"]})
+                f0, uv = pitch_target["f0"], pitch_target["uv"]
+            else:
+                f0 = cwt2f0_norm(cwt[:, :, :10], f0_mean, f0_std * self.cwt_std_scale, mel2ph.shape[1], eps)
+                uv = cwt[:, :, -1] > 0
+            f0_denorm = 2 ** f0
+            f0_denorm = torch.where(uv > 0, torch.zeros_like(f0_denorm), f0_denorm)
+            pitch_ids = f0_to_coarse(f0_denorm)
+        pitch_embedding = self.pitch_embed(pitch_ids)
+        pitch_prediction = {"pitch_pred": None, "f0_denorm": f0_denorm, "cwt": cwt, "f0_mean": f0_mean, "f0_std": f0_std}
+        # ---- energy (phoneme level)   modules.py:950-960,1095-1099 (no gradient scaling: :951 is a no-op)
+        energy_prediction = self.energy_predictor(x_org, squeeze=True)
+        if energy_target is not None:
+            e_ids = torch.bucketize(energy_target, self.energy_bins)
+        else:
+            energy_prediction = energy_prediction * e_control
+            e_ids = torch.bucketize(energy_prediction.detach(), self.energy_bins)
+        energy_embedding = self.energy_embedding(e_ids)
+        e_frames, _, _ = ops.length_regulate(energy_embedding, d_rounded, max_len)
+        x = x + pitch_embedding + e_frames
+        return (x, pitch_target, pitch_prediction, energy_target, energy_prediction, log_d, d_rounded, mel_len, mel_mask,
+                (None, None, None, None), None)
+
+
+# --------------------------------------------------------------------------- postnet
+class _ConvNorm(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = _Conv(cin, cout, k)
+
+
+class PostNet(nn.Module):
+    """reference: modules.py:78-148.  5 x (Conv1d k5 -> BatchNorm1d -> tanh (not last) -> dropout 0.5)."""
+
+    def __init__(self, n_mel=80, dim=512, k=5, n=5):
+        super().__init__()
+        chans = [n_mel] + [dim] * (n - 1) + [n_mel]
+        self.convolutions = nn.ModuleList()
+        for i in range(n):
+            seq = nn.Module()
+            seq.add_module("0", _ConvNorm(chans[i], chans[i + 1], k))
+            seq.add_module("1", _BatchNorm(chans[i + 1]))
+            self.convolutions.append(seq)
+        self.dropout = 0.5   # hard-coded in the reference (modules.py:144-145)
+        self.drop_ctx = None
+
+    def forward(self, x):
+        n = len(self.convolutions)
+        p = self.dropout if self.training else 0.0
+        drop = self.drop_ctx if p > 0 else None
+        for i, seq in enumerate(self.convolutions):
+            cv, bn = getattr(seq, "0").conv, getattr(seq, "1")
+            x = ops.conv1d(x, cv.weight, cv.bias)
+            x = ops.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                   self.training, act=ops.ACT_TANH if i < n - 1 else ops.ACT_NONE, p_drop=p, drop=drop)
+        return x
+
+
+# --------------------------------------------------------------------------- facade
+class CompTransTTS(nn.Module):
+    """Drop-in for model/CompTransTTS.py:12-152."""
+
+    def __init__(self, preprocess_config, model_config, train_config):
+        super().__init__()
+        self.model_config = model_config
+        bt = model_config["block_type"]
+        if bt == "transformer_fs2":
+            enc_cls, dec_cls = TextEncoder, Decoder
+        elif bt in ("transformer", "lstransformer", "fastformer", "conformer", "reformer"):
+            raise NotImplementedError(f"block_type '{bt}' has no MI355X-native plugin yet (SURVEY.md section 8: conformer is "
+                                      "the next plugin; the others are out of scope)")
+        else:
+            raise NotImplementedError
+        self.encoder = enc_cls(model_config)
+        self.variance_adaptor = VarianceAdaptor(preprocess_config, model_config, train_config, self.encoder.d_model)
+        self.decoder = dec_cls(model_config)
+        self.mel_linear = _Linear(self.decoder.d_model, preprocess_config["preprocessing"]["mel"]["n_mel_channels"])
+        self.postnet = PostNet()
+        self.speaker_emb = None
+        if model_config["multi_speaker"]:
+            self.embedder_type = preprocess_config["preprocessing"]["speaker_embedder"]
+            if self.embedder_type == "none":
+                with open(os.path.join(preprocess_config["path"]["preprocessed_path"], "speakers.json")) as f:
+                    n_speaker = len(json.load(f))
+                self.speaker_emb = nn.Embedding(n_speaker, self.encoder.d_model)
+            else:
+                self.speaker_emb = _Linear(model_config["external_speaker_dim"], self.encoder.d_model)
+        self.reset_parameters()
+
+    # reference initialisers restated (blocks.py:10-23 Embedding/Linear, transformer_fs2.py:328-344 attention,
+    # blocks.py:286-288 ConvNorm; torch defaults for nn.Conv1d / nn.Linear elsewhere)
+    def reset_parameters(self):
+        params = dict(self.named_parameters())
+        for name, p in params.items():
+            if name.endswith("pos_embed_alpha") or name.endswith("energy_bins"):
+                continue
+            if name.endswith("in_proj_weight") or name.endswith("out_proj.weight") or name.endswith("ffn_2.weight"):
+                nn.init.xavier_uniform_(p)
+            elif name.endswith("ffn_2.bias"):
+                nn.init.zeros_(p)
+            elif name.startswith("postnet.") and name.endswith("conv.weight"):
+                last = name.startswith(f"postnet.convolutions.{len(self.postnet.convolutions) - 1}.")
+                nn.init.xavier_uniform_(p, gain=nn.init.calculate_gain("linear" if last else "tanh"))
+            elif name in ("encoder.embed_tokens.weight", "variance_adaptor.pitch_embed.weight",
+                          "variance_adaptor.energy_embedding.weight"):
+                nn.init.normal_(p, mean=0, std=p.shape[1] ** -0.5)
+                with torch.no_grad():
+                    p[0].zero_()
+            elif name == "speaker_emb.weight" and p.dim() == 2 and isinstance(self.speaker_emb, nn.Embedding):
+                nn.init.normal_(p)
+            elif p.dim() >= 2:
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+            elif name.endswith(".bias") and (name[:-4] + "weight") in params and params[name[:-4] + "weight"].dim() >= 2:
+                fan_in = params[name[:-4] + "weight"][0].numel()
+                bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+                nn.init.uniform_(p, -bound, bound)
+            # 1-D norm weights / biases keep their ones / zeros
+
+    def _wire(self):
+        ctx = _runtime(self)
+        for m in self.modules():
+            if hasattr(m, "drop_ctx"):
+                m.drop_ctx = ctx
+        return ctx
+
+    def forward(self, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None, max_mel_len=None,
+                p_targets=None, e_targets=None, d_targets=None, attn_priors=None, spker_embeds=None,
+                p_control=1.0, e_control=1.0, d_control=1.0, step=None):
+        ctx = self._wire()
+        ctx.begin_step()
+        if self.training:
+            ctx.advance()
+        dev = texts.device
+        src_masks = torch.arange(max_src_len, device=dev)[None, :] >= src_lens[:, None]
+        mel_masks = (torch.arange(max_mel_len, device=dev)[None, :] >= mel_lens[:, None]) if mel_lens is not None else None
+        enc, text_embeds = self.encoder(texts, src_masks)
+        speaker_embeds = None
+        if self.speaker_emb is not None:
+            if self.embedder_type == "none":
+                speaker_embeds = self.speaker_emb(speakers)
+            else:
+                assert spker_embeds is not None, "Speaker embedding should not be None"
+                speaker_embeds = ops.linear(spker_embeds, self.speaker_emb.weight, self.speaker_emb.bias)
+        (output, p_targets, p_predictions, e_targets, e_predictions, log_d_predictions, d_rounded, mel_lens, mel_masks,
+         attn_outs, prosody_info) = self.variance_adaptor(
+            speaker_embeds, enc, text_embeds, src_lens, src_masks, mels, mel_lens, mel_masks, max_mel_len, p_targets,
+            e_targets, d_targets, attn_priors, p_control, e_control, d_control, step)
+        output, mel_masks = self.decoder(output, mel_masks)
+        output = ops.linear(output, self.mel_linear.weight, self.mel_linear.bias)
+        postnet_output = self.postnet(output) + output
+        return (output, postnet_output, p_predictions, e_predictions, log_d_predictions, d_rounded, src_masks, mel_masks,
+                src_lens, mel_lens, attn_outs, prosody_info, p_targets, e_targets)

@@ -1,0 +1,333 @@
+"""Autograd operators of the hot path.  Every forward AND backward runs hand-written gfx950
+kernels from libctts_hip.so through `kernels.py`; torch is used for device memory, the
+autograd graph and the stream only.
+
+Layout is [B, T, C] (C contiguous) everywhere: Conv1d over time is an implicit GEMM whose A
+operand is the activation itself with overlapping rows (row stride = C_in, K = k*C_in), so the
+reference's transpose/contiguous copies (10.6 % of its CPU time)
+disappear and bias / scale / activation / dropout / residual / pad-mask fuse into the GEMM epilogue.
+"""
+import math
+
+import torch
+
+from . import kernels as K
+from .kernels import ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH  # noqa: F401
+
+
+def _split_k_for(Mo, No, Kred):
+    """split-K factor for weight-gradient GEMMs (small output, long reduction)."""
+    t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
+    want = max(1, -(-512 // t128))
+    return int(max(1, min(want, max(1, Kred // 512))))
+
+
+class _LinearConv(torch.autograd.Function):
+    """y = rowscale * (residual + drop(act(alpha * (x (*) w + b))))      (*) = matmul or Conv1d('same')
+
+    Replaces nn.Linear / nn.Conv1d call sites of transformer_fs2.py:220-239,385-394,
+    modules.py:140-148,1299-1356 and CompTransTTS.py:133 (fwd, dgrad, wgrad all on MFMA)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, rowscale, act, alpha, p_drop, seed, drop_offset, ksize):
+        x = x.contiguous()
+        Cin = x.shape[-1]
+        M = x.numel() // Cin
+        N = w.shape[0]
+        out = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+        Z = torch.empty_like(out) if act != ACT_NONE else None
+        if ksize:
+            T = x.shape[-2]
+            wf = torch.empty(N, ksize * Cin, dtype=torch.float32, device=x.device)
+            K.conv_weight_repack(w.contiguous(), wf, N, Cin, ksize, 0)
+            conv = (T, (ksize - 1) // 2, Cin)
+            Kdim = ksize * Cin
+        else:
+            wf, conv, Kdim = w.contiguous(), None, Cin
+        if residual is not None:
+            residual = residual.contiguous()
+        K.gemm(x, wf, out, M, N, Kdim, Cin, Kdim, N, True, True, conv=conv, alpha=alpha, bias=b, Z=Z, ldz=N, act=act,
+               p_drop=p_drop, seed=seed, drop_offset=drop_offset, R=residual, ldr=N, rowscale=rowscale)
+        ctx.save_for_backward(x, w, Z, rowscale, seed)
+        ctx.cfg = (act, alpha, p_drop, drop_offset, ksize, b is not None, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dY):
+        x, w, Z, rowscale, seed = ctx.saved_tensors
+        act, alpha, p_drop, drop_offset, ksize, has_bias, has_res = ctx.cfg
+        dY = dY.contiguous()
+        Cin = x.shape[-1]
+        M = x.numel() // Cin
+        N = w.shape[0]
+        gm = K.rowscale_dropout(dY, rowscale) if rowscale is not None else dY
+        d_res = gm if has_res else None
+        if act == ACT_NONE:
+            dZ = K.rowscale_dropout(dY, rowscale, p_drop, seed, drop_offset) if p_drop > 0 else gm
+        else:
+            dZ = K.act_dropout_bwd(gm, Z, act, p_drop, seed, drop_offset)
+        dX = dW = dB = None
+        if has_bias and ctx.needs_input_grad[2]:
+            dB = K.colsum(dZ.view(M, N))
+            if alpha != 1.0:
+                dB = dB * alpha
+        if ksize:
+            T = x.shape[-2]
+            pad = (ksize - 1) // 2
+            if ctx.needs_input_grad[0]:
+                wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
+                K.conv_weight_repack(w.contiguous(), wd, N, Cin, ksize, 1)
+                dX = torch.empty_like(x)
+                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, conv=(T, pad, N), alpha=alpha)
+            if ctx.needs_input_grad[1]:
+                Kd = ksize * Cin
+                dwf = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
+                K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
+                       split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha)
+                dW = torch.empty_like(w)
+                K.conv_weight_repack(dwf, dW, N, Cin, ksize, 2)
+        else:
+            if ctx.needs_input_grad[0]:
+                dX = torch.empty_like(x)
+                K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha)
+            if ctx.needs_input_grad[1]:
+                dW = torch.zeros_like(w)
+                K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha)
+        return dX, dW, dB, d_res, None, None, None, None, None, None, None
+
+
+def linear(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None):
+    seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
+    return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off, 0)
+
+
+def conv1d(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None):
+    """x [B,T,Cin], w [Cout,Cin,k] (nn.Conv1d layout), 'same' zero padding, stride 1."""
+    seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
+    return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off,
+                             w.shape[2])
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, rowscale, p_drop, seed, drop_offset):
+        x = x.contiguous()
+        y, mean, rstd = K.layernorm_fwd(x, gamma, beta, eps, p_drop, seed, drop_offset, rowscale)
+        ctx.save_for_backward(x, gamma, mean, rstd, rowscale, seed)
+        ctx.cfg = (p_drop, drop_offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd, rowscale, seed = ctx.saved_tensors
+        p_drop, drop_offset = ctx.cfg
+        dx, dg, db = K.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, p_drop, seed, drop_offset, rowscale)
+        return dx, dg, db, None, None, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps, rowscale=None, p_drop=0.0, drop=None):
+    """y = rowscale * drop(LayerNorm(x)) over the last dim."""
+    seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
+    return _LayerNorm.apply(x, gamma, beta, eps, rowscale, p_drop if seed is not None else 0.0, seed, off)
+
+
+class _SelfAttention(torch.autograd.Function):
+    """Multi-head self-attention core on the packed projection qkv [B,T,3C] with a key-padding
+    mask given as valid lengths (F.multi_head_attention_forward semantics,
+    transformer_fs2.py:385-394: q scaled by d_h^-0.5, padded keys get -inf, no biases, no
+    attention dropout).  Query rows >= len are skipped (their output is zero; the caller
+    multiplies by the non-pad mask anyway, transformer_fs2.py:190)."""
+
+    @staticmethod
+    def forward(ctx, qkv, lens, n_heads):
+        qkv = qkv.contiguous()
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        dh = C // n_heads
+        scale = dh ** -0.5
+        S = torch.empty(B, n_heads, T, T, dtype=torch.float32, device=qkv.device)
+        K.gemm(qkv, qkv, S, T, T, dh, C3, C3, T, True, True, a_off=0, b_off=C, nb0=B, nb1=n_heads,
+               sA=(T * C3, dh), sB=(T * C3, dh), sC=(n_heads * T * T, T * T), lens=lens, lim=(1, 1, 0), alpha=scale)
+        K.softmax_fwd(S, lens, B, n_heads, T)
+        out = torch.zeros(B, T, C, dtype=torch.float32, device=qkv.device)
+        K.gemm(S, qkv, out, T, dh, T, T, C3, C, True, False, b_off=2 * C, nb0=B, nb1=n_heads,
+               sA=(n_heads * T * T, T * T), sB=(T * C3, dh), sC=(T * C, dh), lens=lens, lim=(1, 0, 1))
+        ctx.save_for_backward(qkv, S, lens)
+        ctx.n_heads = n_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, P, lens = ctx.saved_tensors
+        H = ctx.n_heads
+        dO = dO.contiguous()
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        dh = C // H
+        scale = dh ** -0.5
+        sP = (H * T * T, T * T)
+        dqkv = torch.zeros_like(qkv)
+        # dV[key,d] = sum_q P[q,key] dO[q,d]
+        K.gemm(P, dO, dqkv, T, dh, T, T, C, C3, False, False, c_off=2 * C, nb0=B, nb1=H, sA=sP, sB=(T * C, dh),
+               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1))
+        # dP[q,key] = sum_d dO[q,d] V[key,d]
+        dP = torch.empty_like(P)
+        K.gemm(dO, qkv, dP, T, T, dh, C, C3, T, True, True, b_off=2 * C, nb0=B, nb1=H, sA=(T * C, dh), sB=(T * C3, dh),
+               sC=sP, lens=lens, lim=(1, 1, 0))
+        K.softmax_bwd(P, dP, lens, B, H, T)  # dP <- dS
+        # dQ[q,d] = scale * sum_key dS[q,key] K[key,d]
+        K.gemm(dP, qkv, dqkv, T, dh, T, T, C3, C3, True, False, b_off=C, c_off=0, nb0=B, nb1=H, sA=sP, sB=(T * C3, dh),
+               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale)
+        # dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
+        K.gemm(dP, qkv, dqkv, T, dh, T, T, C3, C3, False, False, b_off=0, c_off=C, nb0=B, nb1=H, sA=sP, sB=(T * C3, dh),
+               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale)
+        return dqkv, None, None
+
+
+def self_attention(qkv, lens_i32, n_heads):
+    return _SelfAttention.apply(qkv, lens_i32, n_heads)
+
+
+class _LRGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mel2ph, cum):
+        x = x.contiguous()
+        ctx.save_for_backward(cum)
+        ctx.Ts = x.shape[1]
+        return K.lr_gather_fwd(x, mel2ph)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cum,) = ctx.saved_tensors
+        return K.lr_gather_bwd(dy.contiguous(), cum, ctx.Ts), None, None
+
+
+def length_regulate(x, dur, max_len=None):
+    """LengthRegulator (modules.py:1216-1249): expand row i of x `int(dur[i])` times, pad/crop to
+    max_len.  Returns (out [B,Tm,C], mel_len int64 [B] (un-cropped), mel2ph int32 [B,Tm]).
+    One prefix-scan kernel replaces the reference's B*Ts `.item()` host syncs."""
+    if max_len is None:
+        _, mel_len, _ = K.lr_index(dur, 0, want_mel2ph=False)
+        max_len = max(int(mel_len.max().item()), 1)   # inference only: output width is data dependent
+    mel2ph, mel_len, cum = K.lr_index(dur, int(max_len))
+    return _LRGather.apply(x, mel2ph, cum), mel_len, mel2ph
+
+
+def dur_to_mel2ph(dur, dur_padding=None):
+    """utils/tools.py:598-628 -> int64 [B, max total]."""
+    _, total, _ = K.lr_index(dur, 0, pad=dur_padding, round_mode=1, want_mel2ph=False)
+    Tm = max(int(total.max().item()), 0)
+    mel2ph, _, _ = K.lr_index(dur, Tm, pad=dur_padding, round_mode=1)
+    return mel2ph.long()
+
+
+class _BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, gamma, beta, mean, rstd, act, p_drop, seed, drop_offset, batch_stats):
+        y = K.bn_apply(x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset)
+        ctx.save_for_backward(x2d, gamma, beta, mean, rstd, seed)
+        ctx.cfg = (act, p_drop, drop_offset, batch_stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, gamma, beta, mean, rstd, seed = ctx.saved_tensors
+        act, p_drop, drop_offset, batch_stats = ctx.cfg
+        dx, dg, db = K.bn_bwd(dy.contiguous(), x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats)
+        return dx, dg, db, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, act=ACT_NONE, p_drop=0.0,
+                   drop=None, eps=1e-5, momentum=0.1):
+    """drop(act(BatchNorm1d(x))) on channel-last x [B,T,C]; statistics over all B*T rows,
+    pads included, exactly as nn.BatchNorm1d sees them in modules.py:140-148."""
+    C = x.shape[-1]
+    x2d = x.contiguous().view(-1, C)
+    rows = x2d.shape[0]
+    if training:
+        with torch.no_grad():
+            sums = K.colstats(x2d)
+            mean64 = sums[:C] / rows
+            var64 = (sums[C:] / rows - mean64 * mean64).clamp_(min=0)
+            mean, var = mean64.float(), var64.float()
+            rstd = torch.rsqrt(var + eps)
+            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1 - momentum).add_(var * (rows / max(rows - 1, 1)), alpha=momentum)
+            num_batches_tracked.add_(1)
+    else:
+        mean = running_mean
+        rstd = torch.rsqrt(running_var + eps)
+    seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
+    y = _BatchNormAct.apply(x2d, gamma, beta, mean, rstd, act, p_drop if seed is not None else 0.0, seed, off, bool(training))
+    return y.view(x.shape)
+
+
+def sinusoid_table(n_pos, dim, device):
+    """fs2 SinusoidalPositionalEmbedding.get_embedding (blocks.py:66-83): [sin|cos], row 0 = 0."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    freq = torch.exp(torch.arange(half, dtype=torch.float) * -e)
+    ang = torch.arange(n_pos, dtype=torch.float)[:, None] * freq[None, :]
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    tab[0] = 0
+    return tab.to(device)
+
+
+def mel_spectrogram(y, dft_basis, mel_basis_padded, n_fft, hop, n_mel, nbins, clip=1e-5):
+    """TacotronSTFT.mel_spectrogram (audio/stft.py:166-185) -> (mel [B,n_mel,F], energy [B,F]).
+    Frames are an overlapping-row view of the reflect-padded waveform (row stride = hop), so the
+    windowed DFT is one MFMA GEMM [B*F,1024] x [1026,1024]^T with no framing copy."""
+    B, N = y.shape
+    pad = n_fft // 2
+    F = 1 + N // hop
+    ypad = K.reflect_pad(y.contiguous(), pad)
+    W = ypad.shape[1]
+    nre = dft_basis.shape[0]
+    reim = torch.empty(B * F, nre, dtype=torch.float32, device=y.device)
+    K.gemm(ypad, dft_basis, reim, F, nre, n_fft, hop, n_fft, nre, True, True, nb0=B, nb1=1, sA=(W, 0), sB=(0, 0),
+           sC=(F * nre, 0))
+    ld_mag = mel_basis_padded.shape[1]
+    mag, energy = K.stft_magnitude(reim, B * F, nbins, ld_mag)
+    mel_fm = torch.empty(B * F, n_mel, dtype=torch.float32, device=y.device)
+    K.gemm(mag, mel_basis_padded, mel_fm, B * F, n_mel, ld_mag, ld_mag, ld_mag, n_mel, True, True)
+    mel = K.log_clamp_transpose(mel_fm, B, F, n_mel, clip)
+    return mel, energy.view(B, F), mag
+
+
+class _RowscaleDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rowscale, p_drop, seed, drop_offset):
+        ctx.save_for_backward(rowscale, seed)
+        ctx.cfg = (p_drop, drop_offset)
+        return K.rowscale_dropout(x.contiguous(), rowscale, p_drop, seed, drop_offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rowscale, seed = ctx.saved_tensors
+        p_drop, drop_offset = ctx.cfg
+        return K.rowscale_dropout(dy.contiguous(), rowscale, p_drop, seed, drop_offset), None, None, None, None
+
+
+def rowscale_dropout(x, rowscale=None, p_drop=0.0, drop=None):
+    """y = rowscale[row] * dropout(x)  (F.dropout followed by the non-pad mask multiply)."""
+    seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
+    if rowscale is None and seed is None:
+        return x
+    return _RowscaleDropout.apply(x, rowscale, p_drop if seed is not None else 0.0, seed, off)
+
+
+class _GradScale(torch.autograd.Function):
+    """x.detach() + g * (x - x.detach())  (modules.py:1025-1027): identity forward, gradient * g."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        ctx.g = g
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy * ctx.g, None
+
+
+def grad_scale(x, g):
+    return _GradScale.apply(x, g)

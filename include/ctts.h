@@ -1,0 +1,141 @@
+/* ctts.h - C ABI of libctts_hip.so: the MI355X (gfx950) kernels behind the CompTransTTS hot path.
+ *
+ * Conventions:
+ *   - every pointer is a raw DEVICE pointer (torch `tensor.data_ptr()`), shapes/strides are
+ *     explicit, `stream` is a hipStream_t passed as void* (PyTorch's current stream);
+ *   - functions return 0 on success, <0 on error (ctts_last_error() gives the text);
+ *     no C++ exception crosses the ABI; the library never allocates caller-visible memory,
+ *     all calls are asynchronous and stream-ordered (graph-capturable);
+ *   - layouts are channel-last / row-major: activations are [B, T, C] (C contiguous).
+ *
+ * Each entry point names the reference code it replaces (paths relative to the reference
+ * repository keonlee9420/Comprehensive-Transformer-TTS).  The reference has no FFI of its
+ * own (it is pure Python on torch ops); INTEGRATION.md shows the ctypes binding.
+ */
+#ifndef CTTS_H
+#define CTTS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ctts_last_error(void);
+int ctts_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * General fp32 MFMA GEMM with implicit-im2col ("conv") operand views and fused epilogue.
+ *   C[m,n] = epi( alpha * (sum_k opA[m,k] * opB[k,n] + bias[n]) )
+ *   epi(v) = rowscale[m] * (R[m,n] + drop(act(v)))   (Z, if given, receives v)
+ * opA[m,k] = A[m*lda + k] (a_kc=1) or A[k*lda + m] (a_kc=0); opB[k,n] = B[n*ldb + k] (b_kc=1)
+ * or B[k*ldb + n] (b_kc=0).  Replaces torch.nn.functional.linear / conv1d / bmm call sites:
+ *   - Conv1d(k=9) FFN            model/transformers/transformer_fs2.py:220-239
+ *   - in/out projections, QK^T, PV  (F.multi_head_attention_forward)  transformer_fs2.py:385-394
+ *   - predictor Conv1d(k=3,5)    model/modules.py:1299-1356
+ *   - mel_linear                 model/CompTransTTS.py:133
+ *   - PostNet Conv1d(k=5)        model/modules.py:140-148
+ *   - STFT-as-conv1d + mel matmul  audio/stft.py:72-80,177
+ * Conv view: rows of the operand are (b,t) pairs with t = row % conv_T; element (row, kk)
+ * reads X[(row - conv_pad)*ld + kk] and is zero unless 0 <= t - conv_pad + kk/conv_cin < conv_T.
+ */
+typedef struct ctts_gemm_desc {
+  const float* A; const float* B; float* C;
+  int32_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int32_t a_kc, b_kc;
+  int32_t nb0, nb1;                       /* batch = nb0*nb1 (blockIdx.z = z0*nb1+z1); 1,1 = none   */
+  int64_t sA0, sA1, sB0, sB1, sC0, sC1;   /* element strides per batch level                          */
+  const int32_t* lens;                    /* [nb0] valid length per z0, or NULL                       */
+  int32_t lim_m, lim_n, lim_k;            /* clamp that dim to lens[z0]                               */
+  int32_t conv_T, conv_pad, conv_cin, conv_on_b; /* conv_T=0: plain; conv_on_b=1 applies to B (b_kc=0) */
+  int32_t split_k;                        /* >1: atomicAdd partials into pre-zeroed C, no epilogue    */
+  float alpha;
+  const float* bias;                      /* [N] or NULL                                              */
+  float* Z; int64_t ldz;                  /* optional store of the pre-activation                     */
+  int32_t act;                            /* 0 none, 1 relu, 2 gelu(erf), 3 tanh                      */
+  float p_drop; const uint64_t* seed; uint32_t drop_offset;   /* inverted dropout after act           */
+  const float* R; int64_t ldr;            /* residual added after dropout                             */
+  const float* rowscale;                  /* [M] multiplied last (non-pad mask), or NULL              */
+} ctts_gemm_desc;
+
+int ctts_gemm(const ctts_gemm_desc* d, void* stream);
+
+/* Conv1d weight repack: w[Cout][Cin][K] (reference nn.Conv1d layout) ->
+ *   mode 0: wf[Cout][K][Cin]                 (forward implicit-GEMM B operand)
+ *   mode 1: wd[Cin][K][Cout], taps flipped   (data-gradient implicit-GEMM B operand)
+ *   mode 2: inverse of mode 0 (wgrad result [Cout][K][Cin] -> [Cout][Cin][K])              */
+int ctts_conv_weight_repack(const float* src, float* dst, int cout, int cin, int k, int mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LengthRegulator / dur_to_mel2ph (model/modules.py:1216-1249, utils/tools.py:577-628).
+ * ctts_lr_index: per batch row, prefix-sum of max(trunc(dur),0) by wavefront scan, then
+ *   mel2ph[b,t] = 1 + #{i : cum[i] <= t} for t < min(total, Tm) else 0;  mel_len[b] = total
+ *   (un-cropped).  dur_is_float selects float32 vs int64 input; round_mode 0 = trunc (LR),
+ *   1 = round-half-even (dur_to_mel2ph); pad[b,i] != 0 zeroes that duration (dur_padding).
+ * ctts_lr_gather_fwd: out[b,t,:] = x[b, mel2ph[b,t]-1, :] or 0.      (expand + pad/crop)
+ * ctts_lr_gather_bwd: dx[b,i,:] = sum over the contiguous frame run of phoneme i of dy.   */
+int ctts_lr_index(const void* dur, int dur_is_float, int round_mode, const uint8_t* pad, int B, int Ts, int Tm,
+                  int32_t* mel2ph, int64_t* mel_len, int32_t* cum, void* stream);
+int ctts_lr_gather_fwd(const float* x, const int32_t* mel2ph, float* out, int B, int Ts, int Tm, int C, void* stream);
+int ctts_lr_gather_bwd(const float* dy, const int32_t* cum, float* dx, int B, int Ts, int Tm, int C, void* stream);
+
+/* make_positions (utils/tools.py:640-652): pos = cumsum(x != 0) * (x != 0) along T.
+ * src is float32 (stride `stride` elements between time steps, e.g. channel 0 of [B,T,C]) or int64 tokens. */
+int ctts_positions(const void* src, int src_is_float, int64_t stride, int B, int T, int32_t* pos, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (blocks.py:137-156 eps 1e-12; nn.LayerNorm eps 1e-5), fused with
+ * inverted dropout and the non-pad row mask:  y = rowscale * drop(LN(x)).                    */
+int ctts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       int rows, int C, float eps, float p_drop, const uint64_t* seed, uint32_t drop_offset,
+                       const float* rowscale, void* stream);
+int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       float* dx, float* dgamma, float* dbeta, int rows, int C, float p_drop, const uint64_t* seed,
+                       uint32_t drop_offset, const float* rowscale, void* stream);
+
+/* BatchNorm1d over [rows, C] (channel-last view of nn.BatchNorm1d, modules.py:105,140-148),
+ * fused with tanh (act=3) / none and inverted dropout.
+ * stats: sums[0..C) = sum x, sums[C..2C) = sum x^2 (double, pre-zeroed by the call).
+ * apply: y = drop(act((x-mean)*rstd*gamma+beta)).
+ * bwd_reduce: sums[0..C) = sum dt, sums[C..2C) = sum dt*xhat with dt = dy*dropmask*act'(u).
+ * bwd_apply: dx = gamma*rstd*(dt - sum_dt/rows - xhat*sum_dtxhat/rows); dgamma/dbeta from sums. */
+int ctts_colstats(const float* x, double* sums, int rows, int C, void* stream);
+int ctts_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  float* y, int rows, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset,
+                  void* stream);
+int ctts_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, double* sums, int rows, int C, int act, float p_drop, const uint64_t* seed,
+                       uint32_t drop_offset, void* stream);
+int ctts_bn_bwd_apply(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, const double* sums, float* dx, float* dgamma, float* dbeta, int rows, int C,
+                      int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, int batch_stats, void* stream);
+
+/* Masked row softmax for attention scores S[nbatch, T, T] (in place), keys >= lens[z/nb1] get 0
+ * and query rows >= len are left untouched (F.multi_head_attention_forward key_padding_mask).
+ * bwd: dS = P * (dP - sum_k dP*P), in place on dP.                                            */
+int ctts_softmax_fwd(float* S, const int32_t* lens, int nb0, int nb1, int T, int64_t ld, void* stream);
+int ctts_softmax_bwd(const float* P, float* dP, const int32_t* lens, int nb0, int nb1, int T, int64_t ld,
+                     void* stream);
+
+/* Elementwise helpers of the backward pass.
+ * act_dropout_bwd: dz = dg * dropmask/(1-p) * act'(z)          (GELU/ReLU/tanh from saved pre-activation)
+ * rowscale_dropout_bwd: dv = dy * rowscale[m] * dropmask/(1-p)  (output-side dropout + pad mask)
+ * colsum: out[c] (+)= sum_rows x[r, c]                          (bias gradients)               */
+int ctts_act_dropout_bwd(const float* dg, const float* z, float* dz, int64_t rows, int C, int act, float alpha_unused,
+                         float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream);
+int ctts_rowscale_dropout(const float* x, float* y, int64_t rows, int C, const float* rowscale, float p_drop,
+                          const uint64_t* seed, uint32_t drop_offset, void* stream);
+int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Mel front end (audio/stft.py:59-88,166-185): reflect-pad, |DFT| from the [F, 2*nbins]
+ * re/im GEMM result, energy = L2 norm over bins; the two GEMMs go through ctts_gemm.          */
+int ctts_reflect_pad(const float* y, float* ypad, int B, int N, int pad, int64_t ld_out, void* stream);
+int ctts_stft_magnitude(const float* reim, int64_t ld_reim, float* mag, int64_t ld_mag, float* energy, int64_t frames,
+                        int nbins, void* stream);
+int ctts_log_clamp_transpose(const float* mel_fm, float* out, int B, int F, int n_mel, float clip, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

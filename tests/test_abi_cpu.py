@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/ctts.h declares; the
+Python surface keeps the reference contract; the product has no CPU path."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+import ctts_amd
+from ctts_amd import _lib
+from ctts_amd.configs import get_configs
+from ctts_amd.synthetic import make_batch, as_model_args
+from tests.util import schema
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    hdr = open(os.path.join(ROOT, "include", "ctts.h")).read()
+    declared = set(re.findall(r"\b(ctts_[a-z0-9_]+)\s*\(", hdr))
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in ctts.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert ctypes.sizeof(_lib.GemmDesc) > 0
+    lib.ctts_version.restype = ctypes.c_int
+    assert lib.ctts_version() >= 1
+
+
+def test_forward_signature_matches_reference_contract():
+    sig = inspect.signature(ctts_amd.CompTransTTS.forward)
+    names = list(sig.parameters)[1:]
+    assert names == ["speakers", "texts", "src_lens", "max_src_len", "mels", "mel_lens", "max_mel_len", "p_targets",
+                     "e_targets", "d_targets", "attn_priors", "spker_embeds", "p_control", "e_control", "d_control", "step"]
+    assert list(inspect.signature(ctts_amd.CompTransTTS.__init__).parameters)[1:] == ["preprocess_config", "model_config",
+                                                                                     "train_config"]
+
+
+@pytest.mark.parametrize("dataset", ["LJSpeech", "VCTK"])
+def test_state_dict_schema_matches_reference(dataset):
+    pre, mc, tc = get_configs(dataset)
+    m = ctts_amd.CompTransTTS(pre, mc, tc)
+    sd = m.state_dict()
+    sch = schema(dataset)
+    assert set(sd) == set(sch)
+    params = dict(m.named_parameters())
+    for k, (shape, dtype, is_param) in sch.items():
+        assert list(sd[k].shape) == shape, k
+        assert str(sd[k].dtype) == "torch." + dtype, k
+        assert (k in params) == is_param, k
+    assert sum(p.numel() for p in m.parameters()) == (35094225 if dataset == "LJSpeech" else 35225553)
+    enc, dec = ctts_amd.TextEncoder(mc), ctts_amd.Decoder(mc)
+    assert enc.d_model == 256 and dec.d_model == 256        # block_type plugin surface
+
+
+def test_unsupported_block_types_raise():
+    pre, mc, tc = get_configs()
+    mc["block_type"] = "conformer"
+    with pytest.raises(NotImplementedError):
+        ctts_amd.CompTransTTS(pre, mc, tc)
+    mc["block_type"] = "nope"
+    with pytest.raises(NotImplementedError):
+        ctts_amd.CompTransTTS(pre, mc, tc)
+
+
+def test_no_cpu_fallback_in_product():
+    pre, mc, tc = get_configs()
+    m = ctts_amd.CompTransTTS(pre, mc, tc)
+    with pytest.raises(Exception) as ei:
+        m(*as_model_args(make_batch([8, 5], 4)))
+    assert "CPU" in str(ei.value) or "device" in str(ei.value).lower()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "comprehensive-transformer-tts_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# checker", ""), f

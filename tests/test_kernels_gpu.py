@@ -1,0 +1,281 @@
+"""GPU: every HIP kernel (through the C ABI) against an independent fp64/fp32 torch-CPU
+computation of the same op on seeded inputs.  Integer kernels are compared bit-exactly."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ctts_amd  # noqa: F401
+from ctts_amd import kernels as K
+from ctts_amd import ops
+from tests.util import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(a, b, tol, name=""):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert err <= tol * ref, f"{name}: max-abs err {err:.3e} (ref scale {ref:.3e}, tol {tol})"
+
+
+@pytest.mark.parametrize("M,N,Kd", [(200, 150, 100), (64, 64, 32), (1, 7, 4), (2048, 2048, 64), (130, 129, 260), (300, 11, 256)])
+def test_gemm_nt(M, N, Kd):
+    A, B = rnd(M, Kd, seed=1), rnd(N, Kd, seed=2)
+    C = torch.empty(M, N, device=DEV)
+    K.gemm(A.to(DEV), B.to(DEV), C, M, N, Kd, Kd, Kd, N, True, True)
+    close(C, A.double() @ B.double().t(), 2e-6 * max(1, Kd / 16), "nt")
+
+
+@pytest.mark.parametrize("M,N,Kd", [(200, 152, 100), (2048, 1024, 96), (33, 256, 11)])
+def test_gemm_nn(M, N, Kd):
+    A, B = rnd(M, Kd, seed=3), rnd(Kd, N, seed=4)
+    C = torch.empty(M, N, device=DEV)
+    K.gemm(A.to(DEV), B.to(DEV), C, M, N, Kd, Kd, N, N, True, False)
+    close(C, A.double() @ B.double(), 2e-6 * max(1, Kd / 16), "nn")
+
+
+@pytest.mark.parametrize("M,N,Kd,split", [(200, 152, 300, 1), (256, 256, 4096, 8), (11, 256, 500, 3), (1024, 2304, 2000, 4)])
+def test_gemm_tn_splitk(M, N, Kd, split):
+    A, B = rnd(Kd, M, seed=5), rnd(Kd, N, seed=6)   # C = A^T B
+    C = torch.zeros(M, N, device=DEV)
+    K.gemm(A.to(DEV), B.to(DEV), C, M, N, Kd, M, N, N, False, False, split_k=split, alpha=0.5)
+    close(C, 0.5 * (A.double().t() @ B.double()), 3e-6 * max(1, Kd / 16), "tn")
+
+
+def test_gemm_epilogue_all():
+    M, N, Kd = 150, 200, 64
+    A, B, bias, R, rs = rnd(M, Kd, seed=7), rnd(N, Kd, seed=8), rnd(N, seed=9), rnd(M, N, seed=10), (rnd(M, seed=11) > 0).float()
+    for act, fn in [(0, lambda v: v), (1, torch.relu), (2, F.gelu), (3, torch.tanh)]:
+        C = torch.empty(M, N, device=DEV)
+        Z = torch.empty(M, N, device=DEV)
+        K.gemm(A.to(DEV), B.to(DEV), C, M, N, Kd, Kd, Kd, N, True, True, alpha=0.3, bias=bias.to(DEV), Z=Z, ldz=N, act=act,
+               R=R.to(DEV), ldr=N, rowscale=rs.to(DEV))
+        z = 0.3 * (A.double() @ B.double().t() + bias.double())
+        close(Z, z, 1e-5, f"Z act{act}")
+        close(C, (fn(z) + R.double()) * rs.double()[:, None], 1e-5, f"C act{act}")
+
+
+def test_gemm_dropout_mask_consistency():
+    M, N, Kd, p = 256, 128, 32, 0.3
+    A, B = rnd(M, Kd, seed=12), rnd(N, Kd, seed=13)
+    drop = K.DropCtx(DEV, seed=5)
+    off = drop.next_offset()
+    C0 = torch.empty(M, N, device=DEV)
+    C1 = torch.empty(M, N, device=DEV)
+    K.gemm(A.to(DEV), B.to(DEV), C0, M, N, Kd, Kd, Kd, N, True, True)
+    K.gemm(A.to(DEV), B.to(DEV), C1, M, N, Kd, Kd, Kd, N, True, True, p_drop=p, seed=drop.seed, drop_offset=off)
+    kept = C1 != 0
+    frac = kept.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.02, frac
+    close(C1[kept], C0[kept] / (1 - p), 1e-5, "kept values scaled")
+    # the standalone dropout kernel regenerates the identical mask from (seed, offset, index)
+    ones = torch.ones(M, N, device=DEV)
+    m2 = K.rowscale_dropout(ones, None, p, drop.seed, off)
+    assert torch.equal(m2 != 0, kept)
+    drop.advance()
+    m3 = K.rowscale_dropout(ones, None, p, drop.seed, off)
+    assert not torch.equal(m3 != 0, kept)
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,k", [(3, 50, 256, 64, 9), (2, 37, 80, 512, 5), (4, 130, 128, 256, 5), (2, 9, 256, 256, 3)])
+def test_conv1d_fwd_bwd(B, T, Cin, Cout, k):
+    x, w, b = rnd(B, T, Cin, seed=20), rnd(Cout, Cin, k, seed=21, scale=0.1), rnd(Cout, seed=22)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.conv1d(xr.transpose(1, 2), wr, br, padding=k // 2).transpose(1, 2)
+    xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.conv1d(xg, wg, bg)
+    close(y, yr, 1e-5, "conv fwd")
+    go = rnd(B, T, Cout, seed=23)
+    yr.backward(go.double())
+    y.backward(go.to(DEV))
+    close(xg.grad, xr.grad, 1e-5, "conv dgrad")
+    close(wg.grad, wr.grad, 2e-5, "conv wgrad")
+    close(bg.grad, br.grad, 2e-5, "conv bgrad")
+
+
+def test_linear_fused_fwd_bwd():
+    B, T, Cin, Cout = 3, 40, 256, 128
+    x, w, b, res = rnd(B, T, Cin, seed=30), rnd(Cout, Cin, seed=31, scale=0.1), rnd(Cout, seed=32), rnd(B, T, Cout, seed=33)
+    rs = (rnd(B * T, seed=34) > -0.5).float()
+    for act, fn in [(ops.ACT_NONE, lambda v: v), (ops.ACT_GELU, F.gelu), (ops.ACT_RELU, torch.relu)]:
+        xr, wr, br, rr = [t.double().requires_grad_() for t in (x, w, b, res)]
+        yr = (rr + fn(0.5 * (xr @ wr.t() + br))) * rs.double().view(B, T, 1)
+        xg, wg, bg, rg = [t.to(DEV).requires_grad_() for t in (x, w, b, res)]
+        y = ops.linear(xg, wg, bg, act=act, alpha=0.5, residual=rg, rowscale=rs.to(DEV))
+        close(y, yr, 1e-5, "lin fwd")
+        go = rnd(B, T, Cout, seed=35)
+        yr.backward(go.double())
+        y.backward(go.to(DEV))
+        for n, a, r in [("dx", xg.grad, xr.grad), ("dw", wg.grad, wr.grad), ("db", bg.grad, br.grad), ("dres", rg.grad, rr.grad)]:
+            close(a, r, 2e-5, f"lin {n} act{act}")
+
+
+def test_linear_tiny_heads():
+    # N = 1, 2, 11 heads (duration / stats / cwt linear layers) incl. their backward (unaligned scalar path)
+    for N in (1, 2, 11):
+        x, w, b = rnd(5, 33, 256, seed=40), rnd(N, 256, seed=41, scale=0.1), rnd(N, seed=42)
+        xr, wr, br = [t.double().requires_grad_() for t in (x, w, b)]
+        yr = xr @ wr.t() + br
+        xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+        y = ops.linear(xg, wg, bg)
+        close(y, yr, 1e-5, f"head{N} fwd")
+        go = rnd(5, 33, N, seed=43)
+        yr.backward(go.double())
+        y.backward(go.to(DEV))
+        close(xg.grad, xr.grad, 1e-5, f"head{N} dx")
+        close(wg.grad, wr.grad, 2e-5, f"head{N} dw")
+        close(bg.grad, br.grad, 2e-5, f"head{N} db")
+
+
+@pytest.mark.parametrize("B,T,H,C", [(3, 70, 2, 256), (2, 130, 2, 256), (2, 33, 8, 256)])
+def test_self_attention_fwd_bwd(B, T, H, C):
+    qkv = rnd(B, T, 3 * C, seed=50)
+    lens = torch.tensor([T, max(1, T // 2), max(1, T - 7)][:B], dtype=torch.int32)
+    dh = C // H
+    qr = qkv.double().requires_grad_()
+    q, k, v = qr.split(C, dim=-1)
+    q = q.reshape(B, T, H, dh).transpose(1, 2) * dh ** -0.5
+    k = k.reshape(B, T, H, dh).transpose(1, 2)
+    v = v.reshape(B, T, H, dh).transpose(1, 2)
+    pad = torch.arange(T)[None, :] >= lens[:, None]
+    s = (q @ k.transpose(-1, -2)).masked_fill(pad[:, None, None, :], float("-inf"))
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, C)
+    o = o * (~pad)[..., None]
+    qg = qkv.to(DEV).requires_grad_()
+    out = ops.self_attention(qg, lens.to(DEV), H)
+    close(out, o, 1e-5, "attn fwd")
+    go = rnd(B, T, C, seed=51) * (~pad)[..., None]
+    o.backward(go.double())
+    out.backward(go.to(DEV))
+    close(qg.grad, qr.grad, 2e-5, "attn dqkv")
+
+
+@pytest.mark.parametrize("rows,C,eps", [(100, 256, 1e-12), (37, 128, 1e-5), (64, 1024, 1e-5), (9, 80, 1e-5)])
+def test_layernorm_fwd_bwd(rows, C, eps):
+    x, g, b = rnd(rows, C, seed=60, scale=2.0), rnd(C, seed=61) + 1.5, rnd(C, seed=62)
+    rs = (rnd(rows, seed=63) > -0.3).float()
+    xr, gr, br = [t.double().requires_grad_() for t in (x, g, b)]
+    yr = F.layer_norm(xr, (C,), gr, br, eps) * rs.double()[:, None]
+    xg, gg, bg = [t.to(DEV).requires_grad_() for t in (x, g, b)]
+    y = ops.layer_norm(xg, gg, bg, eps, rowscale=rs.to(DEV))
+    close(y, yr, 1e-5, "ln fwd")
+    go = rnd(rows, C, seed=64)
+    yr.backward(go.double())
+    y.backward(go.to(DEV))
+    close(xg.grad, xr.grad, 2e-5, "ln dx")
+    close(gg.grad, gr.grad, 2e-5, "ln dgamma")
+    close(bg.grad, br.grad, 2e-5, "ln dbeta")
+
+
+def test_layernorm_dropout_consistency():
+    rows, C, p = 300, 256, 0.5
+    x, g, b = rnd(rows, C, seed=65), torch.ones(C), torch.full((C,), 3.0)
+    drop = K.DropCtx(DEV)
+    xg = x.to(DEV).requires_grad_()
+    y = ops.layer_norm(xg, g.to(DEV), b.to(DEV), 1e-5, p_drop=p, drop=drop)
+    kept = y != 0
+    assert abs(kept.float().mean().item() - 0.5) < 0.02
+    y2 = ops.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5)
+    close(y[kept], 2 * y2[kept], 1e-5, "ln dropout scale")
+    # backward uses the same mask: gradient of sum(y) wrt beta = sum(mask/(1-p)) per channel
+    gb = b.to(DEV).requires_grad_()
+    drop2 = K.DropCtx(DEV)
+    yy = ops.layer_norm(x.to(DEV), g.to(DEV), gb, 1e-5, p_drop=p, drop=drop2)
+    yy.sum().backward()
+    close(gb.grad, (yy != 0).float().sum(0) * 2, 1e-5, "ln dropout bwd mask")
+
+
+@pytest.mark.parametrize("act", [ops.ACT_TANH, ops.ACT_NONE])
+def test_batchnorm_train_and_eval(act):
+    B, T, C = 3, 50, 80
+    x, g, b = rnd(B, T, C, seed=70, scale=2.0) + 0.3, rnd(C, seed=71) + 1.5, rnd(C, seed=72)
+    bn = torch.nn.BatchNorm1d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(g); bn.bias.copy_(b)
+    xr = x.double().requires_grad_()
+    yr = bn(xr.transpose(1, 2)).transpose(1, 2)
+    if act == ops.ACT_TANH:
+        yr = torch.tanh(yr)
+    rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.tensor(0, device=DEV)
+    xg, gg, bg = x.to(DEV).requires_grad_(), g.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.batch_norm_act(xg, gg, bg, rm, rv, nbt, True, act=act)
+    close(y, yr, 1e-5, "bn fwd")
+    close(rm, bn.running_mean, 1e-5, "running_mean")
+    close(rv, bn.running_var, 1e-5, "running_var")
+    go = rnd(B, T, C, seed=73)
+    yr.backward(go.double())
+    y.backward(go.to(DEV))
+    close(xg.grad, xr.grad, 2e-5, "bn dx")
+    close(gg.grad, bn.weight.grad, 2e-5, "bn dgamma")
+    close(bg.grad, bn.bias.grad, 2e-5, "bn dbeta")
+    bn.eval()
+    ye = bn(x.double().transpose(1, 2)).transpose(1, 2)
+    if act == ops.ACT_TANH:
+        ye = torch.tanh(ye)
+    y2 = ops.batch_norm_act(x.to(DEV), g.to(DEV), b.to(DEV), rm, rv, nbt, False, act=act)
+    close(y2, ye, 1e-5, "bn eval")
+
+
+def test_length_regulator_bit_exact_vs_reference_golden():
+    g = load_golden("g7_integer")
+    d, x = torch.from_numpy(g["lr.dur"]).to(DEV), torch.from_numpy(g["lr.x"]).to(DEV)
+    for tag, max_len in (("none", None), ("crop", 50), ("pad", 200)):
+        out, mel_len, mel2ph = ops.length_regulate(x, d, max_len)
+        assert np.array_equal(out.cpu().numpy(), g[f"lr.{tag}.out"]), tag
+        assert np.array_equal(mel_len.cpu().numpy(), g[f"lr.{tag}.mel_len"]), tag
+        assert np.array_equal(mel2ph.cpu().numpy().astype(np.int64) - 1, g[f"lr.{tag}.idx"]), tag
+    outf, mlf, _ = ops.length_regulate(torch.from_numpy(g["lrf.x"]).to(DEV), torch.from_numpy(g["lrf.dur"]).to(DEV), None)
+    assert np.array_equal(outf.cpu().numpy(), g["lrf.out"]) and np.array_equal(mlf.cpu().numpy(), g["lrf.mel_len"])
+    pad = torch.from_numpy(g["m2p.pad"]).to(DEV)
+    assert np.array_equal(ops.dur_to_mel2ph(d, pad).cpu().numpy(), g["m2p.out"])
+    assert np.array_equal(ops.dur_to_mel2ph(d, None).cpu().numpy(), g["m2p.out_nopad"])
+    tok = torch.from_numpy(g["pos.in"]).to(DEV)
+    assert np.array_equal(K.positions(tok, 1).cpu().numpy(), g["pos.out"])
+    xf = torch.from_numpy(g["pos.in"]).float().to(DEV)[..., None].repeat(1, 1, 4).contiguous()
+    assert np.array_equal(K.positions(xf, 4).cpu().numpy(), g["pos.out"])
+
+
+def test_length_regulator_backward_and_roundtrip():
+    B, Ts, C = 4, 37, 256
+    g = torch.Generator().manual_seed(5)
+    d = torch.randint(0, 7, (B, Ts), generator=g)
+    x = rnd(B, Ts, C, seed=80)
+    xg = x.to(DEV).requires_grad_()
+    out, mel_len, mel2ph = ops.length_regulate(xg, d.to(DEV), 150)
+    go = rnd(B, 150, C, seed=81)
+    out.backward(go.to(DEV))
+    ref = torch.zeros(B, Ts, C, dtype=torch.float64)
+    m2p = mel2ph.cpu().long()
+    for b in range(B):
+        for t in range(150):
+            if m2p[b, t] > 0:
+                ref[b, m2p[b, t] - 1] += go[b, t].double()
+    close(xg.grad, ref, 1e-6, "lr bwd")
+    # size-independent property: frame counts per phoneme reproduce the (cropped) durations
+    counts = torch.zeros(B, Ts + 1, dtype=torch.long).scatter_add(1, m2p, torch.ones_like(m2p))[:, 1:]
+    cum = torch.cumsum(d, 1)
+    expect = (cum.clamp(max=150) - (cum - d).clamp(max=150))
+    assert torch.equal(counts, expect)
+
+
+def test_mel_spectrogram_vs_reference_golden():
+    g = load_golden("g8_stft")
+    st = ctts_amd.TacotronSTFT(1024, 256, 1024, 80, 22050, 0, 8000).to(DEV)
+    close(st.mel_basis, torch.from_numpy(g["mel_basis"]), 1e-6, "mel basis (librosa 0.7.2 restated)")
+    y = torch.from_numpy(g["y"]).to(DEV)
+    mel, energy = st.mel_spectrogram(y)
+    mag = st.magnitudes(y)
+    assert mel.shape == g["mel"].shape and energy.shape == g["energy"].shape
+    close(mag, torch.from_numpy(g["mag"]), 2e-5, "magnitude")
+    close(energy, torch.from_numpy(g["energy"]), 2e-5, "energy")
+    err = (mel.cpu() - torch.from_numpy(g["mel"])).abs().max().item()
+    assert err < 1e-3, f"log-mel max-abs {err}"

@@ -1,0 +1,182 @@
+"""GPU: the drop-in CompTransTTS (HIP kernels through the C ABI) against (a) the golden vectors
+captured from the live reference and (b) the CPU oracle on the same seeded inputs.
+Tolerance: north_star states mel max-abs <= 1e-3, LengthRegulator indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import ctts_amd
+from ctts_amd.configs import get_configs
+from ctts_amd.synthetic import make_batch, to_device, as_model_args
+from oracle import restate as R
+from oracle.weights import _hash_uniform
+from tests.util import load_golden, closed_form_sd, batch_from_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+MEL_TOL = 1e-3
+
+
+def build(dataset="LJSpeech", sd=None):
+    pre, mc, tc = get_configs(dataset)
+    m = ctts_amd.CompTransTTS(pre, mc, tc)
+    if sd is not None:
+        m.load_state_dict(sd)
+    return m.to(DEV), (pre, mc, tc)
+
+
+def no_dropout(m):
+    for sub in m.modules():
+        if hasattr(sub, "dropout"):
+            sub.dropout = 0.0
+
+
+def args_from(b, dev=DEV):
+    b = to_device(b, dev)
+    return (b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"], b["max_mel_len"],
+            b["p_targets"], b["e_targets"], b["d_targets"], None, b["spker_embeds"])
+
+
+def maxerr(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    return float(np.abs(a - np.asarray(b, dtype=np.float64)).max())
+
+
+def check_against_golden(out, g):
+    mel, post, p_pred, e_pred, log_d, d_rounded, src_mask, mel_mask, src_lens, mel_lens = out[:10]
+    errs = {
+        "mel": maxerr(mel, g["out.mel"]), "postnet_mel": maxerr(post, g["out.postnet_mel"]),
+        "log_d": maxerr(log_d, g["out.log_d"]), "e_pred": maxerr(e_pred, g["out.e_pred"]),
+        "cwt": maxerr(p_pred["cwt"], g["out.cwt"]), "f0_mean": maxerr(p_pred["f0_mean"], g["out.f0_mean"]),
+        "f0_std": maxerr(p_pred["f0_std"], g["out.f0_std"]),
+    }
+    print("max-abs vs reference golden:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= MEL_TOL, (k, v)
+    assert np.array_equal(src_mask.cpu().numpy(), g["out.src_mask"])
+    assert np.array_equal(mel_mask.cpu().numpy(), g["out.mel_mask"])
+    assert np.array_equal(mel_lens.cpu().numpy(), g["out.mel_lens"])
+    assert np.array_equal(d_rounded.cpu().numpy(), g["out.d_rounded"])
+    assert maxerr(p_pred["f0_denorm"], g["out.f0_denorm"]) < 0.05
+    return errs
+
+
+def test_state_dict_roundtrip_reference_keys():
+    sd = closed_form_sd()
+    m, _ = build(sd=sd)
+    out = m.state_dict()
+    assert list(sorted(out.keys())) == list(sorted(sd.keys()))
+    for k in sd:
+        if "_float_tensor" in k:
+            continue
+        assert torch.equal(out[k].cpu(), sd[k]), k
+
+
+def test_g1_eval_matches_reference():
+    g = load_golden("g1_fs2_eval")
+    m, _ = build(sd=closed_form_sd())
+    m.eval()
+    with torch.no_grad():
+        out = m(*args_from(batch_from_golden(g)))
+    check_against_golden(out, g)
+    assert maxerr(out[12]["f0"], g["out.pt_f0"]) < 1e-3
+
+
+def test_g2_train_batchnorm_and_gradients_match_reference():
+    g = load_golden("g2_fs2_train_nodrop")
+    m, _ = build(sd=closed_form_sd())
+    m.train()
+    no_dropout(m)
+    out = m(*args_from(batch_from_golden(g)))
+    check_against_golden(out, g)
+    sd_after = m.state_dict()
+    for k in sd_after:
+        if "running_" in k:
+            assert maxerr(sd_after[k], g["bn." + k]) < 1e-4, k
+
+    def pseudo(name, shape):
+        return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float().to(DEV)
+    mel, post, p_pred, e_pred, log_d = out[:5]
+    loss = ((post * pseudo("post", post.shape)).sum() + (mel * pseudo("mel", mel.shape)).sum()
+            + (log_d * pseudo("logd", log_d.shape)).sum() + (e_pred * pseudo("e", e_pred.shape)).sum()
+            + (p_pred["cwt"] * pseudo("cwt", p_pred["cwt"].shape)).sum()
+            + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum())
+    assert abs(loss.item() - float(g["grad.loss"])) < 5e-2
+    loss.backward()
+    worst = ("", 0.0)
+    n = 0
+    for k, p in m.named_parameters():
+        if "grad.stat." + k not in g:
+            continue
+        gs = g["grad.stat." + k]
+        gr = p.grad.flatten() if p.grad is not None else torch.zeros(p.numel(), device=DEV)
+        scale = max(1.0, float(gs[1]))
+        e = maxerr(gr[:64], g["grad.head." + k]) / scale
+        en = abs(float(gr.double().pow(2).sum().sqrt()) - gs[1]) / scale
+        if max(e, en) > worst[1]:
+            worst = (k, max(e, en))
+        n += 1
+    print("worst relative gradient error:", worst, "over", n, "parameters")
+    assert n > 150 and worst[1] < 2e-3, worst
+
+
+def test_g3_inference_branch_matches_reference():
+    g = load_golden("g3_fs2_infer")
+    m, _ = build(sd=closed_form_sd())
+    m.eval()
+    b = batch_from_golden(g)
+    with torch.no_grad():
+        out = m(*args_from(b), p_control=1.1, e_control=0.9, d_control=2.0)
+    check_against_golden(out, g)
+
+
+def test_g5_vctk_multispeaker_matches_reference():
+    g = load_golden("g5_vctk_eval")
+    m, _ = build("VCTK", sd=closed_form_sd("VCTK"))
+    m.eval()
+    with torch.no_grad():
+        out = m(*args_from(batch_from_golden(g)))
+    check_against_golden(out, g)
+
+
+def test_canonical_batch_vs_oracle_full_size():
+    """BASELINE config 2 shapes (B=16, Ts<=128, Tm<=1024): HIP forward vs the CPU oracle."""
+    torch.manual_seed(1)
+    m, (pre, mc, tc) = build()
+    m.eval()
+    batch = make_batch()
+    with torch.no_grad():
+        out = m(*as_model_args(to_device(batch, DEV)))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = R.comp_trans_tts_forward(sd, mc, pre, *as_model_args(batch), training=False)
+    e_mel, e_post = maxerr(out[0], ref[0].numpy()), maxerr(out[1], ref[1].numpy())
+    print(f"canonical batch: mel max-abs {e_mel:.2e}, postnet mel {e_post:.2e}")
+    assert e_mel <= MEL_TOL and e_post <= MEL_TOL
+    assert torch.equal(out[9].cpu(), ref[9])
+
+
+def test_train_step_with_dropout_runs_and_is_finite():
+    torch.manual_seed(2)
+    m, _ = build()
+    m.train()
+    batch = make_batch([40, 33, 21, 12], 8, seed=9)
+    out = m(*as_model_args(to_device(batch, DEV)))
+    loss = out[0].abs().mean() + out[1].abs().mean() + out[4].pow(2).mean() + out[3].pow(2).mean() + out[2]["cwt"].abs().mean()
+    loss.backward()
+    tot = 0.0
+    for k, p in m.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None, k
+            assert torch.isfinite(p.grad).all(), k
+            tot += float(p.grad.pow(2).sum())
+    assert np.isfinite(tot) and tot > 0
+    out2 = m(*as_model_args(to_device(batch, DEV)))
+    assert not torch.equal(out[0], out2[0])          # fresh dropout mask per step
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    pre, mc, tc = get_configs()
+    m = ctts_amd.CompTransTTS(pre, mc, tc)           # CPU module: no fallback path exists
+    with pytest.raises(Exception):
+        m(*as_model_args(make_batch([8, 5], 4)))
