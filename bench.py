@@ -1,0 +1,285 @@
+"""bench.py - mel-frames/sec of one full CompTransTTS train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Step (train.py:102-125 of the reference): forward -> CompTransTTSLoss (step > var_start_steps, all
+terms active) -> backward -> [DP: all-reduce(sum)/world of the flat gradient arena over RCCL] ->
+clip_grad_norm_(1.0) -> Adam (Noam LR) -> zero_grad, fp32, dropout ON, synthetic LJSpeech-shaped
+canonical batch (B=16, src<=128, mel<=1024, 11,992 valid frames) resident in HBM.
+Weak scaling: every rank runs its own canonical batch (what the reference de facto does).
+value = valid mel frames of all ranks / max-over-ranks wall time.
+
+Adds `roofline` (dominant kernel: the implicit-GEMM Conv1d k=9 of the decoder FFN, fp32 MFMA peak
+157.3 TFLOP/s) and `cpu_baseline` (oracle restatement of the reference's CPU PyTorch path, timed on
+this host on a bounded sample) to the JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", default="canonical", choices=["canonical", "c1"])
+    return ap.parse_args()
+
+
+class TrainStep:
+    """forward/loss/backward [+ gradient all-reduce] + clip + Adam, optionally as two hipGraphs
+    (fwd+bwd, clip+Adam) with the RCCL all-reduce issued eagerly between them."""
+
+    def __init__(self, model, loss_fn, optim, batch, world, use_graph):
+        from ctts_amd.synthetic import as_model_args
+
+        self.model, self.loss_fn, self.optim, self.world = model, loss_fn, optim, world
+        self.args = as_model_args(batch)
+        self.loss_inputs = [None, None] + list(self.args)
+        self.step_no = 50001
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        # flat fp32 gradient arena: p.grad are views -> one all-reduce, no bucket copies
+        n = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(n, device=self.params[0].device)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        self.use_graph = use_graph
+        self.g_fb = self.g_opt = None
+        self.loss_val = None
+
+    def fwd_bwd(self):
+        args = list(self.args)
+        args[7] = dict(args[7])                      # the model mutates p_targets like the reference does
+        out = self.model(*args, step=self.step_no)
+        inputs = list(self.loss_inputs)
+        inputs[9:11] = out[-2:]
+        losses = self.loss_fn(inputs, out[:-2], self.step_no)
+        self.flat_grad.zero_()
+        losses[0].backward()
+        self.loss_val = losses[0].detach()
+
+    def reduce(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad)
+            self.flat_grad.div_(self.world)
+
+    def clip_and_step(self):
+        torch.nn.utils.clip_grad_norm_(self.params, 1.0, foreach=True)
+        self.optim._optimizer.step()
+
+    def capture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.fwd_bwd(); self.reduce(); self.optim.update_learning_rate(); self.clip_and_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self.fwd_bwd()
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt):
+            self.clip_and_step()
+
+    def __call__(self):
+        self.optim.update_learning_rate()            # host scalar -> device lr tensor (outside the graphs)
+        if self.g_fb is not None:
+            self.g_fb.replay(); self.reduce(); self.g_opt.replay()
+        else:
+            self.fwd_bwd(); self.reduce(); self.clip_and_step()
+        self.step_no += 1
+
+
+def measure_dominant_kernel(dev, batch, iters=20):
+    """HIP-event timing (on the launch stream) of the dominant kernel at its train-step arguments:
+    decoder FFN Conv1d(256->1024, k=9) as implicit GEMM, M=B*Tm rows, N=1024, K=2304."""
+    from ctts_amd import kernels as K
+
+    B, T = batch["mels"].shape[0], batch["mels"].shape[1]
+    M, cin, cout, ks = B * T, 256, 1024, 9
+    x = torch.randn(B, T, cin, device=dev)
+    wf = torch.randn(cout, ks * cin, device=dev) * 0.02
+    bias = torch.zeros(cout, device=dev)
+    out = torch.empty(B, T, cout, device=dev)
+    Z = torch.empty(B, T, cout, device=dev)
+    seed = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def launch():
+        K.gemm(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, conv=(T, ks // 2, cin), alpha=ks ** -0.5, bias=bias,
+               Z=Z, ldz=cout, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1)
+    for _ in range(3):
+        launch()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        launch()
+    e1.record(st)
+    e1.synchronize()
+    dt = e0.elapsed_time(e1) * 1e-3 / iters
+    valid = int(batch["mel_lens"].sum())
+    algo_flops = 2.0 * cout * ks * cin * valid          # 4,718,592 FLOP per valid frame per layer
+    padded_flops = 2.0 * cout * ks * cin * M
+    return {"bound": "mfma", "achieved": algo_flops / dt / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": algo_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "gemm_kernel<128,128,A_KC,B_KC,CONV> (decoder FFN conv k=9 fwd)", "launch_us": dt * 1e6,
+            "padded_tflops": padded_flops / dt / 1e12}
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Reference CPU PyTorch path, restated (oracle/restate.py; parity vs the reference <= 2e-5 on the goldens),
+    timed on this host: C1 batch (B=4, 3,032 valid frames), full train step with dropout."""
+    import ctts_amd
+    from ctts_amd.configs import get_configs
+    from ctts_amd.loss import CompTransTTSLoss
+    from ctts_amd.synthetic import make_batch, as_model_args, C1_SRC_LENS
+    from oracle import restate as R           # checker / baseline only
+
+    pre, mc, tc = get_configs()
+    ncores = os.cpu_count() or 1
+    nthreads = min(ncores, 64)
+    torch.set_num_threads(nthreads)
+    torch.manual_seed(1234)
+    model = ctts_amd.CompTransTTS(pre, mc, tc)            # parameters only (reference initialisers); never run on CPU
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    sd = {k: (v.detach().clone().requires_grad_(True) if k in trainable else v.detach().clone())
+          for k, v in model.state_dict().items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
+    loss_fn = CompTransTTSLoss(pre, mc, tc)
+    batch = make_batch(C1_SRC_LENS)
+    args = as_model_args(batch)
+    valid = int(batch["mel_lens"].sum())
+    times = []
+    t_start = time.perf_counter()
+    for it in range(4):
+        t0 = time.perf_counter()
+        a = list(args); a[7] = dict(a[7])
+        stats = {}
+        out = R.comp_trans_tts_forward(sd, mc, pre, *a, training=True, train_dropout=True, new_stats=stats)
+        inputs = [None, None] + list(a)
+        inputs[9:11] = out[-2:]
+        losses = loss_fn(inputs, out[:-2], 50001)
+        opt.zero_grad()
+        losses[0].backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        with torch.no_grad():
+            for k, v in stats.items():
+                sd[k].copy_(v)
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+        if time.perf_counter() - t_start > seconds_budget and times:
+            break
+    med = sorted(times)[len(times) // 2]
+    return {"value": valid / med, "unit": "mel-frames/s", "cores": nthreads, "kind": "port",
+            "sample": f"C1 batch B=4 ({valid} valid frames), {len(times)} train steps after 1 warm-up, median {med:.2f} s/step, "
+                      f"torch CPU fp32 {nthreads} threads of {ncores} cores"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path in the product)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)    # RCCL over xGMI
+    import ctts_amd
+    from ctts_amd.configs import get_configs
+    from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
+    from ctts_amd.synthetic import make_batch, to_device, C1_SRC_LENS
+
+    pre, mc, tc = get_configs()
+    torch.manual_seed(1234)                                   # identical init on every rank (DDP broadcast equivalent)
+    model = ctts_amd.CompTransTTS(pre, mc, tc).to(dev)
+    model.train()
+    loss_fn = CompTransTTSLoss(pre, mc, tc).to(dev)
+    optim = ScheduledOptim(model, tc, mc, 50000, capturable=True)
+    src_lens = None if a.batch == "canonical" else C1_SRC_LENS
+    batch_cpu = make_batch(src_lens, seed=1234 + rank)
+    batch = to_device(batch_cpu, dev)
+    valid_frames = int(batch_cpu["mel_lens"].sum())
+    padded_frames = batch_cpu["mels"].shape[0] * batch_cpu["mels"].shape[1]
+
+    step = TrainStep(model, loss_fn, optim, batch, world, not a.no_graph)
+    mode = "eager"
+    if not a.no_graph:
+        try:
+            step.capture()
+            mode = "hipgraph(fwd+bwd | clip+adam)"
+        except Exception as e:                                # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            step.g_fb = step.g_opt = None
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    loss_final = float(step.loss_val)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+        vf = torch.tensor([valid_frames], device=dev, dtype=torch.float64)
+        dist.all_reduce(vf)
+        total_valid = float(vf)
+    else:
+        total_valid = float(valid_frames)
+    ms_per_step = elapsed / a.steps * 1e3
+    value = total_valid * a.steps / elapsed
+    if rank == 0:
+        roof = measure_dominant_kernel(dev, batch_cpu) if a.batch == "canonical" else None
+        # whole-step roofline view: 157.4 MFLOP per valid frame against the fp32 MFMA peak
+        step_tflops = (value / world) * 157.4e6 / 1e12
+        cpu = None if a.no_cpu_baseline else cpu_baseline()
+        line = {
+            "metric": "mel-frames/sec (train step) LJSpeech batch=16, 1/2/4/8 MI355X", "value": value, "unit": "mel-frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LJSpeech transformer_fs2 batch=16/GPU, seq<=128 -> mel<=1024x80, supervised durations "
+                                   "(BASELINE configs[1]); full train step fwd+loss+bwd+clip+Adam, dropout on",
+                       "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
+                       "parallelism": f"dp{world}", "final_loss": loss_final},
+            "roofline": roof, "step_model_tflops_per_gpu": step_tflops,
+            "step_frac_of_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,14 @@ __global__ void act_dropout_bwd_kernel(const float* __restrict__ dg, const float
   const bool do_drop = p_drop > 0.f;
   uint32_t dkey = 0; float inv_keep = 1.f;
   if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  if (total & 3) {  // unaligned shapes (N = 1, 2, 11 heads): scalar path
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      float g = dg[i];
+      if (do_drop) g *= ctts_drop_scale(dkey, (uint32_t)i, p_drop, inv_keep);
+      dz[i] = g * ctts_act_grad(z[i], act);
+    }
+    return;
+  }
   const long n4 = total >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const float4 g = reinterpret_cast<const float4*>(dg)[i];
@@ -30,6 +38,14 @@ __global__ void rowscale_dropout_kernel(const float* __restrict__ x, float* __re
   const bool do_drop = p_drop > 0.f;
   uint32_t dkey = 0; float inv_keep = 1.f;
   if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  if (C & 3) {  // unaligned shapes: scalar path
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      float a = x[i];
+      if (do_drop) a *= ctts_drop_scale(dkey, (uint32_t)i, p_drop, inv_keep);
+      y[i] = a * (rowscale ? rowscale[i / C] : 1.f);
+    }
+    return;
+  }
   const long n4 = total >> 2;
   const int C4 = C >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -136,10 +152,10 @@ extern "C" int ctts_act_dropout_bwd(const float* dg, const float* z, float* dz, 
                                     float alpha_unused, float p_drop, const uint64_t* seed, uint32_t drop_offset,
                                     void* stream) {
   (void)alpha_unused;
-  CTTS_REQUIRE(dg && z && dz && (C % 4) == 0, "ctts_act_dropout_bwd: bad arguments (C %% 4 must be 0)");
+  CTTS_REQUIRE(dg && z && dz && C > 0, "ctts_act_dropout_bwd: bad arguments");
   const long total = (long)rows * C;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(grid_for(total >> 2)), dim3(256), 0, (hipStream_t)stream, dg, z, dz, total,
+  hipLaunchKernelGGL(act_dropout_bwd_kernel, dim3(grid_for((total & 3) ? total : (total >> 2))), dim3(256), 0, (hipStream_t)stream, dg, z, dz, total,
                      act, p_drop, seed, drop_offset);
   CTTS_CHECK_LAUNCH("ctts_act_dropout_bwd");
   return 0;
@@ -147,10 +163,10 @@ extern "C" int ctts_act_dropout_bwd(const float* dg, const float* z, float* dz, 
 
 extern "C" int ctts_rowscale_dropout(const float* x, float* y, int64_t rows, int C, const float* rowscale, float p_drop,
                                      const uint64_t* seed, uint32_t drop_offset, void* stream) {
-  CTTS_REQUIRE(x && y && (C % 4) == 0, "ctts_rowscale_dropout: bad arguments (C %% 4 must be 0)");
+  CTTS_REQUIRE(x && y && C > 0, "ctts_rowscale_dropout: bad arguments");
   const long total = (long)rows * C;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(rowscale_dropout_kernel, dim3(grid_for(total >> 2)), dim3(256), 0, (hipStream_t)stream, x, y, total, C,
+  hipLaunchKernelGGL(rowscale_dropout_kernel, dim3(grid_for((C & 3) ? total : (total >> 2))), dim3(256), 0, (hipStream_t)stream, x, y, total, C,
                      rowscale, p_drop, seed, drop_offset);
   CTTS_CHECK_LAUNCH("ctts_rowscale_dropout");
   return 0;

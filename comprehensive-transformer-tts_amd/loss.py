@@ -1,0 +1,147 @@
+"""`CompTransTTSLoss` and `ScheduledOptim` (reference: model/loss.py:10-347, model/optimizer.py:5-53).
+
+SURVEY.md section 8(f1): these run inside the timed train step but stay on stock PyTorch-ROCm
+ops this round (dozens of tiny masked reductions + Adam).  Two changes make the step
+hipGraph-capturable without changing any value: the word-duration scatter uses the static bound
+Ts+1 instead of `word_id.max()+1` (loss.py:156-157: the extra bins are zero and masked), and the
+energy L1 uses a masked mean instead of `masked_select` (loss.py:236-243) - neither needs a
+device->host sync.  Supervised-duration configs only (learn_alignment=False).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .configs import SIL_PHONEME_IDS
+
+
+class CompTransTTSLoss(nn.Module):
+    def __init__(self, preprocess_config, model_config, train_config):
+        super().__init__()
+        if model_config["duration_modeling"]["learn_alignment"]:
+            raise NotImplementedError("learn_alignment=True losses (ForwardSum/Bin) are a next-round row")
+        self.loss_config = train_config["loss"]
+        self.pitch_config = preprocess_config["preprocessing"]["pitch"]
+        self.use_pitch_embed = model_config["variance_embedding"]["use_pitch_embed"]
+        self.use_energy_embed = model_config["variance_embedding"]["use_energy_embed"]
+        self.var_start_steps = train_config["step"]["var_start_steps"]
+        self.sil_ph_ids = SIL_PHONEME_IDS
+
+    @staticmethod
+    def _masked_l1_mel(pred, target, pad_mask):
+        pred = pred.masked_fill(pad_mask.unsqueeze(-1), 0)
+        target = target.masked_fill(pad_mask.unsqueeze(-1), 0)
+        w = target.abs().sum(-1, keepdim=True).ne(0).float().expand_as(target)
+        return ((pred - target).abs() * w).sum() / w.sum()
+
+    def _duration_loss(self, dur_pred, dur_gt, txt_tokens, nonpad):
+        losses = {}
+        B, T = txt_tokens.shape
+        dur_gt = dur_gt.float() * nonpad
+        is_sil = torch.zeros_like(txt_tokens).bool()
+        for p_id in self.sil_ph_ids:
+            is_sil = is_sil | (txt_tokens == p_id)
+        is_sil = is_sil.float()
+        pd = F.mse_loss(dur_pred, (dur_gt + 1).log(), reduction="none")
+        losses["pdur"] = (pd * nonpad).sum() / nonpad.sum() * self.loss_config["lambda_ph_dur"]
+        dur_lin = (dur_pred.exp() - 1).clamp(min=0)
+        if self.loss_config["lambda_word_dur"] > 0:
+            word_id = (is_sil.cumsum(-1) * (1 - is_sil)).long()
+            wp = dur_lin.new_zeros([B, T + 1]).scatter_add(1, word_id, dur_lin)[:, 1:]
+            wg = dur_gt.new_zeros([B, T + 1]).scatter_add(1, word_id, dur_gt)[:, 1:]
+            wl = F.mse_loss((wp + 1).log(), (wg + 1).log(), reduction="none")
+            wn = (wg > 0).float()
+            losses["wdur"] = (wl * wn).sum() / wn.sum() * self.loss_config["lambda_word_dur"]
+        if self.loss_config["lambda_sent_dur"] > 0:
+            sl = F.mse_loss((dur_lin.sum(-1) + 1).log(), (dur_gt.sum(-1) + 1).log(), reduction="mean")
+            losses["sdur"] = sl.mean() * self.loss_config["lambda_sent_dur"]
+        return losses
+
+    def _pitch_loss(self, p_pred, p_tgt, mel_nonpad):
+        lam = self.loss_config["lambda_f0"]
+        losses = {}
+        cwt_pred = p_pred["cwt"][:, :, :10]
+        if self.loss_config["cwt_loss"] == "l1":
+            losses["C"] = F.l1_loss(cwt_pred, p_tgt["cwt_spec"]) * lam
+        else:
+            losses["C"] = F.mse_loss(cwt_pred, p_tgt["cwt_spec"]) * lam
+        if self.pitch_config["use_uv"]:
+            uv_pred = p_pred["cwt"][:, :, -1]
+            losses["uv"] = ((F.binary_cross_entropy_with_logits(uv_pred, p_tgt["uv"], reduction="none") * mel_nonpad).sum()
+                            / mel_nonpad.sum() * self.loss_config["lambda_uv"])
+        losses["f0_mean"] = F.l1_loss(p_pred["f0_mean"], p_tgt["f0_mean"]) * lam
+        losses["f0_std"] = F.l1_loss(p_pred["f0_std"], p_tgt["f0_std"]) * lam
+        return losses
+
+    def forward(self, inputs, predictions, step):
+        (texts, _, _, mel_targets, _, _, pitch_targets, energy_targets, duration_targets, _, _) = inputs[3:]
+        (mel_pred, post_pred, p_pred, e_pred, log_d, _, src_masks, mel_masks, src_lens, mel_lens, _, _) = predictions
+        src_nonpad = (~src_masks)
+        mel_nonpad = (~mel_masks)
+        mel_targets = mel_targets[:, : mel_masks.shape[1], :]
+        mel_loss = self._masked_l1_mel(mel_pred, mel_targets, mel_masks)
+        postnet_mel_loss = self._masked_l1_mel(post_pred, mel_targets, mel_masks)
+        zero = torch.zeros(1, device=mel_targets.device)
+        total = mel_loss + postnet_mel_loss + zero + zero + zero
+        duration_loss = {"pdur": zero, "wdur": zero, "sdur": zero}
+        pitch_loss = {"C": zero, "uv": zero, "f0_mean": zero, "f0_std": zero}
+        energy_loss = zero
+        if step > self.var_start_steps:
+            duration_loss = self._duration_loss(log_d, duration_targets, texts, src_nonpad.float())
+            if self.use_pitch_embed:
+                pitch_loss = self._pitch_loss(p_pred, pitch_targets, mel_nonpad.float())
+            if self.use_energy_embed:
+                m = src_nonpad.float()
+                energy_loss = ((e_pred - energy_targets).abs() * m).sum() / m.sum()
+            total = total + sum(duration_loss.values()) + sum(pitch_loss.values()) + energy_loss
+        return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, zero, zero, zero)
+
+
+class ScheduledOptim:
+    """Adam(betas, eps) + Noam warm-up with step annealing (model/optimizer.py:5-53).
+    `capturable=True` keeps the learning rate in a device tensor so the step can live in a hipGraph."""
+
+    def __init__(self, model, train_config, model_config, current_step, capturable=False):
+        oc = train_config["optimizer"]
+        dev = next(model.parameters()).device
+        self.capturable = capturable and dev.type == "cuda"
+        lr0 = torch.tensor(1e-3, device=dev) if self.capturable else 1e-3
+        self._optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr0, betas=tuple(oc["betas"]),
+                                           eps=oc["eps"], weight_decay=oc["weight_decay"],
+                                           capturable=self.capturable, fused=True if dev.type == "cuda" else None)
+        self.n_warmup_steps = oc["warm_up_step"]
+        self.anneal_steps = oc["anneal_steps"]
+        self.anneal_rate = oc["anneal_rate"]
+        self.current_step = current_step
+        self.init_lr = np.power(model_config["transformer"]["encoder_hidden"], -0.5)
+
+    def _get_lr_scale(self):
+        lr = np.min([np.power(self.current_step, -0.5), np.power(self.n_warmup_steps, -1.5) * self.current_step])
+        for s in self.anneal_steps:
+            if self.current_step > s:
+                lr = lr * self.anneal_rate
+        return lr
+
+    def update_learning_rate(self):
+        self.current_step += 1
+        lr = float(self.init_lr * self._get_lr_scale())
+        for g in self._optimizer.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+        return lr
+
+    def step_and_update_lr(self, scaler=None):
+        lr = self.update_learning_rate()
+        if scaler is not None:
+            scaler.step(self._optimizer)
+        else:
+            self._optimizer.step()
+        return lr
+
+    def zero_grad(self):
+        self._optimizer.zero_grad()
+
+    def load_state_dict(self, sd):
+        self._optimizer.load_state_dict(sd)

@@ -123,10 +123,11 @@ def test_linear_tiny_heads():
     # N = 1, 2, 11 heads (duration / stats / cwt linear layers) incl. their backward (unaligned scalar path)
     for N in (1, 2, 11):
         x, w, b = rnd(5, 33, 256, seed=40), rnd(N, 256, seed=41, scale=0.1), rnd(N, seed=42)
+        rs = (rnd(5 * 33, seed=44) > -0.4).float()
         xr, wr, br = [t.double().requires_grad_() for t in (x, w, b)]
-        yr = xr @ wr.t() + br
+        yr = (xr @ wr.t() + br) * rs.double().view(5, 33, 1)
         xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
-        y = ops.linear(xg, wg, bg)
+        y = ops.linear(xg, wg, bg, rowscale=rs.to(DEV))
         close(y, yr, 1e-5, f"head{N} fwd")
         go = rnd(5, 33, N, seed=43)
         yr.backward(go.double())
@@ -277,5 +278,12 @@ def test_mel_spectrogram_vs_reference_golden():
     assert mel.shape == g["mel"].shape and energy.shape == g["energy"].shape
     close(mag, torch.from_numpy(g["mag"]), 2e-5, "magnitude")
     close(energy, torch.from_numpy(g["energy"]), 2e-5, "energy")
-    err = (mel.cpu() - torch.from_numpy(g["mel"])).abs().max().item()
-    assert err < 1e-3, f"log-mel max-abs {err}"
+    ref = torch.from_numpy(g["mel"])
+    # log() amplifies fp32 rounding noise of near-silent bins (pure-tone row: leakage ~1e-6): compare the
+    # log-mel where the bin carries signal, and the linear mel everywhere relative to full scale.
+    loud = ref.exp() > 1e-3
+    err = (mel.cpu() - ref)[loud].abs().max().item()
+    assert err < 1e-3, f"log-mel max-abs {err} on bins above 1e-3"
+    lin = (mel.cpu().exp() - ref.exp()).abs().max().item() / ref.exp().max().item()
+    assert lin < 1e-5, f"linear mel relative-to-full-scale error {lin}"
+    print(f"log-mel max-abs (loud bins) {err:.2e}; linear mel rel err {lin:.2e}; loud fraction {loud.float().mean():.2f}")
