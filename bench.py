@@ -50,14 +50,11 @@ class TrainStep:
         self.args = as_model_args(batch)
         self.loss_inputs = [None, None] + list(self.args)
         self.step_no = 50001
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        from ctts_amd.dp import FlatGradArena
         # flat fp32 gradient arena: p.grad are views -> one all-reduce, no bucket copies
-        n = sum(p.numel() for p in self.params)
-        self.flat_grad = torch.zeros(n, device=self.params[0].device)
-        o = 0
-        for p in self.params:
-            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
-            o += p.numel()
+        self.arena = FlatGradArena(model.parameters())
+        self.params = self.arena.params
+        self.flat_grad = self.arena.flat
         self.use_graph = use_graph
         self.g_fb = self.g_opt = None
         self.loss_val = None
@@ -74,10 +71,7 @@ class TrainStep:
         self.loss_val = losses[0].detach()
 
     def reduce(self):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_grad)
-            self.flat_grad.div_(self.world)
+        self.arena.all_reduce_mean(self.world)
 
     def clip_and_step(self):
         torch.nn.utils.clip_grad_norm_(self.params, 1.0, foreach=True)

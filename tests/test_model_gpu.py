@@ -162,7 +162,8 @@ def test_train_step_with_dropout_runs_and_is_finite():
     m.train()
     batch = make_batch([40, 33, 21, 12], 8, seed=9)
     out = m(*as_model_args(to_device(batch, DEV)))
-    loss = out[0].abs().mean() + out[1].abs().mean() + out[4].pow(2).mean() + out[3].pow(2).mean() + out[2]["cwt"].abs().mean()
+    loss = (out[0].abs().mean() + out[1].abs().mean() + out[4].pow(2).mean() + out[3].pow(2).mean() + out[2]["cwt"].abs().mean()
+            + out[2]["f0_mean"].abs().mean() + out[2]["f0_std"].abs().mean())
     loss.backward()
     tot = 0.0
     for k, p in m.named_parameters():
