@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libctts_hip.so")
+LIB_PATH = os.environ.get("CTTS_LIB") or os.path.join(_HERE, "csrc", "libctts_hip.so")   # CTTS_LIB: tuning A/B builds
 
 _c_f32p = C.c_void_p
 _i32, _i64, _f32, _u32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_void_p
@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("p_drop", _f32), ("seed", _vp), ("drop_offset", _u32),
         ("R", _vp), ("ldr", _i64),
         ("rowscale", _vp),
+        ("row_lens", _vp), ("row_T", _i32), ("row_halo", _i32),
     ]
 
 

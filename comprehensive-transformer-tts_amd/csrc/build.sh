@@ -1,17 +1,21 @@
 #!/bin/bash
 # Build libctts_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+#   CTTS_VARIANT=name CTTS_CXXFLAGS="-DCTTS_BK=64 -DCTTS_GEMM_WAVES=2" build.sh  -> libctts_hip_name.so (tuning A/B builds)
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-OUT=libctts_hip.so
+SUF=${CTTS_VARIANT:+_$CTTS_VARIANT}
+OUT=libctts_hip${SUF}.so
+OBJ=.obj${SUF}
+mkdir -p $OBJ
 SRCS="gemm.hip lr.hip norm.hip elementwise.hip"
-newest=$(ls -t $SRCS ctts_common.h ../../include/ctts.h | head -1)
-if [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then echo "libctts_hip.so up to date"; exit 0; fi
+newest=$(ls -t $SRCS ctts_common.h ../../include/ctts.h build.sh | head -1)
+if [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then echo "$OUT up to date"; exit 0; fi
 objs=""
 for s in $SRCS; do
-  o="${s%.hip}.o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ ctts_common.h -nt "$o" ] || [ ../../include/ctts.h -nt "$o" ]; then
-    $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" &
+  o="$OBJ/${s%.hip}.o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ ctts_common.h -nt "$o" ] || [ ../../include/ctts.h -nt "$o" ] || [ build.sh -nt "$o" ]; then
+    $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC $CTTS_CXXFLAGS -c "$s" -o "$o" &
   fi
   objs="$objs $o"
 done

@@ -15,8 +15,16 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int KC_LD = BK + 4;  // 36 floats = 144 B row stride for K-contiguous operand tiles
+#ifndef CTTS_BK
+#define CTTS_BK 32
+#endif
+#ifndef CTTS_GEMM_WAVES
+#define CTTS_GEMM_WAVES 3
+#endif
+constexpr int BK = CTTS_BK;       // K elements staged per barrier pair (32 or 64); MFMA sub-blocks are always 32 deep
+constexpr int KC_LD = BK + 4;     // row stride of K-contiguous operand tiles: 36 / 68 floats -> conflict-free b128 groups
+constexpr int KCH = BK / 4;       // float4 chunks per tile row
+static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
 
 struct ConvView {
   int T, pad, cin;
@@ -34,11 +42,11 @@ struct LoaderKC {
   int trow[NV];
   __device__ void init(const float* p, long ld_, int row0_, int row_lim_, bool vec_, ConvView cv_) {
     base = p; ld = ld_; row0 = row0_; row_lim = row_lim_; vec = vec_; cv = cv_;
-    kq = (threadIdx.x & 7) << 2;
+    kq = (threadIdx.x % KCH) << 2;
     if (CONV) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        int gr = row0 + ((threadIdx.x + i * 256) >> 3);
+        int gr = row0 + ((threadIdx.x + i * 256) / KCH);
         trow[i] = gr % cv.T;
       }
     }
@@ -49,7 +57,7 @@ struct LoaderKC {
     if (CONV) tap = gk / cv.cin - cv.pad;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int gr = row0 + ((threadIdx.x + i * 256) >> 3);
+      const int gr = row0 + ((threadIdx.x + i * 256) / KCH);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < row_lim && gk < k_end) {
         const float* p = base + (long)gr * ld + gk;
@@ -74,7 +82,7 @@ struct LoaderKC {
   __device__ __forceinline__ void store(float* s, const float4 (&r)[NV]) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int row = (threadIdx.x + i * 256) >> 3;
+      const int row = (threadIdx.x + i * 256) / KCH;
       *reinterpret_cast<float4*>(s + row * KC_LD + kq) = r[i];
     }
   }
@@ -143,23 +151,23 @@ struct LoaderSel<false, EXT, CONV> { using type = LoaderRC<EXT, CONV>; };
 
 // fragment fetch for one 32-wide MFMA tile: 16 k-steps, lane (l31, h) gets element k = h*16 + j
 template <bool KC, int LD>
-__device__ __forceinline__ void fetch_frag(const float* s, int ext0, int l31, int h, float (&f)[16]) {
+__device__ __forceinline__ void fetch_frag(const float* s, int ext0, int l31, int h, int ksub, float (&f)[16]) {
   if (KC) {
-    const float4* p = reinterpret_cast<const float4*>(s + (ext0 + l31) * LD + h * 16);
+    const float4* p = reinterpret_cast<const float4*>(s + (ext0 + l31) * LD + ksub + h * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 v = p[q];
       f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
     }
   } else {
-    const float* p = s + (h * 16) * LD + ext0 + l31;
+    const float* p = s + (ksub + h * 16) * LD + ext0 + l31;
 #pragma unroll
     for (int j = 0; j < 16; ++j) f[j] = p[j * LD];
   }
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(const ctts_gemm_desc d) {
+__global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_gemm_desc d) {
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
   constexpr int A_LD = A_KC ? KC_LD : BM + 4;
   constexpr int B_LD = B_KC ? KC_LD : BN + 4;
@@ -188,6 +196,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ctts_gemm_desc d) {
   const int row0 = (wg / tiles_n) * BM, col0 = (wg % tiles_n) * BN;
   if (row0 >= Mv || col0 >= Nv) return;
 
+  if (A_KC && d.row_lens) {  // whole tile of padded rows -> zeros, no operand traffic, no MFMA
+    const int last = min(row0 + BM, Mv) - 1;
+    const int b0 = row0 / d.row_T, b1 = last / d.row_T;
+    if (b0 == b1 && (row0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo) {
+      float* Cz = d.C + z0 * d.sC0 + z1 * d.sC1;
+      const int ncols = min(BN, Nv - col0), nrows = last - row0 + 1;
+      for (int e = threadIdx.x; e < nrows * ncols; e += 256) {
+        const int r = e / ncols, c = e - r * ncols;
+        Cz[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
+        if (d.Z) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
+      }
+      return;
+    }
+  }
   int k_begin = 0, k_end = Kv;
   if (d.split_k > 1) {
     int chunk = ((Kv + d.split_k - 1) / d.split_k + BK - 1) / BK * BK;
@@ -226,37 +248,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ctts_gemm_desc d) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // weight-gradient reductions run over (b,t) rows: K-blocks that lie entirely in the padding of one
+  // sequence contribute exactly zero (dZ is zero there) and are skipped (block-uniform decision)
+  constexpr bool KSKIP = !A_KC && !B_KC;
+  auto kblock_active = [&](int k0) -> bool {
+    if (!KSKIP || !d.row_lens) return true;
+    const int lastk = min(k0 + BK, k_end) - 1;
+    const int b0 = k0 / d.row_T;
+    return !(b0 == lastk / d.row_T && (k0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo);
+  };
   float4 ra[LA::NV], rb[LB::NV];
-  la.load(k_begin, k_end, ra);
-  lb.load(k_begin, k_end, rb);
-  la.store(sA, ra);
-  lb.store(sB, rb);
+  bool act_cur = kblock_active(k_begin);
+  if (act_cur) {
+    la.load(k_begin, k_end, ra);
+    lb.load(k_begin, k_end, rb);
+    la.store(sA, ra);
+    lb.store(sB, rb);
+  }
   __syncthreads();
 
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     const bool has_next = (k0 + BK) < k_end;
-    if (has_next) {
+    const bool act_next = has_next && kblock_active(k0 + BK);
+    if (act_next) {
       la.load(k0 + BK, k_end, ra);
       lb.load(k0 + BK, k_end, rb);
     }
-    float fa[MT][16], fb[NT][16];
+    if (act_cur) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) fetch_frag<A_KC, A_LD>(sA, wm0 + i * 32, l31, h, fa[i]);
+      for (int ksub = 0; ksub < BK; ksub += 32) {
+        float fa[MT][16], fb[NT][16];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sB, wn0 + j * 32, l31, h, fb[j]);
+        for (int i = 0; i < MT; ++i) fetch_frag<A_KC, A_LD>(sA, wm0 + i * 32, l31, h, ksub, fa[i]);
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
+        for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sB, wn0 + j * 32, l31, h, ksub, fb[j]);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (KSKIP && !act_cur && !act_next) continue;   // nothing staged, nothing to publish: no barrier needed
     __syncthreads();
-    if (has_next) {
+    if (act_next) {
       la.store(sA, ra);
       lb.store(sB, rb);
     }
     __syncthreads();
+    act_cur = act_next;
   }
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

@@ -29,7 +29,7 @@ class _LinearConv(torch.autograd.Function):
     modules.py:140-148,1299-1356 and CompTransTTS.py:133 (fwd, dgrad, wgrad all on MFMA)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, rowscale, act, alpha, p_drop, seed, drop_offset, ksize):
+    def forward(ctx, x, w, b, residual, rowscale, act, alpha, p_drop, seed, drop_offset, ksize, row_lens, row_T):
         x = x.contiguous()
         Cin = x.shape[-1]
         M = x.numel() // Cin
@@ -47,15 +47,17 @@ class _LinearConv(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         K.gemm(x, wf, out, M, N, Kdim, Cin, Kdim, N, True, True, conv=conv, alpha=alpha, bias=b, Z=Z, ldz=N, act=act,
-               p_drop=p_drop, seed=seed, drop_offset=drop_offset, R=residual, ldr=N, rowscale=rowscale)
-        ctx.save_for_backward(x, w, Z, rowscale, seed)
-        ctx.cfg = (act, alpha, p_drop, drop_offset, ksize, b is not None, residual is not None)
+               p_drop=p_drop, seed=seed, drop_offset=drop_offset, R=residual, ldr=N, rowscale=rowscale,
+               row_lens=row_lens, row_T=row_T, row_halo=0)
+        ctx.save_for_backward(x, w, Z, rowscale, seed, row_lens)
+        ctx.cfg = (act, alpha, p_drop, drop_offset, ksize, b is not None, residual is not None, row_T)
         return out
 
     @staticmethod
     def backward(ctx, dY):
-        x, w, Z, rowscale, seed = ctx.saved_tensors
-        act, alpha, p_drop, drop_offset, ksize, has_bias, has_res = ctx.cfg
+        x, w, Z, rowscale, seed, row_lens = ctx.saved_tensors
+        act, alpha, p_drop, drop_offset, ksize, has_bias, has_res, row_T = ctx.cfg
+        rl = dict(row_lens=row_lens, row_T=row_T) if row_lens is not None else {}
         dY = dY.contiguous()
         Cin = x.shape[-1]
         M = x.numel() // Cin
@@ -78,34 +80,42 @@ class _LinearConv(torch.autograd.Function):
                 wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
                 K.conv_weight_repack(w.contiguous(), wd, N, Cin, ksize, 1)
                 dX = torch.empty_like(x)
-                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, conv=(T, pad, N), alpha=alpha)
+                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, conv=(T, pad, N), alpha=alpha, row_halo=pad, **rl)
             if ctx.needs_input_grad[1]:
                 Kd = ksize * Cin
                 dwf = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
                 K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                       split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha)
+                       split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
                 dW = torch.empty_like(w)
                 K.conv_weight_repack(dwf, dW, N, Cin, ksize, 2)
         else:
             if ctx.needs_input_grad[0]:
                 dX = torch.empty_like(x)
-                K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha)
+                K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha, **rl)
             if ctx.needs_input_grad[1]:
                 dW = torch.zeros_like(w)
-                K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha)
-        return dX, dW, dB, d_res, None, None, None, None, None, None, None
+                K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha, **rl)
+        return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None):
+def _pad_rows(pad_rows):
+    return (pad_rows[0], int(pad_rows[1])) if pad_rows is not None else (None, 0)
+
+
+def linear(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None, pad_rows=None):
+    """pad_rows=(lens int32 [B], T): rows (b,t) with t >= lens[b] are padding - their outputs are don't-care
+    (written as zero) and the incoming gradient there is zero, so whole padded tiles / K-blocks are skipped."""
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
-    return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off, 0)
+    rl, rT = _pad_rows(pad_rows)
+    return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off, 0, rl, rT)
 
 
-def conv1d(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None):
+def conv1d(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None, pad_rows=None):
     """x [B,T,Cin], w [Cout,Cin,k] (nn.Conv1d layout), 'same' zero padding, stride 1."""
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
+    rl, rT = _pad_rows(pad_rows)
     return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off,
-                             w.shape[2])
+                             w.shape[2], rl, rT)
 
 
 class _LayerNorm(torch.autograd.Function):

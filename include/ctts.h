@@ -56,6 +56,11 @@ typedef struct ctts_gemm_desc {
   float p_drop; const uint64_t* seed; uint32_t drop_offset;   /* inverted dropout after act           */
   const float* R; int64_t ldr;            /* residual added after dropout                             */
   const float* rowscale;                  /* [M] multiplied last (non-pad mask), or NULL              */
+  /* Padded-row skipping.  Rows (of C for a_kc=1, of the reduction dim for the TN layout) are (b,t) pairs,
+   * t = row % row_T; rows with t >= row_lens[b] + row_halo are padding whose result is defined as ZERO:
+   * whole output tiles of such rows are zero-filled without touching the operands (a_kc=1), and K-blocks
+   * of such rows are skipped in weight-gradient reductions (a_kc=0, b_kc=0).  NULL = off.               */
+  const int32_t* row_lens; int32_t row_T; int32_t row_halo;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);

@@ -287,3 +287,30 @@ def test_mel_spectrogram_vs_reference_golden():
     lin = (mel.cpu().exp() - ref.exp()).abs().max().item() / ref.exp().max().item()
     assert lin < 1e-5, f"linear mel relative-to-full-scale error {lin}"
     print(f"log-mel max-abs (loud bins) {err:.2e}; linear mel rel err {lin:.2e}; loud fraction {loud.float().mean():.2f}")
+
+
+def test_pad_row_skipping_is_equivalent_on_valid_rows():
+    """Padded-row tile / K-block skipping (ctts_gemm_desc.row_lens) changes nothing that the model consumes:
+    valid rows of the forward, and every gradient when the upstream gradient is zero on padded rows."""
+    B, T, C = 3, 384, 256
+    lens = torch.tensor([384, 100, 200], dtype=torch.int32)
+    valid = (torch.arange(T)[None, :] < lens[:, None])
+    rs = valid.float().reshape(-1)
+    x = rnd(B, T, C, seed=90)
+    for kind in ("linear", "conv"):
+        w = rnd(512, C, 9, seed=91, scale=0.05) if kind == "conv" else rnd(512, C, seed=91, scale=0.05)
+        b = rnd(512, seed=92)
+        go = rnd(B, T, 512, seed=93) * valid[..., None]
+        res = []
+        for pr in (None, (lens.to(DEV), T)):
+            xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+            fn = ops.conv1d if kind == "conv" else ops.linear
+            y = fn(xg, wg, bg, act=ops.ACT_GELU, alpha=0.7, pad_rows=pr)
+            y.backward(go.to(DEV))
+            res.append((y.detach(), xg.grad, wg.grad, bg.grad))
+        (y0, dx0, dw0, db0), (y1, dx1, dw1, db1) = res
+        close(y1[valid], y0[valid], 1e-6, f"{kind} fwd valid rows")
+        assert float(y1[2, 256:].abs().max()) == 0.0          # fully padded tile was zero-filled, not computed
+        close(dx1, dx0, 1e-6, f"{kind} dx")
+        close(dw1, dw0, 2e-5, f"{kind} dw")
+        close(db1, db0, 1e-5, f"{kind} db")
