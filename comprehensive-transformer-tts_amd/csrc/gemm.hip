@@ -19,7 +19,7 @@ namespace {
 #define CTTS_BK 32
 #endif
 #ifndef CTTS_GEMM_WAVES
-#define CTTS_GEMM_WAVES 3
+#define CTTS_GEMM_WAVES 2
 #endif
 constexpr int BK = CTTS_BK;       // K elements staged per barrier pair (32 or 64); MFMA sub-blocks are always 32 deep
 constexpr int KC_LD = BK + 4;     // row stride of K-contiguous operand tiles: 36 / 68 floats -> conflict-free b128 groups
@@ -144,10 +144,112 @@ struct LoaderRC {
   }
 };
 
-template <bool KC, int EXT, bool CONV>
+
+// ---------------------------------------------------------------------------------------------
+// Branch-free loaders for the aligned case (VEC): every 16-byte chunk is fetched UNCONDITIONALLY
+// from an in-bounds address (invalid chunks read a safe dummy address) and the validity mask is
+// applied only when the registers are written to LDS.  Nothing between the global_load and the
+// ds_write consumes the loaded value, so hipcc keeps the loads in flight across the MFMA block
+// (a select / branch join on the loaded value would force an s_waitcnt vmcnt(0) before the MFMAs).
+// Requirements (checked on the host): leading dimensions, batch strides and base pointers are
+// multiples of 4 floats and the contiguous extent (K, or M/N for row-contiguous operands) is a
+// multiple of 4, so a chunk that starts inside the hard extent lies entirely inside it.
+__device__ __forceinline__ float4 mask4(float4 v, int nv) {
+  v.x = nv > 0 ? v.x : 0.f; v.y = nv > 1 ? v.y : 0.f; v.z = nv > 2 ? v.z : 0.f; v.w = nv > 3 ? v.w : 0.f;
+  return v;
+}
+
+template <int ROWS, bool CONV>
+struct VLoaderKC {
+  static constexpr int NV = ROWS * BK / 4 / 256;
+  const float* base; const float* safe;
+  long ld;
+  int row0, row_lim, kq;
+  ConvView cv;
+  int trow[NV];
+  int nval[NV];
+  __device__ void init(const float* p, const float* safe_, long ld_, int row0_, int row_lim_, ConvView cv_) {
+    base = p; safe = safe_; ld = ld_; row0 = row0_; row_lim = row_lim_; cv = cv_;
+    kq = (threadIdx.x % KCH) << 2;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int gr = row0 + ((threadIdx.x + i * 256) / KCH);
+      trow[i] = CONV ? gr % cv.T : 0;
+      nval[i] = 0;
+    }
+  }
+  __device__ __forceinline__ void load(int k0, int k_end, float4 (&r)[NV]) {
+    const int gk = k0 + kq;
+    int tap = 0;
+    if (CONV) tap = gk / cv.cin - cv.pad;
+    const int nk = min(4, k_end - gk);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int gr = row0 + ((threadIdx.x + i * 256) / KCH);
+      bool ok = (gr < row_lim) && (nk > 0);
+      if (CONV) { const int tt = trow[i] + tap; ok = ok && (tt >= 0) && (tt < cv.T); }
+      const float* p = ok ? base + (long)gr * ld + gk : safe;
+      r[i] = *reinterpret_cast<const float4*>(p);
+      nval[i] = ok ? nk : 0;
+    }
+  }
+  __device__ __forceinline__ void store(float* s, const float4 (&r)[NV]) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = (threadIdx.x + i * 256) / KCH;
+      *reinterpret_cast<float4*>(s + row * KC_LD + kq) = mask4(r[i], nval[i]);
+    }
+  }
+};
+
+template <int COLS, bool CONV>
+struct VLoaderRC {
+  static constexpr int NV = COLS * BK / 4 / 256;
+  static constexpr int LD = COLS + 4;
+  const float* base; const float* safe;
+  long ld;
+  int col0, col_lim;
+  ConvView cv;
+  int nval[NV];
+  __device__ void init(const float* p, const float* safe_, long ld_, int col0_, int col_lim_, ConvView cv_) {
+    base = p; safe = safe_; ld = ld_; col0 = col0_; col_lim = col_lim_; cv = cv_;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) nval[i] = 0;
+  }
+  __device__ __forceinline__ void load(int k0, int k_end, float4 (&r)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = threadIdx.x + i * 256;
+      const int k = f / (COLS / 4);
+      const int cq = (f % (COLS / 4)) << 2;
+      const int gk = k0 + k, gc = col0 + cq;
+      const int nc = min(4, col_lim - gc);
+      bool ok = (gk < k_end) && (nc > 0);
+      if (CONV) { const int tt = gk % cv.T + gc / cv.cin - cv.pad; ok = ok && (tt >= 0) && (tt < cv.T); }
+      const float* p = ok ? base + (long)gk * ld + gc : safe;
+      r[i] = *reinterpret_cast<const float4*>(p);
+      nval[i] = ok ? nc : 0;
+    }
+  }
+  __device__ __forceinline__ void store(float* s, const float4 (&r)[NV]) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = threadIdx.x + i * 256;
+      const int k = f / (COLS / 4);
+      const int cq = (f % (COLS / 4)) << 2;
+      *reinterpret_cast<float4*>(s + k * LD + cq) = mask4(r[i], nval[i]);
+    }
+  }
+};
+
+template <bool KC, int EXT, bool CONV, bool VEC>
 struct LoaderSel { using type = LoaderKC<EXT, CONV>; };
 template <int EXT, bool CONV>
-struct LoaderSel<false, EXT, CONV> { using type = LoaderRC<EXT, CONV>; };
+struct LoaderSel<false, EXT, CONV, false> { using type = LoaderRC<EXT, CONV>; };
+template <int EXT, bool CONV>
+struct LoaderSel<true, EXT, CONV, true> { using type = VLoaderKC<EXT, CONV>; };
+template <int EXT, bool CONV>
+struct LoaderSel<false, EXT, CONV, true> { using type = VLoaderRC<EXT, CONV>; };
 
 // fragment fetch for one 32-wide MFMA tile: 16 k-steps, lane (l31, h) gets element k = h*16 + j
 template <bool KC, int LD>
@@ -166,7 +268,7 @@ __device__ __forceinline__ void fetch_frag(const float* s, int ext0, int l31, in
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
+template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool VEC>
 __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_gemm_desc d) {
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
   constexpr int A_LD = A_KC ? KC_LD : BM + 4;
@@ -193,7 +295,15 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
   const int nwg = gridDim.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int row0 = (wg / tiles_n) * BM, col0 = (wg % tiles_n) * BN;
+  // m-tiles are visited in a scrambled order (odd-prime stride permutation): with padded-row skipping the
+  // empty tiles of the short sequences would otherwise all land on the same XCD (static block->XCD map)
+  const int tiles_m = nwg / tiles_n;
+  int tm = wg / tiles_n;
+  {
+    const int P = (tiles_m % 37) ? 37 : ((tiles_m % 41) ? 41 : 43);
+    tm = (int)(((long)tm * P) % tiles_m);
+  }
+  const int row0 = tm * BM, col0 = (wg % tiles_n) * BN;
   if (row0 >= Mv || col0 >= Nv) return;
 
   if (A_KC && d.row_lens) {  // whole tile of padded rows -> zeros, no operand traffic, no MFMA
@@ -221,6 +331,8 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
   const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
   const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
   float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
+  const float* Asafe = Ab;   // in-bounds, 16-B aligned dummy addresses for masked-out chunks (VEC loaders)
+  const float* Bsafe = Bb;
   ConvView cv{d.conv_T, d.conv_pad, d.conv_cin};
   ConvView nocv{1, 0, 1};
   constexpr bool CONV_A = CONV && A_KC;
@@ -228,13 +340,16 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
   if (CONV_A) Ab -= (long)d.conv_pad * d.conv_cin;
   if (CONV_B) Bb -= (long)d.conv_pad * d.conv_cin;
 
-  using LA = typename LoaderSel<A_KC, BM, CONV_A>::type;
-  using LB = typename LoaderSel<B_KC, BN, CONV_B>::type;
+  using LA = typename LoaderSel<A_KC, BM, CONV_A, VEC>::type;
+  using LB = typename LoaderSel<B_KC, BN, CONV_B, VEC>::type;
   LA la; LB lb;
-  const bool a_vec = ((d.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(Ab) & 15) == 0);
-  const bool b_vec = ((d.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bb) & 15) == 0);
-  la.init(Ab, d.lda, row0, Mv, a_vec, CONV_A ? cv : nocv);
-  lb.init(Bb, d.ldb, col0, Nv, b_vec, CONV_B ? cv : nocv);
+  if constexpr (VEC) {
+    la.init(Ab, Asafe, d.lda, row0, Mv, CONV_A ? cv : nocv);
+    lb.init(Bb, Bsafe, d.ldb, col0, Nv, CONV_B ? cv : nocv);
+  } else {
+    la.init(Ab, d.lda, row0, Mv, false, CONV_A ? cv : nocv);
+    lb.init(Bb, d.ldb, col0, Nv, false, CONV_B ? cv : nocv);
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -343,24 +458,33 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
+template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool VEC>
 int launch(const ctts_gemm_desc& d, hipStream_t st) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
   const int nz = d.split_k > 1 ? d.split_k : d.nb0 * d.nb1;
   dim3 grid(tiles, 1, nz);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, CONV>), grid, dim3(256), 0, st, d);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, CONV, VEC>), grid, dim3(256), 0, st, d);
   CTTS_CHECK_LAUNCH("ctts_gemm");
   return 0;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool VEC>
 int dispatch_layout(const ctts_gemm_desc& d, hipStream_t st) {
   const bool conv = d.conv_T > 0;
-  if (d.a_kc && d.b_kc) return conv ? launch<BM, BN, true, true, true>(d, st) : launch<BM, BN, true, true, false>(d, st);
-  if (d.a_kc && !d.b_kc) return conv ? launch<BM, BN, true, false, true>(d, st) : launch<BM, BN, true, false, false>(d, st);
-  if (!d.a_kc && !d.b_kc) return conv ? launch<BM, BN, false, false, true>(d, st) : launch<BM, BN, false, false, false>(d, st);
+  if (d.a_kc && d.b_kc) return conv ? launch<BM, BN, true, true, true, VEC>(d, st) : launch<BM, BN, true, true, false, VEC>(d, st);
+  if (d.a_kc && !d.b_kc) return conv ? launch<BM, BN, true, false, true, VEC>(d, st) : launch<BM, BN, true, false, false, VEC>(d, st);
+  if (!d.a_kc && !d.b_kc) return conv ? launch<BM, BN, false, false, true, VEC>(d, st) : launch<BM, BN, false, false, false, VEC>(d, st);
   ctts_set_error("ctts_gemm: layout a_kc=0,b_kc=1 is not instantiated");
   return -1;
+}
+
+// eligibility of the branch-free 16-byte loaders (see VLoaderKC)
+bool vec_ok(const ctts_gemm_desc& d) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool strides = !((d.lda | d.ldb | d.sA0 | d.sA1 | d.sB0 | d.sB1) & 3);
+  const bool a_ext = d.a_kc ? (d.K % 4 == 0) : (d.M % 4 == 0);
+  const bool b_ext = d.b_kc ? (d.K % 4 == 0) : (d.N % 4 == 0);
+  return strides && a_ext && b_ext && al16(d.A) && al16(d.B);
 }
 
 }  // namespace
@@ -381,6 +505,7 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   CTTS_REQUIRE(d.p_drop >= 0.f && d.p_drop < 1.f, "ctts_gemm: p_drop out of range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : d.nb0 * d.nb1);
-  if (tiles128 >= 256 && d.N > 64) return dispatch_layout<128, 128>(d, st);
-  return dispatch_layout<64, 64>(d, st);
+  if (!vec_ok(d)) return dispatch_layout<64, 64, false>(d, st);   // unaligned shapes (N = 1, 2, 11 heads): scalar loaders
+  if (tiles128 >= 256 && d.N > 64) return dispatch_layout<128, 128, true>(d, st);
+  return dispatch_layout<64, 64, true>(d, st);
 }
