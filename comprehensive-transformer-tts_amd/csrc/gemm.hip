@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
   constexpr int B_LD = B_KC ? KC_LD : BN + 4;
   constexpr int A_SZ = A_KC ? BM * KC_LD : BK * (BM + 4);
   constexpr int B_SZ = B_KC ? BN * KC_LD : BK * (BN + 4);
-  __shared__ __attribute__((aligned(16))) float smem[A_SZ + B_SZ];
+  constexpr int STAGE = A_SZ + B_SZ;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
   float* sA = smem;
   float* sB = smem + A_SZ;
 
@@ -372,48 +373,62 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
     const int b0 = k0 / d.row_T;
     return !(b0 == lastk / d.row_T && (k0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo);
   };
+  // ---- main loop: two LDS stages, ONE barrier per K-block.
+  //   iteration i:  [regs(tile i+1) -> LDS stage (i+1)&1]  [global loads of tile i+2 -> regs]
+  //                 [fragments of tile i from stage i&1 -> 64 MFMAs]  barrier
+  // Everything before the barrier is independent of the MFMAs, so staging work overlaps the matrix pipe;
+  // stage (i+1)&1 was last read in iteration i-1, which every wave left through the barrier.
   float4 ra[LA::NV], rb[LB::NV];
-  bool act_cur = kblock_active(k_begin);
-  if (act_cur) {
+  const int nkb = (k_end - k_begin + BK - 1) / BK;
+  bool act0 = kblock_active(k_begin);
+  if (act0) {
     la.load(k_begin, k_end, ra);
     lb.load(k_begin, k_end, rb);
     la.store(sA, ra);
     lb.store(sB, rb);
   }
+  bool act1 = nkb > 1 && kblock_active(k_begin + BK);
+  if (act1) {
+    la.load(k_begin + BK, k_end, ra);
+    lb.load(k_begin + BK, k_end, rb);
+  }
   __syncthreads();
-
-  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    const bool has_next = (k0 + BK) < k_end;
-    const bool act_next = has_next && kblock_active(k0 + BK);
-    if (act_next) {
-      la.load(k0 + BK, k_end, ra);
-      lb.load(k0 + BK, k_end, rb);
+  bool act_cur = act0, act_next = act1;
+  for (int i = 0; i < nkb; ++i) {
+    float* sAc = sA + (i & 1) * STAGE;
+    float* sBc = sB + (i & 1) * STAGE;
+    float* sAn = sA + ((i + 1) & 1) * STAGE;
+    float* sBn = sB + ((i + 1) & 1) * STAGE;
+    if (act_next) {          // tile i+1 is in registers (loaded during iteration i-1)
+      la.store(sAn, ra);
+      lb.store(sBn, rb);
+    }
+    const int k2 = k_begin + (i + 2) * BK;
+    const bool act_nn = (i + 2 < nkb) && kblock_active(k2);
+    if (act_nn) {
+      la.load(k2, k_end, ra);
+      lb.load(k2, k_end, rb);
     }
     if (act_cur) {
 #pragma unroll
       for (int ksub = 0; ksub < BK; ksub += 32) {
         float fa[MT][16], fb[NT][16];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fetch_frag<A_KC, A_LD>(sA, wm0 + i * 32, l31, h, ksub, fa[i]);
+        for (int ii = 0; ii < MT; ++ii) fetch_frag<A_KC, A_LD>(sAc, wm0 + ii * 32, l31, h, ksub, fa[ii]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sB, wn0 + j * 32, l31, h, ksub, fb[j]);
+        for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sBc, wn0 + j * 32, l31, h, ksub, fb[j]);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
+          for (int ii = 0; ii < MT; ++ii)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+              acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ii][kk], fb[j][kk], acc[ii][j], 0, 0, 0);
       }
     }
-    if (KSKIP && !act_cur && !act_next) continue;   // nothing staged, nothing to publish: no barrier needed
-    __syncthreads();
-    if (act_next) {
-      la.store(sA, ra);
-      lb.store(sB, rb);
-    }
-    __syncthreads();
+    if (act_cur || act_next) __syncthreads();   // block-uniform; nothing staged and nothing read -> no barrier needed
     act_cur = act_next;
+    act_next = act_nn;
   }
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

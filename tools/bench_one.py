@@ -1,0 +1,32 @@
+"""Single-shape GEMM loop for PMC collection: python tools/bench_one.py ffn1|dgrad|wgrad|qkv [iters]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ctts_amd import kernels as K, ops
+dev = "cuda"
+which = sys.argv[1] if len(sys.argv) > 1 else "ffn1"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+B, T = 16, 1024
+M = B * T
+if which == "ffn1":
+    x = torch.randn(B, T, 256, device=dev); wf = torch.randn(1024, 2304, device=dev); C = torch.empty(B, T, 1024, device=dev)
+    fn = lambda: K.gemm(x, wf, C, M, 1024, 2304, 256, 2304, 1024, True, True, conv=(T, 4, 256)); fl = 2 * M * 1024 * 2304
+elif which == "dgrad":
+    dz = torch.randn(M, 1024, device=dev); wd = torch.randn(256, 9216, device=dev); C = torch.empty(B, T, 256, device=dev)
+    fn = lambda: K.gemm(dz, wd, C, M, 256, 9216, 1024, 9216, 256, True, True, conv=(T, 4, 1024)); fl = 2 * M * 256 * 9216
+elif which == "wgrad":
+    x = torch.randn(B, T, 256, device=dev); dz = torch.randn(M, 1024, device=dev); C = torch.zeros(1024, 2304, device=dev)
+    fn = lambda: K.gemm(dz, x, C, 1024, 2304, M, 1024, 256, 2304, False, False, conv=(T, 4, 256), conv_on_b=True, split_k=4); fl = 2 * M * 1024 * 2304
+else:
+    x = torch.randn(M, 256, device=dev); w = torch.randn(768, 256, device=dev); C = torch.empty(M, 768, device=dev)
+    fn = lambda: K.gemm(x, w, C, M, 768, 256, 256, 256, 768, True, True); fl = 2 * M * 768 * 256
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(iters):
+    fn()
+e.record(); torch.cuda.synchronize()
+t = s.elapsed_time(e) / iters * 1e-3
+print(f"{which}: {t*1e6:.1f} us  {fl/t/1e12:.2f} TFLOP/s")
