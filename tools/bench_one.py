@@ -17,6 +17,10 @@ elif which == "dgrad":
 elif which == "wgrad":
     x = torch.randn(B, T, 256, device=dev); dz = torch.randn(M, 1024, device=dev); C = torch.zeros(1024, 2304, device=dev)
     fn = lambda: K.gemm(dz, x, C, 1024, 2304, M, 1024, 256, 2304, False, False, conv=(T, 4, 256), conv_on_b=True, split_k=4); fl = 2 * M * 1024 * 2304
+elif which == "sq":
+    n = 4096
+    x = torch.randn(n, n, device=dev); w = torch.randn(n, n, device=dev); C = torch.empty(n, n, device=dev)
+    fn = lambda: K.gemm(x, w, C, n, n, n, n, n, n, True, True); fl = 2 * n ** 3
 else:
     x = torch.randn(M, 256, device=dev); w = torch.randn(768, 256, device=dev); C = torch.empty(M, 768, device=dev)
     fn = lambda: K.gemm(x, w, C, M, 768, 256, 256, 256, 768, True, True); fl = 2 * M * 768 * 256
