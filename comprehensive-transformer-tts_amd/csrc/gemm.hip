@@ -10,6 +10,7 @@
 // batch/length limits for free.  blockIdx.x is remapped so that each XCD owns a contiguous
 // run of tiles (tiles that share an A panel hit the same L2).
 #include "ctts_common.h"
+#include <stdlib.h>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -164,16 +165,16 @@ struct VLoaderKC {
   static constexpr int NV = ROWS * BK / 4 / 256;
   const float* base; const float* safe;
   long ld;
-  int row0, row_lim, kq, tid;
+  int row0, row_lim, kq;
   ConvView cv;
   int trow[NV];
   int nval[NV];
-  __device__ void init(const float* p, const float* safe_, long ld_, int row0_, int row_lim_, ConvView cv_, int tid_) {
-    base = p; safe = safe_; ld = ld_; row0 = row0_; row_lim = row_lim_; cv = cv_; tid = tid_;
-    kq = (tid % KCH) << 2;
+  __device__ void init(const float* p, const float* safe_, long ld_, int row0_, int row_lim_, ConvView cv_) {
+    base = p; safe = safe_; ld = ld_; row0 = row0_; row_lim = row_lim_; cv = cv_;
+    kq = (threadIdx.x % KCH) << 2;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int gr = row0 + ((tid + i * 256) / KCH);
+      const int gr = row0 + ((threadIdx.x + i * 256) / KCH);
       trow[i] = CONV ? gr % cv.T : 0;
       nval[i] = 0;
     }
@@ -185,7 +186,7 @@ struct VLoaderKC {
     const int nk = min(4, k_end - gk);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int gr = row0 + ((tid + i * 256) / KCH);
+      const int gr = row0 + ((threadIdx.x + i * 256) / KCH);
       bool ok = (gr < row_lim) && (nk > 0);
       if (CONV) { const int tt = trow[i] + tap; ok = ok && (tt >= 0) && (tt < cv.T); }
       const float* p = ok ? base + (long)gr * ld + gk : safe;
@@ -196,7 +197,7 @@ struct VLoaderKC {
   __device__ __forceinline__ void store(float* s, const float4 (&r)[NV]) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int row = (tid + i * 256) / KCH;
+      const int row = (threadIdx.x + i * 256) / KCH;
       *reinterpret_cast<float4*>(s + row * KC_LD + kq) = mask4(r[i], nval[i]);
     }
   }
@@ -208,18 +209,18 @@ struct VLoaderRC {
   static constexpr int LD = COLS + 4;
   const float* base; const float* safe;
   long ld;
-  int col0, col_lim, tid;
+  int col0, col_lim;
   ConvView cv;
   int nval[NV];
-  __device__ void init(const float* p, const float* safe_, long ld_, int col0_, int col_lim_, ConvView cv_, int tid_) {
-    base = p; safe = safe_; ld = ld_; col0 = col0_; col_lim = col_lim_; cv = cv_; tid = tid_;
+  __device__ void init(const float* p, const float* safe_, long ld_, int col0_, int col_lim_, ConvView cv_) {
+    base = p; safe = safe_; ld = ld_; col0 = col0_; col_lim = col_lim_; cv = cv_;
 #pragma unroll
     for (int i = 0; i < NV; ++i) nval[i] = 0;
   }
   __device__ __forceinline__ void load(int k0, int k_end, float4 (&r)[NV]) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + i * 256;
+      const int f = threadIdx.x + i * 256;
       const int k = f / (COLS / 4);
       const int cq = (f % (COLS / 4)) << 2;
       const int gk = k0 + k, gc = col0 + cq;
@@ -234,7 +235,7 @@ struct VLoaderRC {
   __device__ __forceinline__ void store(float* s, const float4 (&r)[NV]) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + i * 256;
+      const int f = threadIdx.x + i * 256;
       const int k = f / (COLS / 4);
       const int cq = (f % (COLS / 4)) << 2;
       *reinterpret_cast<float4*>(s + k * LD + cq) = mask4(r[i], nval[i]);
@@ -268,51 +269,6 @@ __device__ __forceinline__ void fetch_frag(const float* s, int ext0, int l31, in
   }
 }
 
-// ---- epilogue shared by both kernels.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int MT, int NT>
-__device__ __forceinline__ void gemm_epilogue(const ctts_gemm_desc& d, floatx16 (&acc)[MT][NT], float* Cb, int z, int row0, int col0,
-                                              int wm0, int wn0, int l31, int h, int Mv, int Nv) {
-  const float alpha = d.alpha;
-  if (d.split_k > 1) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int n = col0 + wn0 + j * 32 + l31;
-          if (m < Mv && n < Nv) atomicAdd(Cb + (long)m * d.ldc + n, alpha * acc[i][j][r]);
-        }
-    return;
-  }
-  const bool do_drop = d.p_drop > 0.f;
-  uint32_t dkey = 0;
-  float inv_keep = 1.f;
-  if (do_drop) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
-  const uint32_t zoff = (uint32_t)z * (uint32_t)d.M * (uint32_t)d.N;
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = col0 + wn0 + j * 32 + l31;
-      const float bv = (d.bias && n < Nv) ? d.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < Mv && n < Nv) {
-          float v = alpha * (acc[i][j][r] + bv);
-          if (d.Z) d.Z[(long)m * d.ldz + n] = v;
-          v = ctts_act(v, d.act);
-          if (do_drop) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
-          if (d.R) v += d.R[(long)m * d.ldr + n];
-          if (d.rowscale) v *= d.rowscale[m];
-          Cb[(long)m * d.ldc + n] = v;
-        }
-      }
-    }
-}
-
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool VEC>
 __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_gemm_desc d) {
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
@@ -320,11 +276,7 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
   constexpr int B_LD = B_KC ? KC_LD : BN + 4;
   constexpr int A_SZ = A_KC ? BM * KC_LD : BK * (BM + 4);
   constexpr int B_SZ = B_KC ? BN * KC_LD : BK * (BN + 4);
-  constexpr int STAGE = A_SZ + B_SZ;
-#ifndef CTTS_LDS_PAD
-#define CTTS_LDS_PAD 0
-#endif
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + CTTS_LDS_PAD];
+  __shared__ __attribute__((aligned(16))) float smem[A_SZ + B_SZ];
   float* sA = smem;
   float* sB = smem + A_SZ;
 
@@ -393,8 +345,8 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
   using LB = typename LoaderSel<B_KC, BN, CONV_B, VEC>::type;
   LA la; LB lb;
   if constexpr (VEC) {
-    la.init(Ab, Asafe, d.lda, row0, Mv, CONV_A ? cv : nocv, threadIdx.x);
-    lb.init(Bb, Bsafe, d.ldb, col0, Nv, CONV_B ? cv : nocv, threadIdx.x);
+    la.init(Ab, Asafe, d.lda, row0, Mv, CONV_A ? cv : nocv);
+    lb.init(Bb, Bsafe, d.ldb, col0, Nv, CONV_B ? cv : nocv);
   } else {
     la.init(Ab, d.lda, row0, Mv, false, CONV_A ? cv : nocv);
     lb.init(Bb, d.ldb, col0, Nv, false, CONV_B ? cv : nocv);
@@ -421,69 +373,90 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
     const int b0 = k0 / d.row_T;
     return !(b0 == lastk / d.row_T && (k0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo);
   };
-  // ---- main loop: two LDS stages, ONE barrier per K-block.
-  //   iteration i:  [regs(tile i+1) -> LDS stage (i+1)&1]  [global loads of tile i+2 -> regs]
-  //                 [fragments of tile i from stage i&1 -> 64 MFMAs]  barrier
-  // Everything before the barrier is independent of the MFMAs, so staging work overlaps the matrix pipe;
-  // stage (i+1)&1 was last read in iteration i-1, which every wave left through the barrier.
   float4 ra[LA::NV], rb[LB::NV];
-  const int nkb = (k_end - k_begin + BK - 1) / BK;
-  bool act0 = kblock_active(k_begin);
-  if (act0) {
+  bool act_cur = kblock_active(k_begin);
+  if (act_cur) {
     la.load(k_begin, k_end, ra);
     lb.load(k_begin, k_end, rb);
     la.store(sA, ra);
     lb.store(sB, rb);
   }
-  bool act1 = nkb > 1 && kblock_active(k_begin + BK);
-  if (act1) {
-    la.load(k_begin + BK, k_end, ra);
-    lb.load(k_begin + BK, k_end, rb);
-  }
   __syncthreads();
-  bool act_cur = act0, act_next = act1;
-  for (int i = 0; i < nkb; ++i) {
-    float* sAc = sA + (i & 1) * STAGE;
-    float* sBc = sB + (i & 1) * STAGE;
-    float* sAn = sA + ((i + 1) & 1) * STAGE;
-    float* sBn = sB + ((i + 1) & 1) * STAGE;
-#ifndef CTTS_DBG_NOSTORE
-    if (act_next) {          // tile i+1 is in registers (loaded during iteration i-1)
-      la.store(sAn, ra);
-      lb.store(sBn, rb);
+
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool has_next = (k0 + BK) < k_end;
+    const bool act_next = has_next && kblock_active(k0 + BK);
+    if (act_next) {
+      la.load(k0 + BK, k_end, ra);
+      lb.load(k0 + BK, k_end, rb);
     }
-#endif
-    const int k2 = k_begin + (i + 2) * BK;
-    const bool act_nn = (i + 2 < nkb) && kblock_active(k2);
-#ifndef CTTS_DBG_NOLOAD
-    if (act_nn) {
-      la.load(k2, k_end, ra);
-      lb.load(k2, k_end, rb);
-    }
-#endif
     if (act_cur) {
 #pragma unroll
       for (int ksub = 0; ksub < BK; ksub += 32) {
         float fa[MT][16], fb[NT][16];
 #pragma unroll
-        for (int ii = 0; ii < MT; ++ii) fetch_frag<A_KC, A_LD>(sAc, wm0 + ii * 32, l31, h, ksub, fa[ii]);
+        for (int i = 0; i < MT; ++i) fetch_frag<A_KC, A_LD>(sA, wm0 + i * 32, l31, h, ksub, fa[i]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sBc, wn0 + j * 32, l31, h, ksub, fb[j]);
+        for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sB, wn0 + j * 32, l31, h, ksub, fb[j]);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
-          for (int ii = 0; ii < MT; ++ii)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ii][kk], fb[j][kk], acc[ii][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
       }
     }
-    if (act_cur || act_next) __syncthreads();   // block-uniform; nothing staged and nothing read -> no barrier needed
+    if (KSKIP && !act_cur && !act_next) continue;   // nothing staged, nothing to publish: no barrier needed
+    __syncthreads();
+    if (act_next) {
+      la.store(sA, ra);
+      lb.store(sB, rb);
+    }
+    __syncthreads();
     act_cur = act_next;
-    act_next = act_nn;
   }
 
-  gemm_epilogue<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const float alpha = d.alpha;
+  if (d.split_k > 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int n = col0 + wn0 + j * 32 + l31;
+          if (m < Mv && n < Nv) atomicAdd(Cb + (long)m * d.ldc + n, alpha * acc[i][j][r]);
+        }
+    return;
+  }
+  const bool do_drop = d.p_drop > 0.f;
+  uint32_t dkey = 0;
+  float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
+  const uint32_t zoff = (uint32_t)z * (uint32_t)d.M * (uint32_t)d.N;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = col0 + wn0 + j * 32 + l31;
+      const float bv = (d.bias && n < Nv) ? d.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < Mv && n < Nv) {
+          float v = alpha * (acc[i][j][r] + bv);
+          if (d.Z) d.Z[(long)m * d.ldz + n] = v;
+          v = ctts_act(v, d.act);
+          if (do_drop) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
+          if (d.R) v += d.R[(long)m * d.ldr + n];
+          if (d.rowscale) v *= d.rowscale[m];
+          Cb[(long)m * d.ldc + n] = v;
+        }
+      }
+    }
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool VEC>
@@ -494,195 +467,6 @@ int launch(const ctts_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, CONV, VEC>), grid, dim3(256), 0, st, d);
   CTTS_CHECK_LAUNCH("ctts_gemm");
   return 0;
-}
-
-// =================================================================================================
-// Ping-pong kernel for the large aligned problems (128x128 tiles): 512 threads = two groups of four
-// waves, each group owns ONE output tile; every SIMD hosts one wave of each group.  The groups run
-// half a K-block out of phase, separated by workgroup barriers:
-//
-//   half-step :      0            1            2            3      ...
-//   group A   :  COMPUTE(0)    STAGE(1)    COMPUTE(1)    STAGE(2)
-//   group B   :    idle       COMPUTE(0)    STAGE(1)    COMPUTE(1)
-//
-// COMPUTE(i) = fragments of K-block i from the group's LDS stage -> 64 MFMAs per wave;
-// STAGE(i)   = registers holding K-block i -> LDS, then issue the global loads of K-block i+1.
-// While one wave of a SIMD feeds the matrix pipe, its partner does the address arithmetic, vmcnt
-// waits and LDS writes, so the pipe never idles on staging work (co-resident workgroups of the
-// 256-thread kernel run in lockstep and stall the pipe together: 72 % MFMA utilisation measured).
-template <bool A_KC, bool B_KC, bool CONV>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const ctts_gemm_desc d) {
-  constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MT = 2, NT = 2;
-  constexpr int A_LD = A_KC ? KC_LD : BM + 4;
-  constexpr int B_LD = B_KC ? KC_LD : BN + 4;
-  constexpr int A_SZ = A_KC ? BM * KC_LD : BK * (BM + 4);
-  constexpr int B_SZ = B_KC ? BN * KC_LD : BK * (BN + 4);
-  constexpr int STAGE = A_SZ + B_SZ;
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
-  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
-  float* sA = smem + grp * STAGE;
-  float* sB = sA + A_SZ;
-
-  const int z = blockIdx.z;
-  int z0 = 0, z1 = 0, split = 0;
-  if (d.split_k > 1) split = z; else { z0 = z / d.nb1; z1 = z - z0 * d.nb1; }
-  int Mv = d.M, Nv = d.N, Kv = d.K;
-  if (d.lens) {
-    const int L = d.lens[z0];
-    if (d.lim_m) Mv = min(Mv, L);
-    if (d.lim_n) Nv = min(Nv, L);
-    if (d.lim_k) Kv = min(Kv, L);
-  }
-  const int tiles_n = (d.N + BN - 1) / BN, tiles_m = (d.M + BM - 1) / BM, total = tiles_m * tiles_n;
-  const int npair = gridDim.x;
-  const int q8 = npair >> 3, r8 = npair & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int pair = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int wg = 2 * pair + grp;       // the two groups take neighbouring tiles (same A panel when tiles_n is even)
-  bool has = wg < total;
-  int row0 = 0, col0 = 0;
-  if (has) {
-    int tm = wg / tiles_n;
-    const int P = (tiles_m % 37) ? 37 : ((tiles_m % 41) ? 41 : 43);
-    tm = (int)(((long)tm * P) % tiles_m);
-    row0 = tm * BM; col0 = (wg % tiles_n) * BN;
-    has = (row0 < Mv) && (col0 < Nv);
-  }
-  float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
-  if (has && A_KC && d.row_lens) {     // tile of padded rows: zero-fill, then only keep the barrier schedule
-    const int last = min(row0 + BM, Mv) - 1;
-    const int b0 = row0 / d.row_T, b1 = last / d.row_T;
-    if (b0 == b1 && (row0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo) {
-      const int ncols = min(BN, Nv - col0), nrows = last - row0 + 1;
-      for (int e = tid; e < nrows * ncols; e += 256) {
-        const int r = e / ncols, c = e - r * ncols;
-        Cb[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
-        if (d.Z) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
-      }
-      has = false;
-    }
-  }
-  int k_begin = 0, k_end = Kv;
-  if (d.split_k > 1) {
-    int chunk = ((Kv + d.split_k - 1) / d.split_k + BK - 1) / BK * BK;
-    k_begin = split * chunk;
-    k_end = min(Kv, k_begin + chunk);
-  }
-  const int nkb = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;   // identical for both groups (depends on z only)
-  if (nkb == 0) return;
-
-  const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
-  const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
-  const float* Asafe = Ab;
-  const float* Bsafe = Bb;
-  ConvView cv{d.conv_T, d.conv_pad, d.conv_cin};
-  ConvView nocv{1, 0, 1};
-  constexpr bool CONV_A = CONV && A_KC;
-  constexpr bool CONV_B = CONV && !A_KC && !B_KC;
-  if (CONV_A) Ab -= (long)d.conv_pad * d.conv_cin;
-  if (CONV_B) Bb -= (long)d.conv_pad * d.conv_cin;
-  using LA = typename LoaderSel<A_KC, BM, CONV_A, true>::type;
-  using LB = typename LoaderSel<B_KC, BN, CONV_B, true>::type;
-  LA la; LB lb;
-  la.init(Ab, Asafe, d.lda, row0, Mv, CONV_A ? cv : nocv, tid);
-  lb.init(Bb, Bsafe, d.ldb, col0, Nv, CONV_B ? cv : nocv, tid);
-
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  floatx16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  constexpr bool KSKIP = !A_KC && !B_KC;
-  auto kb_active = [&](int i) -> bool {
-    if (!KSKIP || !d.row_lens) return true;
-    const int k0 = k_begin + i * BK;
-    const int lastk = min(k0 + BK, k_end) - 1;
-    const int b0 = k0 / d.row_T;
-    return !(b0 == lastk / d.row_T && (k0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo);
-  };
-
-  float4 ra[LA::NV], rb[LB::NV];
-  if (has) {
-    if (kb_active(0)) {
-      la.load(k_begin, k_end, ra);
-      lb.load(k_begin, k_end, rb);
-      la.store(sA, ra);
-      lb.store(sB, rb);
-    }
-    if (nkb > 1 && kb_active(1)) {
-      la.load(k_begin + BK, k_end, ra);
-      lb.load(k_begin + BK, k_end, rb);
-    }
-  }
-  __syncthreads();
-  const int nhalf = 2 * nkb;
-  for (int hs = 0; hs < nhalf; ++hs) {
-    const int mine = hs - grp;            // group B lags by one half-step
-    if (has && mine >= 0) {
-      const int i = mine >> 1;
-      if ((mine & 1) == 0) {
-        // ---------------- COMPUTE(i)
-        if (i < nkb && kb_active(i)) {
-#pragma unroll
-          for (int ksub = 0; ksub < BK; ksub += 32) {
-            float fa[MT][16], fb[NT][16];
-#pragma unroll
-            for (int ii = 0; ii < MT; ++ii) fetch_frag<A_KC, A_LD>(sA, wm0 + ii * 32, l31, h, ksub, fa[ii]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sB, wn0 + j * 32, l31, h, ksub, fb[j]);
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-              for (int ii = 0; ii < MT; ++ii)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                  acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ii][kk], fb[j][kk], acc[ii][j], 0, 0, 0);
-          }
-        }
-      } else {
-        // ---------------- STAGE(i+1): registers (K-block i+1) -> LDS, then prefetch K-block i+2
-        const int nx = i + 1;
-        if (nx < nkb) {
-          if (kb_active(nx)) {
-            la.store(sA, ra);
-            lb.store(sB, rb);
-          }
-          if (nx + 1 < nkb && kb_active(nx + 1)) {
-            const int k2 = k_begin + (nx + 1) * BK;
-            la.load(k2, k_end, ra);
-            lb.load(k2, k_end, rb);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // group A's last COMPUTE is half-step 2*nkb-2, group B's is 2*nkb-1: both are done here
-  if (has) gemm_epilogue<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
-}
-
-template <bool A_KC, bool B_KC, bool CONV>
-int launch_pp(const ctts_gemm_desc& d, hipStream_t st) {
-  const int tiles = ((d.M + 127) / 128) * ((d.N + 127) / 128);
-  const int nz = d.split_k > 1 ? d.split_k : d.nb0 * d.nb1;
-  dim3 grid((tiles + 1) / 2, 1, nz);
-  hipLaunchKernelGGL((gemm_pp_kernel<A_KC, B_KC, CONV>), grid, dim3(512), 0, st, d);
-  CTTS_CHECK_LAUNCH("ctts_gemm(pp)");
-  return 0;
-}
-
-int dispatch_pp(const ctts_gemm_desc& d, hipStream_t st) {
-  const bool conv = d.conv_T > 0;
-  if (d.a_kc && d.b_kc) return conv ? launch_pp<true, true, true>(d, st) : launch_pp<true, true, false>(d, st);
-  if (d.a_kc && !d.b_kc) return conv ? launch_pp<true, false, true>(d, st) : launch_pp<true, false, false>(d, st);
-  if (!d.a_kc && !d.b_kc) return conv ? launch_pp<false, false, true>(d, st) : launch_pp<false, false, false>(d, st);
-  ctts_set_error("ctts_gemm: layout a_kc=0,b_kc=1 is not instantiated");
-  return -1;
 }
 
 template <int BM, int BN, bool VEC>
@@ -722,11 +506,11 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   CTTS_REQUIRE(d.p_drop >= 0.f && d.p_drop < 1.f, "ctts_gemm: p_drop out of range");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : d.nb0 * d.nb1);
-  if (!vec_ok(d)) return dispatch_layout<64, 64, false>(d, st);   // unaligned shapes (N = 1, 2, 11 heads): scalar loaders
-#ifndef CTTS_NO_PP
-  if (tiles128 >= 256 && d.N > 64) return dispatch_pp(d, st);
-#else
-  if (tiles128 >= 256 && d.N > 64) return dispatch_layout<128, 128, true>(d, st);
-#endif
+  static const int force_tile = getenv("CTTS_FORCE_TILE") ? atoi(getenv("CTTS_FORCE_TILE")) : 0;   // tuning knob
+  if (!vec_ok(d)) return dispatch_layout<64, 64, false>(d, st);
+  if (force_tile == 64) return dispatch_layout<64, 64, true>(d, st);
+  if (force_tile == 128) return dispatch_layout<128, 128, true>(d, st);   // unaligned shapes (N = 1, 2, 11 heads): scalar loaders
+  // weight-gradient (TN) reductions measured faster on 64x64 tiles (6 waves/SIMD): 92.6 vs 84.6 TFLOP/s on the FFN conv wgrad
+  if (tiles128 >= 256 && d.N > 64 && (d.a_kc || d.b_kc)) return dispatch_layout<128, 128, true>(d, st);
   return dispatch_layout<64, 64, true>(d, st);
 }
