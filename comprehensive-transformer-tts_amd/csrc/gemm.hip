@@ -243,6 +243,105 @@ struct VLoaderRC {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Buffer-descriptor loaders (VEC = 3) for the large GEMMs without per-batch length limits.
+// The operand is addressed as  SRD(base, 2 GiB window) + 32-bit byte offset.  A masked-out chunk simply
+// gets the offset 0x80000000, which the hardware bounds check answers with zeros: no zero page, no select
+// on the loaded data, no 64-bit pointer arithmetic - per chunk and K-block the address work is one add and
+// (conv / K-tail only) one compare + v_cndmask.  Host guarantees every valid offset is < 2^31 bytes.
+typedef unsigned int ctts_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned CTTS_OOB = 0x80000000u;
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+  ctts_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+  return *reinterpret_cast<float4*>(&v);
+}
+
+template <int ROWS, bool CONV>
+struct BLoaderKC {
+  static constexpr int NV = ROWS * BK / 4 / 256;
+  unsigned boff[NV];      // byte offset of (row, kq) relative to the descriptor base, or CTTS_OOB
+  int trow[NV];
+  int kq, tid, T, cin, pad;
+  __device__ void init(long ld, int row0, int row_lim, ConvView cv, int tid_) {
+    tid = tid_; T = cv.T; cin = cv.cin; pad = cv.pad;
+    kq = (tid % KCH) << 2;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int gr = row0 + ((tid + i * 256) / KCH);
+      const long e = (long)(CONV ? gr - cv.pad : gr) * ld + kq;      // conv: im2col row starts pad rows earlier
+      boff[i] = gr < row_lim ? (unsigned)(e * 4) : CTTS_OOB;
+      trow[i] = CONV ? gr % cv.T : 0;
+    }
+  }
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int k0, int k_end, float4 (&r)[NV]) const {
+    const int gk = k0 + kq;
+    const bool kok = gk < k_end;                       // K tail: whole chunk masked (K % 4 == 0)
+    const unsigned koff = (unsigned)k0 * 4u;
+    int tap = 0;
+    if (CONV) tap = gk / cin - pad;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      bool ok = kok && (boff[i] != CTTS_OOB);
+      if (CONV) ok = ok && ((unsigned)(trow[i] + tap) < (unsigned)T);
+      const unsigned off = ok ? boff[i] + koff : CTTS_OOB;   // select LAST: a wrapped (negative) boff plus an offset must never look valid
+      r[i] = buf_load16(rsrc, off);
+    }
+  }
+  __device__ __forceinline__ void store(float* s, const float4 (&r)[NV]) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = (tid + i * 256) / KCH;
+      *reinterpret_cast<float4*>(s + row * KC_LD + kq) = r[i];
+    }
+  }
+};
+
+template <int COLS, bool CONV>
+struct BLoaderRC {
+  static constexpr int NV = COLS * BK / 4 / 256;
+  static constexpr int LD = COLS + 4;
+  unsigned boff[NV];      // byte offset of (k_local row, column chunk) at k0 = 0, or CTTS_OOB
+  int ctap[NV];           // CONV: gc / cin - pad (loop invariant)
+  unsigned ldb4;          // row stride in bytes
+  int tid, T;
+  __device__ void init(long ld, int col0, int col_lim, ConvView cv, int tid_) {
+    tid = tid_; T = cv.T; ldb4 = (unsigned)(ld * 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      const int k = f / (COLS / 4);
+      const int gc = col0 + ((f % (COLS / 4)) << 2);
+      const long e = (long)(CONV ? k - cv.pad : k) * ld + gc;
+      boff[i] = gc < col_lim ? (unsigned)(e * 4) : CTTS_OOB;
+      ctap[i] = CONV ? gc / cv.cin - cv.pad : 0;
+    }
+  }
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int k0, int k_end, float4 (&r)[NV]) const {
+    const unsigned k0off = (unsigned)k0 * ldb4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int gk = k0 + (tid + i * 256) / (COLS / 4);
+      unsigned off = boff[i] + k0off;
+      bool ok = (boff[i] != CTTS_OOB) && (gk < k_end);
+      if (CONV) ok = ok && ((unsigned)(gk % T + ctap[i]) < (unsigned)T);
+      r[i] = buf_load16(rsrc, ok ? off : CTTS_OOB);
+    }
+  }
+  __device__ __forceinline__ void store(float* s, const float4 (&r)[NV]) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      *reinterpret_cast<float4*>(s + (f / (COLS / 4)) * LD + ((f % (COLS / 4)) << 2)) = r[i];
+    }
+  }
+};
+
+template <bool KC, int EXT, bool CONV>
+struct BLoaderSel { using type = BLoaderKC<EXT, CONV>; };
+template <int EXT, bool CONV>
+struct BLoaderSel<false, EXT, CONV> { using type = BLoaderRC<EXT, CONV>; };
+
 template <bool KC, int EXT, bool CONV, bool VEC>
 struct LoaderSel { using type = LoaderKC<EXT, CONV>; };
 template <int EXT, bool CONV>
@@ -267,6 +366,51 @@ __device__ __forceinline__ void fetch_frag(const float* s, int ext0, int l31, in
 #pragma unroll
     for (int j = 0; j < 16; ++j) f[j] = p[j * LD];
   }
+}
+
+// ---- epilogue shared by the kernels.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue(const ctts_gemm_desc& d, floatx16 (&acc)[MT][NT], float* Cb, int z, int row0, int col0,
+                                              int wm0, int wn0, int l31, int h, int Mv, int Nv) {
+  const float alpha = d.alpha;
+  if (d.split_k > 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int n = col0 + wn0 + j * 32 + l31;
+          if (m < Mv && n < Nv) atomicAdd(Cb + (long)m * d.ldc + n, alpha * acc[i][j][r]);
+        }
+    return;
+  }
+  const bool do_drop = d.p_drop > 0.f;
+  uint32_t dkey = 0;
+  float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
+  const uint32_t zoff = (uint32_t)z * (uint32_t)d.M * (uint32_t)d.N;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = col0 + wn0 + j * 32 + l31;
+      const float bv = (d.bias && n < Nv) ? d.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < Mv && n < Nv) {
+          float v = alpha * (acc[i][j][r] + bv);
+          if (d.Z) d.Z[(long)m * d.ldz + n] = v;
+          v = ctts_act(v, d.act);
+          if (do_drop) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
+          if (d.R) v += d.R[(long)m * d.ldr + n];
+          if (d.rowscale) v *= d.rowscale[m];
+          Cb[(long)m * d.ldc + n] = v;
+        }
+      }
+    }
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool VEC>
@@ -417,46 +561,7 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
     act_cur = act_next;
   }
 
-  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const float alpha = d.alpha;
-  if (d.split_k > 1) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int n = col0 + wn0 + j * 32 + l31;
-          if (m < Mv && n < Nv) atomicAdd(Cb + (long)m * d.ldc + n, alpha * acc[i][j][r]);
-        }
-    return;
-  }
-  const bool do_drop = d.p_drop > 0.f;
-  uint32_t dkey = 0;
-  float inv_keep = 1.f;
-  if (do_drop) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
-  const uint32_t zoff = (uint32_t)z * (uint32_t)d.M * (uint32_t)d.N;
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = col0 + wn0 + j * 32 + l31;
-      const float bv = (d.bias && n < Nv) ? d.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < Mv && n < Nv) {
-          float v = alpha * (acc[i][j][r] + bv);
-          if (d.Z) d.Z[(long)m * d.ldz + n] = v;
-          v = ctts_act(v, d.act);
-          if (do_drop) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
-          if (d.R) v += d.R[(long)m * d.ldr + n];
-          if (d.rowscale) v *= d.rowscale[m];
-          Cb[(long)m * d.ldc + n] = v;
-        }
-      }
-    }
+  gemm_epilogue<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool VEC>
@@ -467,6 +572,158 @@ int launch(const ctts_gemm_desc& d, hipStream_t st) {
   hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, CONV, VEC>), grid, dim3(256), 0, st, d);
   CTTS_CHECK_LAUNCH("ctts_gemm");
   return 0;
+}
+
+// Same tiling / barrier structure as gemm_kernel, operands fetched through buffer descriptors.
+template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
+__global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ctts_gemm_desc d) {
+  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+  constexpr int A_LD = A_KC ? KC_LD : BM + 4;
+  constexpr int B_LD = B_KC ? KC_LD : BN + 4;
+  constexpr int A_SZ = A_KC ? BM * KC_LD : BK * (BM + 4);
+  constexpr int B_SZ = B_KC ? BN * KC_LD : BK * (BN + 4);
+  __shared__ __attribute__((aligned(16))) float smem[A_SZ + B_SZ];
+  float* sA = smem;
+  float* sB = smem + A_SZ;
+  const int z = blockIdx.z;
+  int z0 = 0, z1 = 0, split = 0;
+  if (d.split_k > 1) split = z; else { z0 = z / d.nb1; z1 = z - z0 * d.nb1; }
+  const int Mv = d.M, Nv = d.N, Kv = d.K;
+  const int tiles_n = (d.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int tiles_m = nwg / tiles_n;
+  int tm = wg / tiles_n;
+  {
+    const int P = (tiles_m % 37) ? 37 : ((tiles_m % 41) ? 41 : 43);
+    tm = (int)(((long)tm * P) % tiles_m);
+  }
+  const int row0 = tm * BM, col0 = (wg % tiles_n) * BN;
+  if (row0 >= Mv || col0 >= Nv) return;
+  float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
+  if (A_KC && d.row_lens) {
+    const int last = min(row0 + BM, Mv) - 1;
+    const int b0 = row0 / d.row_T, b1 = last / d.row_T;
+    if (b0 == b1 && (row0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo) {
+      const int ncols = min(BN, Nv - col0), nrows = last - row0 + 1;
+      for (int e = threadIdx.x; e < nrows * ncols; e += 256) {
+        const int r = e / ncols, c = e - r * ncols;
+        Cb[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
+        if (d.Z) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
+      }
+      return;
+    }
+  }
+  int k_begin = 0, k_end = Kv;
+  if (d.split_k > 1) {
+    int chunk = ((Kv + d.split_k - 1) / d.split_k + BK - 1) / BK * BK;
+    k_begin = split * chunk;
+    k_end = min(Kv, k_begin + chunk);
+    if (k_begin >= k_end) return;
+  }
+  const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
+  const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
+  const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7FFFFFFE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7FFFFFFE, 0x00020000);
+  ConvView cv{d.conv_T, d.conv_pad, d.conv_cin};
+  ConvView nocv{1, 0, 1};
+  constexpr bool CONV_A = CONV && A_KC;
+  constexpr bool CONV_B = CONV && !A_KC && !B_KC;
+  using LA = typename BLoaderSel<A_KC, BM, CONV_A>::type;
+  using LB = typename BLoaderSel<B_KC, BN, CONV_B>::type;
+  LA la; LB lb;
+  la.init(d.lda, row0, Mv, CONV_A ? cv : nocv, threadIdx.x);
+  lb.init(d.ldb, col0, Nv, CONV_B ? cv : nocv, threadIdx.x);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  constexpr bool KSKIP = !A_KC && !B_KC;
+  auto kblock_active = [&](int k0) -> bool {
+    if (!KSKIP || !d.row_lens) return true;
+    const int lastk = min(k0 + BK, k_end) - 1;
+    const int b0 = k0 / d.row_T;
+    return !(b0 == lastk / d.row_T && (k0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo);
+  };
+  float4 ra[LA::NV], rb[LB::NV];
+  bool act_cur = kblock_active(k_begin);
+  if (act_cur) {
+    la.load(ra_src, k_begin, k_end, ra);
+    lb.load(rb_src, k_begin, k_end, rb);
+    la.store(sA, ra);
+    lb.store(sB, rb);
+  }
+  __syncthreads();
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool has_next = (k0 + BK) < k_end;
+    const bool act_next = has_next && kblock_active(k0 + BK);
+    if (act_next) {
+      la.load(ra_src, k0 + BK, k_end, ra);
+      lb.load(rb_src, k0 + BK, k_end, rb);
+    }
+    if (act_cur) {
+#pragma unroll
+      for (int ksub = 0; ksub < BK; ksub += 32) {
+        float fa[MT][16], fb[NT][16];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fetch_frag<A_KC, A_LD>(sA, wm0 + i * 32, l31, h, ksub, fa[i]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sB, wn0 + j * 32, l31, h, ksub, fb[j]);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (KSKIP && !act_cur && !act_next) continue;
+    __syncthreads();
+    if (act_next) {
+      la.store(sA, ra);
+      lb.store(sB, rb);
+    }
+    __syncthreads();
+    act_cur = act_next;
+  }
+  gemm_epilogue<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
+int launch_buf(const ctts_gemm_desc& d, hipStream_t st) {
+  const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  const int nz = d.split_k > 1 ? d.split_k : d.nb0 * d.nb1;
+  hipLaunchKernelGGL((gemm_buf_kernel<BM, BN, A_KC, B_KC, CONV>), dim3(tiles, 1, nz), dim3(256), 0, st, d);
+  CTTS_CHECK_LAUNCH("ctts_gemm(buf)");
+  return 0;
+}
+
+template <int BM, int BN>
+int dispatch_buf(const ctts_gemm_desc& d, hipStream_t st) {
+  const bool conv = d.conv_T > 0;
+  if (d.a_kc && d.b_kc) return conv ? launch_buf<BM, BN, true, true, true>(d, st) : launch_buf<BM, BN, true, true, false>(d, st);
+  if (d.a_kc && !d.b_kc) return conv ? launch_buf<BM, BN, true, false, true>(d, st) : launch_buf<BM, BN, true, false, false>(d, st);
+  if (!d.a_kc && !d.b_kc) return conv ? launch_buf<BM, BN, false, false, true>(d, st) : launch_buf<BM, BN, false, false, false>(d, st);
+  ctts_set_error("ctts_gemm: layout a_kc=0,b_kc=1 is not instantiated");
+  return -1;
+}
+
+// buffer loaders need: no per-batch length limits and every operand element within 2 GiB of its (batch) base
+bool buf_ok(const ctts_gemm_desc& d) {
+  if (d.lens && (d.lim_m || d.lim_n || d.lim_k)) return false;
+  const long a_ext = d.a_kc ? ((long)d.M * d.lda + d.K) : ((long)d.K * d.lda + d.M);
+  const long b_ext = d.b_kc ? ((long)d.N * d.ldb + d.K) : ((long)d.K * d.ldb + d.N);
+  return a_ext * 4 < 0x7FFF0000L && b_ext * 4 < 0x7FFF0000L;
 }
 
 template <int BM, int BN, bool VEC>
@@ -510,6 +767,14 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   if (!vec_ok(d)) return dispatch_layout<64, 64, false>(d, st);
   if (force_tile == 64) return dispatch_layout<64, 64, true>(d, st);
   if (force_tile == 128) return dispatch_layout<128, 128, true>(d, st);   // unaligned shapes (N = 1, 2, 11 heads): scalar loaders
+#ifndef CTTS_NO_BUF
+  if (buf_ok(d)) {
+    if (force_tile == 64) return dispatch_buf<64, 64>(d, st);
+    if (force_tile == 128) return dispatch_buf<128, 128>(d, st);
+    if (tiles128 >= 256 && d.N > 64 && (d.a_kc || d.b_kc)) return dispatch_buf<128, 128>(d, st);
+    return dispatch_buf<64, 64>(d, st);
+  }
+#endif
   // weight-gradient (TN) reductions measured faster on 64x64 tiles (6 waves/SIMD): 92.6 vs 84.6 TFLOP/s on the FFN conv wgrad
   if (tiles128 >= 256 && d.N > 64 && (d.a_kc || d.b_kc)) return dispatch_layout<128, 128, true>(d, st);
   return dispatch_layout<64, 64, true>(d, st);
