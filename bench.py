@@ -133,7 +133,7 @@ def measure_dominant_kernel(dev, batch, iters=20):
     padded_flops = 2.0 * cout * ks * cin * M
     return {"bound": "mfma", "achieved": algo_flops / dt / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": algo_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-            "kernel": "gemm_kernel<128,128,A_KC,B_KC,CONV> (decoder FFN conv k=9 fwd)", "launch_us": dt * 1e6,
+            "kernel": "gemm_buf_kernel<128,128,true,true,true,false> (decoder FFN Conv1d k=9 fwd, implicit GEMM)", "launch_us": dt * 1e6,
             "padded_tflops": padded_flops / dt / 1e12}
 
 

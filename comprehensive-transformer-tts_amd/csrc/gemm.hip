@@ -257,12 +257,13 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsign
   return *reinterpret_cast<float4*>(&v);
 }
 
-template <int ROWS, bool CONV>
+template <int ROWS, bool CONV, bool PARTIAL>
 struct BLoaderKC {
   static constexpr int NV = ROWS * BK / 4 / 256;
   unsigned boff[NV];      // byte offset of (row, kq) relative to the descriptor base, or CTTS_OOB
   int trow[NV];
   int kq, tid, T, cin, pad;
+  int nk_cur;             // PARTIAL: valid elements of this thread's chunk in the staged K-block (same for all rows)
   __device__ void init(long ld, int row0, int row_lim, ConvView cv, int tid_) {
     tid = tid_; T = cv.T; cin = cv.cin; pad = cv.pad;
     kq = (tid % KCH) << 2;
@@ -273,10 +274,12 @@ struct BLoaderKC {
       boff[i] = gr < row_lim ? (unsigned)(e * 4) : CTTS_OOB;
       trow[i] = CONV ? gr % cv.T : 0;
     }
+    nk_cur = 4;
   }
-  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int k0, int k_end, float4 (&r)[NV]) const {
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int k0, int k_end, float4 (&r)[NV]) {
     const int gk = k0 + kq;
-    const bool kok = gk < k_end;                       // K tail: whole chunk masked (K % 4 == 0)
+    const bool kok = gk < k_end;                       // K tail: chunk fully masked, or (PARTIAL) cut at k_end
+    if (PARTIAL) nk_cur = min(4, k_end - gk);
     const unsigned koff = (unsigned)k0 * 4u;
     int tap = 0;
     if (CONV) tap = gk / cin - pad;
@@ -292,12 +295,12 @@ struct BLoaderKC {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int row = (tid + i * 256) / KCH;
-      *reinterpret_cast<float4*>(s + row * KC_LD + kq) = r[i];
+      *reinterpret_cast<float4*>(s + row * KC_LD + kq) = PARTIAL ? mask4(r[i], nk_cur) : r[i];
     }
   }
 };
 
-template <int COLS, bool CONV>
+template <int COLS, bool CONV, bool PARTIAL>
 struct BLoaderRC {
   static constexpr int NV = COLS * BK / 4 / 256;
   static constexpr int LD = COLS + 4;
@@ -305,6 +308,7 @@ struct BLoaderRC {
   int ctap[NV];           // CONV: gc / cin - pad (loop invariant)
   unsigned ldb4;          // row stride in bytes
   int tid, T;
+  int ncol[NV];           // PARTIAL: valid elements of the chunk along the contiguous dim (loop invariant)
   __device__ void init(long ld, int col0, int col_lim, ConvView cv, int tid_) {
     tid = tid_; T = cv.T; ldb4 = (unsigned)(ld * 4);
 #pragma unroll
@@ -315,6 +319,7 @@ struct BLoaderRC {
       const long e = (long)(CONV ? k - cv.pad : k) * ld + gc;
       boff[i] = gc < col_lim ? (unsigned)(e * 4) : CTTS_OOB;
       ctap[i] = CONV ? gc / cv.cin - cv.pad : 0;
+      ncol[i] = PARTIAL ? min(4, col_lim - gc) : 4;
     }
   }
   __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int k0, int k_end, float4 (&r)[NV]) const {
@@ -332,15 +337,15 @@ struct BLoaderRC {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + i * 256;
-      *reinterpret_cast<float4*>(s + (f / (COLS / 4)) * LD + ((f % (COLS / 4)) << 2)) = r[i];
+      *reinterpret_cast<float4*>(s + (f / (COLS / 4)) * LD + ((f % (COLS / 4)) << 2)) = PARTIAL ? mask4(r[i], ncol[i]) : r[i];
     }
   }
 };
 
-template <bool KC, int EXT, bool CONV>
-struct BLoaderSel { using type = BLoaderKC<EXT, CONV>; };
-template <int EXT, bool CONV>
-struct BLoaderSel<false, EXT, CONV> { using type = BLoaderRC<EXT, CONV>; };
+template <bool KC, int EXT, bool CONV, bool PARTIAL>
+struct BLoaderSel { using type = BLoaderKC<EXT, CONV, PARTIAL>; };
+template <int EXT, bool CONV, bool PARTIAL>
+struct BLoaderSel<false, EXT, CONV, PARTIAL> { using type = BLoaderRC<EXT, CONV, PARTIAL>; };
 
 template <bool KC, int EXT, bool CONV, bool VEC>
 struct LoaderSel { using type = LoaderKC<EXT, CONV>; };
@@ -575,7 +580,7 @@ int launch(const ctts_gemm_desc& d, hipStream_t st) {
 }
 
 // Same tiling / barrier structure as gemm_kernel, operands fetched through buffer descriptors.
-template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
+template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool PARTIAL>
 __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ctts_gemm_desc d) {
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
   constexpr int A_LD = A_KC ? KC_LD : BM + 4;
@@ -588,7 +593,13 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   const int z = blockIdx.z;
   int z0 = 0, z1 = 0, split = 0;
   if (d.split_k > 1) split = z; else { z0 = z / d.nb1; z1 = z - z0 * d.nb1; }
-  const int Mv = d.M, Nv = d.N, Kv = d.K;
+  int Mv = d.M, Nv = d.N, Kv = d.K;
+  if (PARTIAL && d.lens) {                // per-batch valid lengths (attention over non-padded tokens only)
+    const int L = d.lens[z0];
+    if (d.lim_m) Mv = min(Mv, L);
+    if (d.lim_n) Nv = min(Nv, L);
+    if (d.lim_k) Kv = min(Kv, L);
+  }
   const int tiles_n = (d.N + BN - 1) / BN;
   const int nwg = gridDim.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -630,8 +641,8 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   ConvView nocv{1, 0, 1};
   constexpr bool CONV_A = CONV && A_KC;
   constexpr bool CONV_B = CONV && !A_KC && !B_KC;
-  using LA = typename BLoaderSel<A_KC, BM, CONV_A>::type;
-  using LB = typename BLoaderSel<B_KC, BN, CONV_B>::type;
+  using LA = typename BLoaderSel<A_KC, BM, CONV_A, PARTIAL>::type;
+  using LB = typename BLoaderSel<B_KC, BN, CONV_B, PARTIAL>::type;
   LA la; LB lb;
   la.init(d.lda, row0, Mv, CONV_A ? cv : nocv, threadIdx.x);
   lb.init(d.ldb, col0, Nv, CONV_B ? cv : nocv, threadIdx.x);
@@ -703,7 +714,17 @@ template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
 int launch_buf(const ctts_gemm_desc& d, hipStream_t st) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
   const int nz = d.split_k > 1 ? d.split_k : d.nb0 * d.nb1;
-  hipLaunchKernelGGL((gemm_buf_kernel<BM, BN, A_KC, B_KC, CONV>), dim3(tiles, 1, nz), dim3(256), 0, st, d);
+  if (d.lens && (d.lim_m || d.lim_n || d.lim_k)) {
+    if constexpr (!CONV) {
+      hipLaunchKernelGGL((gemm_buf_kernel<BM, BN, A_KC, B_KC, false, true>), dim3(tiles, 1, nz), dim3(256), 0, st, d);
+      CTTS_CHECK_LAUNCH("ctts_gemm(buf,partial)");
+      return 0;
+    } else {
+      ctts_set_error("ctts_gemm: per-batch length limits together with a conv view are not supported");
+      return -1;
+    }
+  }
+  hipLaunchKernelGGL((gemm_buf_kernel<BM, BN, A_KC, B_KC, CONV, false>), dim3(tiles, 1, nz), dim3(256), 0, st, d);
   CTTS_CHECK_LAUNCH("ctts_gemm(buf)");
   return 0;
 }
@@ -720,7 +741,7 @@ int dispatch_buf(const ctts_gemm_desc& d, hipStream_t st) {
 
 // buffer loaders need: no per-batch length limits and every operand element within 2 GiB of its (batch) base
 bool buf_ok(const ctts_gemm_desc& d) {
-  if (d.lens && (d.lim_m || d.lim_n || d.lim_k)) return false;
+  if (d.lens && (d.lim_m || d.lim_n || d.lim_k) && d.conv_T > 0) return false;
   const long a_ext = d.a_kc ? ((long)d.M * d.lda + d.K) : ((long)d.K * d.lda + d.M);
   const long b_ext = d.b_kc ? ((long)d.N * d.ldb + d.K) : ((long)d.K * d.ldb + d.N);
   return a_ext * 4 < 0x7FFF0000L && b_ext * 4 < 0x7FFF0000L;
