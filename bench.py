@@ -131,8 +131,13 @@ def measure_dominant_kernel(dev, batch, iters=20):
     valid = int(batch["mel_lens"].sum())
     algo_flops = 2.0 * cout * ks * cin * valid          # 4,718,592 FLOP per valid frame per layer
     padded_flops = 2.0 * cout * ks * cin * M
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic_dominant_kernel.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, see profiles/
+    if os.path.exists(tj):
+        with open(tj) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
     return {"bound": "mfma", "achieved": algo_flops / dt / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": algo_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "frac": algo_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
             "kernel": "gemm_buf_kernel<128,128,true,true,true,false> (decoder FFN Conv1d k=9 fwd, implicit GEMM)", "launch_us": dt * 1e6,
             "padded_tflops": padded_flops / dt / 1e12}
 
@@ -195,11 +200,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path in the product)"
+    if os.environ.get("CTTS_BENCH_SAME_DEVICE"):              # test hook: all ranks share cuda:0 (gloo backend)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)    # RCCL over xGMI
+        backend = os.environ.get("CTTS_BENCH_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" only for single-GPU smoke tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import ctts_amd
     from ctts_amd.configs import get_configs
     from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
