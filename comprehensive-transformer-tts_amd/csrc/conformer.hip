@@ -1,0 +1,247 @@
+// Conformer-specific kernels: GLU, depthwise Conv1d (k = 31), relative-position attention softmax with the
+// Transformer-XL shift.  All HBM/L2-bound streaming kernels; the GEMM-shaped parts of the block go through ctts_gemm.
+#include "ctts_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+__global__ void glu_fwd_kernel(const float4* __restrict__ a, float4* __restrict__ out, long rows, int C4) {
+  const long total = rows * C4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / C4; const int c = (int)(e - r * C4);
+    const float4 x = a[r * 2 * C4 + c], g = a[r * 2 * C4 + C4 + c];
+    out[e] = make_float4(x.x * sigmoidf_(g.x), x.y * sigmoidf_(g.y), x.z * sigmoidf_(g.z), x.w * sigmoidf_(g.w));
+  }
+}
+
+__global__ void glu_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ dout, float4* __restrict__ da, long rows,
+                               int C4) {
+  const long total = rows * C4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / C4; const int c = (int)(e - r * C4);
+    const float4 x = a[r * 2 * C4 + c], g = a[r * 2 * C4 + C4 + c], d = dout[e];
+    const float s0 = sigmoidf_(g.x), s1 = sigmoidf_(g.y), s2 = sigmoidf_(g.z), s3 = sigmoidf_(g.w);
+    da[r * 2 * C4 + c] = make_float4(d.x * s0, d.y * s1, d.z * s2, d.w * s3);
+    da[r * 2 * C4 + C4 + c] = make_float4(d.x * x.x * s0 * (1.f - s0), d.y * x.y * s1 * (1.f - s1), d.z * x.z * s2 * (1.f - s2),
+                                          d.w * x.w * s3 * (1.f - s3));
+  }
+}
+
+// depthwise conv: block = (C/4 lanes) x 4 time groups; each thread: 4 channels x DW_TT consecutive time steps,
+// weights [K][C] in LDS, inputs streamed once through a register window.
+constexpr int DW_TT = 8;
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wT,
+                                                          float* __restrict__ y, int T, int C, int K, int flip) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];   // [K][C]
+  const int C4 = C >> 2;
+  for (int e = threadIdx.x; e < K * C; e += blockDim.x) {
+    const int k = e / C, c = e - k * C;
+    s_w[e] = wT[(flip ? (K - 1 - k) : k) * C + c];
+  }
+  __syncthreads();
+  const int pad = (K - 1) / 2;
+  const int lanes = blockDim.x;                 // threads: [tg][c4] with c4 fastest
+  const int groups_per_block = lanes / C4;
+  const int b = blockIdx.y;
+  const int tg = threadIdx.x / C4, c4 = threadIdx.x - tg * C4;
+  const int t0 = (blockIdx.x * groups_per_block + tg) * DW_TT;
+  if (tg >= groups_per_block || t0 >= T) return;
+  const float4* xb = reinterpret_cast<const float4*>(x + (long)b * T * C);
+  float4 acc[DW_TT];
+#pragma unroll
+  for (int j = 0; j < DW_TT; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = t0 - pad; u < t0 + DW_TT + pad; ++u) {
+    if (u < 0 || u >= T) continue;
+    const float4 xv = xb[(long)u * C4 + c4];
+#pragma unroll
+    for (int j = 0; j < DW_TT; ++j) {
+      const int k = u - (t0 + j) + pad;
+      if (k >= 0 && k < K) {
+        const float4 w = *reinterpret_cast<const float4*>(s_w + k * C + c4 * 4);
+        acc[j].x += w.x * xv.x; acc[j].y += w.y * xv.y; acc[j].z += w.z * xv.z; acc[j].w += w.w * xv.w;
+      }
+    }
+  }
+  float4* yb = reinterpret_cast<float4*>(y + (long)b * T * C);
+#pragma unroll
+  for (int j = 0; j < DW_TT; ++j)
+    if (t0 + j < T) yb[(long)(t0 + j) * C4 + c4] = acc[j];
+}
+
+// dw[c,k] += sum over a chunk of (b,t) rows; thread = channel, 32 taps max in registers
+constexpr int DW_MAXK = 32;
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            float* __restrict__ dw, int T, int C, int K, int chunk) {
+  const int c = blockIdx.z * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int b = blockIdx.y;
+  const int t_begin = blockIdx.x * chunk, t_end = min(T, t_begin + chunk);
+  const int pad = (K - 1) / 2;
+  float acc[DW_MAXK];
+#pragma unroll
+  for (int k = 0; k < DW_MAXK; ++k) acc[k] = 0.f;
+  const float* xb = x + (long)b * T * C + c;
+  const float* db = dy + (long)b * T * C + c;
+  for (int t = t_begin; t < t_end; ++t) {
+    const float d = db[(long)t * C];
+#pragma unroll
+    for (int k = 0; k < DW_MAXK; ++k) {
+      const int u = t + k - pad;
+      if (k < K && u >= 0 && u < T) acc[k] += d * xb[(long)u * C];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DW_MAXK; ++k)
+    if (k < K) atomicAdd(dw + (long)c * K + k, acc[k]);
+}
+
+// ---- relative-position scores: shifted[i,j] = padded.flat[i*T + j + T], padded = [0 | PS] rows of T+1  (conformer.py:423-431)
+__device__ __forceinline__ float rel_shifted(const float* __restrict__ PSz, int i, int j, int T) {
+  const int q = j + T - i;                         // in [1, 2T-1]
+  if (q <= T) return PSz[(long)i * T + (q - 1)];
+  const int c = q - T - 1;                         // row i+1, padded column c (0 = the zero column)
+  return c == 0 ? 0.f : PSz[(long)(i + 1) * T + (c - 1)];
+}
+
+__global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ PS,
+                                                                  float* __restrict__ Pd, long nrows, int T, float scale,
+                                                                  float p_drop, const uint64_t* seed, uint32_t drop_offset) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  for (long row = (long)blockIdx.x * 4 + wave; row < nrows; row += (long)gridDim.x * 4) {
+    const long z = row / T;
+    const int i = (int)(row - z * T);
+    float* s = S + row * T;
+    const float* PSz = PS + z * T * T;
+    float mx = -INFINITY;
+    for (int j = lane; j < T; j += 64) {
+      const float v = (s[j] + rel_shifted(PSz, i, j, T)) * scale;
+      s[j] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = ctts_wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < T; j += 64) { const float e = __expf(s[j] - mx); s[j] = e; sum += e; }
+    const float inv = 1.f / ctts_wave_sum(sum);
+    for (int j = lane; j < T; j += 64) {
+      const float p = s[j] * inv;
+      s[j] = p;
+      if (Pd) Pd[row * T + j] = do_drop ? p * ctts_drop_scale(dkey, (uint32_t)(row * T + j), p_drop, inv_keep) : p;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dPd, long nrows,
+                                                                  int T, float scale, float p_drop, const uint64_t* seed,
+                                                                  uint32_t drop_offset) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  for (long row = (long)blockIdx.x * 4 + wave; row < nrows; row += (long)gridDim.x * 4) {
+    const float* p = P + row * T;
+    float* d = dPd + row * T;
+    float dot = 0.f;
+    for (int j = lane; j < T; j += 64) {
+      float g = d[j];
+      if (do_drop) g *= ctts_drop_scale(dkey, (uint32_t)(row * T + j), p_drop, inv_keep);
+      d[j] = g;
+      dot += g * p[j];
+    }
+    dot = ctts_wave_sum(dot);
+    for (int j = lane; j < T; j += 64) d[j] = p[j] * (d[j] - dot) * scale;
+  }
+}
+
+// dPS[z,r,c'] = dS_z.flat[r*(T+1) + c' + 1 - T] when that index is >= 0, else 0
+__global__ void relshift_bwd_kernel(const float* __restrict__ dS, float* __restrict__ dPS, long total, int T) {
+  const long TT = (long)T * T;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long z = e / TT;
+    const long rc = e - z * TT;
+    const int r = (int)(rc / T), c = (int)(rc - (long)r * T);
+    const long n = (long)r * (T + 1) + c + 1 - T;
+    dPS[e] = n >= 0 ? dS[z * TT + n] : 0.f;
+  }
+}
+
+inline int grid_for(long n, int cap = 8192) { return (int)min((n + 255) / 256, (long)cap); }
+
+}  // namespace
+
+extern "C" int ctts_glu_fwd(const float* a, float* out, int64_t rows, int C, void* stream) {
+  CTTS_REQUIRE(a && out && (C % 4) == 0 && C > 0, "ctts_glu_fwd: bad arguments (C %% 4 must be 0)");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for((long)rows * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<float4*>(out), (long)rows, C / 4);
+  CTTS_CHECK_LAUNCH("ctts_glu_fwd");
+  return 0;
+}
+
+extern "C" int ctts_glu_bwd(const float* a, const float* dout, float* da, int64_t rows, int C, void* stream) {
+  CTTS_REQUIRE(a && dout && da && (C % 4) == 0 && C > 0, "ctts_glu_bwd: bad arguments (C %% 4 must be 0)");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for((long)rows * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(dout), reinterpret_cast<float4*>(da),
+                     (long)rows, C / 4);
+  CTTS_CHECK_LAUNCH("ctts_glu_bwd");
+  return 0;
+}
+
+extern "C" int ctts_dwconv_fwd(const float* x, const float* wT, float* y, int B, int T, int C, int K, int flip, void* stream) {
+  CTTS_REQUIRE(x && wT && y && (C % 4) == 0 && C >= 4 && C <= 1024 && (K & 1) && K >= 1, "ctts_dwconv_fwd: need C %% 4 == 0, C <= 1024, odd K");
+  CTTS_REQUIRE((size_t)K * C * 4 <= 64 * 1024, "ctts_dwconv_fwd: K*C weights do not fit the LDS staging buffer");
+  if (B == 0 || T == 0) return 0;
+  const int C4 = C / 4;
+  const int groups = max(1, 256 / C4);
+  const int threads = groups * C4;
+  dim3 grid((T + groups * DW_TT - 1) / (groups * DW_TT), B);
+  hipLaunchKernelGGL(dwconv_fwd_kernel, grid, dim3(threads), (size_t)K * C * sizeof(float), (hipStream_t)stream, x, wT, y, T, C, K,
+                     flip);
+  CTTS_CHECK_LAUNCH("ctts_dwconv_fwd");
+  return 0;
+}
+
+extern "C" int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, int B, int T, int C, int K, void* stream) {
+  CTTS_REQUIRE(dy && x && dw && K <= DW_MAXK && (K & 1), "ctts_dwconv_wgrad: need odd K <= 32");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * K, st) != hipSuccess) { ctts_set_error("ctts_dwconv_wgrad: memset failed"); return -2; }
+  if (B == 0 || T == 0) return 0;
+  const int chunk = 64;
+  dim3 grid((T + chunk - 1) / chunk, B, (C + 255) / 256);
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, grid, dim3(256), 0, st, dy, x, dw, T, C, K, chunk);
+  CTTS_CHECK_LAUNCH("ctts_dwconv_wgrad");
+  return 0;
+}
+
+extern "C" int ctts_relpos_softmax_fwd(float* S, const float* PS, float* Pd, int nbatch, int T, float scale, float p_drop,
+                                       const uint64_t* seed, uint32_t drop_offset, void* stream) {
+  CTTS_REQUIRE(S && PS && nbatch > 0 && T > 0, "ctts_relpos_softmax_fwd: bad arguments");
+  CTTS_REQUIRE((long)nbatch * T * T < 0xFFFFFFFFL, "ctts_relpos_softmax_fwd: tensor too large for the 32-bit dropout index");
+  const long nrows = (long)nbatch * T;
+  hipLaunchKernelGGL(relpos_softmax_fwd_kernel, dim3((int)min((nrows + 3) / 4, (long)16384)), dim3(256), 0, (hipStream_t)stream, S,
+                     PS, Pd, nrows, T, scale, p_drop, seed, drop_offset);
+  CTTS_CHECK_LAUNCH("ctts_relpos_softmax_fwd");
+  return 0;
+}
+
+extern "C" int ctts_relpos_softmax_bwd(const float* P, float* dPd, int nbatch, int T, float scale, float p_drop,
+                                       const uint64_t* seed, uint32_t drop_offset, void* stream) {
+  CTTS_REQUIRE(P && dPd && nbatch > 0 && T > 0, "ctts_relpos_softmax_bwd: bad arguments");
+  const long nrows = (long)nbatch * T;
+  hipLaunchKernelGGL(relpos_softmax_bwd_kernel, dim3((int)min((nrows + 3) / 4, (long)16384)), dim3(256), 0, (hipStream_t)stream, P,
+                     dPd, nrows, T, scale, p_drop, seed, drop_offset);
+  CTTS_CHECK_LAUNCH("ctts_relpos_softmax_bwd");
+  return 0;
+}
+
+extern "C" int ctts_relshift_bwd(const float* dS, float* dPS, int nbatch, int T, void* stream) {
+  CTTS_REQUIRE(dS && dPS && nbatch > 0 && T > 0, "ctts_relshift_bwd: bad arguments");
+  const long total = (long)nbatch * T * T;
+  hipLaunchKernelGGL(relshift_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, (hipStream_t)stream, dS, dPS, total, T);
+  CTTS_CHECK_LAUNCH("ctts_relshift_bwd");
+  return 0;
+}

@@ -52,6 +52,7 @@ __device__ __forceinline__ float ctts_act(float v, int act) {
     case 1: return v > 0.f ? v : 0.f;
     case 2: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
     case 3: return tanhf(v);
+    case 4: return v / (1.0f + __expf(-v));          // swish = v * sigmoid(v)
     default: return v;
   }
 }
@@ -65,6 +66,7 @@ __device__ __forceinline__ float ctts_act_grad(float z, int act) {
       return cdf + z * pdf;
     }
     case 3: { float t = tanhf(z); return 1.f - t * t; }
+    case 4: { float sg = 1.0f / (1.0f + __expf(-z)); return sg * (1.f + z * (1.f - sg)); }
     default: return 1.f;
   }
 }

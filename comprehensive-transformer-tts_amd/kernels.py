@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import GemmDesc
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3, 4
 
 
 def _stream():
@@ -265,3 +265,66 @@ def log_clamp_transpose(mel_fm, B, F, n_mel, clip):
     lib = _lib.load()
     _lib.check(lib.ctts_log_clamp_transpose(_p(mel_fm), _p(out), B, F, n_mel, clip, _stream()), "ctts_log_clamp_transpose")
     return out
+
+
+# ------------------------------------------------------------------------- conformer kernels
+def glu_fwd(a):
+    C2 = a.shape[-1]
+    rows = a.numel() // C2
+    out = torch.empty(*a.shape[:-1], C2 // 2, dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_glu_fwd(_p(_f32c(a, "a")), _p(out), rows, C2 // 2, _stream()), "ctts_glu_fwd")
+    return out
+
+
+def glu_bwd(a, dout):
+    C2 = a.shape[-1]
+    rows = a.numel() // C2
+    da = torch.empty_like(a)
+    lib = _lib.load()
+    _lib.check(lib.ctts_glu_bwd(_p(a), _p(_f32c(dout, "dout")), _p(da), rows, C2 // 2, _stream()), "ctts_glu_bwd")
+    return da
+
+
+def dwconv_fwd(x, wT, flip=False):
+    """x [B,T,C], wT [K,C] -> y [B,T,C] (depthwise 'same' conv; flip=True is the data gradient)."""
+    B, T, Cc = x.shape
+    Kk = wT.shape[0]
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.ctts_dwconv_fwd(_p(_f32c(x, "x")), _p(_f32c(wT, "wT")), _p(y), B, T, Cc, Kk, int(flip), _stream()),
+               "ctts_dwconv_fwd")
+    return y
+
+
+def dwconv_wgrad(dy, x, Kk):
+    B, T, Cc = x.shape
+    dw = torch.empty(Cc, Kk, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_dwconv_wgrad(_p(_f32c(dy, "dy")), _p(x), _p(dw), B, T, Cc, Kk, _stream()), "ctts_dwconv_wgrad")
+    return dw
+
+
+def relpos_softmax_fwd(S, PS, T, scale, p_drop=0.0, seed=None, drop_offset=0, want_dropped=True):
+    nb = S.numel() // (T * T)
+    Pd = torch.empty_like(S) if want_dropped else None
+    lib = _lib.load()
+    _lib.check(lib.ctts_relpos_softmax_fwd(_p(S), _p(PS), _p(Pd), nb, T, scale, p_drop, _p(seed), drop_offset, _stream()),
+               "ctts_relpos_softmax_fwd")
+    return Pd
+
+
+def relpos_softmax_bwd(P, dPd, T, scale, p_drop=0.0, seed=None, drop_offset=0):
+    nb = P.numel() // (T * T)
+    lib = _lib.load()
+    _lib.check(lib.ctts_relpos_softmax_bwd(_p(P), _p(dPd), nb, T, scale, p_drop, _p(seed), drop_offset, _stream()),
+               "ctts_relpos_softmax_bwd")
+    return dPd
+
+
+def relshift_bwd(dS, T):
+    nb = dS.numel() // (T * T)
+    dPS = torch.empty_like(dS)
+    lib = _lib.load()
+    _lib.check(lib.ctts_relshift_bwd(_p(dS), _p(dPS), nb, T, _stream()), "ctts_relshift_bwd")
+    return dPS

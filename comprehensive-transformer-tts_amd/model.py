@@ -11,9 +11,9 @@ Contract kept from the reference:
   * the `block_type` plugin surface: `TextEncoder(config)`, `Decoder(config)`, `.d_model`.
 
 Not a module-tree translation: activations stay [B,T,C]; each reference sub-layer maps to one
-or two fused kernel launches (see ops.py).  Supported here: block_type transformer_fs2,
-learn_alignment False, pitch_type cwt, phoneme-level energy, prosody model "none"
-(BASELINE.json configs 1, 2 and 4); anything else raises NotImplementedError loudly.
+or two fused kernel launches (see ops.py).  Supported here: block_type transformer_fs2 and conformer
+(conformer.py), learn_alignment False, pitch_type cwt, phoneme-level energy, prosody model "none"
+(BASELINE.json configs 1-4); anything else raises NotImplementedError loudly.
 """
 import json
 import math
@@ -437,9 +437,11 @@ class CompTransTTS(nn.Module):
         bt = model_config["block_type"]
         if bt == "transformer_fs2":
             enc_cls, dec_cls = TextEncoder, Decoder
-        elif bt in ("transformer", "lstransformer", "fastformer", "conformer", "reformer"):
-            raise NotImplementedError(f"block_type '{bt}' has no MI355X-native plugin yet (SURVEY.md section 8: conformer is "
-                                      "the next plugin; the others are out of scope)")
+        elif bt == "conformer":
+            from .conformer import TextEncoder as enc_cls, Decoder as dec_cls
+        elif bt in ("transformer", "lstransformer", "fastformer", "reformer"):
+            raise NotImplementedError(f"block_type '{bt}' has no MI355X-native plugin (SURVEY.md section 2 #6: out of scope; the "
+                                      "plugin contract is kept, so a third-party TextEncoder/Decoder pair still plugs in)")
         else:
             raise NotImplementedError
         self.encoder = enc_cls(model_config)
@@ -462,8 +464,15 @@ class CompTransTTS(nn.Module):
     # blocks.py:286-288 ConvNorm; torch defaults for nn.Conv1d / nn.Linear elsewhere)
     def reset_parameters(self):
         params = dict(self.named_parameters())
+        conformer = self.model_config["block_type"] == "conformer"
+        if conformer:
+            from .conformer import reset_conformer_parameters
+            reset_conformer_parameters(self.encoder)
+            reset_conformer_parameters(self.decoder)
         for name, p in params.items():
             if name.endswith("pos_embed_alpha") or name.endswith("energy_bins"):
+                continue
+            if conformer and (name.startswith("encoder.") or name.startswith("decoder.")):
                 continue
             if name.endswith("in_proj_weight") or name.endswith("out_proj.weight") or name.endswith("ffn_2.weight"):
                 nn.init.xavier_uniform_(p)

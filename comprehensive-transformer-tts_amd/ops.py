@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import kernels as K
-from .kernels import ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH  # noqa: F401
+from .kernels import ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SWISH  # noqa: F401
 
 
 def _split_k_for(Mo, No, Kred):
@@ -341,3 +341,109 @@ class _GradScale(torch.autograd.Function):
 
 def grad_scale(x, g):
     return _GradScale.apply(x, g)
+
+
+# ------------------------------------------------------------------------- conformer operators
+class _GLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        a = a.contiguous()
+        ctx.save_for_backward(a)
+        return K.glu_fwd(a)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (a,) = ctx.saved_tensors
+        return K.glu_bwd(a, dout.contiguous())
+
+
+def glu(a):
+    """GLU over the last dim: a[..., :C] * sigmoid(a[..., C:])  (blocks.GLU with channel-last layout)."""
+    return _GLU.apply(a)
+
+
+class _DepthwiseConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x = x.contiguous()
+        C, _, Kk = w.shape
+        wT = w.view(C, Kk).t().contiguous()          # [K, C] tap-major copy (31 x 256 floats)
+        ctx.save_for_backward(x, wT)
+        ctx.wshape = w.shape
+        return K.dwconv_fwd(x, wT, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wT = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = K.dwconv_fwd(dy, wT, True) if ctx.needs_input_grad[0] else None
+        dw = K.dwconv_wgrad(dy, x, wT.shape[0]).view(ctx.wshape) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def depthwise_conv1d(x, w):
+    """x [B,T,C], w [C,1,k] (nn.Conv1d groups=C layout), 'same' padding, no bias (conformer.py:522-560)."""
+    return _DepthwiseConv.apply(x, w)
+
+
+class _RelPosAttention(torch.autograd.Function):
+    """Core of RelativeMultiHeadAttention (conformer.py:396-421) on channel-last projections.
+
+    qu = q + u_bias, qv = q + v_bias [B,T,C]; kv [B,T,2C] (k | v); pos [T,C] (projected sinusoid table, shared by
+    the batch).  score = (qu k^T + shift(qv pos^T)) / sqrt(d_model), softmax over ALL keys (the reference never passes
+    the mask, conformer.py:243), dropout on the probabilities, context = P v."""
+
+    @staticmethod
+    def forward(ctx, qu, qv, kv, pos, n_heads, scale, p_drop, seed, drop_offset):
+        qu, qv, kv, pos = qu.contiguous(), qv.contiguous(), kv.contiguous(), pos.contiguous()
+        B, T, C = qu.shape
+        dh = C // n_heads
+        H = n_heads
+        sS = (H * T * T, T * T)
+        S = torch.empty(B, H, T, T, dtype=torch.float32, device=qu.device)
+        PS = torch.empty(B, H, T, T, dtype=torch.float32, device=qu.device)
+        K.gemm(qu, kv, S, T, T, dh, C, 2 * C, T, True, True, nb0=B, nb1=H, sA=(T * C, dh), sB=(T * 2 * C, dh), sC=sS)
+        K.gemm(qv, pos, PS, T, T, dh, C, C, T, True, True, nb0=B, nb1=H, sA=(T * C, dh), sB=(0, dh), sC=sS)
+        Pd = K.relpos_softmax_fwd(S, PS, T, scale, p_drop, seed, drop_offset, want_dropped=True)   # S <- P
+        del PS
+        out = torch.empty(B, T, C, dtype=torch.float32, device=qu.device)
+        K.gemm(Pd, kv, out, T, dh, T, T, 2 * C, C, True, False, b_off=C, nb0=B, nb1=H, sA=sS, sB=(T * 2 * C, dh), sC=(T * C, dh))
+        ctx.save_for_backward(qu, qv, kv, pos, S, seed)
+        ctx.cfg = (n_heads, scale, p_drop, drop_offset)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qu, qv, kv, pos, P, seed = ctx.saved_tensors
+        H, scale, p_drop, drop_offset = ctx.cfg
+        dO = dO.contiguous()
+        B, T, C = qu.shape
+        dh = C // H
+        sS = (H * T * T, T * T)
+        dkv = torch.empty_like(kv)
+        # dV = Pd^T dO   (Pd regenerated from P and the counter-based mask)
+        Pd = K.rowscale_dropout(P, None, p_drop, seed, drop_offset) if p_drop > 0 else P
+        K.gemm(Pd, dO, dkv, T, dh, T, T, C, 2 * C, False, False, c_off=C, nb0=B, nb1=H, sA=sS, sB=(T * C, dh), sC=(T * 2 * C, dh))
+        del Pd
+        # dPd = dO V^T ; dS = P * (dP - sum dP P) * scale
+        dS = torch.empty_like(P)
+        K.gemm(dO, kv, dS, T, T, dh, C, 2 * C, T, True, True, b_off=C, nb0=B, nb1=H, sA=(T * C, dh), sB=(T * 2 * C, dh), sC=sS)
+        K.relpos_softmax_bwd(P, dS, T, scale, p_drop, seed, drop_offset)
+        # content path: dQU = dS K ; dK = dS^T QU
+        dqu = torch.empty_like(qu)
+        K.gemm(dS, kv, dqu, T, dh, T, T, 2 * C, C, True, False, nb0=B, nb1=H, sA=sS, sB=(T * 2 * C, dh), sC=(T * C, dh))
+        K.gemm(dS, qu, dkv, T, dh, T, T, C, 2 * C, False, False, c_off=0, nb0=B, nb1=H, sA=sS, sB=(T * C, dh), sC=(T * 2 * C, dh))
+        # position path: dPS = unshift(dS) ; dQV = dPS pos ; dpos = sum_b dPS^T QV
+        dPS = K.relshift_bwd(dS, T)
+        del dS
+        dqv = torch.empty_like(qv)
+        K.gemm(dPS, pos, dqv, T, dh, T, T, C, C, True, False, nb0=B, nb1=H, sA=sS, sB=(0, dh), sC=(T * C, dh))
+        dpos_b = torch.empty(B, T, C, dtype=torch.float32, device=qu.device)
+        K.gemm(dPS, qv, dpos_b, T, dh, T, T, C, C, False, False, nb0=B, nb1=H, sA=sS, sB=(T * C, dh), sC=(T * C, dh))
+        dpos = dpos_b.sum(0)
+        return dqu, dqv, dkv, dpos, None, None, None, None, None
+
+
+def relpos_attention(qu, qv, kv, pos, n_heads, scale, p_drop=0.0, drop=None):
+    seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
+    return _RelPosAttention.apply(qu, qv, kv, pos, n_heads, scale, p_drop if seed is not None else 0.0, seed, off)

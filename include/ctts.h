@@ -52,7 +52,7 @@ typedef struct ctts_gemm_desc {
   float alpha;
   const float* bias;                      /* [N] or NULL                                              */
   float* Z; int64_t ldz;                  /* optional store of the pre-activation                     */
-  int32_t act;                            /* 0 none, 1 relu, 2 gelu(erf), 3 tanh                      */
+  int32_t act;                            /* 0 none, 1 relu, 2 gelu(erf), 3 tanh, 4 swish             */
   float p_drop; const uint64_t* seed; uint32_t drop_offset;   /* inverted dropout after act           */
   const float* R; int64_t ldr;            /* residual added after dropout                             */
   const float* rowscale;                  /* [M] multiplied last (non-pad mask), or NULL              */
@@ -139,6 +139,27 @@ int ctts_reflect_pad(const float* y, float* ypad, int B, int N, int pad, int64_t
 int ctts_stft_magnitude(const float* reim, int64_t ld_reim, float* mag, int64_t ld_mag, float* energy, int64_t frames,
                         int nbins, void* stream);
 int ctts_log_clamp_transpose(const float* mel_fm, float* out, int B, int F, int n_mel, float clip, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Conformer block pieces (model/transformers/conformer.py).
+ * GLU over the channel dim (blocks.py GLU, conformer.py:458): a [rows, 2C] -> out[r,c] = a[r,c] * sigmoid(a[r,C+c]).
+ * Depthwise Conv1d k (odd), 'same' padding, no bias, channel-last (conformer.py:522-560, DepthwiseConv1d):
+ *   y[b,t,c] = sum_k wT[k,c] * x[b,t+k-pad,c];  flip=1 uses wT[K-1-k] (data gradient);
+ *   wgrad: dw[c,k] += sum_{b,t} dy[b,t,c] * x[b,t+k-pad,c]   (dw [C,K], pre-zeroed by the call).
+ * Relative-position attention scores (conformer.py:347-431, RelativeMultiHeadAttention):
+ *   relpos_softmax_fwd: P = softmax_j( (S[i,j] + shift(PS)[i,j]) * scale ) over ALL keys (no mask, conformer.py:243 vs :326),
+ *     shift = Transformer-XL _relative_shift (conformer.py:423-431); P overwrites S, Pd = inverted-dropout(P) (optional).
+ *   relpos_softmax_bwd: dS = P * (dP - sum_j dP*P) * scale with dP = dropmask/(1-p) * dPd, in place on dPd;
+ *   relshift_bwd: dPS = inverse of the shift applied to dS.                                               */
+int ctts_glu_fwd(const float* a, float* out, int64_t rows, int C, void* stream);
+int ctts_glu_bwd(const float* a, const float* dout, float* da, int64_t rows, int C, void* stream);
+int ctts_dwconv_fwd(const float* x, const float* wT, float* y, int B, int T, int C, int K, int flip, void* stream);
+int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, int B, int T, int C, int K, void* stream);
+int ctts_relpos_softmax_fwd(float* S, const float* PS, float* Pd, int nbatch, int T, float scale, float p_drop,
+                            const uint64_t* seed, uint32_t drop_offset, void* stream);
+int ctts_relpos_softmax_bwd(const float* P, float* dPd, int nbatch, int T, float scale, float p_drop, const uint64_t* seed,
+                            uint32_t drop_offset, void* stream);
+int ctts_relshift_bwd(const float* dS, float* dPS, int nbatch, int T, void* stream);
 
 #ifdef __cplusplus
 }

@@ -346,3 +346,114 @@ def comp_trans_tts_forward(sd, model_cfg, pre_cfg, speakers, texts, src_lens, ma
     post = postnet(sd, mel, training, train_dropout, new_stats) + mel
     return (mel, post, p_pred, e_pred, log_d, d_rounded, src_pad, mel_pad, src_lens, mel_lens,
             (None, None, None, None), None, p_targets, e_targets)
+
+
+# ============================================================================= a15: conformer plugin
+def interleaved_sinusoid_table(n_position, d_hid):
+    """blocks.py:26-46 get_sinusoid_encoding_table: angle = pos / 10000^(2*(j//2)/d), sin on even j, cos on odd j
+    (computed in float64 numpy, stored as float32)."""
+    import numpy as np
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    ang = pos / np.power(10000, 2 * (j // 2) / d_hid)
+    tab = np.array(ang)
+    tab[:, 0::2] = np.sin(ang[:, 0::2])
+    tab[:, 1::2] = np.cos(ang[:, 1::2])
+    return torch.from_numpy(tab).float()
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _relative_shift(ps):
+    """conformer.py:423-431 (Transformer-XL shift)"""
+    B, H, T1, T2 = ps.shape
+    padded = torch.cat([ps.new_zeros(B, H, T1, 1), ps], dim=-1).view(B, H, T2 + 1, T1)
+    return padded[:, :, 1:].reshape(B, H, T1, T2)
+
+
+def conformer_stack(sd, pre, x, pad_mask, n_layers, n_heads, p_drop, training_bn, train_dropout=False, new_stats=None, taps=None):
+    """conformer.py:162-246 ConformerBlock x n_layers.  NOTE the attention receives no mask (nn.Sequential drops it,
+    conformer.py:243 vs :326) and scores are scaled by sqrt(d_model) (:375,:409)."""
+    B, T, C = x.shape
+    dh = C // n_heads
+    pos_table = sd[pre + "position_enc"][0, :T]
+    for l in range(n_layers):
+        p = f"{pre}layer_stack.{l}.sequential."
+        for ff in ("0", "3"):       # half-step feed-forward modules
+            q = p + ff + ".module.sequential."
+            h = layer_norm(x, sd[q + "0.weight"], sd[q + "0.bias"], 1e-5)
+            h = _drop(_swish(h @ sd[q + "1.linear.weight"].t() + sd[q + "1.linear.bias"]), p_drop, train_dropout)
+            h = _drop(h @ sd[q + "4.linear.weight"].t() + sd[q + "4.linear.bias"], p_drop, train_dropout)
+            x = x + 0.5 * h
+            if ff == "3":
+                break
+            # multi-headed self attention with relative positions
+            a = p + "1.module."
+            h = layer_norm(x, sd[a + "layer_norm.weight"], sd[a + "layer_norm.bias"], 1e-5)
+            qh = (h @ sd[a + "attention.query_proj.linear.weight"].t()).view(B, T, n_heads, dh)
+            kh = (h @ sd[a + "attention.key_proj.linear.weight"].t()).view(B, T, n_heads, dh).permute(0, 2, 1, 3)
+            vh = (h @ sd[a + "attention.value_proj.linear.weight"].t()).view(B, T, n_heads, dh).permute(0, 2, 1, 3)
+            ph = (pos_table @ sd[a + "attention.pos_proj.linear.weight"].t()).view(T, n_heads, dh)
+            content = (qh + sd[a + "attention.u_bias"]).transpose(1, 2) @ kh.transpose(2, 3)
+            pscore = (qh + sd[a + "attention.v_bias"]).transpose(1, 2) @ ph.permute(1, 2, 0)[None]
+            score = (content + _relative_shift(pscore)) / math.sqrt(C)
+            attn = _drop(torch.softmax(score, -1), p_drop, train_dropout)
+            ctxv = (attn @ vh).transpose(1, 2).reshape(B, T, C)
+            x = x + _drop(ctxv @ sd[a + "attention.out_proj.linear.weight"].t(), p_drop, train_dropout)
+            # convolution module
+            c = p + "2.module.sequential."
+            h = layer_norm(x, sd[c + "0.weight"], sd[c + "0.bias"], 1e-5)
+            h = h @ sd[c + "2.conv.weight"][:, :, 0].t() + sd[c + "2.conv.bias"]
+            h = h[..., :C] * torch.sigmoid(h[..., C:])
+            wdw = sd[c + "4.conv.weight"]
+            h = F.conv1d(h.transpose(1, 2), wdw, None, padding=(wdw.shape[-1] - 1) // 2, groups=C).transpose(1, 2)
+            if training_bn:
+                flat = h.reshape(-1, C)
+                mean, var = flat.mean(0), flat.var(0, unbiased=False)
+                if new_stats is not None:
+                    n = flat.shape[0]
+                    new_stats[c + "5.running_mean"] = 0.9 * sd[c + "5.running_mean"] + 0.1 * mean.detach()
+                    new_stats[c + "5.running_var"] = 0.9 * sd[c + "5.running_var"] + 0.1 * var.detach() * n / (n - 1)
+            else:
+                mean, var = sd[c + "5.running_mean"], sd[c + "5.running_var"]
+            h = _swish((h - mean) / torch.sqrt(var + 1e-5) * sd[c + "5.weight"] + sd[c + "5.bias"])
+            h = _drop(h @ sd[c + "7.conv.weight"][:, :, 0].t() + sd[c + "7.conv.bias"], p_drop, train_dropout)
+            x = x + h
+        x = layer_norm(x, sd[p + "4.weight"], sd[p + "4.bias"], 1e-5)
+        x = x.masked_fill(pad_mask[..., None], 0)
+        if taps is not None:
+            taps[f"{pre}layer{l}"] = x
+    return x
+
+
+def comp_trans_tts_forward_conformer(sd, model_cfg, pre_cfg, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None,
+                                     max_mel_len=None, p_targets=None, e_targets=None, d_targets=None, attn_priors=None,
+                                     spker_embeds=None, p_control=1.0, e_control=1.0, d_control=1.0, step=None,
+                                     training=False, train_dropout=False, taps=None, new_stats=None):
+    """model/CompTransTTS.py:64-152 with block_type == conformer (conformer.py:20-159 encoder/decoder wrappers)."""
+    assert model_cfg["block_type"] == "conformer" and attn_priors is None and not model_cfg["multi_speaker"]
+    c = model_cfg["conformer"]
+    src_pad = mask_from_lengths(src_lens, max_src_len)
+    mel_pad = mask_from_lengths(mel_lens, max_mel_len) if mel_lens is not None else None
+    emb = F.embedding(texts, sd["encoder.src_word_emb.weight"], padding_idx=0)
+    x = emb + sd["encoder.position_enc"][:, : texts.shape[1]]
+    enc = conformer_stack(sd, "encoder.", x, src_pad, c["encoder_layer"], c["encoder_head"], c["encoder_dropout"], training,
+                          train_dropout, new_stats, taps)
+    if taps is not None:
+        taps["encoder_out"] = enc
+    (x, p_targets, p_pred, e_targets, e_pred, log_d, d_rounded, mel_lens, mel_pad) = variance_adaptor(
+        sd, model_cfg, pre_cfg, enc, src_lens, src_pad, mel_lens, mel_pad, max_mel_len, p_targets, e_targets, d_targets, None,
+        p_control, e_control, d_control, train_dropout, taps)
+    T = min(x.shape[1], model_cfg["max_seq_len"])          # conformer.py:148-154 crop (training and short inference)
+    x = x[:, :T] + sd["decoder.position_enc"][:, :T]
+    mel_pad = mel_pad[:, :T]
+    dec = conformer_stack(sd, "decoder.", x, mel_pad, c["decoder_layer"], c["decoder_head"], c["decoder_dropout"], training,
+                          train_dropout, new_stats, taps)
+    if taps is not None:
+        taps["decoder_out"] = dec
+    mel = dec @ sd["mel_linear.weight"].t() + sd["mel_linear.bias"]
+    post = postnet(sd, mel, training, train_dropout, new_stats) + mel
+    return (mel, post, p_pred, e_pred, log_d, d_rounded, src_pad, mel_pad, src_lens, mel_lens, (None, None, None, None), None,
+            p_targets, e_targets)

@@ -247,6 +247,11 @@ def main():
     run_case(model_v, vb, "eval", "g5_vctk_eval")
     golden_integer_vectors()
     golden_stft()
+    # G4: conformer block_type (unmasked relative attention, GLU / depthwise conv / BatchNorm module)
+    model_c, cfgs_c = build("LJSpeech", "conformer")
+    cb = make_batch([24, 17], 6, seed=4321)
+    run_case(model_c, cb, "eval", "g4_conformer_eval")
+    run_case(model_c, cb, "train", "g4_conformer_train_nodrop", with_grads=True)
 
 
 if __name__ == "__main__":

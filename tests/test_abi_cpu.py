@@ -58,9 +58,25 @@ def test_state_dict_schema_matches_reference(dataset):
     assert enc.d_model == 256 and dec.d_model == 256        # block_type plugin surface
 
 
-def test_unsupported_block_types_raise():
+def test_conformer_state_dict_schema_matches_reference():
     pre, mc, tc = get_configs()
     mc["block_type"] = "conformer"
+    m = ctts_amd.CompTransTTS(pre, mc, tc)
+    sd, sch = m.state_dict(), schema("LJSpeech", "conformer")
+    assert set(sd) == set(sch), (set(sd) ^ set(sch))
+    params = dict(m.named_parameters())
+    for k, (shape, dtype, is_param) in sch.items():
+        assert list(sd[k].shape) == shape, k
+        assert (k in params) == is_param, k
+    assert sum(p.numel() for p in m.parameters()) == 22623952        # SURVEY.md headline facts
+    # the sinusoid table is ONE Parameter object shared by the stack and every attention module (conformer.py:322)
+    assert m.encoder.layer_stack[2].sequential.__getattr__("1").module.positional_encoding is m.encoder.position_enc
+    assert m.encoder.d_model == 256 and m.decoder.d_model == 256
+
+
+def test_unsupported_block_types_raise():
+    pre, mc, tc = get_configs()
+    mc["block_type"] = "reformer"
     with pytest.raises(NotImplementedError):
         ctts_amd.CompTransTTS(pre, mc, tc)
     mc["block_type"] = "nope"

@@ -314,3 +314,83 @@ def test_pad_row_skipping_is_equivalent_on_valid_rows():
         close(dx1, dx0, 1e-6, f"{kind} dx")
         close(dw1, dw0, 2e-5, f"{kind} dw")
         close(db1, db0, 1e-5, f"{kind} db")
+
+
+def test_swish_linear_glu_depthwise_fwd_bwd():
+    B, T, C = 3, 45, 256
+    x, w, b = rnd(B, T, C, seed=100), rnd(128, C, seed=101, scale=0.1), rnd(128, seed=102)
+    xr, wr, br = [t.double().requires_grad_() for t in (x, w, b)]
+    z = xr @ wr.t() + br
+    yr = z * torch.sigmoid(z)
+    xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+    y = ops.linear(xg, wg, bg, act=ops.ACT_SWISH)
+    close(y, yr, 1e-5, "swish fwd")
+    go = rnd(B, T, 128, seed=103)
+    yr.backward(go.double()); y.backward(go.to(DEV))
+    close(xg.grad, xr.grad, 2e-5, "swish dx"); close(wg.grad, wr.grad, 2e-5, "swish dw")
+    # GLU
+    a = rnd(B, T, 2 * C, seed=104)
+    ar = a.double().requires_grad_()
+    gr = ar[..., :C] * torch.sigmoid(ar[..., C:])
+    ag = a.to(DEV).requires_grad_()
+    g = ops.glu(ag)
+    close(g, gr, 1e-5, "glu fwd")
+    go = rnd(B, T, C, seed=105)
+    gr.backward(go.double()); g.backward(go.to(DEV))
+    close(ag.grad, ar.grad, 2e-5, "glu bwd")
+    # depthwise conv k=31 (and a short sequence, T < k)
+    for (Bq, Tq) in ((3, 45), (2, 9), (2, 130)):
+        xx, ww = rnd(Bq, Tq, C, seed=106), rnd(C, 1, 31, seed=107, scale=0.2)
+        xr, wr = xx.double().requires_grad_(), ww.double().requires_grad_()
+        yr = F.conv1d(xr.transpose(1, 2), wr, None, padding=15, groups=C).transpose(1, 2)
+        xg, wg = xx.to(DEV).requires_grad_(), ww.to(DEV).requires_grad_()
+        y = ops.depthwise_conv1d(xg, wg)
+        close(y, yr, 1e-5, "dwconv fwd")
+        go = rnd(Bq, Tq, C, seed=108)
+        yr.backward(go.double()); y.backward(go.to(DEV))
+        close(xg.grad, xr.grad, 2e-5, "dwconv dx"); close(wg.grad, wr.grad, 3e-5, "dwconv dw")
+
+
+@pytest.mark.parametrize("B,T,H,C", [(2, 36, 8, 256), (2, 51, 8, 256), (1, 132, 4, 128)])
+def test_relpos_attention_fwd_bwd(B, T, H, C):
+    dh = C // H
+    qu, qv, kv, pos = rnd(B, T, C, seed=110), rnd(B, T, C, seed=111), rnd(B, T, 2 * C, seed=112), rnd(T, C, seed=113)
+    scale = 1.0 / C ** 0.5 * 4
+
+    def ref(qu, qv, kv, pos):
+        q1 = qu.view(B, T, H, dh).transpose(1, 2)
+        q2 = qv.view(B, T, H, dh).transpose(1, 2)
+        k = kv[..., :C].reshape(B, T, H, dh).permute(0, 2, 1, 3)
+        v = kv[..., C:].reshape(B, T, H, dh).permute(0, 2, 1, 3)
+        p = pos.view(T, H, dh).permute(1, 2, 0)[None]
+        content = q1 @ k.transpose(2, 3)
+        ps = q2 @ p
+        padded = torch.cat([ps.new_zeros(B, H, T, 1), ps], dim=-1).view(B, H, T + 1, T)
+        shifted = padded[:, :, 1:].reshape(B, H, T, T)
+        attn = torch.softmax((content + shifted) * scale, -1)
+        return (attn @ v).transpose(1, 2).reshape(B, T, C)
+    tr = [t.double().requires_grad_() for t in (qu, qv, kv, pos)]
+    tg = [t.to(DEV).requires_grad_() for t in (qu, qv, kv, pos)]
+    yr = ref(*tr)
+    y = ops.relpos_attention(*tg, H, scale)
+    close(y, yr, 1e-5, "relpos fwd")
+    go = rnd(B, T, C, seed=114)
+    yr.backward(go.double()); y.backward(go.to(DEV))
+    for n, a, r in zip(("dqu", "dqv", "dkv", "dpos"), tg, tr):
+        close(a.grad, r.grad, 3e-5, "relpos " + n)
+
+
+def test_relpos_attention_dropout_consistency():
+    B, T, H, C, p = 2, 64, 8, 256, 0.3
+    qu, qv, kv, pos = [t.to(DEV) for t in (rnd(B, T, C, seed=120), rnd(B, T, C, seed=121), rnd(B, T, 2 * C, seed=122), rnd(T, C, seed=123))]
+    kv = kv.clone()
+    kv[..., C:] = 1.0                                  # V = 1  ->  context = sum_j dropped probs = kept mass / (1-p)
+    drop = K.DropCtx(DEV)
+    kvg = kv.requires_grad_()
+    y = ops.relpos_attention(qu, qv, kvg, pos, H, 0.1, p_drop=p, drop=drop)
+    mass = y.detach()[..., 0]
+    assert abs(mass.mean().item() - 1.0) < 0.05 and mass.std().item() > 0.01
+    # backward regenerates the same mask: d/dV of sum(y) is the column sum of the dropped probabilities = same kept mass
+    y.sum().backward()
+    tot = kvg.grad[..., C:].sum().item()
+    assert abs(tot - y.detach().sum().item()) < 1e-2 * abs(tot)

@@ -17,8 +17,9 @@ DEV = "cuda"
 MEL_TOL = 1e-3
 
 
-def build(dataset="LJSpeech", sd=None):
+def build(dataset="LJSpeech", sd=None, block="transformer_fs2"):
     pre, mc, tc = get_configs(dataset)
+    mc["block_type"] = block
     m = ctts_amd.CompTransTTS(pre, mc, tc)
     if sd is not None:
         m.load_state_dict(sd)
@@ -181,3 +182,61 @@ def test_product_fails_loudly_on_cpu_tensors():
     m = ctts_amd.CompTransTTS(pre, mc, tc)           # CPU module: no fallback path exists
     with pytest.raises(Exception):
         m(*as_model_args(make_batch([8, 5], 4)))
+
+
+def test_g4_conformer_eval_matches_reference():
+    g = load_golden("g4_conformer_eval")
+    m, _ = build(sd=closed_form_sd("LJSpeech", "conformer"), block="conformer")
+    m.eval()
+    with torch.no_grad():
+        out = m(*args_from(batch_from_golden(g)))
+    check_against_golden(out, g)
+
+
+def test_g4_conformer_train_gradients_match_reference():
+    g = load_golden("g4_conformer_train_nodrop")
+    m, _ = build(sd=closed_form_sd("LJSpeech", "conformer"), block="conformer")
+    m.train()
+    no_dropout(m)
+    out = m(*args_from(batch_from_golden(g)))
+    check_against_golden(out, g)
+    sd_after = m.state_dict()
+    for k in sd_after:
+        if "running_" in k:
+            assert maxerr(sd_after[k], g["bn." + k]) < 1e-4, k
+
+    def pseudo(name, shape):
+        return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float().to(DEV)
+    mel, post, p_pred, e_pred, log_d = out[:5]
+    loss = ((post * pseudo("post", post.shape)).sum() + (mel * pseudo("mel", mel.shape)).sum()
+            + (log_d * pseudo("logd", log_d.shape)).sum() + (e_pred * pseudo("e", e_pred.shape)).sum()
+            + (p_pred["cwt"] * pseudo("cwt", p_pred["cwt"].shape)).sum()
+            + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum())
+    loss.backward()
+    worst, n = ("", 0.0), 0
+    for k, p in m.named_parameters():
+        if "grad.stat." + k not in g:
+            continue
+        gs = g["grad.stat." + k]
+        gr = p.grad.flatten() if p.grad is not None else torch.zeros(p.numel(), device=DEV)
+        scale = max(1.0, float(gs[1]))
+        e = max(maxerr(gr[:64], g["grad.head." + k]) / scale, abs(float(gr.double().pow(2).sum().sqrt()) - gs[1]) / scale)
+        if e > worst[1]:
+            worst = (k, e)
+        n += 1
+    print("conformer worst relative gradient error:", worst, "over", n, "parameters")
+    assert n > 300 and worst[1] < 2e-3, worst
+
+
+def test_conformer_train_step_with_dropout_runs():
+    torch.manual_seed(3)
+    m, _ = build(block="conformer")
+    m.train()
+    batch = make_batch([40, 33, 21, 12], 8, seed=9)
+    out = m(*as_model_args(to_device(batch, DEV)))
+    loss = (out[0].abs().mean() + out[1].abs().mean() + out[4].pow(2).mean() + out[3].pow(2).mean() + out[2]["cwt"].abs().mean()
+            + out[2]["f0_mean"].abs().mean() + out[2]["f0_std"].abs().mean())
+    loss.backward()
+    for k, p in m.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k

@@ -118,3 +118,29 @@ def test_g7_integer_vectors_bit_exact():
     assert np.array_equal(R.f0_to_coarse(torch.from_numpy(g["f0c.in"])).numpy(), g["f0c.out"])
     assert np.array_equal(torch.bucketize(torch.from_numpy(g["bkt.in"]), torch.from_numpy(g["bkt.bins"])).numpy(),
                           g["bkt.out"])
+
+
+def _run_conformer(gname, training):
+    g = load_golden(gname)
+    sd = closed_form_sd("LJSpeech", "conformer")
+    pre, mc, tc = get_configs()
+    mc["block_type"] = "conformer"
+    b = batch_from_golden(g)
+    taps, stats = {}, {}
+    out = R.comp_trans_tts_forward_conformer(sd, mc, pre, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"],
+                                             b["mel_lens"], b["max_mel_len"], b["p_targets"], b["e_targets"], b["d_targets"],
+                                             training=training, taps=taps, new_stats=stats)
+    return g, out, taps, stats
+
+
+def test_g4_conformer_eval():
+    g, out, taps, _ = _run_conformer("g4_conformer_eval", False)
+    _check_outputs(g, out, taps)
+
+
+def test_g4_conformer_train_batch_stats():
+    g, out, taps, stats = _run_conformer("g4_conformer_train_nodrop", True)
+    _check_outputs(g, out, taps)
+    assert len(stats) == 10 * 2 + 5 * 2
+    for k, v in stats.items():
+        _close(v, g["bn." + k], 5e-5, name=k)

@@ -31,6 +31,9 @@ def closed_form_sd(dataset="LJSpeech", block="transformer_fs2"):
             with open(os.path.join(pre["path"]["preprocessed_path"], "stats.json")) as f:
                 emin, emax = json.load(f)["energy_sup_phone"][:2]
             sd[k] = torch.linspace(emin, emax, shape[0])
+        elif "position_enc" in k or "positional_encoding" in k:
+            from oracle.restate import interleaved_sinusoid_table
+            sd[k] = interleaved_sinusoid_table(shape[1], shape[2]).unsqueeze(0)
         elif any(s in k for s in SKIP):
             sd[k] = torch.zeros(shape)
         else:
