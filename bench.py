@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", default="canonical", choices=["canonical", "c1"])
+    ap.add_argument("--block", default="transformer_fs2", choices=["transformer_fs2", "conformer"],
+                    help="block_type plugin; the headline metric (BASELINE configs[1]) is transformer_fs2, conformer = configs[2]")
     return ap.parse_args()
 
 
@@ -217,13 +219,15 @@ def main():
     from ctts_amd.synthetic import make_batch, to_device, C1_SRC_LENS
 
     pre, mc, tc = get_configs()
+    mc["block_type"] = a.block
     torch.manual_seed(1234)                                   # identical init on every rank (DDP broadcast equivalent)
     model = ctts_amd.CompTransTTS(pre, mc, tc).to(dev)
     model.train()
     loss_fn = CompTransTTSLoss(pre, mc, tc).to(dev)
     optim = ScheduledOptim(model, tc, mc, 50000, capturable=True)
     src_lens = None if a.batch == "canonical" else C1_SRC_LENS
-    batch_cpu = make_batch(src_lens, seed=1234 + rank)
+    # conformer decoders crop to max_seq_len = 1000 in training (conformer.py:148-154): cap mel length
+    batch_cpu = make_batch(src_lens, seed=1234 + rank, max_mel_cap=1000 if a.block == "conformer" else None)
     batch = to_device(batch_cpu, dev)
     valid_frames = int(batch_cpu["mel_lens"].sum())
     padded_frames = batch_cpu["mels"].shape[0] * batch_cpu["mels"].shape[1]
@@ -264,16 +268,17 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = total_valid * a.steps / elapsed
     if rank == 0:
-        roof = measure_dominant_kernel(dev, batch_cpu) if a.batch == "canonical" else None
-        # whole-step roofline view: 157.4 MFLOP per valid frame against the fp32 MFMA peak
-        step_tflops = (value / world) * 157.4e6 / 1e12
+        roof = measure_dominant_kernel(dev, batch_cpu) if (a.batch == "canonical" and a.block == "transformer_fs2") else None
+        # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
+        step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
         cpu = None if a.no_cpu_baseline else cpu_baseline()
         line = {
             "metric": "mel-frames/sec (train step) LJSpeech batch=16, 1/2/4/8 MI355X", "value": value, "unit": "mel-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LJSpeech transformer_fs2 batch=16/GPU, seq<=128 -> mel<=1024x80, supervised durations "
-                                   "(BASELINE configs[1]); full train step fwd+loss+bwd+clip+Adam, dropout on",
+            "config": {"workload": (f"LJSpeech {a.block} batch={len(batch_cpu['src_lens'])}/GPU, seq<=128 -> mel<={batch_cpu['mels'].shape[1]}x80, "
+                                    f"supervised durations (BASELINE configs[{1 if a.block == 'transformer_fs2' else 2}]); full train step "
+                                    "fwd+loss+bwd+clip+Adam, dropout on"),
                        "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
                        "parallelism": f"dp{world}", "final_loss": loss_final},
             "roofline": roof, "step_model_tflops_per_gpu": step_tflops,
