@@ -53,6 +53,8 @@ class TrainStep:
         self.loss_inputs = [None, None] + list(self.args)
         self.step_no = 50001
         from ctts_amd.dp import FlatGradArena
+        from ctts_amd import ops
+        ops.set_grad_accumulation_fusion(True)     # kernels accumulate straight into the flat gradient arena
         # flat fp32 gradient arena: p.grad are views -> one all-reduce, no bucket copies
         self.arena = FlatGradArena(model.parameters())
         self.params = self.arena.params

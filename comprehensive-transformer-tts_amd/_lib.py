@@ -46,7 +46,7 @@ _SIGNATURES = {
     "ctts_lr_gather_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_positions": [_vp, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp],
     "ctts_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp, _vp],
-    "ctts_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _u32, _vp, _vp],
+    "ctts_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _u32, _vp, C.c_int, _vp],
     "ctts_colstats": [_vp, _vp, C.c_int, C.c_int, _vp],
     "ctts_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp],
     "ctts_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp],
@@ -56,7 +56,7 @@ _SIGNATURES = {
     "ctts_softmax_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_act_dropout_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_rowscale_dropout": [_vp, _vp, _i64, C.c_int, _vp, _f32, _vp, _u32, _vp],
-    "ctts_colsum": [_vp, _vp, _i64, C.c_int, _i64, _vp],
+    "ctts_colsum": [_vp, _vp, _i64, C.c_int, _i64, _f32, C.c_int, _vp],
     "ctts_reflect_pad": [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_stft_magnitude": [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _vp],
     "ctts_log_clamp_transpose": [_vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],

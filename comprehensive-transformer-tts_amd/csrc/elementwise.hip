@@ -62,7 +62,7 @@ __global__ void rowscale_dropout_kernel(const float* __restrict__ x, float* __re
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C,
-                                                      long ld) {
+                                                      long ld, float scale) {
   __shared__ float s[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
   const long stripe = (rows + gridDim.y - 1) / gridDim.y;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   __syncthreads();
   if (ty == 0 && c < C) {
     const int l = threadIdx.x;
-    atomicAdd(out + c, s[0][l] + s[1][l] + s[2][l] + s[3][l]);
+    atomicAdd(out + c, scale * (s[0][l] + s[1][l] + s[2][l] + s[3][l]));
   }
 }
 
@@ -172,13 +172,13 @@ extern "C" int ctts_rowscale_dropout(const float* x, float* y, int64_t rows, int
   return 0;
 }
 
-extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, void* stream) {
+extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* stream) {
   CTTS_REQUIRE(x && out && C > 0, "ctts_colsum: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { ctts_set_error("ctts_colsum: memset failed"); return -2; }
+  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { ctts_set_error("ctts_colsum: memset failed"); return -2; }
   if (rows == 0) return 0;
   const int gy = (int)max((long)1, min((long)64, (long)rows / 64));
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, st, x, out, (long)rows, C, (long)ld);
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, st, x, out, (long)rows, C, (long)ld, scale);
   CTTS_CHECK_LAUNCH("ctts_colsum");
   return 0;
 }

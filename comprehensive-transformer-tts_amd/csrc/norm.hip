@@ -286,11 +286,11 @@ extern "C" int ctts_layernorm_fwd(const float* x, const float* gamma, const floa
 extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
                                   float p_drop, const uint64_t* seed, uint32_t drop_offset, const float* rowscale,
-                                  void* stream) {
+                                  int accumulate, void* stream) {
   CTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "ctts_layernorm_bwd: null pointer");
   CTTS_REQUIRE((C % 4) == 0 && C <= 1024 && C > 0, "ctts_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess) {
+  if (!accumulate && (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)) {
     ctts_set_error("ctts_layernorm_bwd: memset failed");
     return -2;
   }

@@ -156,16 +156,20 @@ def layernorm_fwd(x, gamma, beta, eps, p_drop=0.0, seed=None, drop_offset=0, row
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, p_drop=0.0, seed=None, drop_offset=0, rowscale=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, p_drop=0.0, seed=None, drop_offset=0, rowscale=None, acc_into=None):
+    """acc_into=(dgamma_buf, dbeta_buf): accumulate the parameter gradients into existing buffers (param.grad)."""
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     dx = torch.empty_like(x)
-    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    if acc_into is None:
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    else:
+        dgamma, dbeta = acc_into
     lib = _lib.load()
     _lib.check(lib.ctts_layernorm_bwd(_p(_f32c(dy, "dy")), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
-                                      _p(dbeta), rows, Cc, p_drop, _p(seed), drop_offset, _p(rowscale), _stream()),
-               "ctts_layernorm_bwd")
+                                      _p(dbeta), rows, Cc, p_drop, _p(seed), drop_offset, _p(rowscale), int(acc_into is not None),
+                                      _stream()), "ctts_layernorm_bwd")
     return dx, dgamma, dbeta
 
 
@@ -233,11 +237,13 @@ def rowscale_dropout(x, rowscale=None, p_drop=0.0, seed=None, drop_offset=0):
     return y
 
 
-def colsum(x2d, ld=None):
+def colsum(x2d, ld=None, scale=1.0, acc_into=None):
+    """out[c] = scale * sum_r x[r,c]; acc_into: add into an existing buffer (param.grad) instead."""
     rows, Cc = x2d.shape
-    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device) if acc_into is None else acc_into
     lib = _lib.load()
-    _lib.check(lib.ctts_colsum(_p(x2d), _p(out), rows, Cc, ld if ld is not None else Cc, _stream()), "ctts_colsum")
+    _lib.check(lib.ctts_colsum(_p(x2d), _p(out), rows, Cc, ld if ld is not None else Cc, float(scale), int(acc_into is not None),
+                               _stream()), "ctts_colsum")
     return out
 
 

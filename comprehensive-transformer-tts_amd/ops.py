@@ -15,6 +15,23 @@ from . import kernels as K
 from .kernels import ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SWISH  # noqa: F401
 
 
+_FUSE_GRAD_ACCUM = False
+
+
+def set_grad_accumulation_fusion(flag):
+    """When on, weight / bias / LayerNorm gradients are accumulated by the kernels straight into an existing,
+    contiguous `param.grad` (e.g. the flat DP arena) and autograd gets `None` for them: no zero-fill, no temporary,
+    no accumulate-add launch per parameter (~320 tiny launches per fs2 train step).  Off by default: plain autograd
+    semantics (hooks on parameter gradients, double backward) need the unfused path."""
+    global _FUSE_GRAD_ACCUM
+    _FUSE_GRAD_ACCUM = bool(flag)
+
+
+def _fusable(p):
+    return (_FUSE_GRAD_ACCUM and p is not None and p.requires_grad and p.grad is not None and p.grad.is_contiguous()
+            and p.grad.dtype == torch.float32)
+
+
 def _split_k_for(Mo, No, Kred):
     """split-K factor for weight-gradient GEMMs (small output, long reduction)."""
     t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
@@ -49,13 +66,13 @@ class _LinearConv(torch.autograd.Function):
         K.gemm(x, wf, out, M, N, Kdim, Cin, Kdim, N, True, True, conv=conv, alpha=alpha, bias=b, Z=Z, ldz=N, act=act,
                p_drop=p_drop, seed=seed, drop_offset=drop_offset, R=residual, ldr=N, rowscale=rowscale,
                row_lens=row_lens, row_T=row_T, row_halo=0)
-        ctx.save_for_backward(x, w, Z, rowscale, seed, row_lens)
+        ctx.save_for_backward(x, w, Z, rowscale, seed, row_lens, b)
         ctx.cfg = (act, alpha, p_drop, drop_offset, ksize, b is not None, residual is not None, row_T)
         return out
 
     @staticmethod
     def backward(ctx, dY):
-        x, w, Z, rowscale, seed, row_lens = ctx.saved_tensors
+        x, w, Z, rowscale, seed, row_lens, b = ctx.saved_tensors
         act, alpha, p_drop, drop_offset, ksize, has_bias, has_res, row_T = ctx.cfg
         rl = dict(row_lens=row_lens, row_T=row_T) if row_lens is not None else {}
         dY = dY.contiguous()
@@ -70,9 +87,10 @@ class _LinearConv(torch.autograd.Function):
             dZ = K.act_dropout_bwd(gm, Z, act, p_drop, seed, drop_offset)
         dX = dW = dB = None
         if has_bias and ctx.needs_input_grad[2]:
-            dB = K.colsum(dZ.view(M, N))
-            if alpha != 1.0:
-                dB = dB * alpha
+            if _fusable(b):
+                K.colsum(dZ.view(M, N), scale=alpha, acc_into=b.grad)
+            else:
+                dB = K.colsum(dZ.view(M, N), scale=alpha)
         if ksize:
             T = x.shape[-2]
             pad = (ksize - 1) // 2
@@ -93,8 +111,11 @@ class _LinearConv(torch.autograd.Function):
                 dX = torch.empty_like(x)
                 K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha, **rl)
             if ctx.needs_input_grad[1]:
-                dW = torch.zeros_like(w)
+                fused = _fusable(w)
+                dW = w.grad if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
                 K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha, **rl)
+                if fused:
+                    dW = None
         return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None
 
 
@@ -123,14 +144,18 @@ class _LayerNorm(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps, rowscale, p_drop, seed, drop_offset):
         x = x.contiguous()
         y, mean, rstd = K.layernorm_fwd(x, gamma, beta, eps, p_drop, seed, drop_offset, rowscale)
-        ctx.save_for_backward(x, gamma, mean, rstd, rowscale, seed)
+        ctx.save_for_backward(x, gamma, mean, rstd, rowscale, seed, beta)
         ctx.cfg = (p_drop, drop_offset)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean, rstd, rowscale, seed = ctx.saved_tensors
+        x, gamma, mean, rstd, rowscale, seed, beta = ctx.saved_tensors
         p_drop, drop_offset = ctx.cfg
+        if _fusable(gamma) and _fusable(beta):
+            dx, _, _ = K.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, p_drop, seed, drop_offset, rowscale,
+                                       acc_into=(gamma.grad, beta.grad))
+            return dx, None, None, None, None, None, None, None
         dx, dg, db = K.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, p_drop, seed, drop_offset, rowscale)
         return dx, dg, db, None, None, None, None, None
 

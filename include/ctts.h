@@ -96,7 +96,8 @@ int ctts_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
                        const float* rowscale, void* stream);
 int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx, float* dgamma, float* dbeta, int rows, int C, float p_drop, const uint64_t* seed,
-                       uint32_t drop_offset, const float* rowscale, void* stream);
+                       uint32_t drop_offset, const float* rowscale, int accumulate, void* stream);
+/* accumulate != 0: dgamma / dbeta (and ctts_colsum's out) are ADDED to - gradient-accumulation fusion straight into param.grad */
 
 /* BatchNorm1d over [rows, C] (channel-last view of nn.BatchNorm1d, modules.py:105,140-148),
  * fused with tanh (act=3) / none and inverted dropout.
@@ -125,12 +126,12 @@ int ctts_softmax_bwd(const float* P, float* dP, const int32_t* lens, int nb0, in
 /* Elementwise helpers of the backward pass.
  * act_dropout_bwd: dz = dg * dropmask/(1-p) * act'(z)          (GELU/ReLU/tanh from saved pre-activation)
  * rowscale_dropout_bwd: dv = dy * rowscale[m] * dropmask/(1-p)  (output-side dropout + pad mask)
- * colsum: out[c] (+)= sum_rows x[r, c]                          (bias gradients)               */
+ * colsum: out[c] (+)= scale * sum_rows x[r, c]                  (bias gradients)               */
 int ctts_act_dropout_bwd(const float* dg, const float* z, float* dz, int64_t rows, int C, int act, float alpha_unused,
                          float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream);
 int ctts_rowscale_dropout(const float* x, float* y, int64_t rows, int C, const float* rowscale, float p_drop,
                           const uint64_t* seed, uint32_t drop_offset, void* stream);
-int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, void* stream);
+int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Mel front end (audio/stft.py:59-88,166-185): reflect-pad, |DFT| from the [F, 2*nbins]

@@ -240,3 +240,32 @@ def test_conformer_train_step_with_dropout_runs():
     for k, p in m.named_parameters():
         if p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+def test_grad_accumulation_fusion_matches_plain_autograd():
+    """ops.set_grad_accumulation_fusion: kernels add straight into param.grad (flat DP arena) - same gradients."""
+    from ctts_amd import ops
+    from ctts_amd.dp import FlatGradArena
+    torch.manual_seed(5)
+    m, _ = build()
+    m.train()
+    no_dropout(m)
+    batch = make_batch([40, 33, 21, 12], 8, seed=9)
+
+    def run(fuse):
+        arena = FlatGradArena(m.parameters())
+        ops.set_grad_accumulation_fusion(fuse)
+        try:
+            for bn in [x for x in m.modules() if hasattr(x, "running_mean")]:
+                bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+            out = m(*as_model_args(to_device(batch, DEV)))
+            loss = (out[0].abs().mean() + out[1].abs().mean() + out[4].pow(2).mean() + out[3].pow(2).mean()
+                    + out[2]["cwt"].abs().mean() + out[2]["f0_mean"].abs().mean() + out[2]["f0_std"].abs().mean())
+            loss.backward()
+        finally:
+            ops.set_grad_accumulation_fusion(False)
+        return arena.flat.clone()
+    g0, g1 = run(False), run(True)
+    assert g0.abs().sum() > 0
+    err = (g0 - g1).abs().max().item()
+    assert err <= 1e-5 * max(1.0, g0.abs().max().item()), err
