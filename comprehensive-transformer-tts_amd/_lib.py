@@ -67,6 +67,8 @@ _SIGNATURES = {
     "ctts_relpos_softmax_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_relpos_softmax_bwd": [_vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_relshift_bwd": [_vp, _vp, C.c_int, C.c_int, _vp],
+    "ctts_neg_sqdist": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _vp],
+    "ctts_mas": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version"])
 

@@ -1,0 +1,105 @@
+// Unsupervised-alignment kernels:
+//  * ctts_neg_sqdist : the aligner's "Gaussian isotropic attention" scores  attn[b,t,s] = -temp * sum_c (q[b,t,c]-k[b,s,c])^2
+//                      (model/modules.py:1199-1200) without the reference's [B,80,Tm,Ts] broadcast intermediate (671 MB at B=16).
+//  * ctts_mas        : monotonic alignment search, width 1 (model/modules.py:36-75 mas_width1 / b_mas), on the device:
+//                      one workgroup per utterance, threads over text positions, rows of the DP relaxed in sequence with the
+//                      previous row in LDS; back-pointers as one byte per cell; the backtrack by a single lane.  Replaces the
+//                      reference's device->host->device round trip through numba (modules.py:869-872).
+#include "ctts_common.h"
+
+namespace {
+
+// q [B,Tq,C], k [B,Tk,C] (channel-last), out [B,Tq,Tk].  Block: 64 q-rows x all C of k tile in LDS.
+__global__ __launch_bounds__(256) void neg_sqdist_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          float* __restrict__ out, int Tq, int Tk, int C, float temp) {
+  extern __shared__ float s_k[];                  // [64][C+1] tile of keys
+  const int b = blockIdx.z;
+  const int s0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+  const int ld = C + 1;
+  for (int e = threadIdx.x; e < 64 * C; e += 256) {
+    const int s = e / C, c = e - s * C;
+    s_k[s * ld + c] = (s0 + s < Tk) ? k[((long)b * Tk + s0 + s) * C + c] : 0.f;
+  }
+  __syncthreads();
+  const int sl = threadIdx.x & 63, tg = threadIdx.x >> 6;     // lane -> key, wave -> 16 query rows
+  for (int tt = tg; tt < 64; tt += 4) {
+    const int t = t0 + tt;
+    if (t >= Tq) break;
+    const float* qr = q + ((long)b * Tq + t) * C;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float d = qr[c] - s_k[sl * ld + c];            // qr[c]: wave-uniform address (broadcast load)
+      acc += d * d;
+    }
+    if (s0 + sl < Tk) out[((long)b * Tq + t) * Tk + s0 + sl] = -temp * acc;
+  }
+}
+
+// attn [B, Tq, Tk] probabilities (soft attention); opt [B,Tq,Tk] (zero-filled here); dur [B,Tk] float.
+__global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ attn, const int* __restrict__ in_lens,
+                                                   const int* __restrict__ out_lens, float* __restrict__ opt,
+                                                   float* __restrict__ dur, unsigned char* __restrict__ back, int Tq, int Tk) {
+  extern __shared__ float s_row[];                // two rows of log_p: [2][Tk]
+  const int b = blockIdx.x;
+  const int T1 = min(out_lens[b], Tq), T2 = min(in_lens[b], Tk);
+  const float* A = attn + (long)b * Tq * Tk;
+  float* O = opt + (long)b * Tq * Tk;
+  unsigned char* Bk = back + (long)b * Tq * Tk;
+  for (long e = threadIdx.x; e < (long)Tq * Tk; e += 256) O[e] = 0.f;
+  for (int j = threadIdx.x; j < Tk; j += 256) dur[(long)b * Tk + j] = 0.f;
+  if (T1 <= 0 || T2 <= 0) return;
+  // row 0: log(attn[0,0]), -inf elsewhere     (attn_map[0, 1:] = -inf)
+  for (int j = threadIdx.x; j < T2; j += 256) s_row[j] = j == 0 ? (float)log((double)A[0]) : -INFINITY;
+  __syncthreads();
+  for (int i = 1; i < T1; ++i) {
+    const float* prev = s_row + ((i - 1) & 1) * Tk;
+    float* cur = s_row + (i & 1) * Tk;
+    for (int j = threadIdx.x; j < T2; j += 256) {
+      float pl = prev[j];
+      unsigned char from_left = 0;
+      if (j >= 1 && prev[j - 1] >= pl) { pl = prev[j - 1]; from_left = 1; }
+      cur[j] = (float)log((double)A[(long)i * Tk + j]) + pl;
+      Bk[(long)i * Tk + j] = from_left;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int curj = T2 - 1;
+    for (int i = T1 - 1; i >= 0; --i) {
+      O[(long)i * Tk + curj] = 1.f;
+      if (i > 0 && Bk[(long)i * Tk + curj]) curj -= 1;       // prev_ind[0, :] = 0 in the reference: opt[0, 0] is set below
+      else if (i == 0) curj = 0;
+    }
+    O[curj] = 1.f;                                            // opt[0, curr_text_idx] = 1 with curr_text_idx = prev_ind[0, .] = 0
+  }
+  __syncthreads();
+  // durations = column sums of the hard alignment (attn_hard.sum(2), modules.py:1042)
+  for (int j = threadIdx.x; j < T2; j += 256) {
+    float s = 0.f;
+    for (int i = 0; i < T1; ++i) s += O[(long)i * Tk + j];
+    dur[(long)b * Tk + j] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int ctts_neg_sqdist(const float* q, const float* k, float* out, int B, int Tq, int Tk, int C, float temp, void* stream) {
+  CTTS_REQUIRE(q && k && out && C > 0 && (size_t)64 * (C + 1) * 4 <= 64 * 1024, "ctts_neg_sqdist: bad arguments (C too large for the LDS tile)");
+  if (B == 0 || Tq == 0 || Tk == 0) return 0;
+  dim3 grid((Tq + 63) / 64, (Tk + 63) / 64, B);
+  hipLaunchKernelGGL(neg_sqdist_kernel, grid, dim3(256), (size_t)64 * (C + 1) * sizeof(float), (hipStream_t)stream, q, k, out, Tq, Tk,
+                     C, temp);
+  CTTS_CHECK_LAUNCH("ctts_neg_sqdist");
+  return 0;
+}
+
+extern "C" int ctts_mas(const float* attn, const int32_t* in_lens, const int32_t* out_lens, float* opt, float* dur,
+                        uint8_t* back, int B, int Tq, int Tk, void* stream) {
+  CTTS_REQUIRE(attn && in_lens && out_lens && opt && dur && back, "ctts_mas: null pointer");
+  CTTS_REQUIRE((size_t)2 * Tk * 4 <= 64 * 1024, "ctts_mas: Tk=%d too large for the LDS row buffers", Tk);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(mas_kernel, dim3(B), dim3(256), (size_t)2 * Tk * sizeof(float), (hipStream_t)stream, attn, in_lens, out_lens, opt,
+                     dur, back, Tq, Tk);
+  CTTS_CHECK_LAUNCH("ctts_mas");
+  return 0;
+}

@@ -334,3 +334,27 @@ def relshift_bwd(dS, T):
     lib = _lib.load()
     _lib.check(lib.ctts_relshift_bwd(_p(dS), _p(dPS), nb, T, _stream()), "ctts_relshift_bwd")
     return dPS
+
+
+# ------------------------------------------------------------------------- unsupervised alignment kernels
+def neg_sqdist(q, k, temp):
+    """q [B,Tq,C], k [B,Tk,C] -> [B,Tq,Tk] = -temp * ||q_t - k_s||^2"""
+    B, Tq, Cc = q.shape
+    Tk = k.shape[1]
+    out = torch.empty(B, Tq, Tk, dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_neg_sqdist(_p(_f32c(q, "q")), _p(_f32c(k, "k")), _p(out), B, Tq, Tk, Cc, float(temp), _stream()),
+               "ctts_neg_sqdist")
+    return out
+
+
+def mas(attn, in_lens, out_lens):
+    """attn [B,Tq,Tk] soft attention -> (hard [B,Tq,Tk] 0/1 float, dur [B,Tk] float)"""
+    B, Tq, Tk = attn.shape
+    opt = torch.empty_like(attn)
+    dur = torch.empty(B, Tk, dtype=torch.float32, device=attn.device)
+    back = torch.empty(B, Tq, Tk, dtype=torch.uint8, device=attn.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_mas(_p(_f32c(attn, "attn")), _p(in_lens.to(torch.int32).contiguous()), _p(out_lens.to(torch.int32).contiguous()),
+                            _p(opt), _p(dur), _p(back), B, Tq, Tk, _stream()), "ctts_mas")
+    return opt, dur

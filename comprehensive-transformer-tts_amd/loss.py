@@ -5,7 +5,7 @@ ops this round (dozens of tiny masked reductions + Adam).  Two changes make the 
 hipGraph-capturable without changing any value: the word-duration scatter uses the static bound
 Ts+1 instead of `word_id.max()+1` (loss.py:156-157: the extra bins are zero and masked), and the
 energy L1 uses a masked mean instead of `masked_select` (loss.py:236-243) - neither needs a
-device->host sync.  Supervised-duration configs only (learn_alignment=False).
+device->host sync.  learn_alignment=True adds ForwardSumLoss (one batched CTC call) and BinLoss.
 """
 import numpy as np
 import torch
@@ -18,8 +18,9 @@ from .configs import SIL_PHONEME_IDS
 class CompTransTTSLoss(nn.Module):
     def __init__(self, preprocess_config, model_config, train_config):
         super().__init__()
-        if model_config["duration_modeling"]["learn_alignment"]:
-            raise NotImplementedError("learn_alignment=True losses (ForwardSum/Bin) are a next-round row")
+        self.learn_alignment = model_config["duration_modeling"]["learn_alignment"]
+        self.binarization_loss_enable_steps = train_config["duration"]["binarization_loss_enable_steps"]
+        self.binarization_loss_warmup_steps = train_config["duration"]["binarization_loss_warmup_steps"]
         self.loss_config = train_config["loss"]
         self.pitch_config = preprocess_config["preprocessing"]["pitch"]
         self.use_pitch_embed = model_config["variance_embedding"]["use_pitch_embed"]
@@ -73,16 +74,44 @@ class CompTransTTSLoss(nn.Module):
         losses["f0_std"] = F.l1_loss(p_pred["f0_std"], p_tgt["f0_std"]) * lam
         return losses
 
+    @staticmethod
+    def forward_sum_loss(attn_logprob, in_lens, out_lens, blank_logprob=-1.0):
+        """ForwardSumLoss (loss.py:350-377) as ONE batched CTC call instead of a per-sample Python loop: classes beyond
+        key_len are excluded from each sample's log-softmax (the reference slices them away) by masking them to -inf."""
+        B, _, Tm, Ts = attn_logprob.shape
+        logits = F.pad(attn_logprob[:, 0], (1, 0), value=blank_logprob)                     # [B,Tm,Ts+1], class 0 = blank
+        cls = torch.arange(Ts + 1, device=logits.device)[None, None, :]
+        logits = logits.masked_fill(cls > in_lens[:, None, None], float("-inf"))
+        logp = torch.log_softmax(logits, dim=-1).transpose(0, 1)                             # [Tm,B,Ts+1]
+        targets = torch.arange(1, Ts + 1, device=logits.device)[None, :].expand(B, -1)
+        per = F.ctc_loss(logp, targets, out_lens, in_lens, blank=0, reduction="none", zero_infinity=True)
+        return (per / in_lens.clamp(min=1).to(per.dtype)).sum() / B          # nn.CTCLoss 'mean' per sample, then / batch
+
+    @staticmethod
+    def bin_loss(hard, soft):
+        """BinLoss (loss.py:380-386) with a mask product instead of boolean indexing (no host sync)."""
+        return -(torch.log(torch.clamp(soft, min=1e-12)) * hard).sum() / hard.sum()
+
     def forward(self, inputs, predictions, step):
         (texts, _, _, mel_targets, _, _, pitch_targets, energy_targets, duration_targets, _, _) = inputs[3:]
-        (mel_pred, post_pred, p_pred, e_pred, log_d, _, src_masks, mel_masks, src_lens, mel_lens, _, _) = predictions
+        (mel_pred, post_pred, p_pred, e_pred, log_d, _, src_masks, mel_masks, src_lens, mel_lens, attn_outs, _) = predictions
         src_nonpad = (~src_masks)
         mel_nonpad = (~mel_masks)
         mel_targets = mel_targets[:, : mel_masks.shape[1], :]
         mel_loss = self._masked_l1_mel(mel_pred, mel_targets, mel_masks)
         postnet_mel_loss = self._masked_l1_mel(post_pred, mel_targets, mel_masks)
         zero = torch.zeros(1, device=mel_targets.device)
-        total = mel_loss + postnet_mel_loss + zero + zero + zero
+        ctc_loss = bin_loss = zero
+        if self.learn_alignment:
+            attn_soft, attn_hard, attn_hard_dur, attn_logprob = attn_outs
+            duration_targets = attn_hard_dur
+            ctc_loss = self.forward_sum_loss(attn_logprob, src_lens, mel_lens)
+            if step < self.binarization_loss_enable_steps:
+                w = 0.0
+            else:
+                w = min((step - self.binarization_loss_enable_steps) / self.binarization_loss_warmup_steps, 1.0)
+            bin_loss = self.bin_loss(attn_hard, attn_soft) * w
+        total = mel_loss + postnet_mel_loss + ctc_loss + bin_loss + zero
         duration_loss = {"pdur": zero, "wdur": zero, "sdur": zero}
         pitch_loss = {"C": zero, "uv": zero, "f0_mean": zero, "f0_std": zero}
         energy_loss = zero
@@ -94,7 +123,7 @@ class CompTransTTSLoss(nn.Module):
                 m = src_nonpad.float()
                 energy_loss = ((e_pred - energy_targets).abs() * m).sum() / m.sum()
             total = total + sum(duration_loss.values()) + sum(pitch_loss.values()) + energy_loss
-        return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, zero, zero, zero)
+        return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, zero)
 
 
 class ScheduledOptim:

@@ -303,13 +303,69 @@ def f0_to_coarse(f0):
     return (f0_mel + 0.5).long()
 
 
+class _ConvNormK(nn.Module):
+    """ConvNorm wrapper (blocks.py:255-298): key `<idx>.conv.{weight,bias}`."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = _Conv(cin, cout, k)
+
+
+class AlignmentEncoder(nn.Module):
+    """reference: modules.py:1117-1213 (single-speaker form).  key_proj: Conv k3 (256->512) ReLU Conv k1 (512->80);
+    query_proj: Conv k3 (80->160) ReLU Conv k1 (160->80) ReLU Conv k1 (80->80); Gaussian isotropic scores."""
+
+    def __init__(self, n_mel, n_att, n_text, temperature, multi_speaker):
+        super().__init__()
+        if multi_speaker:
+            raise NotImplementedError("AlignmentEncoder speaker projections (multi_speaker + learn_alignment) are not built yet")
+        self.temperature = temperature
+        self.key_proj = nn.Module()
+        self.key_proj.add_module("0", _ConvNormK(n_text, 2 * n_text, 3))
+        self.key_proj.add_module("2", _ConvNormK(2 * n_text, n_att, 1))
+        self.query_proj = nn.Module()
+        self.query_proj.add_module("0", _ConvNormK(n_mel, 2 * n_mel, 3))
+        self.query_proj.add_module("2", _ConvNormK(2 * n_mel, n_mel, 1))
+        self.query_proj.add_module("4", _ConvNormK(n_mel, n_att, 1))
+
+    def forward(self, mel, text_emb, src_pad, attn_prior):
+        """mel [B,Tm,80], text_emb [B,Ts,256], src_pad [B,Ts] bool, attn_prior [B,Tm,Ts] -> (soft, logprob) [B,1,Tm,Ts]"""
+        kp, qp = self.key_proj, self.query_proj
+        k0, k2 = getattr(kp, "0").conv, getattr(kp, "2").conv
+        q0, q2, q4 = getattr(qp, "0").conv, getattr(qp, "2").conv, getattr(qp, "4").conv
+        k = ops.conv1d(text_emb, k0.weight, k0.bias, act=ops.ACT_RELU)
+        k = ops.linear(k, k2.weight.view(k2.weight.shape[0], -1), k2.bias)
+        q = ops.conv1d(mel, q0.weight, q0.bias, act=ops.ACT_RELU)
+        q = ops.linear(q, q2.weight.view(q2.weight.shape[0], -1), q2.bias, act=ops.ACT_RELU)
+        q = ops.linear(q, q4.weight.view(q4.weight.shape[0], -1), q4.bias)
+        attn = ops.neg_sqdist(q, k, self.temperature)                                   # [B,Tm,Ts]
+        attn = torch.log_softmax(attn, dim=-1) + torch.log(attn_prior + 1e-8)
+        logprob = attn
+        soft = torch.softmax(attn.masked_fill(src_pad[:, None, :], float("-inf")), dim=-1)
+        return soft.unsqueeze(1), logprob.unsqueeze(1)
+
+
+def phoneme_level_mean(frame_values, dur, src_lens):
+    """get_phoneme_level_energy (utils/tools.py:56-66, modules.py:882-888): per-phoneme mean of a frame-level
+    feature over the phoneme's contiguous frame run, 0 where the duration is 0 - as a prefix-sum difference on device."""
+    d = dur.long()
+    ends = torch.cumsum(d, 1)
+    starts = ends - d
+    Tm = frame_values.shape[1]
+    cs = torch.cat([frame_values.new_zeros(frame_values.shape[0], 1, dtype=torch.float64), frame_values.double().cumsum(1)], 1)
+    seg = cs.gather(1, ends.clamp(max=Tm)) - cs.gather(1, starts.clamp(max=Tm))
+    out = torch.where(d > 0, seg / d.clamp(min=1).double(), torch.zeros_like(seg)).float()
+    valid = torch.arange(d.shape[1], device=d.device)[None, :] < src_lens[:, None]
+    return out * valid
+
+
 class VarianceAdaptor(nn.Module):
-    """reference: modules.py:726-1114 (supervised and inference branches)."""
+    """reference: modules.py:726-1114 (supervised, unsupervised (aligner + MAS) and inference branches)."""
 
     def __init__(self, preprocess_config, model_config, train_config, d_model):
         super().__init__()
-        if model_config["duration_modeling"]["learn_alignment"]:
-            raise NotImplementedError("learn_alignment=True (AlignmentEncoder/MAS, SURVEY section 8 row a16) is a next-round row")
+        self.learn_alignment = model_config["duration_modeling"]["learn_alignment"]
+        self.binarization_start_steps = train_config["duration"]["binarization_start_steps"]
         if model_config["prosody_modeling"]["model_type"] != "none":
             raise NotImplementedError("prosody_modeling other than 'none' is not on the round-1 hot path")
         pitch = preprocess_config["preprocessing"]["pitch"]
@@ -323,8 +379,10 @@ class VarianceAdaptor(nn.Module):
         self.cwt_std_scale = vp["cwt_std_scale"]
         hidden = model_config["transformer"]["encoder_hidden"]  # sic: modules.py:739 reads the 'transformer' section
         filt, drop = vp["filter_size"], vp["dropout"]
+        # modules.py:788-799: learn_alignment reads the frame-level "unsup" statistics
+        stats_key = "energy_unsup_frame" if self.learn_alignment else "energy_sup_phone"
         with open(os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")) as f:
-            emin, emax = json.load(f)["energy_sup_phone"][:2]
+            emin, emax = json.load(f)[stats_key][:2]
         n_ebins = model_config["variance_embedding"]["energy_n_bins"]
         if model_config["variance_embedding"]["energy_quantization"] == "log":
             bins = torch.exp(torch.linspace(math.log(emin), math.log(emax), n_ebins - 1))
@@ -338,18 +396,36 @@ class VarianceAdaptor(nn.Module):
         self.pitch_embed = nn.Embedding(model_config["variance_embedding"]["pitch_n_bins"], hidden, padding_idx=0)
         self.energy_predictor = PitchPredictor(hidden, vp["predictor_layers"], filt, 1, vp["predictor_kernel"], drop)
         self.energy_embedding = nn.Embedding(n_ebins, hidden, padding_idx=0)
+        if self.learn_alignment:
+            n_mel = preprocess_config["preprocessing"]["mel"]["n_mel_channels"]
+            self.aligner = AlignmentEncoder(n_mel, n_mel, d_model, model_config["duration_modeling"]["aligner_temperature"],
+                                            model_config["multi_speaker"])
 
     def forward(self, speaker_embedding, text, text_embedding, src_len, src_mask, mel, mel_len, mel_mask=None,
                 max_len=None, pitch_target=None, energy_target=None, duration_target=None, attn_prior=None,
                 p_control=1.0, e_control=1.0, d_control=1.0, step=None):
-        if attn_prior is not None:
-            raise NotImplementedError("unsupervised duration modeling (attn_prior) is a next-round row")
         x = text
         if speaker_embedding is not None:
             x = x + speaker_embedding.unsqueeze(1)
         log_d = self.duration_predictor(ops.grad_scale(x, self.predictor_grad), src_mask)
         x_org = x
-        if duration_target is not None:
+        attn_out = (None, None, None, None)
+        if attn_prior is not None:      # training of unsupervised duration modelling (modules.py:1031-1053)
+            assert self.learn_alignment and duration_target is None and mel is not None
+            attn_soft, attn_logprob = self.aligner(mel, text_embedding, src_mask, attn_prior.transpose(1, 2))
+            attn_hard, attn_hard_dur = ops.mas_binarize(attn_soft, src_len, mel_len)
+            attn_out = (attn_soft, attn_hard, attn_hard_dur, attn_logprob)
+            if step < self.binarization_start_steps:
+                x = ops.bmm_nn(attn_soft.squeeze(1), x_org)
+            else:
+                x, mel_len, _ = ops.length_regulate(x_org, attn_hard_dur, max_len)
+            d_rounded = attn_hard_dur
+            mel2ph, _, _ = K.lr_index(d_rounded, int(max_len), pad=src_mask, round_mode=1)    # dur_to_mel2ph(...)[:, :max_len]
+            pitch_target["mel2ph"] = mel2ph.long()
+            energy_target = phoneme_level_mean(energy_target, attn_hard_dur, src_len)
+            mel2ph = None
+        elif duration_target is not None:
+            assert not self.learn_alignment
             x, mel_len, _ = ops.length_regulate(x_org, duration_target, max_len)
             d_rounded = duration_target
             mel2ph = None
@@ -390,7 +466,7 @@ class VarianceAdaptor(nn.Module):
         e_frames, _, _ = ops.length_regulate(energy_embedding, d_rounded, max_len)
         x = x + pitch_embedding + e_frames
         return (x, pitch_target, pitch_prediction, energy_target, energy_prediction, log_d, d_rounded, mel_len, mel_mask,
-                (None, None, None, None), None)
+                attn_out, None)
 
 
 # --------------------------------------------------------------------------- postnet
@@ -478,6 +554,9 @@ class CompTransTTS(nn.Module):
                 nn.init.xavier_uniform_(p)
             elif name.endswith("ffn_2.bias"):
                 nn.init.zeros_(p)
+            elif name.startswith("variance_adaptor.aligner.") and name.endswith("conv.weight"):
+                relu = name.endswith("key_proj.0.conv.weight") or name.endswith("query_proj.0.conv.weight")
+                nn.init.xavier_uniform_(p, gain=nn.init.calculate_gain("relu" if relu else "linear"))
             elif name.startswith("postnet.") and name.endswith("conv.weight"):
                 last = name.startswith(f"postnet.convolutions.{len(self.postnet.convolutions) - 1}.")
                 nn.init.xavier_uniform_(p, gain=nn.init.calculate_gain("linear" if last else "tanh"))

@@ -472,3 +472,74 @@ class _RelPosAttention(torch.autograd.Function):
 def relpos_attention(qu, qv, kv, pos, n_heads, scale, p_drop=0.0, drop=None):
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
     return _RelPosAttention.apply(qu, qv, kv, pos, n_heads, scale, p_drop if seed is not None else 0.0, seed, off)
+
+
+# ------------------------------------------------------------------------- unsupervised alignment operators
+class _BmmNN(torch.autograd.Function):
+    """out[b] = A[b] @ X[b]  (A [B,M,K], X [B,K,N]) on ctts_gemm; used for the soft-attention upsampling
+    `torch.bmm(A_soft, x)` of modules.py:1048-1049."""
+
+    @staticmethod
+    def forward(ctx, A, X):
+        A, X = A.contiguous(), X.contiguous()
+        B, M, Kd = A.shape
+        N = X.shape[2]
+        out = torch.empty(B, M, N, dtype=torch.float32, device=A.device)
+        K.gemm(A, X, out, M, N, Kd, Kd, N, N, True, False, nb0=B, nb1=1, sA=(M * Kd, 0), sB=(Kd * N, 0), sC=(M * N, 0))
+        ctx.save_for_backward(A, X)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        A, X = ctx.saved_tensors
+        dO = dO.contiguous()
+        B, M, Kd = A.shape
+        N = X.shape[2]
+        dA = dX = None
+        if ctx.needs_input_grad[0]:
+            dA = torch.empty_like(A)          # dA[m,k] = sum_n dO[m,n] X[k,n]
+            K.gemm(dO, X, dA, M, Kd, N, N, N, Kd, True, True, nb0=B, nb1=1, sA=(M * N, 0), sB=(Kd * N, 0), sC=(M * Kd, 0))
+        if ctx.needs_input_grad[1]:
+            dX = torch.empty_like(X)          # dX[k,n] = sum_m A[m,k] dO[m,n]
+            K.gemm(A, dO, dX, Kd, N, M, Kd, N, N, False, False, nb0=B, nb1=1, sA=(M * Kd, 0), sB=(M * N, 0), sC=(Kd * N, 0))
+        return dA, dX
+
+
+def bmm_nn(A, X):
+    return _BmmNN.apply(A, X)
+
+
+class _NegSqDist(torch.autograd.Function):
+    """attn[b,t,s] = -temp * sum_c (q[b,t,c] - k[b,s,c])^2   (AlignmentEncoder, modules.py:1199-1200)"""
+
+    @staticmethod
+    def forward(ctx, q, k, temp):
+        q, k = q.contiguous(), k.contiguous()
+        ctx.save_for_backward(q, k)
+        ctx.temp = temp
+        return K.neg_sqdist(q, k, temp)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k = ctx.saved_tensors
+        g = g.contiguous()
+        t2 = -2.0 * ctx.temp
+        # d/dq = -2 temp (q * rowsum(g) - g k);   d/dk = -2 temp (k * colsum(g) - g^T q)
+        dq = t2 * (q * g.sum(2, keepdim=True) - bmm_nn(g, k))
+        gtq = torch.empty_like(k)
+        B, Tq, Tk = g.shape
+        Cc = q.shape[2]
+        K.gemm(g, q, gtq, Tk, Cc, Tq, Tk, Cc, Cc, False, False, nb0=B, nb1=1, sA=(Tq * Tk, 0), sB=(Tq * Cc, 0), sC=(Tk * Cc, 0))
+        dk = t2 * (k * g.sum(1).unsqueeze(-1) - gtq)
+        return dq, dk, None
+
+
+def neg_sqdist(q, k, temp):
+    return _NegSqDist.apply(q, k, temp)
+
+
+def mas_binarize(attn_soft, in_lens, out_lens):
+    """binarize_attention_parallel (modules.py:863-872) on the device: attn_soft [B,1,Tm,Ts] -> (hard [B,1,Tm,Ts], dur [B,Ts])."""
+    with torch.no_grad():
+        hard, dur = K.mas(attn_soft[:, 0].contiguous(), in_lens, out_lens)
+    return hard.unsqueeze(1), dur

@@ -162,6 +162,16 @@ int ctts_relpos_softmax_bwd(const float* P, float* dPd, int nbatch, int T, float
                             uint32_t drop_offset, void* stream);
 int ctts_relshift_bwd(const float* dS, float* dPS, int nbatch, int T, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Unsupervised duration modelling.
+ * ctts_neg_sqdist: AlignmentEncoder scores out[b,t,s] = -temp * sum_c (q[b,t,c]-k[b,s,c])^2  (model/modules.py:1199-1200), channel-last.
+ * ctts_mas: monotonic alignment search, width 1 (model/modules.py:36-75 mas_width1/b_mas; called from :863-872).
+ *   attn [B,Tq,Tk] soft attention (probabilities), in_lens/out_lens [B] valid text / mel lengths;
+ *   opt [B,Tq,Tk] <- hard 0/1 alignment, dur [B,Tk] <- frames per phoneme (attn_hard.sum(2)), back [B,Tq,Tk] scratch bytes. */
+int ctts_neg_sqdist(const float* q, const float* k, float* out, int B, int Tq, int Tk, int C, float temp, void* stream);
+int ctts_mas(const float* attn, const int32_t* in_lens, const int32_t* out_lens, float* opt, float* dur, uint8_t* back, int B,
+             int Tq, int Tk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,9 +223,79 @@ def _grad_scale(x, g):
 
 
 # ----------------------------------------------------------------------------- a12
+def mas_width1(attn_map):
+    """model/modules.py:36-64 (numba-jitted in the reference; plain numpy here).  attn_map [T1 (mel), T2 (text)] float32."""
+    import numpy as np
+    opt = np.zeros_like(attn_map)
+    with np.errstate(divide="ignore"):
+        attn_map = np.log(attn_map)
+    attn_map[0, 1:] = -np.inf
+    log_p = np.zeros_like(attn_map)
+    log_p[0, :] = attn_map[0, :]
+    prev_ind = np.zeros_like(attn_map, dtype=np.int64)
+    for i in range(1, attn_map.shape[0]):
+        prev = log_p[i - 1]
+        left = np.concatenate([[-np.inf], prev[:-1]]).astype(prev.dtype)
+        take_left = left >= prev
+        take_left[0] = False
+        log_p[i] = attn_map[i] + np.where(take_left, left, prev)
+        prev_ind[i] = np.arange(attn_map.shape[1]) - take_left.astype(np.int64)
+    cur = attn_map.shape[1] - 1
+    for i in range(attn_map.shape[0] - 1, -1, -1):
+        opt[i, cur] = 1
+        cur = prev_ind[i, cur]
+    opt[0, cur] = 1
+    return opt
+
+
+def binarize_attention(attn_soft, in_lens, out_lens):
+    """model/modules.py:66-75,863-872 b_mas over the batch.  attn_soft [B,1,Tm,Ts] -> hard 0/1 of the same shape."""
+    import numpy as np
+    a = attn_soft.detach().cpu().numpy()
+    out = np.zeros_like(a)
+    for b in range(a.shape[0]):
+        o, i = int(out_lens[b]), int(in_lens[b])
+        out[b, 0, :o, :i] = mas_width1(a[b, 0, :o, :i].copy())
+    return torch.from_numpy(out)
+
+
+def alignment_encoder(sd, mel, text_emb, src_pad, attn_prior, temperature):
+    """model/modules.py:1176-1213 AlignmentEncoder.forward (single speaker).  mel [B,Tm,80], text_emb [B,Ts,256],
+    attn_prior [B,Tm,Ts] -> (attn_soft [B,1,Tm,Ts], attn_logprob [B,1,Tm,Ts])."""
+    a = "variance_adaptor.aligner."
+    k = torch.relu(conv1d_btc(text_emb, sd[a + "key_proj.0.conv.weight"], sd[a + "key_proj.0.conv.bias"], 1))
+    k = conv1d_btc(k, sd[a + "key_proj.2.conv.weight"], sd[a + "key_proj.2.conv.bias"], 0)
+    q = torch.relu(conv1d_btc(mel, sd[a + "query_proj.0.conv.weight"], sd[a + "query_proj.0.conv.bias"], 1))
+    q = torch.relu(conv1d_btc(q, sd[a + "query_proj.2.conv.weight"], sd[a + "query_proj.2.conv.bias"], 0))
+    q = conv1d_btc(q, sd[a + "query_proj.4.conv.weight"], sd[a + "query_proj.4.conv.bias"], 0)
+    attn = -temperature * ((q[:, :, None, :] - k[:, None, :, :]) ** 2).sum(-1)          # [B,Tm,Ts]
+    attn = torch.log_softmax(attn, dim=-1) + torch.log(attn_prior + 1e-8)
+    logprob = attn.clone()
+    attn = attn.masked_fill(src_pad[:, None, :], float("-inf"))
+    return torch.softmax(attn, dim=-1)[:, None], logprob[:, None]
+
+
+def phoneme_level_energy(dur, src_lens, energy_frame):
+    """utils/tools.py:56-66 + model/modules.py:882-888: per-phoneme mean of the frame-level energy."""
+    import numpy as np
+    B, Ts = dur.shape
+    out = torch.zeros(B, int(src_lens.max()))
+    d_np, e_np = dur.int().cpu().numpy(), energy_frame.cpu().numpy()
+    for b in range(B):
+        e = e_np[b].copy()
+        pos = 0
+        for i in range(int(src_lens[b])):
+            d = int(d_np[b, i])
+            e[i] = e[pos:pos + d].mean() if d > 0 else 0
+            pos += d
+        out[b, : int(src_lens[b])] = torch.from_numpy(e[: int(src_lens[b])])
+    return out
+
+
 def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pad, max_mel_len,
                      p_targets, e_targets, d_targets, speaker_embedding=None,
-                     p_control=1.0, e_control=1.0, d_control=1.0, train_dropout=False, taps=None):
+                     p_control=1.0, e_control=1.0, d_control=1.0, train_dropout=False, taps=None,
+                     text_embedding=None, mel=None, attn_prior=None, step=None, bin_start_steps=None, attn_out=None):
     vp = cfg["variance_predictor"]
     va = "variance_adaptor."
     pitch_cfg = pre_cfg["preprocessing"]["pitch"]
@@ -236,7 +306,23 @@ def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pa
     log_d = duration_predictor(sd, cfg, _grad_scale(x, vp["predictor_grad"]), src_pad, train_dropout)
     x_org = x
     mel2ph_inf = None
-    if d_targets is not None:
+    if attn_prior is not None:         # unsupervised duration modelling (modules.py:1031-1053)
+        attn_soft, attn_logprob = alignment_encoder(sd, mel, text_embedding, src_pad, attn_prior.transpose(1, 2),
+                                                    cfg["duration_modeling"]["aligner_temperature"])
+        attn_hard = binarize_attention(attn_soft, src_lens, mel_lens)
+        attn_hard_dur = attn_hard.sum(2)[:, 0, :]
+        if attn_out is not None:
+            attn_out.extend([attn_soft, attn_hard, attn_hard_dur, attn_logprob])
+        if step < bin_start_steps:
+            x = torch.bmm(attn_soft.squeeze(1), x)
+            mel_len = mel_lens
+        else:
+            x, mel_len = length_regulate(x, attn_hard_dur, max_mel_len)
+        d_rounded = attn_hard_dur
+        p_targets = dict(p_targets)
+        p_targets["mel2ph"] = dur_to_mel2ph(d_rounded, src_pad)[:, :max_mel_len]
+        e_targets = phoneme_level_energy(attn_hard_dur, src_lens, e_targets)
+    elif d_targets is not None:
         x, mel_len = length_regulate(x, d_targets, max_mel_len)
         d_rounded = d_targets
     else:
@@ -318,14 +404,14 @@ def postnet(sd, x, training_bn, train_dropout=False, new_stats=None):
 def comp_trans_tts_forward(sd, model_cfg, pre_cfg, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None,
                            max_mel_len=None, p_targets=None, e_targets=None, d_targets=None, attn_priors=None,
                            spker_embeds=None, p_control=1.0, e_control=1.0, d_control=1.0, step=None,
-                           training=False, train_dropout=False, taps=None, new_stats=None):
+                           training=False, train_dropout=False, taps=None, new_stats=None, bin_start_steps=6000):
     """Restates model/CompTransTTS.py:64-152 for block_type == transformer_fs2,
     learn_alignment == False.  `training` selects BatchNorm batch statistics;
     `train_dropout` additionally turns the dropouts on (for CPU-baseline timing)."""
-    assert model_cfg["block_type"] == "transformer_fs2" and attn_priors is None
+    assert model_cfg["block_type"] == "transformer_fs2"
     src_pad = mask_from_lengths(src_lens, max_src_len)
     mel_pad = mask_from_lengths(mel_lens, max_mel_len) if mel_lens is not None else None
-    enc, _ = text_encoder(sd, model_cfg, texts, src_pad, train_dropout, taps)
+    enc, text_emb = text_encoder(sd, model_cfg, texts, src_pad, train_dropout, taps)
     if taps is not None:
         taps["encoder_out"] = enc
     spk = None
@@ -334,9 +420,11 @@ def comp_trans_tts_forward(sd, model_cfg, pre_cfg, speakers, texts, src_lens, ma
             spk = spker_embeds @ sd["speaker_emb.weight"].t() + sd["speaker_emb.bias"]
         else:
             spk = F.embedding(speakers, sd["speaker_emb.weight"])
+    attn_out = []
     (x, p_targets, p_pred, e_targets, e_pred, log_d, d_rounded, mel_lens, mel_pad) = variance_adaptor(
         sd, model_cfg, pre_cfg, enc, src_lens, src_pad, mel_lens, mel_pad, max_mel_len, p_targets, e_targets,
-        d_targets, spk, p_control, e_control, d_control, train_dropout, taps)
+        d_targets, spk, p_control, e_control, d_control, train_dropout, taps, text_embedding=text_emb, mel=mels,
+        attn_prior=attn_priors, step=step, bin_start_steps=bin_start_steps, attn_out=attn_out)
     c = model_cfg["transformer_fs2"]
     dec = fft_blocks(sd, "decoder.", x, mel_pad, c["decoder_layer"], c["decoder_head"], c["ffn_kernel_size"],
                      c["decoder_dropout"], True, train_dropout, taps)
@@ -345,7 +433,7 @@ def comp_trans_tts_forward(sd, model_cfg, pre_cfg, speakers, texts, src_lens, ma
     mel = dec @ sd["mel_linear.weight"].t() + sd["mel_linear.bias"]
     post = postnet(sd, mel, training, train_dropout, new_stats) + mel
     return (mel, post, p_pred, e_pred, log_d, d_rounded, src_pad, mel_pad, src_lens, mel_lens,
-            (None, None, None, None), None, p_targets, e_targets)
+            tuple(attn_out) if attn_out else (None, None, None, None), None, p_targets, e_targets)
 
 
 # ============================================================================= a15: conformer plugin

@@ -36,17 +36,17 @@ def pseudo(name, shape):
     return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float()
 
 
-def build(dataset="LJSpeech", block_type="transformer_fs2"):
+def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=False):
     from model import CompTransTTS
 
     pre, mc, tc = ref_import.load_configs(dataset)
-    mc["duration_modeling"]["learn_alignment"] = False
+    mc["duration_modeling"]["learn_alignment"] = learn_alignment
     mc["block_type"] = block_type
     model = CompTransTTS(pre, mc, tc)
     sd = closed_form_state_dict(model.state_dict())
     model.load_state_dict(sd)
     import json
-    tag = f"{dataset}_{block_type}"
+    tag = f"{dataset}_{block_type}" + ("_unsup" if learn_alignment else "")
     with open(os.path.join(OUT, f"state_dict_schema_{tag}.json"), "w") as f:
         json.dump({k: [list(v.shape), str(v.dtype).replace("torch.", ""), bool(k in dict(model.named_parameters()))]
                    for k, v in model.state_dict().items()}, f, indent=0)
@@ -65,11 +65,15 @@ def flatten_outputs(out, prefix="out."):
     if p_t is not None:
         d["pt_f0"] = _np(p_t["f0"])
         d["pt_mel2ph"] = _np(p_t["mel2ph"])
+    if attn is not None and attn[0] is not None:
+        d["attn_soft"], d["attn_hard"], d["attn_hard_dur"], d["attn_logprob"] = [_np(a) for a in attn]
+        d["e_targets_out"] = _np(e_t)
     return {prefix + k: v for k, v in d.items() if v is not None}
 
 
 def batch_arrays(batch):
     d = {}
+    batch = {k: v for k, v in batch.items() if v is not None}
     for k, v in batch.items():
         if isinstance(v, dict):
             for kk, vv in v.items():
@@ -94,7 +98,10 @@ def run_case(model, batch, mode, name, with_grads=False, extra_kwargs=None):
         model.train()
         F.dropout = lambda x, p=0.5, training=True, inplace=False: x
     args = list(as_model_args(batch))
-    # the reference mutates p_targets in place: hand it a copy
+    if "attn_priors" in batch:
+        args[10] = batch["attn_priors"]
+    # the reference mutates inputs in place (p_targets dict; e_targets through a shared numpy view, modules.py:882-888): pass copies
+    args = [a.clone() if torch.is_tensor(a) else a for a in args]
     if args[7] is not None:
         args[7] = {k: v.clone() for k, v in args[7].items()}
     kw = dict(extra_kwargs or {})
@@ -118,6 +125,9 @@ def run_case(model, batch, mode, name, with_grads=False, extra_kwargs=None):
                 + (log_d * pseudo("logd", log_d.shape)).sum() + (e_pred * pseudo("e", e_pred.shape)).sum()
                 + (p_pred["cwt"] * pseudo("cwt", p_pred["cwt"].shape)).sum()
                 + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum())
+        if out[10][0] is not None:      # unsupervised: attention outputs enter the loss too
+            a_soft, _, _, a_logp = out[10]
+            loss = loss + (a_soft * pseudo("asoft", a_soft.shape)).sum() * 10 + (a_logp * pseudo("alogp", a_logp.shape)).sum() * 0.1
         model.zero_grad()
         loss.backward()
         arrs["grad.loss"] = _np(loss)
@@ -134,7 +144,7 @@ def run_case(model, batch, mode, name, with_grads=False, extra_kwargs=None):
     return out
 
 
-def golden_loss(model_out, batch, cfgs, name):
+def golden_loss(model_out, batch, cfgs, name, step=None):
     """G9: CompTransTTSLoss 9-tuple (model/loss.py:266-347) on a train-mode output."""
     from model import CompTransTTSLoss
 
@@ -144,7 +154,7 @@ def golden_loss(model_out, batch, cfgs, name):
     b = [None, None] + list(as_model_args(batch))
     out = model_out
     b[9:11], output = out[-2:], out[:-2]
-    step = tc["step"]["var_start_steps"] + 1
+    step = step or tc["step"]["var_start_steps"] + 1
     losses = L(b, output, step=step)
     arrs = {}
     names = ["total", "mel", "postnet_mel", "pitch", "energy", "duration", "ctc", "bin", "prosody"]
@@ -232,6 +242,24 @@ def golden_stft():
     print("wrote", path, mel.shape, energy.shape)
 
 
+def make_unsup_batch(src_lens, fpp, seed):
+    """learn_alignment=True inputs: no durations, frame-level energy targets, attention prior [B,Ts,Tm]."""
+    b = make_batch(src_lens, fpp, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    B, Ts, Tm = b["texts"].shape[0], b["texts"].shape[1], b["mels"].shape[1]
+    prior = torch.zeros(B, Ts, Tm)
+    for i in range(B):
+        P, M = int(b["src_lens"][i]), int(b["mel_lens"][i])
+        # smooth diagonal-ish positive prior (stands in for the beta-binomial prior of preprocessor.py:551-560)
+        t = torch.arange(M)[None, :] / M
+        s_ = torch.arange(P)[:, None] / P
+        prior[i, :P, :M] = torch.exp(-((t - s_) ** 2) / 0.02) + 0.05 * torch.rand(P, M, generator=g)
+    b["attn_priors"] = prior
+    b["d_targets"] = None
+    b["e_targets"] = torch.randn(B, Tm, generator=g) * (torch.arange(Tm)[None, :] < b["mel_lens"][:, None])
+    return b
+
+
 def main():
     torch.manual_seed(0)
     model, cfgs = build("LJSpeech")
@@ -247,6 +275,12 @@ def main():
     run_case(model_v, vb, "eval", "g5_vctk_eval")
     golden_integer_vectors()
     golden_stft()
+    # G6: unsupervised duration modelling (learn_alignment=True, the reference's default yaml): aligner + MAS
+    model_u, cfgs_u = build("LJSpeech", "transformer_fs2", learn_alignment=True)
+    ub = make_unsup_batch([24, 17], 6, seed=99)
+    run_case(model_u, ub, "train", "g6_unsup_soft_step100", with_grads=True, extra_kwargs=dict(step=100))
+    out_u = run_case(model_u, ub, "train", "g6_unsup_hard_step60000", with_grads=True, extra_kwargs=dict(step=60000))
+    golden_loss(out_u, ub, cfgs_u, "g6_unsup_loss_step60000", step=60000)
     # G4: conformer block_type (unmasked relative attention, GLU / depthwise conv / BatchNorm module)
     model_c, cfgs_c = build("LJSpeech", "conformer")
     cb = make_batch([24, 17], 6, seed=4321)

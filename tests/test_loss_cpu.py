@@ -42,3 +42,23 @@ def test_noam_schedule_values():
     a = so.update_learning_rate()
     b = so.update_learning_rate()
     assert abs(a - init * 300000 ** -0.5) < 1e-12 and abs(b - init * 300001 ** -0.5 * 0.3) < 1e-12
+
+
+def test_unsupervised_loss_matches_reference_golden():
+    """ForwardSumLoss (batched CTC restatement) + BinLoss + the rest at step 60000 (bin-loss weight 1)."""
+    g, g9 = load_golden("g6_unsup_hard_step60000"), load_golden("g6_unsup_loss_step60000")
+    pre, mc, tc = get_configs()
+    mc["duration_modeling"]["learn_alignment"] = True
+    b = batch_from_golden(g)
+    args = [b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"], b["max_mel_len"],
+            b["p_targets"], b["e_targets"], None, b["attn_priors"], None]
+    out = R.comp_trans_tts_forward(closed_form_sd(unsup=True), mc, pre, *args, step=60000, training=True)
+    inputs = [None, None] + list(args)
+    inputs[9:11] = out[-2:]
+    L = CompTransTTSLoss(pre, mc, tc)
+    total, mel, post, pitch, energy, dur, ctc, binl, pros = L(inputs, out[:-2], 60000)
+    exp = {"total": total, "mel": mel, "postnet_mel": post, "energy": energy, "pitch.C": pitch["C"], "pitch.uv": pitch["uv"],
+           "duration.pdur": dur["pdur"], "duration.wdur": dur["wdur"], "duration.sdur": dur["sdur"], "ctc": ctc, "bin": binl}
+    for k, v in exp.items():
+        ref = float(np.asarray(g9["loss." + k]).reshape(-1)[0])
+        assert abs(float(v.reshape(-1)[0]) - ref) <= 3e-4 * max(1.0, abs(ref)), (k, float(v.reshape(-1)[0]), ref)

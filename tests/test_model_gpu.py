@@ -269,3 +269,65 @@ def test_grad_accumulation_fusion_matches_plain_autograd():
     assert g0.abs().sum() > 0
     err = (g0 - g1).abs().max().item()
     assert err <= 1e-5 * max(1.0, g0.abs().max().item()), err
+
+
+@pytest.mark.parametrize("gname,step", [("g6_unsup_soft_step100", 100), ("g6_unsup_hard_step60000", 60000)])
+def test_g6_unsupervised_alignment_matches_reference(gname, step):
+    """learn_alignment=True (the reference's default yaml): AlignmentEncoder + MAS on the device + soft/hard upsampling."""
+    g = load_golden(gname)
+    pre, mc, tc = get_configs()
+    mc["duration_modeling"]["learn_alignment"] = True
+    m = ctts_amd.CompTransTTS(pre, mc, tc)
+    m.load_state_dict(closed_form_sd(unsup=True))
+    m = m.to(DEV)
+    m.train()
+    no_dropout(m)
+    b = to_device(batch_from_golden(g), DEV)
+    out = m(b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"], b["max_mel_len"], b["p_targets"],
+            b["e_targets"], None, b["attn_priors"], None, step=step)
+    a_soft, a_hard, a_dur, a_logp = out[10]
+    assert maxerr(a_soft, g["out.attn_soft"]) < 1e-5 and maxerr(a_logp, g["out.attn_logprob"]) < 1e-3
+    assert np.array_equal(a_hard.cpu().numpy(), g["out.attn_hard"])          # MAS: bit-exact hard alignment
+    assert np.array_equal(a_dur.cpu().numpy(), g["out.attn_hard_dur"])
+    assert np.array_equal(out[12]["mel2ph"].cpu().numpy(), g["out.pt_mel2ph"])
+    assert maxerr(out[13], g["out.e_targets_out"]) < 1e-5
+    for name, i in (("mel", 0), ("postnet_mel", 1), ("log_d", 4), ("e_pred", 3)):
+        assert maxerr(out[i], g["out." + name]) <= MEL_TOL, name
+
+    def pseudo(name, shape):
+        return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float().to(DEV)
+    mel, post, p_pred, e_pred, log_d = out[:5]
+    loss = ((post * pseudo("post", post.shape)).sum() + (mel * pseudo("mel", mel.shape)).sum()
+            + (log_d * pseudo("logd", log_d.shape)).sum() + (e_pred * pseudo("e", e_pred.shape)).sum()
+            + (p_pred["cwt"] * pseudo("cwt", p_pred["cwt"].shape)).sum()
+            + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum()
+            + (a_soft * pseudo("asoft", a_soft.shape)).sum() * 10 + (a_logp * pseudo("alogp", a_logp.shape)).sum() * 0.1)
+    loss.backward()
+    worst, n = ("", 0.0), 0
+    for k, p in m.named_parameters():
+        if "grad.stat." + k not in g:
+            continue
+        gs = g["grad.stat." + k]
+        gr = p.grad.flatten() if p.grad is not None else torch.zeros(p.numel(), device=DEV)
+        scale = max(1.0, float(gs[1]))
+        e = max(maxerr(gr[:64], g["grad.head." + k]) / scale, abs(float(gr.double().pow(2).sum().sqrt()) - gs[1]) / scale)
+        if e > worst[1]:
+            worst = (k, e)
+        n += 1
+    print(f"unsup step {step}: worst relative gradient error", worst, "over", n)
+    assert n > 170 and worst[1] < 2e-3, worst
+
+
+def test_mas_kernel_vs_oracle_random():
+    """MAS on random soft attentions (ragged lengths) against the numpy restatement of mas_width1."""
+    from ctts_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, Tm, Ts = 5, 97, 23
+    attn = torch.softmax(torch.randn(B, 1, Tm, Ts, generator=g) * 3, -1)
+    in_lens = torch.tensor([23, 17, 5, 1, 23])
+    out_lens = torch.tensor([97, 60, 40, 9, 23])
+    hard, dur = ops.mas_binarize(attn.to(DEV), in_lens.to(DEV), out_lens.to(DEV))
+    ref = R.binarize_attention(attn, in_lens, out_lens)
+    assert np.array_equal(hard.cpu().numpy(), ref.numpy())
+    assert np.array_equal(dur.cpu().numpy(), ref.sum(2)[:, 0].numpy())
+    assert torch.equal(dur.sum(1).cpu(), out_lens.float())      # every valid frame is assigned to exactly one phoneme

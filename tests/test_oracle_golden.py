@@ -144,3 +144,27 @@ def test_g4_conformer_train_batch_stats():
     assert len(stats) == 10 * 2 + 5 * 2
     for k, v in stats.items():
         _close(v, g["bn." + k], 5e-5, name=k)
+
+
+@pytest.mark.parametrize("gname,step", [("g6_unsup_soft_step100", 100), ("g6_unsup_hard_step60000", 60000)])
+def test_g6_unsupervised_alignment(gname, step):
+    g = load_golden(gname)
+    sd = closed_form_sd(unsup=True)
+    pre, mc, tc = get_configs()
+    mc["duration_modeling"]["learn_alignment"] = True
+    b = batch_from_golden(g)
+    taps, stats = {}, {}
+    out = R.comp_trans_tts_forward(sd, mc, pre, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"],
+                                   b["mel_lens"], b["max_mel_len"], b["p_targets"], b["e_targets"], None, b["attn_priors"], None,
+                                   step=step, training=True, taps=taps, new_stats=stats)
+    a_soft, a_hard, a_dur, a_logp = out[10]
+    _close(a_soft, g["out.attn_soft"], 1e-6, "attn_soft")
+    _close(a_logp, g["out.attn_logprob"], 1e-4, "attn_logprob")
+    assert np.array_equal(a_hard.numpy(), g["out.attn_hard"])            # MAS path: exact
+    assert np.array_equal(a_dur.numpy(), g["out.attn_hard_dur"])
+    _close(out[13], g["out.e_targets_out"], 1e-5, "phoneme-level energy targets")
+    assert np.array_equal(out[12]["mel2ph"].numpy(), g["out.pt_mel2ph"])
+    _close(out[0], g["out.mel"], name="mel")
+    _close(out[1], g["out.postnet_mel"], 5e-5, name="postnet_mel")
+    _close(out[4], g["out.log_d"], name="log_d")
+    _close(out[3], g["out.e_pred"], name="e_pred")

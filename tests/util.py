@@ -17,19 +17,19 @@ def load_golden(name):
     return {k: z[k] for k in z.files}
 
 
-def schema(dataset="LJSpeech", block="transformer_fs2"):
-    with open(os.path.join(GOLDEN, f"state_dict_schema_{dataset}_{block}.json")) as f:
+def schema(dataset="LJSpeech", block="transformer_fs2", unsup=False):
+    with open(os.path.join(GOLDEN, f"state_dict_schema_{dataset}_{block}{'_unsup' if unsup else ''}.json")) as f:
         return json.load(f)
 
 
-def closed_form_sd(dataset="LJSpeech", block="transformer_fs2"):
+def closed_form_sd(dataset="LJSpeech", block="transformer_fs2", unsup=False):
     """Closed-form weights for every schema key (energy_bins from stats.json like modules.py:795-818)."""
     pre, mc, tc = get_configs(dataset)
     sd = {}
-    for k, (shape, dtype, is_param) in schema(dataset, block).items():
+    for k, (shape, dtype, is_param) in schema(dataset, block, unsup).items():
         if k.endswith("energy_bins"):
             with open(os.path.join(pre["path"]["preprocessed_path"], "stats.json")) as f:
-                emin, emax = json.load(f)["energy_sup_phone"][:2]
+                emin, emax = json.load(f)["energy_unsup_frame" if unsup else "energy_sup_phone"][:2]
             sd[k] = torch.linspace(emin, emax, shape[0])
         elif "position_enc" in k or "positional_encoding" in k:
             from oracle.restate import interleaved_sinusoid_table
@@ -51,5 +51,5 @@ def batch_from_golden(g):
         max_src_len=int(g["in.max_src_len"]), mels=t("in.mels"), mel_lens=t("in.mel_lens"),
         max_mel_len=int(g["in.max_mel_len"]) if "in.max_mel_len" in g else None,
         p_targets=p_targets or None, e_targets=t("in.e_targets"), d_targets=t("in.d_targets"),
-        spker_embeds=t("in.spker_embeds"),
+        spker_embeds=t("in.spker_embeds"), attn_priors=t("in.attn_priors"),
     )
