@@ -355,6 +355,9 @@ def mas(attn, in_lens, out_lens):
     dur = torch.empty(B, Tk, dtype=torch.float32, device=attn.device)
     back = torch.empty(B, Tq, Tk, dtype=torch.uint8, device=attn.device)
     lib = _lib.load()
-    _lib.check(lib.ctts_mas(_p(_f32c(attn, "attn")), _p(in_lens.to(torch.int32).contiguous()), _p(out_lens.to(torch.int32).contiguous()),
-                            _p(opt), _p(dur), _p(back), B, Tq, Tk, _stream()), "ctts_mas")
+    # keep both converted tensors alive across the launch: a temporary freed between the two conversions would hand the same
+    # allocator block to the second one and the two pointers would alias
+    in32 = in_lens.to(torch.int32).contiguous()
+    out32 = out_lens.to(torch.int32).contiguous()
+    _lib.check(lib.ctts_mas(_p(_f32c(attn, "attn")), _p(in32), _p(out32), _p(opt), _p(dur), _p(back), B, Tq, Tk, _stream()), "ctts_mas")
     return opt, dur
