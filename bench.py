@@ -55,6 +55,10 @@ class TrainStep:
         from ctts_amd.dp import FlatGradArena
         from ctts_amd import ops
         ops.set_grad_accumulation_fusion(True)     # kernels accumulate straight into the flat gradient arena
+        if os.environ.get("CTTS_WGRAD_STREAM", "0") == "1":
+            # opt-in A/B knob: wgrad GEMMs on a side stream.  Measured SLOWER on MI355X (31.1 vs 29.9 ms/step): the
+            # co-scheduled GEMMs evict each other's L2 working set, which costs more than the tail rounds they fill.
+            ops.set_wgrad_stream(torch.cuda.Stream())
         # flat fp32 gradient arena: p.grad are views -> one all-reduce, no bucket copies
         self.arena = FlatGradArena(model.parameters())
         self.params = self.arena.params

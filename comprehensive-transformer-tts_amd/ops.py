@@ -32,6 +32,59 @@ def _fusable(p):
             and p.grad.dtype == torch.float32)
 
 
+# ---- weight-gradient side stream -------------------------------------------------------------------------------
+# dgrad and wgrad of a layer both consume dZ and are otherwise independent.  With a side stream set (and gradient
+# accumulation fusion on, so the wgrad kernels write param.grad themselves and autograd never touches the result),
+# every wgrad GEMM is issued on that stream: its workgroups fill the partially occupied last rounds ("tails") of the
+# dgrad GEMMs running on the main stream, and vice versa.  The streams are re-joined by an autograd engine callback
+# at the end of the backward pass, so callers (and hipGraph capture) see ordinary single-stream semantics.
+_WGRAD = {"stream": None, "keep": [], "main": None}
+
+
+def set_wgrad_stream(stream):
+    """`stream`: a torch.cuda.Stream for weight-gradient GEMMs, or None for single-stream execution."""
+    _WGRAD["stream"] = stream
+
+
+def _wgrad_join():
+    side, main = _WGRAD["stream"], _WGRAD["main"]
+    if side is not None and main is not None:
+        main.wait_stream(side)
+    _WGRAD["keep"].clear()          # operands read by the side stream may be recycled only after the join
+    _WGRAD["main"] = None
+
+
+class _OnWgradStream:
+    def __init__(self, *operands):
+        self.operands = operands
+
+    def __enter__(self):
+        side = _WGRAD["stream"]
+        cur = torch.cuda.current_stream()
+        if _WGRAD["main"] is None:
+            _WGRAD["main"] = cur
+            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join)
+        side.wait_stream(cur)                                   # dZ (and everything before it) is ready
+        _WGRAD["keep"].extend(self.operands)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+class _Inline:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _wgrad_scope(fused, *operands):
+    return _OnWgradStream(*operands) if (fused and _WGRAD["stream"] is not None) else _Inline()
+
+
 def _split_k_for(Mo, No, Kred):
     """split-K factor for weight-gradient GEMMs (small output, long reduction)."""
     t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
@@ -101,11 +154,16 @@ class _LinearConv(torch.autograd.Function):
                 K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, conv=(T, pad, N), alpha=alpha, row_halo=pad, **rl)
             if ctx.needs_input_grad[1]:
                 Kd = ksize * Cin
+                fused = _fusable(w)
                 dwf = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
-                K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                       split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
-                dW = torch.empty_like(w)
-                K.conv_weight_repack(dwf, dW, N, Cin, ksize, 2)
+                with _wgrad_scope(fused, dZ, x, dwf):
+                    K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
+                           split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
+                    if fused:
+                        K.conv_weight_repack(dwf, w.grad, N, Cin, ksize, 3)
+                    else:
+                        dW = torch.empty_like(w)
+                        K.conv_weight_repack(dwf, dW, N, Cin, ksize, 2)
         else:
             if ctx.needs_input_grad[0]:
                 dX = torch.empty_like(x)
@@ -113,7 +171,9 @@ class _LinearConv(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 fused = _fusable(w)
                 dW = w.grad if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
-                K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha, **rl)
+                with _wgrad_scope(fused, dZ, x):
+                    K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha,
+                           **rl)
                 if fused:
                     dW = None
         return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None

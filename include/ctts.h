@@ -68,7 +68,8 @@ int ctts_gemm(const ctts_gemm_desc* d, void* stream);
 /* Conv1d weight repack: w[Cout][Cin][K] (reference nn.Conv1d layout) ->
  *   mode 0: wf[Cout][K][Cin]                 (forward implicit-GEMM B operand)
  *   mode 1: wd[Cin][K][Cout], taps flipped   (data-gradient implicit-GEMM B operand)
- *   mode 2: inverse of mode 0 (wgrad result [Cout][K][Cin] -> [Cout][Cin][K])              */
+ *   mode 2: inverse of mode 0 (wgrad result [Cout][K][Cin] -> [Cout][Cin][K])
+ *   mode 3: as mode 2 but ADDED to dst (gradient accumulation straight into param.grad)      */
 int ctts_conv_weight_repack(const float* src, float* dst, int cout, int cin, int k, int mode, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -252,9 +252,10 @@ def test_grad_accumulation_fusion_matches_plain_autograd():
     no_dropout(m)
     batch = make_batch([40, 33, 21, 12], 8, seed=9)
 
-    def run(fuse):
+    def run(fuse, side_stream=False):
         arena = FlatGradArena(m.parameters())
         ops.set_grad_accumulation_fusion(fuse)
+        ops.set_wgrad_stream(torch.cuda.Stream() if side_stream else None)
         try:
             for bn in [x for x in m.modules() if hasattr(x, "running_mean")]:
                 bn.running_mean.zero_(); bn.running_var.fill_(1.0)
@@ -264,11 +265,13 @@ def test_grad_accumulation_fusion_matches_plain_autograd():
             loss.backward()
         finally:
             ops.set_grad_accumulation_fusion(False)
+            ops.set_wgrad_stream(None)
         return arena.flat.clone()
-    g0, g1 = run(False), run(True)
+    g0, g1, g2 = run(False), run(True), run(True, side_stream=True)   # g2: wgrad GEMMs on the side stream, joined by the engine callback
     assert g0.abs().sum() > 0
-    err = (g0 - g1).abs().max().item()
-    assert err <= 1e-5 * max(1.0, g0.abs().max().item()), err
+    for gx in (g1, g2):
+        err = (g0 - gx).abs().max().item()
+        assert err <= 1e-5 * max(1.0, g0.abs().max().item()), err
 
 
 @pytest.mark.parametrize("gname,step", [("g6_unsup_soft_step100", 100), ("g6_unsup_hard_step60000", 60000)])
