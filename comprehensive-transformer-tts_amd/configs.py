@@ -13,7 +13,12 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 _MODEL = {
     "block_type": "transformer_fs2",
     "duration_modeling": {"learn_alignment": False, "aligner_temperature": 0.0005},
-    "prosody_modeling": {"model_type": "none"},
+    "prosody_modeling": {
+        "model_type": "none",            # "none" | "liu2021"   ("du2021" is outside SURVEY.md section 8)
+        "liu2021": {"bottleneck_size_u": 256, "bottleneck_size_p": 4, "ref_enc_filters": [32, 32, 64, 64, 128, 128],
+                    "ref_enc_size": [3, 3], "ref_enc_strides": [1, 2], "ref_enc_pad": [1, 1], "ref_enc_gru_size": 32,
+                    "ref_attention_dropout": 0.0, "token_num": 32, "predictor_kernel_size": 3, "predictor_dropout": 0.5},
+    },
     "transformer_fs2": {
         "encoder_layer": 4, "encoder_head": 2, "encoder_hidden": 256,
         "decoder_layer": 6, "decoder_head": 2, "decoder_hidden": 256,

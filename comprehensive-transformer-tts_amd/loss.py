@@ -5,7 +5,8 @@ ops this round (dozens of tiny masked reductions + Adam).  Two changes make the 
 hipGraph-capturable without changing any value: the word-duration scatter uses the static bound
 Ts+1 instead of `word_id.max()+1` (loss.py:156-157: the extra bins are zero and masked), and the
 energy L1 uses a masked mean instead of `masked_select` (loss.py:236-243) - neither needs a
-device->host sync.  learn_alignment=True adds ForwardSumLoss (one batched CTC call) and BinLoss.
+device->host sync.  learn_alignment=True adds ForwardSumLoss (one batched CTC call) and BinLoss;
+prosody_modeling.model_type == "liu2021" adds the prosody L1 terms (loss.py:319-324).
 """
 import numpy as np
 import torch
@@ -26,6 +27,8 @@ class CompTransTTSLoss(nn.Module):
         self.use_pitch_embed = model_config["variance_embedding"]["use_pitch_embed"]
         self.use_energy_embed = model_config["variance_embedding"]["use_energy_embed"]
         self.var_start_steps = train_config["step"]["var_start_steps"]
+        self.model_type = model_config["prosody_modeling"]["model_type"]
+        self.prosody_loss_enable_steps = train_config["prosody"]["prosody_loss_enable_steps"]
         self.sil_ph_ids = SIL_PHONEME_IDS
 
     @staticmethod
@@ -94,7 +97,7 @@ class CompTransTTSLoss(nn.Module):
 
     def forward(self, inputs, predictions, step):
         (texts, _, _, mel_targets, _, _, pitch_targets, energy_targets, duration_targets, _, _) = inputs[3:]
-        (mel_pred, post_pred, p_pred, e_pred, log_d, _, src_masks, mel_masks, src_lens, mel_lens, attn_outs, _) = predictions
+        (mel_pred, post_pred, p_pred, e_pred, log_d, _, src_masks, mel_masks, src_lens, mel_lens, attn_outs, prosody_info) = predictions
         src_nonpad = (~src_masks)
         mel_nonpad = (~mel_masks)
         mel_targets = mel_targets[:, : mel_masks.shape[1], :]
@@ -111,7 +114,14 @@ class CompTransTTSLoss(nn.Module):
             else:
                 w = min((step - self.binarization_loss_enable_steps) / self.binarization_loss_warmup_steps, 1.0)
             bin_loss = self.bin_loss(attn_hard, attn_soft) * w
-        total = mel_loss + postnet_mel_loss + ctc_loss + bin_loss + zero
+        prosody_loss = zero
+        if self.training and self.model_type == "liu2021" and step > self.prosody_loss_enable_steps:
+            # loss.py:319-324.  The phoneme-level term selects with `src_masks` (True = PAD) exactly as the reference does:
+            # it averages |pp_tgt - pp_vec| over the PADDED phoneme positions (0/0 = NaN for a batch without padding).
+            up_tgt, pp_tgt, up_vec, pp_vec, _ = prosody_info
+            sel = src_masks.unsqueeze(-1).to(pp_vec.dtype)
+            prosody_loss = F.l1_loss(up_tgt, up_vec) + ((pp_tgt - pp_vec).abs() * sel).sum() / (sel.sum() * pp_vec.shape[-1])
+        total = mel_loss + postnet_mel_loss + ctc_loss + bin_loss + prosody_loss + zero
         duration_loss = {"pdur": zero, "wdur": zero, "sdur": zero}
         pitch_loss = {"C": zero, "uv": zero, "f0_mean": zero, "f0_std": zero}
         energy_loss = zero
@@ -123,7 +133,7 @@ class CompTransTTSLoss(nn.Module):
                 m = src_nonpad.float()
                 energy_loss = ((e_pred - energy_targets).abs() * m).sum() / m.sum()
             total = total + sum(duration_loss.values()) + sum(pitch_loss.values()) + energy_loss
-        return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, zero)
+        return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, prosody_loss)
 
 
 class ScheduledOptim:

@@ -22,6 +22,8 @@ state dict, what the reference computes on the path SURVEY.md section 8(a) lists
   a12 VarianceAdaptor.forward              model/modules.py:962-1114
   a13 mel_linear                           model/CompTransTTS.py:133
   a14 PostNet                              model/modules.py:140-148
+  a16 AlignmentEncoder / MAS               model/modules.py:36-75,863-888,1176-1213
+  a17 liu2021 prosody encoders/predictors  model/modules.py:332-648, model/coordconv.py:33-70,140-159
 
 Parity pinning: the reference has no tests / golden vectors, so this
 restatement is pinned against the reference itself imported in the build container
@@ -292,10 +294,138 @@ def phoneme_level_energy(dur, src_lens, energy_frame):
     return out
 
 
+# ============================================================================= a17: liu2021 implicit prosody modelling
+def coord_channels(T, W):
+    """AddCoords rank 2, with_r (coordconv.py:33-70): planes xx (varies along dim_y = time), yy (varies along dim_x = mel bin)
+    in [-1,1] and rr = sqrt((xx-.5)^2 + (yy-.5)^2), each [T,W] float32.  NOTE: T is the PADDED batch length."""
+    xx = torch.arange(T, dtype=torch.int32)[:, None].expand(T, W).float() / (T - 1)
+    yy = torch.arange(W, dtype=torch.int32)[None, :].expand(T, W).float() / (W - 1)
+    xx = xx * 2 - 1
+    yy = yy * 2 - 1
+    rr = torch.sqrt(torch.pow(xx - 0.5, 2) + torch.pow(yy - 0.5, 2))
+    return xx, yy, rr
+
+
+def gru_sequence(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
+    """single-layer nn.GRU, batch_first, zero initial state (gate order r|z|n; n = tanh(gi_n + r*(W_hn h + b_hn))).
+    Runs over ALL T steps, pads included - the reference never packs (modules.py:390-391, 636-637)."""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    gi = x @ w_ih.t() + b_ih
+    h = x.new_zeros(B, H)
+    outs = [None] * T
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        gh = h @ w_hh.t() + b_hh
+        r = torch.sigmoid(gi[:, t, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, t, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, t, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        outs[t] = h
+    return torch.stack(outs, 1), h
+
+
+def _bn_nd(sd, p, x, cdim, training_bn, new_stats):
+    """BatchNorm over every dim but `cdim` (batch statistics incl. pads when training_bn)."""
+    C = x.shape[cdim]
+    shape = [1] * x.dim()
+    shape[cdim] = C
+    if training_bn:
+        flat = x.transpose(cdim, -1).reshape(-1, C)
+        mean, var = flat.mean(0), flat.var(0, unbiased=False)
+        if new_stats is not None:
+            nrow = flat.shape[0]
+            new_stats[p + "running_mean"] = 0.9 * sd[p + "running_mean"] + 0.1 * mean.detach()
+            new_stats[p + "running_var"] = 0.9 * sd[p + "running_var"] + 0.1 * var.detach() * nrow / (nrow - 1)
+    else:
+        mean, var = sd[p + "running_mean"], sd[p + "running_var"]
+    return (x - mean.view(shape)) / torch.sqrt(var.view(shape) + 1e-5) * sd[p + "weight"].view(shape) + sd[p + "bias"].view(shape)
+
+
+def reference_encoder(sd, p, mel, mel_pad, training_bn, new_stats=None):
+    """ReferenceEncoder.forward (modules.py:371-392): 6x [Conv2d 3x3 stride (1,2) pad 1 -> BN2d -> ReLU], the first conv on
+    [mel | xx | yy | rr]; -> [N,T,C*W'] (channel-major) -> pad rows zeroed -> GRU.  Returns (memory [N,T,G], last [N,G])."""
+    N, T, W = mel.shape
+    xx, yy, rr = coord_channels(T, W)
+    out = torch.stack([mel, xx.expand(N, T, W), yy.expand(N, T, W), rr.expand(N, T, W)], 1)      # [N,4,T,W]
+    i = 0
+    while (p + f"bns.{i}.weight") in sd:
+        wkey = p + (f"convs.{i}.conv." if i == 0 else f"convs.{i}.")
+        out = F.conv2d(out, sd[wkey + "weight"], sd[wkey + "bias"], stride=(1, 2), padding=(1, 1))
+        out = torch.relu(_bn_nd(sd, p + f"bns.{i}.", out, 1, training_bn, new_stats))
+        i += 1
+    out = out.transpose(1, 2).contiguous().view(N, T, -1)
+    if mel_pad is not None:
+        out = out.masked_fill(mel_pad.unsqueeze(-1), 0)
+    g = p + "gru."
+    return gru_sequence(out, sd[g + "weight_ih_l0"], sd[g + "weight_hh_l0"], sd[g + "bias_ih_l0"], sd[g + "bias_hh_l0"])
+
+
+def utterance_prosody_encoder(sd, p, mel, mel_pad, E, training_bn, new_stats=None):
+    """UtteranceLevelProsodyEncoder.forward (modules.py:555-569) + STL / StyleEmbedAttention with one head (:453-534)."""
+    _, last = reference_encoder(sd, p + "encoder.", mel, mel_pad, training_bn, new_stats)
+    ep = last @ sd[p + "encoder_prj.weight"].t() + sd[p + "encoder_prj.bias"]                 # [N,E/2]
+    keys_in = torch.tanh(sd[p + "stl.embed"])                                                   # [tokens,E]
+    a = p + "stl.attention."
+    q = ep @ sd[a + "W_query.weight"].t()
+    k = keys_in @ sd[a + "W_key.weight"].t()
+    v = keys_in @ sd[a + "W_value.weight"].t()
+    sc = torch.softmax(q @ k.t() / (E ** 0.5), -1)                                              # key_dim = E // num_heads = E
+    out = (sc @ v) @ sd[p + "encoder_bottleneck.weight"].t() + sd[p + "encoder_bottleneck.bias"]
+    return out.unsqueeze(1)                                                                     # [N,1,bottleneck_u]; dropout p = 0.
+
+
+def phoneme_prosody_encoder(sd, p, x, src_pad, mel, mel_pad, E, training_bn, new_stats=None):
+    """PhonemeLevelProsodyEncoder.forward (modules.py:420-450)."""
+    mem, _ = reference_encoder(sd, p + "encoder.", mel, mel_pad, training_bn, new_stats)
+    ep = mem @ sd[p + "encoder_prj.weight"].t() + sd[p + "encoder_prj.bias"]                  # [N,Tm,2E]
+    k, v = ep[..., :E], ep[..., E:]
+    q = x @ sd[p + "linears.0.linear.weight"].t()
+    k = k @ sd[p + "linears.1.linear.weight"].t()
+    attn = q @ k.transpose(1, 2) / math.sqrt(E)
+    attn = attn.masked_fill(mel_pad.unsqueeze(1), float("-inf"))
+    attn = torch.softmax(attn, -1).masked_fill(src_pad.unsqueeze(-1), 0.0)
+    out = torch.bmm(attn, v) @ sd[p + "encoder_bottleneck.weight"].t() + sd[p + "encoder_bottleneck.bias"]
+    return out.masked_fill(src_pad.unsqueeze(-1), 0.0), attn
+
+
+def parallel_prosody_predictor(sd, p, x, E, phoneme_level, p_drop, train_dropout=False):
+    """ParallelProsodyPredictor.forward (modules.py:626-648): 2x [Conv1d k3 -> ReLU -> LayerNorm(1e-5) -> dropout] -> bi-GRU."""
+    for i in (1, 2):
+        w, b = sd[p + f"conv_layer.conv1d_{i}.conv.weight"], sd[p + f"conv_layer.conv1d_{i}.conv.bias"]
+        x = torch.relu(conv1d_btc(x, w, b, 1 if i == 2 else (w.shape[2] - 1) // 2))
+        x = layer_norm(x, sd[p + f"conv_layer.layer_norm_{i}.weight"], sd[p + f"conv_layer.layer_norm_{i}.bias"], 1e-5)
+        x = _drop(x, p_drop, train_dropout)
+    g = p + "gru."
+    mf, hf = gru_sequence(x, sd[g + "weight_ih_l0"], sd[g + "weight_hh_l0"], sd[g + "bias_ih_l0"], sd[g + "bias_hh_l0"])
+    mb, hb = gru_sequence(x, sd[g + "weight_ih_l0_reverse"], sd[g + "weight_hh_l0_reverse"], sd[g + "bias_ih_l0_reverse"],
+                          sd[g + "bias_hh_l0_reverse"], reverse=True)
+    pv = torch.cat([mf, mb], -1) if phoneme_level else torch.cat([hf, hb], -1).unsqueeze(1)
+    return pv @ sd[p + "predictor_bottleneck.weight"].t() + sd[p + "predictor_bottleneck.bias"]
+
+
+def liu2021_prosody(sd, cfg, x, src_pad, mel, mel_pad, training, train_dropout=False, new_stats=None):
+    """VarianceAdaptor liu2021 branch (modules.py:1002-1022).  Returns (x, prosody_info)."""
+    va = "variance_adaptor."
+    E = cfg["transformer"]["encoder_hidden"]
+    pd = cfg["prosody_modeling"]["liu2021"]["predictor_dropout"]
+    up_emb = pp_emb = pp_attn = None
+    if training:
+        up_emb = utterance_prosody_encoder(sd, va + "utterance_prosody_encoder.", mel, mel_pad, E, True, new_stats)
+        pp_emb, pp_attn = phoneme_prosody_encoder(sd, va + "phoneme_prosody_encoder.", x, src_pad, mel, mel_pad, E, True, new_stats)
+    up_vec = parallel_prosody_predictor(sd, va + "utterance_prosody_predictor.", x, E, False, pd, train_dropout)
+    u = up_emb if training else up_vec
+    x = x + (u @ sd[va + "utterance_prosody_prj.weight"].t() + sd[va + "utterance_prosody_prj.bias"])
+    pp_vec = parallel_prosody_predictor(sd, va + "phoneme_prosody_predictor.", x, E, True, pd, train_dropout)
+    pp = pp_emb if training else pp_vec
+    x = x + (pp @ sd[va + "phoneme_prosody_prj.weight"].t() + sd[va + "phoneme_prosody_prj.bias"])
+    return x, (up_emb, pp_emb, up_vec, pp_vec, pp_attn)
+
+
 def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pad, max_mel_len,
                      p_targets, e_targets, d_targets, speaker_embedding=None,
                      p_control=1.0, e_control=1.0, d_control=1.0, train_dropout=False, taps=None,
-                     text_embedding=None, mel=None, attn_prior=None, step=None, bin_start_steps=None, attn_out=None):
+                     text_embedding=None, mel=None, attn_prior=None, step=None, bin_start_steps=None, attn_out=None,
+                     training=False, new_stats=None, prosody_out=None):
     vp = cfg["variance_predictor"]
     va = "variance_adaptor."
     pitch_cfg = pre_cfg["preprocessing"]["pitch"]
@@ -303,6 +433,10 @@ def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pa
     x = text.clone()
     if speaker_embedding is not None:
         x = x + speaker_embedding[:, None, :]
+    if cfg["prosody_modeling"]["model_type"] == "liu2021":
+        x, pros = liu2021_prosody(sd, cfg, x, src_pad, mel, mel_pad, training, train_dropout, new_stats)
+        if prosody_out is not None:
+            prosody_out.append(pros)
     log_d = duration_predictor(sd, cfg, _grad_scale(x, vp["predictor_grad"]), src_pad, train_dropout)
     x_org = x
     mel2ph_inf = None
@@ -420,11 +554,12 @@ def comp_trans_tts_forward(sd, model_cfg, pre_cfg, speakers, texts, src_lens, ma
             spk = spker_embeds @ sd["speaker_emb.weight"].t() + sd["speaker_emb.bias"]
         else:
             spk = F.embedding(speakers, sd["speaker_emb.weight"])
-    attn_out = []
+    attn_out, prosody_out = [], []
     (x, p_targets, p_pred, e_targets, e_pred, log_d, d_rounded, mel_lens, mel_pad) = variance_adaptor(
         sd, model_cfg, pre_cfg, enc, src_lens, src_pad, mel_lens, mel_pad, max_mel_len, p_targets, e_targets,
         d_targets, spk, p_control, e_control, d_control, train_dropout, taps, text_embedding=text_emb, mel=mels,
-        attn_prior=attn_priors, step=step, bin_start_steps=bin_start_steps, attn_out=attn_out)
+        attn_prior=attn_priors, step=step, bin_start_steps=bin_start_steps, attn_out=attn_out, training=training,
+        new_stats=new_stats, prosody_out=prosody_out)
     c = model_cfg["transformer_fs2"]
     dec = fft_blocks(sd, "decoder.", x, mel_pad, c["decoder_layer"], c["decoder_head"], c["ffn_kernel_size"],
                      c["decoder_dropout"], True, train_dropout, taps)
@@ -433,7 +568,7 @@ def comp_trans_tts_forward(sd, model_cfg, pre_cfg, speakers, texts, src_lens, ma
     mel = dec @ sd["mel_linear.weight"].t() + sd["mel_linear.bias"]
     post = postnet(sd, mel, training, train_dropout, new_stats) + mel
     return (mel, post, p_pred, e_pred, log_d, d_rounded, src_pad, mel_pad, src_lens, mel_lens,
-            tuple(attn_out) if attn_out else (None, None, None, None), None, p_targets, e_targets)
+            tuple(attn_out) if attn_out else (None, None, None, None), prosody_out[0] if prosody_out else None, p_targets, e_targets)
 
 
 # ============================================================================= a15: conformer plugin

@@ -36,17 +36,18 @@ def pseudo(name, shape):
     return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float()
 
 
-def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=False):
+def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=False, prosody="none"):
     from model import CompTransTTS
 
     pre, mc, tc = ref_import.load_configs(dataset)
     mc["duration_modeling"]["learn_alignment"] = learn_alignment
+    mc["prosody_modeling"]["model_type"] = prosody
     mc["block_type"] = block_type
     model = CompTransTTS(pre, mc, tc)
     sd = closed_form_state_dict(model.state_dict())
     model.load_state_dict(sd)
     import json
-    tag = f"{dataset}_{block_type}" + ("_unsup" if learn_alignment else "")
+    tag = f"{dataset}_{block_type}" + ("_unsup" if learn_alignment else "") + ("" if prosody == "none" else "_" + prosody)
     with open(os.path.join(OUT, f"state_dict_schema_{tag}.json"), "w") as f:
         json.dump({k: [list(v.shape), str(v.dtype).replace("torch.", ""), bool(k in dict(model.named_parameters()))]
                    for k, v in model.state_dict().items()}, f, indent=0)
@@ -68,6 +69,9 @@ def flatten_outputs(out, prefix="out."):
     if attn is not None and attn[0] is not None:
         d["attn_soft"], d["attn_hard"], d["attn_hard_dur"], d["attn_logprob"] = [_np(a) for a in attn]
         d["e_targets_out"] = _np(e_t)
+    if pros is not None:
+        for n, v in zip(("up_emb", "pp_emb", "up_vec", "pp_vec", "pp_attn"), pros):
+            d["pros." + n] = _np(v)
     return {prefix + k: v for k, v in d.items() if v is not None}
 
 
@@ -128,6 +132,8 @@ def run_case(model, batch, mode, name, with_grads=False, extra_kwargs=None):
         if out[10][0] is not None:      # unsupervised: attention outputs enter the loss too
             a_soft, _, _, a_logp = out[10]
             loss = loss + (a_soft * pseudo("asoft", a_soft.shape)).sum() * 10 + (a_logp * pseudo("alogp", a_logp.shape)).sum() * 0.1
+        if out[11] is not None:         # liu2021: the predictors only reach the loss through prosody_info
+            loss = loss + (out[11][2] * pseudo("upvec", out[11][2].shape)).sum() + (out[11][3] * pseudo("ppvec", out[11][3].shape)).sum()
         model.zero_grad()
         loss.backward()
         arrs["grad.loss"] = _np(loss)
@@ -288,5 +294,23 @@ def main():
     run_case(model_c, cb, "train", "g4_conformer_train_nodrop", with_grads=True)
 
 
+def main_liu2021():
+    """G10: prosody_modeling.model_type = liu2021, supervised and with learn_alignment=True (config C5)."""
+    torch.manual_seed(0)
+    model, cfgs = build("LJSpeech", "transformer_fs2", prosody="liu2021")
+    small = make_batch([24, 17], 6, seed=1234)
+    run_case(model, small, "eval", "g10_liu2021_eval")
+    out = run_case(model, small, "train", "g10_liu2021_train_nodrop", with_grads=True)
+    golden_loss(out, small, cfgs, "g10_liu2021_loss", step=100001)
+    model_u, cfgs_u = build("LJSpeech", "transformer_fs2", learn_alignment=True, prosody="liu2021")
+    ub = make_unsup_batch([24, 17], 6, seed=99)
+    out_u = run_case(model_u, ub, "train", "g10_liu2021_unsup_step60000", with_grads=True, extra_kwargs=dict(step=60000))
+    golden_loss(out_u, ub, cfgs_u, "g10_liu2021_unsup_loss_step100001", step=100001)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "liu2021":
+        main_liu2021()
+    else:
+        main()
+        main_liu2021()

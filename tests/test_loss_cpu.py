@@ -62,3 +62,29 @@ def test_unsupervised_loss_matches_reference_golden():
     for k, v in exp.items():
         ref = float(np.asarray(g9["loss." + k]).reshape(-1)[0])
         assert abs(float(v.reshape(-1)[0]) - ref) <= 3e-4 * max(1.0, abs(ref)), (k, float(v.reshape(-1)[0]), ref)
+
+
+def test_liu2021_prosody_loss_matches_reference_golden():
+    """prosody L1 terms (loss.py:319-324, incl. the pad-position selection quirk) after prosody_loss_enable_steps,
+    supervised and with learn_alignment=True (config C5)."""
+    for gname, lname, unsup in (("g10_liu2021_train_nodrop", "g10_liu2021_loss", False),
+                                ("g10_liu2021_unsup_step60000", "g10_liu2021_unsup_loss_step100001", True)):
+        g, g9 = load_golden(gname), load_golden(lname)
+        pre, mc, tc = get_configs()
+        mc["duration_modeling"]["learn_alignment"] = unsup
+        mc["prosody_modeling"]["model_type"] = "liu2021"
+        b = batch_from_golden(g)
+        args = [b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"], b["max_mel_len"],
+                b["p_targets"], b["e_targets"], b["d_targets"], b["attn_priors"] if unsup else None, None]
+        out = R.comp_trans_tts_forward(closed_form_sd(unsup=unsup, prosody="liu2021"), mc, pre, *args,
+                                       step=60000 if unsup else None, training=True)
+        inputs = [None, None] + list(args)
+        inputs[9:11] = out[-2:]
+        L = CompTransTTSLoss(pre, mc, tc)
+        step = int(g9["step"])
+        total, mel, post, pitch, energy, dur, ctc, binl, pros = L(inputs, out[:-2], step)
+        exp = {"total": total, "mel": mel, "postnet_mel": post, "prosody": pros, "ctc": ctc, "bin": binl, "energy": energy}
+        for k, v in exp.items():
+            ref = float(np.asarray(g9["loss." + k]).reshape(-1)[0])
+            assert abs(float(v.reshape(-1)[0]) - ref) <= 3e-4 * max(1.0, abs(ref)), (gname, k, float(v.reshape(-1)[0]), ref)
+        assert float(L(inputs, out[:-2], 1000)[8]) == 0.0          # before prosody_loss_enable_steps

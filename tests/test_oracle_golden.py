@@ -168,3 +168,69 @@ def test_g6_unsupervised_alignment(gname, step):
     _close(out[1], g["out.postnet_mel"], 5e-5, name="postnet_mel")
     _close(out[4], g["out.log_d"], name="log_d")
     _close(out[3], g["out.e_pred"], name="e_pred")
+
+
+def _pseudo(name, shape):
+    from oracle.weights import _hash_uniform
+    return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float()
+
+
+PROS_NAMES = ("up_emb", "pp_emb", "up_vec", "pp_vec", "pp_attn")
+
+
+@pytest.mark.parametrize("gname,unsup,training", [("g10_liu2021_eval", False, False), ("g10_liu2021_train_nodrop", False, True),
+                                                  ("g10_liu2021_unsup_step60000", True, True)])
+def test_g10_liu2021_prosody(gname, unsup, training):
+    """reference encoders (CoordConv2d stack + BN2d + GRU), STL, phoneme-level attention, bi-GRU predictors."""
+    g = load_golden(gname)
+    sd = closed_form_sd(unsup=unsup, prosody="liu2021")
+    if training:
+        sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    pre, mc, tc = get_configs()
+    mc["duration_modeling"]["learn_alignment"] = unsup
+    mc["prosody_modeling"]["model_type"] = "liu2021"
+    b = batch_from_golden(g)
+    taps, stats = {}, {}
+    out = R.comp_trans_tts_forward(sd, mc, pre, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"],
+                                   b["mel_lens"], b["max_mel_len"], b["p_targets"], b["e_targets"], b["d_targets"],
+                                   b["attn_priors"] if unsup else None, None, step=60000 if unsup else None,
+                                   training=training, taps=taps, new_stats=stats)
+    for n, v in zip(PROS_NAMES, out[11]):
+        if v is None:
+            assert "out.pros." + n not in g
+        else:
+            _close(v, g["out.pros." + n], 2e-5, "prosody " + n)
+    _close(out[0], g["out.mel"], 5e-5, name="mel")
+    _close(out[1], g["out.postnet_mel"], 1e-4, name="postnet_mel")
+    _close(out[4], g["out.log_d"], 5e-5, name="log_d")
+    _close(out[3], g["out.e_pred"], 5e-5, name="e_pred")
+    if not training:
+        return
+    for k, v in stats.items():
+        _close(v, g["bn." + k], 5e-5, name=k)
+    assert sum("prosody_encoder" in k for k in stats) == 24          # 2 encoders x 6 BN2d x (mean, var)
+    mel, post, p_pred, e_pred, log_d = out[:5]
+    loss = ((post * _pseudo("post", post.shape)).sum() + (mel * _pseudo("mel", mel.shape)).sum()
+            + (log_d * _pseudo("logd", log_d.shape)).sum() + (e_pred * _pseudo("e", e_pred.shape)).sum()
+            + (p_pred["cwt"] * _pseudo("cwt", p_pred["cwt"].shape)).sum()
+            + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum())
+    if unsup:
+        a_soft, _, _, a_logp = out[10]
+        loss = loss + (a_soft * _pseudo("asoft", a_soft.shape)).sum() * 10 + (a_logp * _pseudo("alogp", a_logp.shape)).sum() * 0.1
+    loss = loss + (out[11][2] * _pseudo("upvec", out[11][2].shape)).sum() + (out[11][3] * _pseudo("ppvec", out[11][3].shape)).sum()
+    _close(loss, g["grad.loss"], 5e-3, name="probe loss")
+    loss.backward()
+    n = 0
+    for k, v in sd.items():
+        if "grad.stat." + k not in g or "prosody" not in k:
+            continue
+        gs = g["grad.stat." + k]
+        gr = v.grad.flatten() if v.grad is not None else torch.zeros(v.numel())
+        scale = max(1.0, float(gs[1]))
+        # one BN2d output of the unsup fixture sits within 5e-6 of the ReLU kink: its derivative (0 or 1) is decided by
+        # rounding noise and moves the conv-stack gradients below it by ~5e-3 relative (traced against the live reference)
+        tol = (1e-2 if (unsup and "phoneme_prosody_encoder.encoder." in k) else 3e-4) * scale
+        _close(gr[:64], g["grad.head." + k], tol, name="grad " + k)
+        assert abs(float(gr.double().pow(2).sum().sqrt()) - gs[1]) <= tol, k
+        n += 1
+    assert n > 80, n
