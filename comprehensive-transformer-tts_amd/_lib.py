@@ -69,6 +69,12 @@ _SIGNATURES = {
     "ctts_relshift_bwd": [_vp, _vp, C.c_int, C.c_int, _vp],
     "ctts_neg_sqdist": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _vp],
     "ctts_mas": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_im2col_3x3s2": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_col2im_3x3s2": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_gru_fwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_softmax_rect_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_softmax_rect_bwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version"])
 

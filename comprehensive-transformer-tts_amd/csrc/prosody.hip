@@ -1,0 +1,314 @@
+// liu2021 implicit prosody modelling kernels (reference model/modules.py:332-648, model/coordconv.py).
+//
+//  * ctts_im2col_3x3s2 / ctts_col2im_3x3s2 : Conv2d 3x3, stride (1,2), padding (1,1) of ReferenceEncoder (modules.py:351-361) on
+//      channel-last activations x[B,T,W,C]: the patch matrix col[(b,t,wo)][(kh,kw,c)] feeds ctts_gemm (forward, dgrad and wgrad
+//      all on MFMA); col2im is the adjoint written as a GATHER (each input element sums the <= 6 patch entries that read
+//      it) - deterministic, no atomics.  Both are pure streaming kernels (HBM bound).
+//  * ctts_gru_fwd / ctts_gru_bwd : the sequential part of nn.GRU (modules.py:359-361,391 and :618-621,637).  The input projection
+//      W_ih x + b_ih of ALL time steps is one GEMM done by the caller; here one workgroup per (utterance, direction) walks the T steps
+//      with its W_hh slice held in REGISTERS (thread g owns row g: H floats), h_{t-1} broadcast from LDS, two barriers per step, next
+//      step's operands prefetched.  Backward is BPTT with the same structure (thread (p,j) owns W_hh[pH..pH+H-1][j]); it emits
+//      dgi (-> W_ih / input gradients by GEMM), dgh and h_{t-1} (-> dW_hh = dgh^T h_prev by one split-K GEMM, db_hh by a column sum).
+//  * ctts_softmax_rect_fwd / _bwd : masked row softmax of a rectangular score matrix [nb,Tq,Tk] (PhonemeLevelProsodyEncoder
+//      attention, modules.py:443-446: keys >= klens masked to -inf, query rows >= qlens zeroed; also the 32-token STL softmax).
+#include "ctts_common.h"
+
+namespace {
+
+inline int grid_for(long n, int block = 256) { return (int)((n + block - 1) / block > 65535 * 16 ? 65535 * 16 : (n + block - 1) / block); }
+
+__global__ void im2col_3x3s2_kernel(const float4* __restrict__ x, float4* __restrict__ col, int T, int W, int Wo, int C4, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % C4);
+    long r = e / C4;
+    const int tap = (int)(r % 9);
+    r /= 9;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int t = (int)(r % T);
+    const long b = r / T;
+    const int ti = t + tap / 3 - 1, wi = 2 * wo - 1 + tap % 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ti >= 0 && ti < T && wi >= 0 && wi < W) v = x[((b * T + ti) * W + wi) * C4 + c4];
+    col[e] = v;
+  }
+}
+
+__global__ void col2im_3x3s2_kernel(const float4* __restrict__ dcol, float4* __restrict__ dx, int T, int W, int Wo, int C4, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % C4);
+    long r = e / C4;
+    const int w = (int)(r % W);
+    r /= W;
+    const int t = (int)(r % T);
+    const long b = r / T;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int to = t - kh + 1;
+      if (to < 0 || to >= T) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int num = w + 1 - kw;
+        if (num < 0 || (num & 1)) continue;
+        const int wo = num >> 1;
+        if (wo >= Wo) continue;
+        const float4 v = dcol[(((b * T + to) * Wo + wo) * 9 + kh * 3 + kw) * C4 + c4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    dx[e] = acc;
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// gi [B,T,ndir,3H], whh [ndir,3H,H], bhh [ndir,3H], out [B,T,ndir,H], gates [B,T,ndir,4H] (r|z|n|W_hn h + b_hn) or NULL
+template <int H>
+__global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+                                                                         const float* __restrict__ bhh, float* __restrict__ out,
+                                                                         float* __restrict__ gates, int T, int ndir) {
+  __shared__ float s_h[H];
+  __shared__ float s_gh[3 * H];
+  const int b = blockIdx.x, dir = blockIdx.y, g = threadIdx.x;
+  float w[H];
+  float bias = 0.f;
+  if (g < 3 * H) {
+    const float* wr = whh + ((long)dir * 3 * H + g) * H;
+#pragma unroll
+    for (int k = 0; k < H; ++k) w[k] = wr[k];
+    bias = bhh[dir * 3 * H + g];
+  }
+  if (g < H) s_h[g] = 0.f;
+  const long gs = (long)ndir * 3 * H;
+  const float* gib = gi + (long)b * T * gs + (long)dir * 3 * H;
+  float gr = 0.f, gz = 0.f, gn = 0.f;
+  if (g < H && T > 0) {
+    const float* p = gib + (long)(dir ? T - 1 : 0) * gs;
+    gr = p[g]; gz = p[H + g]; gn = p[2 * H + g];
+  }
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    float ngr = 0.f, ngz = 0.f, ngn = 0.f;
+    if (g < H && s + 1 < T) {                       // prefetch the next step's input projection
+      const float* p = gib + (long)(dir ? t - 1 : t + 1) * gs;
+      ngr = p[g]; ngz = p[H + g]; ngn = p[2 * H + g];
+    }
+    if (g < 3 * H) {
+      float acc = bias;
+#pragma unroll
+      for (int k = 0; k < H; ++k) acc = fmaf(w[k], s_h[k], acc);
+      s_gh[g] = acc;
+    }
+    __syncthreads();
+    if (g < H) {
+      const float r = sigmoidf_(gr + s_gh[g]);
+      const float z = sigmoidf_(gz + s_gh[H + g]);
+      const float ghn = s_gh[2 * H + g];
+      const float n = tanhf(gn + r * ghn);
+      const float h = (1.0f - z) * n + z * s_h[g];
+      const long o = ((long)b * T + t) * ndir + dir;
+      out[o * H + g] = h;
+      if (gates) {
+        float* gp = gates + o * 4 * H;
+        gp[g] = r; gp[H + g] = z; gp[2 * H + g] = n; gp[3 * H + g] = ghn;
+      }
+      s_h[g] = h;
+    }
+    __syncthreads();
+    gr = ngr; gz = ngz; gn = ngn;
+  }
+}
+
+// dout [B,T,ndir,H]; dgi, dgh [B,T,ndir,3H]; hprev [B,T,ndir,H]
+template <int H>
+__global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                                         const float* __restrict__ gates, const float* __restrict__ whh,
+                                                                         float* __restrict__ dgi, float* __restrict__ dgh,
+                                                                         float* __restrict__ hprev, int T, int ndir) {
+  __shared__ float s_dgh[3 * H];
+  __shared__ float s_part[3 * H];
+  const int b = blockIdx.x, dir = blockIdx.y, id = threadIdx.x;
+  const int p = id / H, j = id - p * H;
+  float wc[H];
+  if (id < 3 * H) {
+#pragma unroll
+    for (int k = 0; k < H; ++k) wc[k] = whh[((long)dir * 3 * H + p * H + k) * H + j];
+  }
+  float dh = 0.f;
+  // operands of the current step (threads id < H)
+  float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, d_o = 0.f, hp = 0.f;
+  auto fetch = [&](int s, float& r_, float& z_, float& n_, float& ghn_, float& do_, float& hp_) {
+    const int t = dir ? T - 1 - s : s;
+    const long o = ((long)b * T + t) * ndir + dir;
+    const float* gp = gates + o * 4 * H;
+    r_ = gp[id]; z_ = gp[H + id]; n_ = gp[2 * H + id]; ghn_ = gp[3 * H + id];
+    do_ = dout[o * H + id];
+    hp_ = 0.f;
+    if (s > 0) {
+      const int tp = dir ? t + 1 : t - 1;
+      hp_ = out[(((long)b * T + tp) * ndir + dir) * H + id];
+    }
+  };
+  if (id < H && T > 0) fetch(T - 1, r, z, n, ghn, d_o, hp);
+  for (int s = T - 1; s >= 0; --s) {
+    const int t = dir ? T - 1 - s : s;
+    float nr = 0.f, nz = 0.f, nn = 0.f, nghn = 0.f, ndo = 0.f, nhp = 0.f;
+    if (id < H && s > 0) fetch(s - 1, nr, nz, nn, nghn, ndo, nhp);
+    float dcarry = 0.f;
+    if (id < H) {
+      const float d = dh + d_o;
+      const float dn = d * (1.0f - z);
+      const float dz = d * (hp - n);
+      dcarry = d * z;
+      const float dnp = dn * (1.0f - n * n);
+      const float dzp = dz * z * (1.0f - z);
+      const float drp = dnp * ghn * r * (1.0f - r);
+      const long o = ((long)b * T + t) * ndir + dir;
+      float* a = dgi + o * 3 * H;
+      a[id] = drp; a[H + id] = dzp; a[2 * H + id] = dnp;
+      float* c = dgh + o * 3 * H;
+      c[id] = drp; c[H + id] = dzp; c[2 * H + id] = dnp * r;
+      s_dgh[id] = drp; s_dgh[H + id] = dzp; s_dgh[2 * H + id] = dnp * r;
+      hprev[o * H + id] = hp;
+    }
+    __syncthreads();
+    if (id < 3 * H) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < H; ++k) acc = fmaf(wc[k], s_dgh[p * H + k], acc);
+      s_part[id] = acc;
+    }
+    __syncthreads();
+    if (id < H) dh = dcarry + s_part[id] + s_part[H + id] + s_part[2 * H + id];
+    r = nr; z = nz; n = nn; ghn = nghn; d_o = ndo; hp = nhp;
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void softmax_rect_kernel(float* __restrict__ S, const float* __restrict__ P,
+                                                            const int32_t* __restrict__ klens, const int32_t* __restrict__ qlens,
+                                                            int Tq, int Tk, long nrows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < nrows; row += (long)gridDim.x * 4) {
+    const long zb = row / Tq;
+    const int q = (int)(row - zb * Tq);
+    const int L = klens ? min(klens[zb], Tk) : Tk;
+    const int Lq = qlens ? min(qlens[zb], Tq) : Tq;
+    float* s = S + row * Tk;
+    if (q >= Lq || L <= 0) {
+      for (int k = lane; k < Tk; k += 64) s[k] = 0.f;
+      continue;
+    }
+    if (!BWD) {
+      float mx = -INFINITY;
+      for (int k = lane; k < L; k += 64) mx = fmaxf(mx, s[k]);
+      mx = ctts_wave_max(mx);
+      float sum = 0.f;
+      for (int k = lane; k < L; k += 64) sum += expf(s[k] - mx);
+      const float inv = 1.f / ctts_wave_sum(sum);
+      for (int k = lane; k < Tk; k += 64) s[k] = k < L ? expf(s[k] - mx) * inv : 0.f;
+    } else {
+      const float* p = P + row * Tk;
+      float dot = 0.f;
+      for (int k = lane; k < L; k += 64) dot += s[k] * p[k];
+      dot = ctts_wave_sum(dot);
+      for (int k = lane; k < Tk; k += 64) s[k] = k < L ? p[k] * (s[k] - dot) : 0.f;
+    }
+  }
+}
+
+template <int H>
+int launch_gru_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* gates, int B, int T, int ndir, hipStream_t st) {
+  hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3(B, ndir), dim3((3 * H + 63) / 64 * 64), 0, st, gi, whh, bhh, out, gates, T, ndir);
+  CTTS_CHECK_LAUNCH("ctts_gru_fwd");
+  return 0;
+}
+template <int H>
+int launch_gru_bwd(const float* dout, const float* out, const float* gates, const float* whh, float* dgi, float* dgh, float* hprev,
+                   int B, int T, int ndir, hipStream_t st) {
+  hipLaunchKernelGGL((gru_bwd_kernel<H>), dim3(B, ndir), dim3((3 * H + 63) / 64 * 64), 0, st, dout, out, gates, whh, dgi, dgh, hprev, T,
+                     ndir);
+  CTTS_CHECK_LAUNCH("ctts_gru_bwd");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ctts_im2col_3x3s2(const float* x, float* col, int B, int T, int W, int C, void* stream) {
+  CTTS_REQUIRE(x && col && B >= 0 && T > 0 && W > 0 && C > 0 && (C % 4) == 0, "ctts_im2col_3x3s2: bad arguments (C %% 4 must be 0)");
+  const int Wo = (W - 1) / 2 + 1;
+  const long total = (long)B * T * Wo * 9 * (C / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(im2col_3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)col, T, W,
+                     Wo, C / 4, total);
+  CTTS_CHECK_LAUNCH("ctts_im2col_3x3s2");
+  return 0;
+}
+
+extern "C" int ctts_col2im_3x3s2(const float* dcol, float* dx, int B, int T, int W, int C, void* stream) {
+  CTTS_REQUIRE(dcol && dx && B >= 0 && T > 0 && W > 0 && C > 0 && (C % 4) == 0, "ctts_col2im_3x3s2: bad arguments (C %% 4 must be 0)");
+  const int Wo = (W - 1) / 2 + 1;
+  const long total = (long)B * T * W * (C / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(col2im_3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)dcol, (float4*)dx, T,
+                     W, Wo, C / 4, total);
+  CTTS_CHECK_LAUNCH("ctts_col2im_3x3s2");
+  return 0;
+}
+
+extern "C" int ctts_gru_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* gates, int B, int T, int H, int ndir,
+                            void* stream) {
+  CTTS_REQUIRE(gi && whh && bhh && out && B >= 0 && T >= 0 && (ndir == 1 || ndir == 2), "ctts_gru_fwd: bad arguments");
+  if (B == 0 || T == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (H) {
+    case 16: return launch_gru_fwd<16>(gi, whh, bhh, out, gates, B, T, ndir, st);
+    case 32: return launch_gru_fwd<32>(gi, whh, bhh, out, gates, B, T, ndir, st);
+    case 64: return launch_gru_fwd<64>(gi, whh, bhh, out, gates, B, T, ndir, st);
+    case 128: return launch_gru_fwd<128>(gi, whh, bhh, out, gates, B, T, ndir, st);
+    default:
+      ctts_set_error("ctts_gru_fwd: hidden size %d is not instantiated (16, 32, 64, 128: W_hh rows live in registers)", H);
+      return -1;
+  }
+}
+
+extern "C" int ctts_gru_bwd(const float* dout, const float* out, const float* gates, const float* whh, float* dgi, float* dgh,
+                            float* hprev, int B, int T, int H, int ndir, void* stream) {
+  CTTS_REQUIRE(dout && out && gates && whh && dgi && dgh && hprev && B >= 0 && T >= 0 && (ndir == 1 || ndir == 2),
+               "ctts_gru_bwd: bad arguments");
+  if (B == 0 || T == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (H) {
+    case 16: return launch_gru_bwd<16>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, st);
+    case 32: return launch_gru_bwd<32>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, st);
+    case 64: return launch_gru_bwd<64>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, st);
+    case 128: return launch_gru_bwd<128>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, st);
+    default:
+      ctts_set_error("ctts_gru_bwd: hidden size %d is not instantiated (16, 32, 64, 128)", H);
+      return -1;
+  }
+}
+
+extern "C" int ctts_softmax_rect_fwd(float* S, const int32_t* klens, const int32_t* qlens, int nb, int Tq, int Tk, void* stream) {
+  CTTS_REQUIRE(S && nb >= 0 && Tq > 0 && Tk > 0, "ctts_softmax_rect_fwd: bad arguments");
+  const long nrows = (long)nb * Tq;
+  if (nrows == 0) return 0;
+  const int blocks = (int)((nrows + 3) / 4 > 8192 ? 8192 : (nrows + 3) / 4);
+  hipLaunchKernelGGL((softmax_rect_kernel<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, (const float*)nullptr, klens,
+                     qlens, Tq, Tk, nrows);
+  CTTS_CHECK_LAUNCH("ctts_softmax_rect_fwd");
+  return 0;
+}
+
+extern "C" int ctts_softmax_rect_bwd(const float* P, float* dP, const int32_t* klens, const int32_t* qlens, int nb, int Tq, int Tk,
+                                     void* stream) {
+  CTTS_REQUIRE(P && dP && nb >= 0 && Tq > 0 && Tk > 0, "ctts_softmax_rect_bwd: bad arguments");
+  const long nrows = (long)nb * Tq;
+  if (nrows == 0) return 0;
+  const int blocks = (int)((nrows + 3) / 4 > 8192 ? 8192 : (nrows + 3) / 4);
+  hipLaunchKernelGGL((softmax_rect_kernel<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dP, P, klens, qlens, Tq, Tk, nrows);
+  CTTS_CHECK_LAUNCH("ctts_softmax_rect_bwd");
+  return 0;
+}

@@ -361,3 +361,60 @@ def mas(attn, in_lens, out_lens):
     out32 = out_lens.to(torch.int32).contiguous()
     _lib.check(lib.ctts_mas(_p(_f32c(attn, "attn")), _p(in32), _p(out32), _p(opt), _p(dur), _p(back), B, Tq, Tk, _stream()), "ctts_mas")
     return opt, dur
+
+
+# ---- liu2021 prosody modelling (csrc/prosody.hip) -----------------------------------------------------------------------
+def im2col_3x3s2(x):
+    """x [B,T,W,C] channel-last -> col [B*T*Wo, 9*C] of Conv2d(3x3, stride (1,2), padding (1,1)); Wo = (W-1)//2+1"""
+    B, T, W, Cc = x.shape
+    Wo = (W - 1) // 2 + 1
+    col = torch.empty(B * T * Wo, 9 * Cc, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_im2col_3x3s2(_p(_f32c(x, "x")), _p(col), B, T, W, Cc, _stream()), "ctts_im2col_3x3s2")
+    return col
+
+
+def col2im_3x3s2(dcol, B, T, W, Cc):
+    dx = torch.empty(B, T, W, Cc, dtype=torch.float32, device=dcol.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_col2im_3x3s2(_p(_f32c(dcol, "dcol")), _p(dx), B, T, W, Cc, _stream()), "ctts_col2im_3x3s2")
+    return dx
+
+
+def gru_fwd(gi, whh, bhh, H, ndir, save_gates=True):
+    """gi [B,T,ndir*3H], whh [ndir,3H,H], bhh [ndir,3H] -> (out [B,T,ndir*H], gates [B,T,ndir*4H] or None)"""
+    B, T = gi.shape[0], gi.shape[1]
+    out = torch.empty(B, T, ndir * H, dtype=torch.float32, device=gi.device)
+    gates = torch.empty(B, T, ndir * 4 * H, dtype=torch.float32, device=gi.device) if save_gates else None
+    lib = _lib.load()
+    _lib.check(lib.ctts_gru_fwd(_p(_f32c(gi, "gi")), _p(_f32c(whh, "whh")), _p(_f32c(bhh, "bhh")), _p(out), _p(gates), B, T, H, ndir,
+                                _stream()), "ctts_gru_fwd")
+    return out, gates
+
+
+def gru_bwd(dout, out, gates, whh, H, ndir):
+    """-> (dgi, dgh [B,T,ndir*3H], hprev [B,T,ndir*H])"""
+    B, T = out.shape[0], out.shape[1]
+    dgi = torch.empty(B, T, ndir * 3 * H, dtype=torch.float32, device=out.device)
+    dgh = torch.empty_like(dgi)
+    hprev = torch.empty_like(out)
+    lib = _lib.load()
+    _lib.check(lib.ctts_gru_bwd(_p(_f32c(dout, "dout")), _p(out), _p(gates), _p(_f32c(whh, "whh")), _p(dgi), _p(dgh), _p(hprev), B, T, H,
+                                ndir, _stream()), "ctts_gru_bwd")
+    return dgi, dgh, hprev
+
+
+def softmax_rect_fwd(S, klens, qlens):
+    """in-place masked softmax over the last dim of S [nb,Tq,Tk]; klens/qlens int32 [nb] or None"""
+    nb, Tq, Tk = S.shape
+    lib = _lib.load()
+    _lib.check(lib.ctts_softmax_rect_fwd(_p(_f32c(S, "S")), _p(klens), _p(qlens), nb, Tq, Tk, _stream()), "ctts_softmax_rect_fwd")
+    return S
+
+
+def softmax_rect_bwd(P, dP, klens, qlens):
+    nb, Tq, Tk = P.shape
+    lib = _lib.load()
+    _lib.check(lib.ctts_softmax_rect_bwd(_p(P), _p(_f32c(dP, "dP")), _p(klens), _p(qlens), nb, Tq, Tk, _stream()),
+               "ctts_softmax_rect_bwd")
+    return dP

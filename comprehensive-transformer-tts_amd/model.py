@@ -366,8 +366,10 @@ class VarianceAdaptor(nn.Module):
         super().__init__()
         self.learn_alignment = model_config["duration_modeling"]["learn_alignment"]
         self.binarization_start_steps = train_config["duration"]["binarization_start_steps"]
-        if model_config["prosody_modeling"]["model_type"] != "none":
-            raise NotImplementedError("prosody_modeling other than 'none' is not on the round-1 hot path")
+        self.model_type = model_config["prosody_modeling"]["model_type"]
+        if self.model_type not in ("none", "liu2021"):
+            raise NotImplementedError(f"prosody_modeling.model_type '{self.model_type}': only 'none' and 'liu2021' are built "
+                                      "(du2021 is outside SURVEY.md section 8)")
         pitch = preprocess_config["preprocessing"]["pitch"]
         if pitch["pitch_type"] != "cwt" or pitch["pitch_norm"] != "log" or not pitch["use_uv"]:
             raise NotImplementedError("only pitch_type=cwt / pitch_norm=log / use_uv=True (the shipped configs)")
@@ -400,6 +402,33 @@ class VarianceAdaptor(nn.Module):
             n_mel = preprocess_config["preprocessing"]["mel"]["n_mel_channels"]
             self.aligner = AlignmentEncoder(n_mel, n_mel, d_model, model_config["duration_modeling"]["aligner_temperature"],
                                             model_config["multi_speaker"])
+        if self.model_type == "liu2021":          # modules.py:845-861
+            from . import prosody as P
+            cfg = model_config["prosody_modeling"]["liu2021"]
+            self.utterance_prosody_encoder = P.UtteranceLevelProsodyEncoder(preprocess_config, model_config)
+            self.phoneme_prosody_encoder = P.PhonemeLevelProsodyEncoder(preprocess_config, model_config)
+            self.utterance_prosody_predictor = P.ParallelProsodyPredictor(model_config, phoneme_level=False)
+            self.phoneme_prosody_predictor = P.ParallelProsodyPredictor(model_config, phoneme_level=True)
+            self.utterance_prosody_prj = _Linear(cfg["bottleneck_size_u"], hidden)
+            self.phoneme_prosody_prj = _Linear(cfg["bottleneck_size_p"], hidden)
+
+    def _liu2021(self, x, src_len, src_mask, mel, mel_len, mel_mask):
+        """Implicit prosody modelling branch (modules.py:1002-1022): encoders only in training, predictors always."""
+        up_emb = pp_emb = pp_attn = None
+        if self.training:
+            assert mel is not None and mel_mask is not None, "liu2021 prosody encoders need the reference mel in training"
+            mel_nonpad = (~mel_mask).to(torch.float32).reshape(-1).contiguous()
+            src_nonpad = (~src_mask).to(torch.float32).reshape(-1).contiguous()
+            up_emb = self.utterance_prosody_encoder(mel, mel_nonpad)
+            pp_emb, pp_attn = self.phoneme_prosody_encoder(x, src_len.to(torch.int32), src_nonpad, mel, mel_len.to(torch.int32),
+                                                           mel_nonpad)
+        up_vec = self.utterance_prosody_predictor(x)
+        u = up_emb if self.training else up_vec
+        x = x + ops.linear(u, self.utterance_prosody_prj.weight, self.utterance_prosody_prj.bias)      # [N,1,H] broadcast over Ts
+        pp_vec = self.phoneme_prosody_predictor(x)
+        pp = pp_emb if self.training else pp_vec
+        x = ops.linear(pp, self.phoneme_prosody_prj.weight, self.phoneme_prosody_prj.bias, residual=x)
+        return x, (up_emb, pp_emb, up_vec, pp_vec, pp_attn)
 
     def forward(self, speaker_embedding, text, text_embedding, src_len, src_mask, mel, mel_len, mel_mask=None,
                 max_len=None, pitch_target=None, energy_target=None, duration_target=None, attn_prior=None,
@@ -407,6 +436,9 @@ class VarianceAdaptor(nn.Module):
         x = text
         if speaker_embedding is not None:
             x = x + speaker_embedding.unsqueeze(1)
+        prosody_info = None
+        if self.model_type == "liu2021":
+            x, prosody_info = self._liu2021(x, src_len, src_mask, mel, mel_len, mel_mask)
         log_d = self.duration_predictor(ops.grad_scale(x, self.predictor_grad), src_mask)
         x_org = x
         attn_out = (None, None, None, None)
@@ -466,7 +498,7 @@ class VarianceAdaptor(nn.Module):
         e_frames, _, _ = ops.length_regulate(energy_embedding, d_rounded, max_len)
         x = x + pitch_embedding + e_frames
         return (x, pitch_target, pitch_prediction, energy_target, energy_prediction, log_d, d_rounded, mel_len, mel_mask,
-                attn_out, None)
+                attn_out, prosody_info)
 
 
 # --------------------------------------------------------------------------- postnet
@@ -545,8 +577,15 @@ class CompTransTTS(nn.Module):
             from .conformer import reset_conformer_parameters
             reset_conformer_parameters(self.encoder)
             reset_conformer_parameters(self.decoder)
+        prosody_mods = [m for n, m in self.variance_adaptor.named_children() if "prosody" in n and not n.endswith("_prj")]
+        if prosody_mods:
+            from .prosody import reset_prosody_parameters
+            for m in prosody_mods:
+                reset_prosody_parameters(m)
         for name, p in params.items():
             if name.endswith("pos_embed_alpha") or name.endswith("energy_bins"):
+                continue
+            if name.startswith("variance_adaptor.") and "_prosody_" in name and "_prosody_prj." not in name:
                 continue
             if conformer and (name.startswith("encoder.") or name.startswith("decoder.")):
                 continue

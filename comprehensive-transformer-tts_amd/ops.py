@@ -603,3 +603,122 @@ def mas_binarize(attn_soft, in_lens, out_lens):
     with torch.no_grad():
         hard, dur = K.mas(attn_soft[:, 0].contiguous(), in_lens, out_lens)
     return hard.unsqueeze(1), dur
+
+
+# ---- liu2021 prosody modelling -----------------------------------------------------------------------------
+class _Im2Col3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.shape = tuple(x.shape)
+        return K.im2col_3x3s2(x)
+
+    @staticmethod
+    def backward(ctx, dcol):
+        return K.col2im_3x3s2(dcol.contiguous(), *ctx.shape)
+
+
+def conv2d_3x3s2(x, w, b):
+    """nn.Conv2d(kernel 3x3, stride (1,2), padding (1,1)) of ReferenceEncoder (modules.py:351-361) on channel-last x [B,T,W,Cin];
+    w [Cout,Cin,3,3] (reference layout), b [Cout] -> [B,T,Wo,Cout].  Patch matrix (csrc/prosody.hip) + implicit... explicit GEMM on
+    MFMA: forward, dgrad (then col2im) and wgrad all go through ctts_gemm."""
+    B, T, W, Cin = x.shape
+    Cout = w.shape[0]
+    col = _Im2Col3x3s2.apply(x) if x.requires_grad else K.im2col_3x3s2(x.contiguous())
+    wf = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)              # [Cout][kh][kw][Cin]: tiny, autograd un-permutes the gradient
+    y = linear(col, wf, b)
+    return y.view(B, T, (W - 1) // 2 + 1, Cout)
+
+
+class _GRU(torch.autograd.Function):
+    """Recurrent part of a one-layer nn.GRU (batch_first, h0 = 0, ndir 1|2) on csrc/prosody.hip; gi = W_ih x + b_ih comes from
+    `linear` (so W_ih / b_ih / input gradients are ordinary GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, gi, whh, bhh, H, ndir):
+        gi, whh, bhh = gi.contiguous(), whh.contiguous(), bhh.contiguous()
+        need = gi.requires_grad or whh.requires_grad or bhh.requires_grad
+        out, gates = K.gru_fwd(gi, whh, bhh, H, ndir, save_gates=need)
+        ctx.save_for_backward(out, gates, whh)
+        ctx.cfg = (H, ndir)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, gates, whh = ctx.saved_tensors
+        H, ndir = ctx.cfg
+        B, T = out.shape[0], out.shape[1]
+        dgi, dgh, hprev = K.gru_bwd(dout.contiguous(), out, gates, whh, H, ndir)
+        rows = B * T
+        dwhh = torch.zeros_like(whh)
+        for d in range(ndir):              # dW_hh[d] = dgh_d^T h_prev_d : [3H, H], reduction over all B*T steps (split-K on MFMA)
+            K.gemm(dgh, hprev, dwhh, 3 * H, H, rows, ndir * 3 * H, ndir * H, H, False, False, a_off=d * 3 * H, b_off=d * H,
+                   c_off=d * 3 * H * H, split_k=max(2, _split_k_for(3 * H, H, rows)))
+        dbhh = K.colsum(dgh.view(rows, ndir * 3 * H)).view(ndir, 3 * H)
+        return dgi, dwhh, dbhh, None, None
+
+
+def gru(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None, b_hh_r=None):
+    """nn.GRU(batch_first=True[, bidirectional=True]) forward over ALL T steps (the reference never packs padded batches,
+    modules.py:390-391,636-637).  x [B,T,In] -> out [B,T,ndir*H] (forward | backward halves, as torch lays them out)."""
+    H = w_hh.shape[1]
+    if w_ih_r is None:
+        gi = linear(x, w_ih, b_ih)
+        return _GRU.apply(gi, w_hh.unsqueeze(0), b_hh.unsqueeze(0), H, 1)
+    gi = linear(x, torch.cat([w_ih, w_ih_r], 0), torch.cat([b_ih, b_ih_r], 0))      # one GEMM for both directions
+    return _GRU.apply(gi, torch.stack([w_hh, w_hh_r], 0), torch.stack([b_hh, b_hh_r], 0), H, 2)
+
+
+class _BmmNT(torch.autograd.Function):
+    """out[b] = alpha * A[b] @ Bm[b]^T   (A [B,M,K], Bm [B,N,K]) - attention scores of PhonemeLevelProsodyEncoder (modules.py:443)."""
+
+    @staticmethod
+    def forward(ctx, A, Bm, alpha):
+        A, Bm = A.contiguous(), Bm.contiguous()
+        B, M, Kd = A.shape
+        N = Bm.shape[1]
+        out = torch.empty(B, M, N, dtype=torch.float32, device=A.device)
+        K.gemm(A, Bm, out, M, N, Kd, Kd, Kd, N, True, True, nb0=B, nb1=1, sA=(M * Kd, 0), sB=(N * Kd, 0), sC=(M * N, 0), alpha=alpha)
+        ctx.save_for_backward(A, Bm)
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        A, Bm = ctx.saved_tensors
+        dO = dO.contiguous()
+        B, M, Kd = A.shape
+        N = Bm.shape[1]
+        dA = dB = None
+        if ctx.needs_input_grad[0]:        # dA[m,k] = alpha * sum_n dO[m,n] Bm[n,k]
+            dA = torch.empty_like(A)
+            K.gemm(dO, Bm, dA, M, Kd, N, N, Kd, Kd, True, False, nb0=B, nb1=1, sA=(M * N, 0), sB=(N * Kd, 0), sC=(M * Kd, 0),
+                   alpha=ctx.alpha)
+        if ctx.needs_input_grad[1]:        # dB[n,k] = alpha * sum_m dO[m,n] A[m,k]
+            dB = torch.empty_like(Bm)
+            K.gemm(dO, A, dB, N, Kd, M, N, Kd, Kd, False, False, nb0=B, nb1=1, sA=(M * N, 0), sB=(M * Kd, 0), sC=(N * Kd, 0),
+                   alpha=ctx.alpha)
+        return dA, dB, None
+
+
+def bmm_nt(A, Bm, alpha=1.0):
+    return _BmmNT.apply(A, Bm, alpha)
+
+
+class _SoftmaxRect(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, S, klens, qlens):
+        P = K.softmax_rect_fwd(S.contiguous().clone(), klens, qlens)
+        ctx.save_for_backward(P, klens, qlens)
+        return P
+
+    @staticmethod
+    def backward(ctx, dP):
+        P, klens, qlens = ctx.saved_tensors
+        return K.softmax_rect_bwd(P, dP.contiguous().clone(), klens, qlens), None, None
+
+
+def masked_softmax(S, key_lens=None, query_lens=None):
+    """softmax over the last dim of S [nb,Tq,Tk]; keys >= key_lens[b] get probability 0 (masked_fill(-inf) before the softmax),
+    query rows >= query_lens[b] are zero rows (masked_fill(0) after it) - modules.py:444-446.  lens: int32 device tensors."""
+    return _SoftmaxRect.apply(S, key_lens, query_lens)

@@ -74,6 +74,26 @@ def test_conformer_state_dict_schema_matches_reference():
     assert m.encoder.d_model == 256 and m.decoder.d_model == 256
 
 
+@pytest.mark.parametrize("unsup", [False, True])
+def test_liu2021_state_dict_schema_matches_reference(unsup):
+    """prosody_modeling.model_type = liu2021, alone and as config C5 (with learn_alignment=True)."""
+    pre, mc, tc = get_configs()
+    mc["prosody_modeling"]["model_type"] = "liu2021"
+    mc["duration_modeling"]["learn_alignment"] = unsup
+    m = ctts_amd.CompTransTTS(pre, mc, tc)
+    sd, sch = m.state_dict(), schema("LJSpeech", "transformer_fs2", unsup, "liu2021")
+    assert set(sd) == set(sch), (set(sd) ^ set(sch))
+    params = dict(m.named_parameters())
+    for k, (shape, dtype, is_param) in sch.items():
+        assert list(sd[k].shape) == shape, k
+        assert str(sd[k].dtype) == "torch." + dtype, k
+        assert (k in params) == is_param, k
+        assert torch.isfinite(sd[k].float()).all(), k
+    mc["prosody_modeling"]["model_type"] = "du2021"
+    with pytest.raises(NotImplementedError):
+        ctts_amd.CompTransTTS(pre, mc, tc)
+
+
 def test_unsupported_block_types_raise():
     pre, mc, tc = get_configs()
     mc["block_type"] = "reformer"

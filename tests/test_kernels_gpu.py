@@ -394,3 +394,75 @@ def test_relpos_attention_dropout_consistency():
     y.sum().backward()
     tot = kvg.grad[..., C:].sum().item()
     assert abs(tot - y.detach().sum().item()) < 1e-2 * abs(tot)
+
+
+# ---- liu2021 prosody kernels (csrc/prosody.hip) ---------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,W,Cin,Cout", [(2, 13, 80, 4, 32), (3, 7, 5, 64, 128), (1, 9, 3, 128, 128), (2, 6, 40, 32, 32)])
+def test_conv2d_3x3s2_fwd_bwd(B, T, W, Cin, Cout):
+    """Conv2d 3x3 stride (1,2) pad (1,1): patch matrix + ctts_gemm + col2im against F.conv2d (fp64 CPU)."""
+    x = rnd(B, T, W, Cin, seed=1).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.2).requires_grad_(True)
+    b = rnd(Cout, seed=3).requires_grad_(True)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), stride=(1, 2), padding=(1, 1)).permute(0, 2, 3, 1)
+    gy = rnd(*ref.shape, seed=4)
+    ref.backward(gy.double())
+    xd, wd, bd = [t.detach().to(DEV).requires_grad_(True) for t in (x, w, b)]
+    y = ops.conv2d_3x3s2(xd, wd, bd)
+    assert y.shape == ref.shape
+    close(y, ref, 2e-5, "conv2d fwd")
+    y.backward(gy.to(DEV))
+    close(xd.grad, x.grad, 2e-5, "conv2d dx")
+    close(wd.grad, w.grad, 2e-5, "conv2d dw")
+    close(bd.grad, b.grad, 2e-5, "conv2d db")
+
+
+@pytest.mark.parametrize("B,T,In,H,bi", [(3, 37, 256, 32, False), (2, 19, 256, 128, True), (1, 5, 48, 16, True), (4, 130, 64, 64, False)])
+def test_gru_fwd_bwd_vs_torch(B, T, In, H, bi):
+    """ctts_gru_fwd/bwd (+ the input-projection and dW_hh GEMMs) against torch.nn.GRU on the CPU in fp64."""
+    torch.manual_seed(B * 100 + T)
+    ref = torch.nn.GRU(In, H, batch_first=True, bidirectional=bi).double()
+    x = rnd(B, T, In, seed=5).requires_grad_(True)
+    mem, _ = ref(x.double())
+    gy = rnd(*mem.shape, seed=6)
+    mem.backward(gy.double())
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    if bi:
+        names += [n + "_reverse" for n in names]
+    prm = {n: getattr(ref, n).detach().float().to(DEV).requires_grad_(True) for n in names}
+    xd = x.detach().to(DEV).requires_grad_(True)
+    args = [prm["weight_ih_l0"], prm["weight_hh_l0"], prm["bias_ih_l0"], prm["bias_hh_l0"]]
+    if bi:
+        args += [prm["weight_ih_l0_reverse"], prm["weight_hh_l0_reverse"], prm["bias_ih_l0_reverse"], prm["bias_hh_l0_reverse"]]
+    out = ops.gru(xd, *args)
+    close(out, mem, 2e-5, "gru out")
+    out.backward(gy.to(DEV))
+    close(xd.grad, x.grad, 5e-5, "gru dx")
+    for n in names:
+        close(prm[n].grad, getattr(ref, n).grad, 5e-5, "gru d" + n)
+
+
+def test_gru_unsupported_hidden_size_fails_loudly():
+    from ctts_amd._lib import CttsError
+    with pytest.raises(CttsError):
+        K.gru_fwd(torch.zeros(1, 2, 3 * 24, device=DEV), torch.zeros(1, 72, 24, device=DEV), torch.zeros(1, 72, device=DEV), 24, 1)
+
+
+def test_masked_softmax_rect_and_bmm_nt():
+    B, Tq, Tk, C = 3, 11, 70, 32
+    q, k = rnd(B, Tq, C, seed=7).requires_grad_(True), rnd(B, Tk, C, seed=8).requires_grad_(True)
+    klens, qlens = torch.tensor([70, 33, 1]), torch.tensor([11, 4, 7])
+    s = torch.einsum("bqc,bkc->bqk", q.double(), k.double()) * 0.25
+    s = s.masked_fill(torch.arange(Tk)[None, None, :] >= klens[:, None, None], float("-inf"))
+    ref = torch.softmax(s, -1).masked_fill(torch.arange(Tq)[None, :, None] >= qlens[:, None, None], 0.0)
+    gy = rnd(B, Tq, Tk, seed=9)
+    ref.backward(gy.double())
+    qd, kd = [t.detach().to(DEV).requires_grad_(True) for t in (q, k)]
+    P = ops.masked_softmax(ops.bmm_nt(qd, kd, 0.25), klens.to(DEV).int(), qlens.to(DEV).int())
+    close(P, ref, 1e-5, "softmax")
+    assert (P[1, :, 33:] == 0).all() and (P[1, 4:] == 0).all()
+    P.backward(gy.to(DEV))
+    close(qd.grad, q.grad, 2e-5, "dq")
+    close(kd.grad, k.grad, 2e-5, "dk")
+    # no masks (STL token attention)
+    P2 = ops.masked_softmax(torch.randn(1, 5, 32, device=DEV))
+    close(P2.sum(-1), torch.ones(1, 5), 1e-6, "rows sum to 1")
