@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--batch", default="canonical", choices=["canonical", "c1"])
     ap.add_argument("--block", default="transformer_fs2", choices=["transformer_fs2", "conformer"],
                     help="block_type plugin; the headline metric (BASELINE configs[1]) is transformer_fs2, conformer = configs[2]")
+    ap.add_argument("--prosody", default="none", choices=["none", "liu2021"], help="prosody_modeling.model_type (SURVEY a17)")
+    ap.add_argument("--learn-alignment", action="store_true",
+                    help="unsupervised durations: aligner + device MAS + ForwardSum/Bin losses (SURVEY a16); with --prosody liu2021 "
+                         "this is SURVEY config C5")
     return ap.parse_args()
 
 
@@ -223,10 +227,12 @@ def main():
     import ctts_amd
     from ctts_amd.configs import get_configs
     from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
-    from ctts_amd.synthetic import make_batch, to_device, C1_SRC_LENS
+    from ctts_amd.synthetic import make_batch, make_unsup_batch, to_device, C1_SRC_LENS
 
     pre, mc, tc = get_configs()
     mc["block_type"] = a.block
+    mc["prosody_modeling"]["model_type"] = a.prosody
+    mc["duration_modeling"]["learn_alignment"] = a.learn_alignment
     torch.manual_seed(1234)                                   # identical init on every rank (DDP broadcast equivalent)
     model = ctts_amd.CompTransTTS(pre, mc, tc).to(dev)
     model.train()
@@ -234,12 +240,17 @@ def main():
     optim = ScheduledOptim(model, tc, mc, 50000, capturable=True)
     src_lens = None if a.batch == "canonical" else C1_SRC_LENS
     # conformer decoders crop to max_seq_len = 1000 in training (conformer.py:148-154): cap mel length
-    batch_cpu = make_batch(src_lens, seed=1234 + rank, max_mel_cap=1000 if a.block == "conformer" else None)
+    mk = make_unsup_batch if a.learn_alignment else make_batch
+    batch_cpu = mk(src_lens, seed=1234 + rank, max_mel_cap=1000 if a.block == "conformer" else None)
+    if a.learn_alignment:         # host copies of the lengths keep F.ctc_loss free of device->host syncs (graph capture)
+        loss_fn.host_lens = (batch_cpu["src_lens"].tolist(), batch_cpu["mel_lens"].tolist())
     batch = to_device(batch_cpu, dev)
     valid_frames = int(batch_cpu["mel_lens"].sum())
     padded_frames = batch_cpu["mels"].shape[0] * batch_cpu["mels"].shape[1]
 
     step = TrainStep(model, loss_fn, optim, batch, world, not a.no_graph)
+    if a.prosody != "none" or a.learn_alignment:
+        step.step_no = 100001                                 # every loss term on: bin-loss weight 1, prosody loss enabled
     mode = "eager"
     if not a.no_graph:
         try:
@@ -275,7 +286,8 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = total_valid * a.steps / elapsed
     if rank == 0:
-        roof = measure_dominant_kernel(dev, batch_cpu) if (a.batch == "canonical" and a.block == "transformer_fs2") else None
+        headline = a.batch == "canonical" and a.block == "transformer_fs2" and a.prosody == "none" and not a.learn_alignment
+        roof = measure_dominant_kernel(dev, batch_cpu) if headline else None
         # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
         step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
         cpu = None if a.no_cpu_baseline else cpu_baseline()
@@ -284,8 +296,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"LJSpeech {a.block} batch={len(batch_cpu['src_lens'])}/GPU, seq<=128 -> mel<={batch_cpu['mels'].shape[1]}x80, "
-                                    f"supervised durations (BASELINE configs[{1 if a.block == 'transformer_fs2' else 2}]); full train step "
-                                    "fwd+loss+bwd+clip+Adam, dropout on"),
+                                    + (f"supervised durations (BASELINE configs[{1 if a.block == 'transformer_fs2' else 2}])"
+                                       if not (a.learn_alignment or a.prosody != "none") else
+                                       f"learn_alignment={a.learn_alignment} prosody={a.prosody} (BASELINE configs[4] / SURVEY C5 family)")
+                                    + "; full train step fwd+loss+bwd+clip+Adam, dropout on"),
                        "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
                        "parallelism": f"dp{world}", "final_loss": loss_final},
             "roofline": roof, "step_model_tflops_per_gpu": step_tflops,

@@ -81,6 +81,92 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ attn
   }
 }
 
+// Fast path: back-pointers as BIT masks in LDS (one ballot per wave and row), attention rows prefetched one 8-row chunk ahead, the
+// back-track walks LDS (not HBM) and the hard alignment / durations are written by all threads from the recorded path.
+// Same arithmetic and tie rules as mas_kernel above.  NJ = columns per thread (Tk <= 256 * NJ).
+constexpr int MAS_CH = 8;
+template <int NJ>
+__global__ __launch_bounds__(256) void mas_lds_kernel(const float* __restrict__ attn, const int* __restrict__ in_lens,
+                                                       const int* __restrict__ out_lens, float* __restrict__ opt,
+                                                       float* __restrict__ dur, int Tq, int Tk) {
+  extern __shared__ __attribute__((aligned(8))) unsigned char mas_smem[];
+  const int W64 = (Tk + 63) / 64;
+  unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(mas_smem);              // [Tq][W64]
+  float* s_row = reinterpret_cast<float*>(s_bits + (size_t)Tq * W64);                         // [2][Tk]
+  int* s_dur = reinterpret_cast<int*>(s_row + 2 * Tk);                                        // [Tk]
+  short* s_path = reinterpret_cast<short*>(s_dur + Tk);                                       // [Tq]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T1 = min(out_lens[b], Tq), T2 = min(in_lens[b], Tk);
+  const float* A = attn + (long)b * Tq * Tk;
+  float* O = opt + (long)b * Tq * Tk;
+  for (int j = tid; j < Tk; j += 256) s_dur[j] = 0;
+  if (T1 <= 0 || T2 <= 0) {
+    for (long e = tid; e < (long)Tq * Tk; e += 256) O[e] = 0.f;
+    for (int j = tid; j < Tk; j += 256) dur[(long)b * Tk + j] = 0.f;
+    return;
+  }
+  for (int j = tid; j < T2; j += 256) s_row[j] = j == 0 ? (float)log((double)A[0]) : -INFINITY;
+  float nx[MAS_CH][NJ];
+  auto load_chunk = [&](int i0) {
+#pragma unroll
+    for (int r = 0; r < MAS_CH; ++r)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int i = i0 + r, j = tid + 256 * jj;
+        nx[r][jj] = (i < T1 && j < T2) ? A[(long)i * Tk + j] : 1.f;
+      }
+  };
+  load_chunk(1);
+  __syncthreads();
+  for (int i0 = 1; i0 < T1; i0 += MAS_CH) {
+    float la[MAS_CH][NJ];
+#pragma unroll
+    for (int r = 0; r < MAS_CH; ++r)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) la[r][jj] = (float)log((double)nx[r][jj]);
+    if (i0 + MAS_CH < T1) load_chunk(i0 + MAS_CH);              // in flight while this chunk's 8 DP rows run
+#pragma unroll
+    for (int r = 0; r < MAS_CH; ++r) {
+      const int i = i0 + r;
+      if (i >= T1) break;
+      const float* prev = s_row + ((i - 1) & 1) * Tk;
+      float* cur = s_row + (i & 1) * Tk;
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int j = tid + 256 * jj;
+        bool from_left = false;
+        if (j < T2) {
+          float pl = prev[j];
+          if (j >= 1 && prev[j - 1] >= pl) { pl = prev[j - 1]; from_left = true; }
+          cur[j] = la[r][jj] + pl;
+        }
+        const unsigned long long m = __ballot(from_left);
+        const int word = wave + 4 * jj;
+        if (lane == 0 && word < W64) s_bits[(size_t)i * W64 + word] = m;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    int curj = T2 - 1;
+    for (int i = T1 - 1; i >= 0; --i) {
+      s_path[i] = (short)curj;
+      if (i > 0 && ((s_bits[(size_t)i * W64 + (curj >> 6)] >> (curj & 63)) & 1ULL)) curj -= 1;
+    }
+  }
+  __syncthreads();
+  // hard alignment: one at (i, path[i]) for i < T1, plus the reference's extra opt[0, 0] = 1 (prev_ind[0, :] = 0)
+  for (long e = tid; e < (long)Tq * Tk; e += 256) {
+    const int i = (int)(e / Tk), j = (int)(e - (long)i * Tk);
+    O[e] = (i < T1 && (j == s_path[i] || (i == 0 && j == 0))) ? 1.f : 0.f;
+  }
+  for (int i = tid; i < T1; i += 256) atomicAdd(&s_dur[s_path[i]], 1);
+  __syncthreads();
+  if (tid == 0 && s_path[0] != 0) s_dur[0] += 1;
+  __syncthreads();
+  for (int j = tid; j < Tk; j += 256) dur[(long)b * Tk + j] = (float)s_dur[j];
+}
+
 }  // namespace
 
 extern "C" int ctts_neg_sqdist(const float* q, const float* k, float* out, int B, int Tq, int Tk, int C, float temp, void* stream) {
@@ -98,8 +184,16 @@ extern "C" int ctts_mas(const float* attn, const int32_t* in_lens, const int32_t
   CTTS_REQUIRE(attn && in_lens && out_lens && opt && dur && back, "ctts_mas: null pointer");
   CTTS_REQUIRE((size_t)2 * Tk * 4 <= 64 * 1024, "ctts_mas: Tk=%d too large for the LDS row buffers", Tk);
   if (B == 0) return 0;
-  hipLaunchKernelGGL(mas_kernel, dim3(B), dim3(256), (size_t)2 * Tk * sizeof(float), (hipStream_t)stream, attn, in_lens, out_lens, opt,
-                     dur, back, Tq, Tk);
+  const size_t lds = (size_t)Tq * ((Tk + 63) / 64) * 8 + (size_t)2 * Tk * 4 + (size_t)Tk * 4 + (size_t)Tq * 2;
+  if (lds <= 60 * 1024 && Tk <= 512 && Tk < 32768) {       // back-pointer bits fit in LDS: fast path
+    if (Tk <= 256)
+      hipLaunchKernelGGL((mas_lds_kernel<1>), dim3(B), dim3(256), lds, (hipStream_t)stream, attn, in_lens, out_lens, opt, dur, Tq, Tk);
+    else
+      hipLaunchKernelGGL((mas_lds_kernel<2>), dim3(B), dim3(256), lds, (hipStream_t)stream, attn, in_lens, out_lens, opt, dur, Tq, Tk);
+  } else {
+    hipLaunchKernelGGL(mas_kernel, dim3(B), dim3(256), (size_t)2 * Tk * sizeof(float), (hipStream_t)stream, attn, in_lens, out_lens,
+                       opt, dur, back, Tq, Tk);
+  }
   CTTS_CHECK_LAUNCH("ctts_mas");
   return 0;
 }

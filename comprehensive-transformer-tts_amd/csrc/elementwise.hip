@@ -61,20 +61,24 @@ __global__ void rowscale_dropout_kernel(const float* __restrict__ x, float* __re
   }
 }
 
+// C = row width of the (possibly folded) view; a dense narrow matrix [R, creal] (creal < 64) is read as [R/k, k*creal] so that all
+// 64 lanes carry data; view column c accumulates into channel c % creal.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C,
-                                                      long ld, float scale) {
+                                                      int creal, long ld, float scale) {
   __shared__ float s[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
   const long stripe = (rows + gridDim.y - 1) / gridDim.y;
   const long r0 = blockIdx.y * stripe, r1 = min(rows, r0 + stripe);
   float a = 0.f;
-  if (c < C)
+  if (c < C) {
+#pragma unroll 4
     for (long r = r0 + ty; r < r1; r += 4) a += x[r * ld + c];
+  }
   s[ty][threadIdx.x & 63] = a;
   __syncthreads();
   if (ty == 0 && c < C) {
     const int l = threadIdx.x;
-    atomicAdd(out + c, scale * (s[0][l] + s[1][l] + s[2][l] + s[3][l]));
+    atomicAdd(out + (c % creal), scale * (s[0][l] + s[1][l] + s[2][l] + s[3][l]));
   }
 }
 
@@ -178,8 +182,13 @@ extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int6
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { ctts_set_error("ctts_colsum: memset failed"); return -2; }
   if (rows == 0) return 0;
-  const int gy = (int)max((long)1, min((long)64, (long)rows / 64));
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, gy), dim3(256), 0, st, x, out, (long)rows, C, (long)ld, scale);
+  int k = 1;                                   // fold narrow dense matrices so that a wave reads 64 useful floats per row
+  if (ld == C)
+    while (C * k * 2 <= 64 && rows % (k * 2) == 0) k *= 2;
+  const int Cv = C * k, gx = (Cv + 63) / 64;
+  const long Rv = rows / k;
+  const int gy = (int)max((long)1, min((long)max(1, 1024 / gx), Rv / 64));
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, out, Rv, Cv, C, (long)ld * k, scale);
   CTTS_CHECK_LAUNCH("ctts_colsum");
   return 0;
 }

@@ -146,10 +146,13 @@ template <int MODE>  // 0: sum x, sum x^2   1: BN-bwd sums (dt, dt*xhat)
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         double* __restrict__ sums, int rows, int C, int act, float p_drop,
-                                                         const uint64_t* seed, uint32_t drop_offset) {
+                                                         double* __restrict__ sums, int rows, int C, int creal, int act,
+                                                         float p_drop, const uint64_t* seed, uint32_t drop_offset) {
+  // C is the row width of the (possibly folded) view: a narrow matrix [R, creal] with creal < 64 is read as [R/k, k*creal] so that
+  // all 64 lanes of a wave carry data; column c of the view is channel c % creal.
   __shared__ float s1[4][64], s2[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+  const int ch = c % creal;
   const int stripe = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * stripe, r1 = min(rows, r0 + stripe);
   float a = 0.f, b = 0.f;
@@ -157,8 +160,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     float mu = 0.f, rs = 1.f, g = 1.f, be = 0.f, inv_keep = 1.f;
     uint32_t dkey = 0;
     const bool do_drop = (MODE == 1) && p_drop > 0.f;
-    if (MODE == 1) { mu = mean[c]; rs = rstd[c]; g = gamma[c]; be = beta[c]; }
+    if (MODE == 1) { mu = mean[ch]; rs = rstd[ch]; g = gamma[ch]; be = beta[ch]; }
     if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+#pragma unroll 4
     for (int r = r0 + ty; r < r1; r += 4) {
       const float xv = x[(long)r * C + c];
       if (MODE == 0) { a += xv; b += xv * xv; }
@@ -177,8 +181,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     const int l = threadIdx.x;
     const double A = (double)s1[0][l] + s1[1][l] + s1[2][l] + s1[3][l];
     const double Bv = (double)s2[0][l] + s2[1][l] + s2[2][l] + s2[3][l];
-    atomicAdd(sums + c, A);
-    atomicAdd(sums + C + c, Bv);
+    atomicAdd(sums + ch, A);
+    atomicAdd(sums + creal + ch, Bv);
   }
 }
 
@@ -302,14 +306,21 @@ extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* 
   return 0;
 }
 
-static int colreduce_grid_y(int rows) { return max(1, min(64, rows / 64)); }
+// fold factor for narrow matrices and a grid of ~1024 workgroups (HBM-bound reduction: keep every CU streaming)
+static int colreduce_fold(int rows, int C) {
+  int k = 1;
+  while (C * k * 2 <= 64 && rows % (k * 2) == 0) k *= 2;
+  return k;
+}
+static int colreduce_grid_y(int rows, int gx) { return max(1, min(max(1, 1024 / gx), rows / 64)); }
 
 extern "C" int ctts_colstats(const float* x, double* sums, int rows, int C, void* stream) {
   CTTS_REQUIRE(x && sums && rows > 0 && C > 0, "ctts_colstats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { ctts_set_error("ctts_colstats: memset failed"); return -2; }
-  hipLaunchKernelGGL((colreduce_kernel<0>), dim3((C + 63) / 64, colreduce_grid_y(rows)), dim3(256), 0, st, x, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, sums, rows, C, 0, 0.f, nullptr, 0u);
+  const int k = colreduce_fold(rows, C), Cv = C * k, Rv = rows / k, gx = (Cv + 63) / 64;
+  hipLaunchKernelGGL((colreduce_kernel<0>), dim3(gx, colreduce_grid_y(Rv, gx)), dim3(256), 0, st, x, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, sums, Rv, Cv, C, 0, 0.f, nullptr, 0u);
   CTTS_CHECK_LAUNCH("ctts_colstats");
   return 0;
 }
@@ -333,8 +344,9 @@ extern "C" int ctts_bn_bwd_reduce(const float* dy, const float* x, const float* 
   CTTS_REQUIRE(dy && x && mean && rstd && gamma && beta && sums && rows > 0, "ctts_bn_bwd_reduce: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { ctts_set_error("ctts_bn_bwd_reduce: memset failed"); return -2; }
-  hipLaunchKernelGGL((colreduce_kernel<1>), dim3((C + 63) / 64, colreduce_grid_y(rows)), dim3(256), 0, st, x, dy, mean, rstd,
-                     gamma, beta, sums, rows, C, act, p_drop, seed, drop_offset);
+  const int k = colreduce_fold(rows, C), Cv = C * k, Rv = rows / k, gx = (Cv + 63) / 64;
+  hipLaunchKernelGGL((colreduce_kernel<1>), dim3(gx, colreduce_grid_y(Rv, gx)), dim3(256), 0, st, x, dy, mean, rstd,
+                     gamma, beta, sums, Rv, Cv, C, act, p_drop, seed, drop_offset);
   CTTS_CHECK_LAUNCH("ctts_bn_bwd_reduce");
   return 0;
 }

@@ -6,8 +6,8 @@
 //      it) - deterministic, no atomics.  Both are pure streaming kernels (HBM bound).
 //  * ctts_gru_fwd / ctts_gru_bwd : the sequential part of nn.GRU (modules.py:359-361,391 and :618-621,637).  The input projection
 //      W_ih x + b_ih of ALL time steps is one GEMM done by the caller; here one workgroup per (utterance, direction) walks the T steps
-//      with its W_hh slice held in REGISTERS (thread g owns row g: H floats), h_{t-1} broadcast from LDS, two barriers per step, next
-//      step's operands prefetched.  Backward is BPTT with the same structure (thread (p,j) owns W_hh[pH..pH+H-1][j]); it emits
+//      with its W_hh slice held in REGISTERS (thread g owns row g: H floats), h_{t-1} broadcast from LDS, two barriers per step; the
+//      per-step operands are prefetched in chunks of 8 steps (registers -> double-buffered LDS) so that no step waits on HBM latency.  Backward is BPTT with the same structure (thread (p,j) owns W_hh[pH..pH+H-1][j]); it emits
 //      dgi (-> W_ih / input gradients by GEMM), dgh and h_{t-1} (-> dW_hh = dgh^T h_prev by one split-K GEMM, db_hh by a column sum).
 //  * ctts_softmax_rect_fwd / _bwd : masked row softmax of a rectangular score matrix [nb,Tq,Tk] (PhonemeLevelProsodyEncoder
 //      attention, modules.py:443-446: keys >= klens masked to -inf, query rows >= qlens zeroed; also the 32-token STL softmax).
@@ -63,6 +63,8 @@ __global__ void col2im_3x3s2_kernel(const float4* __restrict__ dcol, float4* __r
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+constexpr int GRU_CH = 8;   // time steps per prefetch chunk: global loads are issued >= 8 steps (~2 us) before their first use
+
 // gi [B,T,ndir,3H], whh [ndir,3H,H], bhh [ndir,3H], out [B,T,ndir,H], gates [B,T,ndir,4H] (r|z|n|W_hn h + b_hn) or NULL
 template <int H>
 __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
@@ -70,10 +72,12 @@ __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_fwd_kernel(const f
                                                                          float* __restrict__ gates, int T, int ndir) {
   __shared__ float s_h[H];
   __shared__ float s_gh[3 * H];
+  __shared__ float s_gi[2][GRU_CH][3 * H];       // double-buffered chunk of input projections
   const int b = blockIdx.x, dir = blockIdx.y, g = threadIdx.x;
+  const bool act = g < 3 * H;
   float w[H];
   float bias = 0.f;
-  if (g < 3 * H) {
+  if (act) {
     const float* wr = whh + ((long)dir * 3 * H + g) * H;
 #pragma unroll
     for (int k = 0; k < H; ++k) w[k] = wr[k];
@@ -82,42 +86,55 @@ __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_fwd_kernel(const f
   if (g < H) s_h[g] = 0.f;
   const long gs = (long)ndir * 3 * H;
   const float* gib = gi + (long)b * T * gs + (long)dir * 3 * H;
-  float gr = 0.f, gz = 0.f, gn = 0.f;
-  if (g < H && T > 0) {
-    const float* p = gib + (long)(dir ? T - 1 : 0) * gs;
-    gr = p[g]; gz = p[H + g]; gn = p[2 * H + g];
+  float nx[GRU_CH];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i) {
+      const int s = c0 + i;
+      nx[i] = (act && s < T) ? gib[(long)(dir ? T - 1 - s : s) * gs + g] : 0.f;
+    }
+  };
+  load_chunk(0);
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i) s_gi[0][i][g] = nx[i];
   }
   __syncthreads();
-  for (int s = 0; s < T; ++s) {
-    const int t = dir ? T - 1 - s : s;
-    float ngr = 0.f, ngz = 0.f, ngn = 0.f;
-    if (g < H && s + 1 < T) {                       // prefetch the next step's input projection
-      const float* p = gib + (long)(dir ? t - 1 : t + 1) * gs;
-      ngr = p[g]; ngz = p[H + g]; ngn = p[2 * H + g];
-    }
-    if (g < 3 * H) {
-      float acc = bias;
+  for (int c0 = 0; c0 < T; c0 += GRU_CH) {
+    const int buf = (c0 / GRU_CH) & 1;
+    if (c0 + GRU_CH < T) load_chunk(c0 + GRU_CH);
 #pragma unroll
-      for (int k = 0; k < H; ++k) acc = fmaf(w[k], s_h[k], acc);
-      s_gh[g] = acc;
-    }
-    __syncthreads();
-    if (g < H) {
-      const float r = sigmoidf_(gr + s_gh[g]);
-      const float z = sigmoidf_(gz + s_gh[H + g]);
-      const float ghn = s_gh[2 * H + g];
-      const float n = tanhf(gn + r * ghn);
-      const float h = (1.0f - z) * n + z * s_h[g];
-      const long o = ((long)b * T + t) * ndir + dir;
-      out[o * H + g] = h;
-      if (gates) {
-        float* gp = gates + o * 4 * H;
-        gp[g] = r; gp[H + g] = z; gp[2 * H + g] = n; gp[3 * H + g] = ghn;
+    for (int i = 0; i < GRU_CH; ++i) {
+      const int s = c0 + i;
+      if (s >= T) break;
+      const int t = dir ? T - 1 - s : s;
+      if (act) {
+        float acc = bias;
+#pragma unroll
+        for (int k = 0; k < H; ++k) acc = fmaf(w[k], s_h[k], acc);
+        s_gh[g] = acc;
       }
-      s_h[g] = h;
+      __syncthreads();
+      if (g < H) {
+        const float r = sigmoidf_(s_gi[buf][i][g] + s_gh[g]);
+        const float z = sigmoidf_(s_gi[buf][i][H + g] + s_gh[H + g]);
+        const float ghn = s_gh[2 * H + g];
+        const float n = tanhf(s_gi[buf][i][2 * H + g] + r * ghn);
+        const float h = (1.0f - z) * n + z * s_h[g];
+        const long o = ((long)b * T + t) * ndir + dir;
+        out[o * H + g] = h;
+        if (gates) {
+          float* gp = gates + o * 4 * H;
+          gp[g] = r; gp[H + g] = z; gp[2 * H + g] = n; gp[3 * H + g] = ghn;
+        }
+        s_h[g] = h;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    gr = ngr; gz = ngz; gn = ngn;
+    if (act && c0 + GRU_CH < T) {                 // the other buffer was last read one chunk ago: every thread has passed barriers since
+#pragma unroll
+      for (int i = 0; i < GRU_CH; ++i) s_gi[buf ^ 1][i][g] = nx[i];
+    }
   }
 }
 
@@ -129,60 +146,84 @@ __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_bwd_kernel(const f
                                                                          float* __restrict__ hprev, int T, int ndir) {
   __shared__ float s_dgh[3 * H];
   __shared__ float s_part[3 * H];
+  __shared__ float s_in[2][GRU_CH][6 * H];       // per step: r|z|n|ghn (4H) | dout (H) | h_{prev} (H)
   const int b = blockIdx.x, dir = blockIdx.y, id = threadIdx.x;
+  const bool act = id < 3 * H;
   const int p = id / H, j = id - p * H;
   float wc[H];
-  if (id < 3 * H) {
+  if (act) {
 #pragma unroll
     for (int k = 0; k < H; ++k) wc[k] = whh[((long)dir * 3 * H + p * H + k) * H + j];
   }
-  float dh = 0.f;
-  // operands of the current step (threads id < H)
-  float r = 0.f, z = 0.f, n = 0.f, ghn = 0.f, d_o = 0.f, hp = 0.f;
-  auto fetch = [&](int s, float& r_, float& z_, float& n_, float& ghn_, float& do_, float& hp_) {
-    const int t = dir ? T - 1 - s : s;
-    const long o = ((long)b * T + t) * ndir + dir;
-    const float* gp = gates + o * 4 * H;
-    r_ = gp[id]; z_ = gp[H + id]; n_ = gp[2 * H + id]; ghn_ = gp[3 * H + id];
-    do_ = dout[o * H + id];
-    hp_ = 0.f;
-    if (s > 0) {
-      const int tp = dir ? t + 1 : t - 1;
-      hp_ = out[(((long)b * T + tp) * ndir + dir) * H + id];
+  float nx[GRU_CH][2];
+  auto load_chunk = [&](int c0) {                // chunk element i is processing step s = T-1-(c0+i)
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i) {
+      const int s = T - 1 - (c0 + i);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int v = id + q * 3 * H;
+        float val = 0.f;
+        if (act && s >= 0) {
+          const int t = dir ? T - 1 - s : s;
+          const long o = ((long)b * T + t) * ndir + dir;
+          if (v < 4 * H) val = gates[o * 4 * H + v];
+          else if (v < 5 * H) val = dout[o * H + (v - 4 * H)];
+          else if (s > 0) val = out[(((long)b * T + (dir ? t + 1 : t - 1)) * ndir + dir) * H + (v - 5 * H)];
+        }
+        nx[i][q] = val;
+      }
     }
   };
-  if (id < H && T > 0) fetch(T - 1, r, z, n, ghn, d_o, hp);
-  for (int s = T - 1; s >= 0; --s) {
-    const int t = dir ? T - 1 - s : s;
-    float nr = 0.f, nz = 0.f, nn = 0.f, nghn = 0.f, ndo = 0.f, nhp = 0.f;
-    if (id < H && s > 0) fetch(s - 1, nr, nz, nn, nghn, ndo, nhp);
-    float dcarry = 0.f;
-    if (id < H) {
-      const float d = dh + d_o;
-      const float dn = d * (1.0f - z);
-      const float dz = d * (hp - n);
-      dcarry = d * z;
-      const float dnp = dn * (1.0f - n * n);
-      const float dzp = dz * z * (1.0f - z);
-      const float drp = dnp * ghn * r * (1.0f - r);
-      const long o = ((long)b * T + t) * ndir + dir;
-      float* a = dgi + o * 3 * H;
-      a[id] = drp; a[H + id] = dzp; a[2 * H + id] = dnp;
-      float* c = dgh + o * 3 * H;
-      c[id] = drp; c[H + id] = dzp; c[2 * H + id] = dnp * r;
-      s_dgh[id] = drp; s_dgh[H + id] = dzp; s_dgh[2 * H + id] = dnp * r;
-      hprev[o * H + id] = hp;
-    }
-    __syncthreads();
-    if (id < 3 * H) {
-      float acc = 0.f;
+  load_chunk(0);
+  if (act) {
 #pragma unroll
-      for (int k = 0; k < H; ++k) acc = fmaf(wc[k], s_dgh[p * H + k], acc);
-      s_part[id] = acc;
+    for (int i = 0; i < GRU_CH; ++i) { s_in[0][i][id] = nx[i][0]; s_in[0][i][id + 3 * H] = nx[i][1]; }
+  }
+  __syncthreads();
+  float dh = 0.f;
+  for (int c0 = 0; c0 < T; c0 += GRU_CH) {
+    const int buf = (c0 / GRU_CH) & 1;
+    if (c0 + GRU_CH < T) load_chunk(c0 + GRU_CH);
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i) {
+      const int s = T - 1 - (c0 + i);
+      if (s < 0) break;
+      const int t = dir ? T - 1 - s : s;
+      float dcarry = 0.f;
+      if (id < H) {
+        const float* in = s_in[buf][i];
+        const float r = in[id], z = in[H + id], n = in[2 * H + id], ghn = in[3 * H + id], hp = in[5 * H + id];
+        const float d = dh + in[4 * H + id];
+        const float dn = d * (1.0f - z);
+        const float dz = d * (hp - n);
+        dcarry = d * z;
+        const float dnp = dn * (1.0f - n * n);
+        const float dzp = dz * z * (1.0f - z);
+        const float drp = dnp * ghn * r * (1.0f - r);
+        const long o = ((long)b * T + t) * ndir + dir;
+        float* a = dgi + o * 3 * H;
+        a[id] = drp; a[H + id] = dzp; a[2 * H + id] = dnp;
+        float* c = dgh + o * 3 * H;
+        c[id] = drp; c[H + id] = dzp; c[2 * H + id] = dnp * r;
+        s_dgh[id] = drp; s_dgh[H + id] = dzp; s_dgh[2 * H + id] = dnp * r;
+        hprev[o * H + id] = hp;
+      }
+      __syncthreads();
+      if (act) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < H; ++k) acc = fmaf(wc[k], s_dgh[p * H + k], acc);
+        s_part[id] = acc;
+      }
+      __syncthreads();
+      if (id < H) dh = dcarry + s_part[id] + s_part[H + id] + s_part[2 * H + id];
     }
-    __syncthreads();
-    if (id < H) dh = dcarry + s_part[id] + s_part[H + id] + s_part[2 * H + id];
-    r = nr; z = nz; n = nn; ghn = nghn; d_o = ndo; hp = nhp;
+    if (act && c0 + GRU_CH < T) {
+#pragma unroll
+      for (int i = 0; i < GRU_CH; ++i) { s_in[buf ^ 1][i][id] = nx[i][0]; s_in[buf ^ 1][i][id + 3 * H] = nx[i][1]; }
+    }
+    __syncthreads();                             // the next chunk's first phase reads s_in right away
   }
 }
 

@@ -78,16 +78,19 @@ class CompTransTTSLoss(nn.Module):
         return losses
 
     @staticmethod
-    def forward_sum_loss(attn_logprob, in_lens, out_lens, blank_logprob=-1.0):
+    def forward_sum_loss(attn_logprob, in_lens, out_lens, blank_logprob=-1.0, host_lens=None):
         """ForwardSumLoss (loss.py:350-377) as ONE batched CTC call instead of a per-sample Python loop: classes beyond
-        key_len are excluded from each sample's log-softmax (the reference slices them away) by masking them to -inf."""
+        key_len are excluded from each sample's log-softmax (the reference slices them away) by masking them to -inf.
+        `host_lens=(in_list, out_list)`: the same lengths as Python ints - F.ctc_loss otherwise copies the device tensors
+        to the host (a sync that a hipGraph capture cannot contain)."""
         B, _, Tm, Ts = attn_logprob.shape
         logits = F.pad(attn_logprob[:, 0], (1, 0), value=blank_logprob)                     # [B,Tm,Ts+1], class 0 = blank
         cls = torch.arange(Ts + 1, device=logits.device)[None, None, :]
         logits = logits.masked_fill(cls > in_lens[:, None, None], float("-inf"))
         logp = torch.log_softmax(logits, dim=-1).transpose(0, 1)                             # [Tm,B,Ts+1]
         targets = torch.arange(1, Ts + 1, device=logits.device)[None, :].expand(B, -1)
-        per = F.ctc_loss(logp, targets, out_lens, in_lens, blank=0, reduction="none", zero_infinity=True)
+        ctc_in, ctc_tgt = (list(host_lens[1]), list(host_lens[0])) if host_lens is not None else (out_lens, in_lens)
+        per = F.ctc_loss(logp, targets, ctc_in, ctc_tgt, blank=0, reduction="none", zero_infinity=True)
         return (per / in_lens.clamp(min=1).to(per.dtype)).sum() / B          # nn.CTCLoss 'mean' per sample, then / batch
 
     @staticmethod
@@ -108,7 +111,7 @@ class CompTransTTSLoss(nn.Module):
         if self.learn_alignment:
             attn_soft, attn_hard, attn_hard_dur, attn_logprob = attn_outs
             duration_targets = attn_hard_dur
-            ctc_loss = self.forward_sum_loss(attn_logprob, src_lens, mel_lens)
+            ctc_loss = self.forward_sum_loss(attn_logprob, src_lens, mel_lens, host_lens=getattr(self, "host_lens", None))
             if step < self.binarization_loss_enable_steps:
                 w = 0.0
             else:

@@ -28,7 +28,7 @@ def set_grad_accumulation_fusion(flag):
 
 
 def _fusable(p):
-    return (_FUSE_GRAD_ACCUM and p is not None and p.requires_grad and p.grad is not None and p.grad.is_contiguous()
+    return (_FUSE_GRAD_ACCUM and p is not None and p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_contiguous()
             and p.grad.dtype == torch.float32)
 
 

@@ -237,6 +237,7 @@ def reset_prosody_parameters(module):
     """torch default initialisers of the reference layers: nn.Linear / nn.Conv2d / nn.Conv1d kaiming_uniform(a=sqrt 5) + fan-in bias,
     nn.GRU U(-1/sqrt(H), 1/sqrt(H)), LinearNorm xavier_uniform, STL.embed N(0, 0.5) (modules.py:464)."""
     for name, p in module.named_parameters():
+        name = "." + name
         if name.endswith("stl.embed"):
             nn.init.normal_(p, mean=0, std=0.5)
         elif ".gru." in name:
@@ -249,6 +250,6 @@ def reset_prosody_parameters(module):
         elif name.endswith("weight") and p.dim() >= 2:
             nn.init.kaiming_uniform_(p, a=math.sqrt(5))
         elif name.endswith("bias"):
-            w = dict(module.named_parameters())[name[:-4] + "weight"]
+            w = dict(module.named_parameters())[name[1:-4] + "weight"]
             fan_in = w[0].numel()
             nn.init.uniform_(p, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))

@@ -73,8 +73,25 @@ def to_device(batch, device):
     return out
 
 
+def make_unsup_batch(src_lens=None, frames_per_phone=8, seed=1234, **kw):
+    """learn_alignment=True inputs: no duration targets, frame-level energy targets [B,Tm] and a positive
+    attention prior [B,Ts,Tm] (a smooth diagonal band standing in for the beta-binomial prior of preprocessor.py:551-560)."""
+    b = make_batch(src_lens, frames_per_phone, seed=seed, **kw)
+    g = torch.Generator().manual_seed(seed + 1)
+    B, Ts, Tm = b["texts"].shape[0], b["texts"].shape[1], b["mels"].shape[1]
+    P, M = b["src_lens"].float()[:, None, None], b["mel_lens"].float()[:, None, None]
+    s_ = torch.arange(Ts)[None, :, None] / P
+    t_ = torch.arange(Tm)[None, None, :] / M
+    prior = torch.exp(-((t_ - s_) ** 2) / 0.02) + 0.05 * torch.rand(B, Ts, Tm, generator=g)
+    valid = (torch.arange(Ts)[None, :, None] < P) & (torch.arange(Tm)[None, None, :] < M)
+    b["attn_priors"] = prior * valid
+    b["d_targets"] = None
+    b["e_targets"] = torch.randn(B, Tm, generator=g) * (torch.arange(Tm)[None, :] < b["mel_lens"][:, None])
+    return b
+
+
 def as_model_args(batch):
     """Positional args in the order of CompTransTTS.forward (model/CompTransTTS.py:64-82)."""
     return (batch["speakers"], batch["texts"], batch["src_lens"], batch["max_src_len"], batch["mels"],
             batch["mel_lens"], batch["max_mel_len"], batch["p_targets"], batch["e_targets"], batch["d_targets"],
-            None, batch["spker_embeds"])
+            batch.get("attn_priors"), batch["spker_embeds"])

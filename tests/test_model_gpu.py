@@ -336,6 +336,21 @@ def test_mas_kernel_vs_oracle_random():
     assert torch.equal(dur.sum(1).cpu(), out_lens.float())      # every valid frame is assigned to exactly one phoneme
 
 
+@pytest.mark.parametrize("Tm,Ts", [(1024, 128), (700, 300), (2100, 300)])
+def test_mas_kernel_paths_large(Tm, Ts):
+    """LDS-bitmask fast path with 1 and 2 columns per thread, and the global-memory fallback (Tq * Tk bits beyond 60 KB of LDS)."""
+    from ctts_amd import ops
+    g = torch.Generator().manual_seed(Tm + Ts)
+    B = 2
+    attn = torch.softmax(torch.randn(B, 1, Tm, Ts, generator=g) * 2, -1)
+    in_lens = torch.tensor([Ts, Ts - 37])
+    out_lens = torch.tensor([Tm, Tm - 211])
+    hard, dur = ops.mas_binarize(attn.to(DEV), in_lens.to(DEV), out_lens.to(DEV))
+    ref = R.binarize_attention(attn, in_lens, out_lens)
+    assert np.array_equal(hard.cpu().numpy(), ref.numpy())
+    assert np.array_equal(dur.cpu().numpy(), ref.sum(2)[:, 0].numpy())
+
+
 PROS_NAMES = ("up_emb", "pp_emb", "up_vec", "pp_vec", "pp_attn")
 
 
