@@ -69,6 +69,8 @@ _SIGNATURES = {
     "ctts_relshift_bwd": [_vp, _vp, C.c_int, C.c_int, _vp],
     "ctts_neg_sqdist": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _vp],
     "ctts_mas": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_forward_sum_fwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_forward_sum_bwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_im2col_3x3s2": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_col2im_3x3s2": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_gru_fwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],

@@ -167,6 +167,180 @@ __global__ __launch_bounds__(256) void mas_lds_kernel(const float* __restrict__ 
   for (int j = tid; j < Tk; j += 256) dur[(long)b * Tk + j] = (float)s_dur[j];
 }
 
+// ---------------------------------------------------------------- ForwardSumLoss (model/loss.py:350-377) on the device
+// Per utterance: CTC negative log-likelihood of the target 1..K (every text token once, in order) under
+// lp[t, c] = log_softmax_c([blank_logprob, a[t, 0..K-1]]) for the T valid frames.  Extended label sequence l' = [0,1,0,2,...,K,0],
+// S = 2K+1 states; all labels are distinct, so the skip transition s-2 -> s is open for every odd s.  One workgroup per utterance,
+// threads over the states, the T steps in sequence with the previous row in LDS; rows of `a` are prefetched 8 steps ahead.
+// Same float32 log-space recursion as torch's ctc_loss (which the reference calls once per utterance from a Python loop).
+constexpr int FS_CH = 8;
+__device__ __forceinline__ float lse2(float a, float b) {
+  const float m = fmaxf(a, b);
+  return m == -INFINITY ? -INFINITY : m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  return m == -INFINITY ? -INFINITY : m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// lse[b,t] = log(exp(blank) + sum_{k<K} exp(a[t,k]))   (wave per row)
+__device__ __forceinline__ void fs_row_lse(const float* __restrict__ A, float* __restrict__ s_lse, int T, int K, int Tk, float blank) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = wave; t < T; t += 4) {
+    float mx = blank;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, A[(long)t * Tk + k]);
+    mx = ctts_wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < K; k += 64) sum += expf(A[(long)t * Tk + k] - mx);
+    sum = ctts_wave_sum(sum);
+    if (lane == 0) s_lse[t] = mx + logf(sum + expf(blank - mx));
+  }
+}
+
+template <int NS>   // states per thread: S = 2K+1 <= 256 * NS
+__global__ __launch_bounds__(256) void forward_sum_fwd_kernel(const float* __restrict__ attn, const int* __restrict__ in_lens,
+                                                               const int* __restrict__ out_lens, float blank, float* __restrict__ lse,
+                                                               float* __restrict__ alpha, float* __restrict__ nll, int Tq, int Tk) {
+  extern __shared__ float fs_smem[];
+  const int SM = 2 * Tk + 1;
+  float* s_lse = fs_smem;                 // [Tq]
+  float* s_row = fs_smem + Tq;            // [2][SM]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int T = min(out_lens[b], Tq), K = min(in_lens[b], Tk), S = 2 * K + 1;
+  const float* A = attn + (long)b * Tq * Tk;
+  float* AL = alpha + (long)b * Tq * SM;
+  if (T <= 0 || K <= 0) { if (tid == 0) nll[b] = INFINITY; return; }
+  fs_row_lse(A, s_lse, T, K, Tk, blank);
+  __syncthreads();
+  for (int t = tid; t < T; t += 256) lse[(long)b * Tq + t] = s_lse[t];
+  float nx[FS_CH][NS];
+  auto load_chunk = [&](int t0) {
+#pragma unroll
+    for (int r = 0; r < FS_CH; ++r)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const int t = t0 + r, st = tid + 256 * q;
+        nx[r][q] = (t < T && st < S && (st & 1)) ? A[(long)t * Tk + (st >> 1)] : blank;     // raw logit of the state's class
+      }
+  };
+  load_chunk(0);
+  for (int t0 = 0; t0 < T; t0 += FS_CH) {
+    float cur[FS_CH][NS];
+#pragma unroll
+    for (int r = 0; r < FS_CH; ++r)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) cur[r][q] = nx[r][q];
+    if (t0 + FS_CH < T) load_chunk(t0 + FS_CH);
+#pragma unroll
+    for (int r = 0; r < FS_CH; ++r) {
+      const int t = t0 + r;
+      if (t >= T) break;
+      const float* prev = s_row + ((t - 1) & 1) * SM;
+      float* now = s_row + (t & 1) * SM;
+      const float norm = s_lse[t];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const int st = tid + 256 * q;
+        if (st < S) {
+          float v;
+          const float lp = cur[r][q] - norm;
+          if (t == 0) v = st < 2 ? lp : -INFINITY;
+          else {
+            const float a0 = prev[st], a1 = st >= 1 ? prev[st - 1] : -INFINITY;
+            const float a2 = ((st & 1) && st >= 3) ? prev[st - 2] : -INFINITY;
+            v = lp + lse3(a0, a1, a2);
+          }
+          now[st] = v;
+          AL[(long)t * SM + st] = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    const float* last = s_row + ((T - 1) & 1) * SM;
+    nll[b] = -lse2(last[S - 1], S >= 2 ? last[S - 2] : -INFINITY);
+  }
+}
+
+// grad[b,t,k] = gscale[b] * (softmax prob of class k+1 at frame t - posterior occupancy of state 2k+1 at frame t); 0 outside (T, K)
+template <int NS>
+__global__ __launch_bounds__(256) void forward_sum_bwd_kernel(const float* __restrict__ attn, const int* __restrict__ in_lens,
+                                                               const int* __restrict__ out_lens, float blank,
+                                                               const float* __restrict__ lse, const float* __restrict__ alpha,
+                                                               const float* __restrict__ nll, const float* __restrict__ gscale,
+                                                               float* __restrict__ grad, int Tq, int Tk) {
+  extern __shared__ float fs_smem[];
+  const int SM = 2 * Tk + 1;
+  float* s_lse = fs_smem;
+  float* s_row = fs_smem + Tq;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int T = min(out_lens[b], Tq), K = min(in_lens[b], Tk), S = 2 * K + 1;
+  const float* A = attn + (long)b * Tq * Tk;
+  const float* AL = alpha + (long)b * Tq * SM;
+  float* G = grad + (long)b * Tq * Tk;
+  const float nl = (T > 0 && K > 0) ? nll[b] : INFINITY;
+  const float gs = gscale[b];
+  const bool dead = !(nl < INFINITY) || gs == 0.f;          // zero_infinity / nothing to propagate
+  // rows >= T and classes >= K receive no gradient
+  for (long e = tid; e < (long)Tq * Tk; e += 256) {
+    const int t = (int)(e / Tk), k = (int)(e - (long)t * Tk);
+    if (dead || t >= T || k >= K) G[e] = 0.f;
+  }
+  if (dead) return;
+  for (int t = tid; t < T; t += 256) s_lse[t] = lse[(long)b * Tq + t];
+  __syncthreads();
+  float nxa[FS_CH][NS], nxl[FS_CH][NS];
+  auto load_chunk = [&](int c0) {               // chunk element r is frame t = T-1-(c0+r)
+#pragma unroll
+    for (int r = 0; r < FS_CH; ++r)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const int t = T - 1 - (c0 + r), st = tid + 256 * q;
+        const bool ok = t >= 0 && st < S;
+        nxa[r][q] = (ok && (st & 1)) ? A[(long)t * Tk + (st >> 1)] : blank;
+        nxl[r][q] = ok ? AL[(long)t * SM + st] : -INFINITY;
+      }
+  };
+  load_chunk(0);
+  for (int c0 = 0; c0 < T; c0 += FS_CH) {
+    float ca[FS_CH][NS], cl[FS_CH][NS];
+#pragma unroll
+    for (int r = 0; r < FS_CH; ++r)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) { ca[r][q] = nxa[r][q]; cl[r][q] = nxl[r][q]; }
+    if (c0 + FS_CH < T) load_chunk(c0 + FS_CH);
+#pragma unroll
+    for (int r = 0; r < FS_CH; ++r) {
+      const int t = T - 1 - (c0 + r);
+      if (t < 0) break;
+      const float* nextb = s_row + ((t + 1) & 1) * SM;
+      float* now = s_row + (t & 1) * SM;
+      const float norm = s_lse[t];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const int st = tid + 256 * q;
+        if (st < S) {
+          const float lp = ca[r][q] - norm;
+          float v;
+          if (t == T - 1) v = st >= S - 2 ? lp : -INFINITY;
+          else {
+            const float b0 = nextb[st], b1 = st + 1 < S ? nextb[st + 1] : -INFINITY;
+            const float b2 = ((st & 1) && st + 2 < S) ? nextb[st + 2] : -INFINITY;
+            v = lp + lse3(b0, b1, b2);
+          }
+          now[st] = v;
+          if (st & 1) {
+            const float occ = expf(cl[r][q] + v - lp + nl);
+            G[(long)t * Tk + (st >> 1)] = gs * (expf(lp) - occ);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int ctts_neg_sqdist(const float* q, const float* k, float* out, int B, int Tq, int Tk, int C, float temp, void* stream) {
@@ -195,5 +369,41 @@ extern "C" int ctts_mas(const float* attn, const int32_t* in_lens, const int32_t
                        opt, dur, back, Tq, Tk);
   }
   CTTS_CHECK_LAUNCH("ctts_mas");
+  return 0;
+}
+
+static int fs_ns(int Tk) { return (2 * Tk + 1 + 255) / 256; }
+
+extern "C" int ctts_forward_sum_fwd(const float* attn_logprob, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
+                                    float* lse, float* alpha, float* nll, int B, int Tq, int Tk, void* stream) {
+  CTTS_REQUIRE(attn_logprob && in_lens && out_lens && lse && alpha && nll && Tq > 0 && Tk > 0, "ctts_forward_sum_fwd: bad arguments");
+  const size_t lds = ((size_t)Tq + 2 * (2 * (size_t)Tk + 1)) * sizeof(float);
+  CTTS_REQUIRE(lds <= 60 * 1024 && fs_ns(Tk) <= 5, "ctts_forward_sum_fwd: Tq=%d / Tk=%d beyond the LDS row buffers (Tk <= 639)", Tq, Tk);
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+#define CTTS_FS_FWD(NS) hipLaunchKernelGGL((forward_sum_fwd_kernel<NS>), dim3(B), dim3(256), lds, st, attn_logprob, in_lens, out_lens, \
+                                           blank_logprob, lse, alpha, nll, Tq, Tk)
+  switch (fs_ns(Tk)) { case 1: CTTS_FS_FWD(1); break; case 2: CTTS_FS_FWD(2); break; case 3: CTTS_FS_FWD(3); break;
+                       case 4: CTTS_FS_FWD(4); break; default: CTTS_FS_FWD(5); }
+#undef CTTS_FS_FWD
+  CTTS_CHECK_LAUNCH("ctts_forward_sum_fwd");
+  return 0;
+}
+
+extern "C" int ctts_forward_sum_bwd(const float* attn_logprob, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
+                                    const float* lse, const float* alpha, const float* nll, const float* gscale, float* grad, int B,
+                                    int Tq, int Tk, void* stream) {
+  CTTS_REQUIRE(attn_logprob && in_lens && out_lens && lse && alpha && nll && gscale && grad && Tq > 0 && Tk > 0,
+               "ctts_forward_sum_bwd: bad arguments");
+  const size_t lds = ((size_t)Tq + 2 * (2 * (size_t)Tk + 1)) * sizeof(float);
+  CTTS_REQUIRE(lds <= 60 * 1024 && fs_ns(Tk) <= 5, "ctts_forward_sum_bwd: Tq=%d / Tk=%d beyond the LDS row buffers (Tk <= 639)", Tq, Tk);
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+#define CTTS_FS_BWD(NS) hipLaunchKernelGGL((forward_sum_bwd_kernel<NS>), dim3(B), dim3(256), lds, st, attn_logprob, in_lens, out_lens, \
+                                           blank_logprob, lse, alpha, nll, gscale, grad, Tq, Tk)
+  switch (fs_ns(Tk)) { case 1: CTTS_FS_BWD(1); break; case 2: CTTS_FS_BWD(2); break; case 3: CTTS_FS_BWD(3); break;
+                       case 4: CTTS_FS_BWD(4); break; default: CTTS_FS_BWD(5); }
+#undef CTTS_FS_BWD
+  CTTS_CHECK_LAUNCH("ctts_forward_sum_bwd");
   return 0;
 }

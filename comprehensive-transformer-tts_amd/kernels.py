@@ -418,3 +418,25 @@ def softmax_rect_bwd(P, dP, klens, qlens):
     _lib.check(lib.ctts_softmax_rect_bwd(_p(P), _p(_f32c(dP, "dP")), _p(klens), _p(qlens), nb, Tq, Tk, _stream()),
                "ctts_softmax_rect_bwd")
     return dP
+
+
+def forward_sum_fwd(attn_logprob, in32, out32, blank):
+    """attn_logprob [B,Tq,Tk] -> (nll [B], lse [B,Tq], alpha [B,Tq,2Tk+1])"""
+    B, Tq, Tk = attn_logprob.shape
+    dev = attn_logprob.device
+    lse = torch.empty(B, Tq, dtype=torch.float32, device=dev)
+    alpha = torch.empty(B, Tq, 2 * Tk + 1, dtype=torch.float32, device=dev)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.ctts_forward_sum_fwd(_p(_f32c(attn_logprob, "attn_logprob")), _p(in32), _p(out32), float(blank), _p(lse), _p(alpha),
+                                        _p(nll), B, Tq, Tk, _stream()), "ctts_forward_sum_fwd")
+    return nll, lse, alpha
+
+
+def forward_sum_bwd(attn_logprob, in32, out32, blank, lse, alpha, nll, gscale):
+    B, Tq, Tk = attn_logprob.shape
+    grad = torch.empty_like(attn_logprob)
+    lib = _lib.load()
+    _lib.check(lib.ctts_forward_sum_bwd(_p(attn_logprob), _p(in32), _p(out32), float(blank), _p(lse), _p(alpha), _p(nll),
+                                        _p(_f32c(gscale, "gscale")), _p(grad), B, Tq, Tk, _stream()), "ctts_forward_sum_bwd")
+    return grad

@@ -84,6 +84,13 @@ class CompTransTTSLoss(nn.Module):
         `host_lens=(in_list, out_list)`: the same lengths as Python ints - F.ctc_loss otherwise copies the device tensors
         to the host (a sync that a hipGraph capture cannot contain)."""
         B, _, Tm, Ts = attn_logprob.shape
+        if attn_logprob.is_cuda:
+            # device path (csrc/align.hip): the alpha/beta recursions of all utterances in one launch each, no host round trip
+            from . import ops
+            per = ops.forward_sum_nll(attn_logprob[:, 0], in_lens, out_lens, blank_logprob)
+            per = torch.where(torch.isinf(per), torch.zeros_like(per), per)                # zero_infinity=True
+            return (per / in_lens.clamp(min=1).to(per.dtype)).sum() / B
+        # host tensors (CPU-side consumers: tests of the loss arithmetic, bench.py's cpu_baseline): stock torch CTC
         logits = F.pad(attn_logprob[:, 0], (1, 0), value=blank_logprob)                     # [B,Tm,Ts+1], class 0 = blank
         cls = torch.arange(Ts + 1, device=logits.device)[None, None, :]
         logits = logits.masked_fill(cls > in_lens[:, None, None], float("-inf"))

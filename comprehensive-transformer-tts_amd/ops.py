@@ -722,3 +722,27 @@ def masked_softmax(S, key_lens=None, query_lens=None):
     """softmax over the last dim of S [nb,Tq,Tk]; keys >= key_lens[b] get probability 0 (masked_fill(-inf) before the softmax),
     query rows >= query_lens[b] are zero rows (masked_fill(0) after it) - modules.py:444-446.  lens: int32 device tensors."""
     return _SoftmaxRect.apply(S, key_lens, query_lens)
+
+
+class _ForwardSum(torch.autograd.Function):
+    """per-utterance CTC negative log-likelihood of ForwardSumLoss (loss.py:350-377) - csrc/align.hip, one launch per batch."""
+
+    @staticmethod
+    def forward(ctx, attn_logprob, in_lens, out_lens, blank):
+        a = attn_logprob.contiguous()
+        in32, out32 = in_lens.to(torch.int32).contiguous(), out_lens.to(torch.int32).contiguous()
+        nll, lse, alpha = K.forward_sum_fwd(a, in32, out32, blank)
+        ctx.save_for_backward(a, in32, out32, lse, alpha, nll)
+        ctx.blank = blank
+        return nll
+
+    @staticmethod
+    def backward(ctx, g):
+        a, in32, out32, lse, alpha, nll = ctx.saved_tensors
+        return K.forward_sum_bwd(a, in32, out32, ctx.blank, lse, alpha, nll, g.contiguous()), None, None, None
+
+
+def forward_sum_nll(attn_logprob, in_lens, out_lens, blank_logprob=-1.0):
+    """attn_logprob [B,Tm,Ts] (device) -> nll [B]: -log p(1..K_b | frames) with a blank of log-prob `blank_logprob` prepended
+    to every frame's logits and the log-softmax taken over [blank, first K_b tokens]."""
+    return _ForwardSum.apply(attn_logprob, in_lens, out_lens, float(blank_logprob))

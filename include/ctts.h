@@ -172,6 +172,16 @@ int ctts_relshift_bwd(const float* dS, float* dPS, int nbatch, int T, void* stre
 int ctts_neg_sqdist(const float* q, const float* k, float* out, int B, int Tq, int Tk, int C, float temp, void* stream);
 int ctts_mas(const float* attn, const int32_t* in_lens, const int32_t* out_lens, float* opt, float* dur, uint8_t* back, int B,
              int Tq, int Tk, void* stream);
+/* ForwardSumLoss (model/loss.py:350-377) for the whole batch in one launch: per utterance b the CTC negative
+ * log-likelihood nll[b] of the target sequence 1..K_b under log_softmax([blank_logprob, attn_logprob[b,t,0..K_b-1]]) over the
+ * T_b = out_lens[b] valid frames (K_b = in_lens[b]).  The reference's loss is mean_b(nll[b] / K_b) with infinities zeroed.
+ *   fwd: attn_logprob [B,Tq,Tk] -> lse [B,Tq] (row normalisers), alpha [B,Tq,2*Tk+1] (log forward variables), nll [B]
+ *   bwd: grad [B,Tq,Tk] = gscale[b] * d nll[b] / d attn_logprob (zero for frames >= T_b, tokens >= K_b, or nll[b] = inf)   */
+int ctts_forward_sum_fwd(const float* attn_logprob, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob, float* lse,
+                         float* alpha, float* nll, int B, int Tq, int Tk, void* stream);
+int ctts_forward_sum_bwd(const float* attn_logprob, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
+                         const float* lse, const float* alpha, const float* nll, const float* gscale, float* grad, int B, int Tq,
+                         int Tk, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * liu2021 implicit prosody modelling (model/modules.py:332-648, model/coordconv.py:140-159).

@@ -466,3 +466,30 @@ def test_masked_softmax_rect_and_bmm_nt():
     # no masks (STL token attention)
     P2 = ops.masked_softmax(torch.randn(1, 5, 32, device=DEV))
     close(P2.sum(-1), torch.ones(1, 5), 1e-6, "rows sum to 1")
+
+
+@pytest.mark.parametrize("B,Tm,Ts", [(3, 61, 17), (2, 300, 130), (2, 40, 260)])
+def test_forward_sum_kernel_vs_torch_ctc(B, Tm, Ts):
+    """ctts_forward_sum_fwd/bwd against torch's CPU ctc_loss applied per utterance exactly as ForwardSumLoss does (loss.py:350-377),
+    incl. an utterance with more tokens than frames (infinite nll -> zero loss and zero gradient)."""
+    g = torch.Generator().manual_seed(B * Tm + Ts)
+    a = (torch.randn(B, 1, Tm, Ts, generator=g) * 2).requires_grad_(True)
+    in_lens = torch.tensor([Ts, max(1, Ts - 5), 3][:B])
+    out_lens = torch.tensor([Tm, max(2, Tm - 7), 2][:B])          # B == 3: the last utterance has 3 tokens but 2 frames -> inf
+    # reference formulation, float64 on the CPU
+    total = 0.0
+    pad = F.pad(a.double(), (1, 0), value=-1.0)
+    for b in range(B):
+        K_, T_ = int(in_lens[b]), int(out_lens[b])
+        lp = torch.log_softmax(pad[b].permute(1, 0, 2)[:T_, :, :K_ + 1], dim=-1)
+        total = total + F.ctc_loss(lp, torch.arange(1, K_ + 1)[None], torch.tensor([T_]), torch.tensor([K_]), blank=0,
+                                   reduction="mean", zero_infinity=True)
+    total = total / B
+    total.backward()
+    ad = a.detach().to(DEV).requires_grad_(True)
+    from ctts_amd.loss import CompTransTTSLoss
+    loss = CompTransTTSLoss.forward_sum_loss(ad, in_lens.to(DEV), out_lens.to(DEV))
+    assert abs(float(loss) - float(total)) <= 2e-5 * max(1.0, abs(float(total))), (float(loss), float(total))
+    loss.backward()
+    close(ad.grad, a.grad, 2e-5, "forward-sum grad")
+    assert torch.isfinite(ad.grad).all()
