@@ -85,10 +85,16 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ attn
 // back-track walks LDS (not HBM) and the hard alignment / durations are written by all threads from the recorded path.
 // Same arithmetic and tie rules as mas_kernel above.  NJ = columns per thread (Tk <= 256 * NJ).
 constexpr int MAS_CH = 8;
+// log of the soft attention for ALL utterances in parallel (correctly rounded float log via double), written into the `opt` output
+// buffer, which the DP kernel reads as its input and overwrites with the hard alignment only after its last DP row.
+__global__ void mas_log_kernel(const float* __restrict__ attn, float* __restrict__ out, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    out[e] = (float)log((double)attn[e]);
+}
+
 template <int NJ>
-__global__ __launch_bounds__(256) void mas_lds_kernel(const float* __restrict__ attn, const int* __restrict__ in_lens,
-                                                       const int* __restrict__ out_lens, float* __restrict__ opt,
-                                                       float* __restrict__ dur, int Tq, int Tk) {
+__global__ __launch_bounds__(256) void mas_lds_kernel(const int* __restrict__ in_lens, const int* __restrict__ out_lens,
+                                                       float* __restrict__ opt, float* __restrict__ dur, int Tq, int Tk) {
   extern __shared__ __attribute__((aligned(8))) unsigned char mas_smem[];
   const int W64 = (Tk + 63) / 64;
   unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(mas_smem);              // [Tq][W64]
@@ -97,15 +103,15 @@ __global__ __launch_bounds__(256) void mas_lds_kernel(const float* __restrict__ 
   short* s_path = reinterpret_cast<short*>(s_dur + Tk);                                       // [Tq]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T1 = min(out_lens[b], Tq), T2 = min(in_lens[b], Tk);
-  const float* A = attn + (long)b * Tq * Tk;
   float* O = opt + (long)b * Tq * Tk;
+  const float* A = O;                       // log(attn), produced by mas_log_kernel
   for (int j = tid; j < Tk; j += 256) s_dur[j] = 0;
   if (T1 <= 0 || T2 <= 0) {
     for (long e = tid; e < (long)Tq * Tk; e += 256) O[e] = 0.f;
     for (int j = tid; j < Tk; j += 256) dur[(long)b * Tk + j] = 0.f;
     return;
   }
-  for (int j = tid; j < T2; j += 256) s_row[j] = j == 0 ? (float)log((double)A[0]) : -INFINITY;
+  for (int j = tid; j < T2; j += 256) s_row[j] = j == 0 ? A[0] : -INFINITY;
   float nx[MAS_CH][NJ];
   auto load_chunk = [&](int i0) {
 #pragma unroll
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void mas_lds_kernel(const float* __restrict__ 
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int i = i0 + r, j = tid + 256 * jj;
-        nx[r][jj] = (i < T1 && j < T2) ? A[(long)i * Tk + j] : 1.f;
+        nx[r][jj] = (i < T1 && j < T2) ? A[(long)i * Tk + j] : 0.f;
       }
   };
   load_chunk(1);
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void mas_lds_kernel(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < MAS_CH; ++r)
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) la[r][jj] = (float)log((double)nx[r][jj]);
+      for (int jj = 0; jj < NJ; ++jj) la[r][jj] = nx[r][jj];
     if (i0 + MAS_CH < T1) load_chunk(i0 + MAS_CH);              // in flight while this chunk's 8 DP rows run
 #pragma unroll
     for (int r = 0; r < MAS_CH; ++r) {
@@ -176,17 +182,17 @@ __global__ __launch_bounds__(256) void mas_lds_kernel(const float* __restrict__ 
 constexpr int FS_CH = 8;
 __device__ __forceinline__ float lse2(float a, float b) {
   const float m = fmaxf(a, b);
-  return m == -INFINITY ? -INFINITY : m + logf(expf(a - m) + expf(b - m));
+  return m == -INFINITY ? -INFINITY : m + __logf(__expf(a - m) + __expf(b - m));
 }
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   const float m = fmaxf(a, fmaxf(b, c));
-  return m == -INFINITY ? -INFINITY : m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+  return m == -INFINITY ? -INFINITY : m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
 // lse[b,t] = log(exp(blank) + sum_{k<K} exp(a[t,k]))   (wave per row)
 __device__ __forceinline__ void fs_row_lse(const float* __restrict__ A, float* __restrict__ s_lse, int T, int K, int Tk, float blank) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = wave; t < T; t += 4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  for (int t = wave; t < T; t += nwave) {
     float mx = blank;
     for (int k = lane; k < K; k += 64) mx = fmaxf(mx, A[(long)t * Tk + k]);
     mx = ctts_wave_max(mx);
@@ -197,29 +203,29 @@ __device__ __forceinline__ void fs_row_lse(const float* __restrict__ A, float* _
   }
 }
 
-template <int NS>   // states per thread: S = 2K+1 <= 256 * NS
-__global__ __launch_bounds__(256) void forward_sum_fwd_kernel(const float* __restrict__ attn, const int* __restrict__ in_lens,
+template <int NS>   // states per thread: S = 2K+1 <= blockDim.x * NS; blockDim.x = min(1024, roundup(2 Tk + 1, 64))
+__global__ __launch_bounds__(1024) void forward_sum_fwd_kernel(const float* __restrict__ attn, const int* __restrict__ in_lens,
                                                                const int* __restrict__ out_lens, float blank, float* __restrict__ lse,
                                                                float* __restrict__ alpha, float* __restrict__ nll, int Tq, int Tk) {
   extern __shared__ float fs_smem[];
   const int SM = 2 * Tk + 1;
   float* s_lse = fs_smem;                 // [Tq]
   float* s_row = fs_smem + Tq;            // [2][SM]
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int T = min(out_lens[b], Tq), K = min(in_lens[b], Tk), S = 2 * K + 1;
   const float* A = attn + (long)b * Tq * Tk;
   float* AL = alpha + (long)b * Tq * SM;
   if (T <= 0 || K <= 0) { if (tid == 0) nll[b] = INFINITY; return; }
   fs_row_lse(A, s_lse, T, K, Tk, blank);
   __syncthreads();
-  for (int t = tid; t < T; t += 256) lse[(long)b * Tq + t] = s_lse[t];
+  for (int t = tid; t < T; t += nthr) lse[(long)b * Tq + t] = s_lse[t];
   float nx[FS_CH][NS];
   auto load_chunk = [&](int t0) {
 #pragma unroll
     for (int r = 0; r < FS_CH; ++r)
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
-        const int t = t0 + r, st = tid + 256 * q;
+        const int t = t0 + r, st = tid + nthr * q;
         nx[r][q] = (t < T && st < S && (st & 1)) ? A[(long)t * Tk + (st >> 1)] : blank;     // raw logit of the state's class
       }
   };
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) void forward_sum_fwd_kernel(const float* __res
       const float norm = s_lse[t];
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
-        const int st = tid + 256 * q;
+        const int st = tid + nthr * q;
         if (st < S) {
           float v;
           const float lp = cur[r][q] - norm;
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void forward_sum_fwd_kernel(const float* __res
 
 // grad[b,t,k] = gscale[b] * (softmax prob of class k+1 at frame t - posterior occupancy of state 2k+1 at frame t); 0 outside (T, K)
 template <int NS>
-__global__ __launch_bounds__(256) void forward_sum_bwd_kernel(const float* __restrict__ attn, const int* __restrict__ in_lens,
+__global__ __launch_bounds__(1024) void forward_sum_bwd_kernel(const float* __restrict__ attn, const int* __restrict__ in_lens,
                                                                const int* __restrict__ out_lens, float blank,
                                                                const float* __restrict__ lse, const float* __restrict__ alpha,
                                                                const float* __restrict__ nll, const float* __restrict__ gscale,
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256) void forward_sum_bwd_kernel(const float* __res
   const int SM = 2 * Tk + 1;
   float* s_lse = fs_smem;
   float* s_row = fs_smem + Tq;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int T = min(out_lens[b], Tq), K = min(in_lens[b], Tk), S = 2 * K + 1;
   const float* A = attn + (long)b * Tq * Tk;
   const float* AL = alpha + (long)b * Tq * SM;
@@ -283,12 +289,12 @@ __global__ __launch_bounds__(256) void forward_sum_bwd_kernel(const float* __res
   const float gs = gscale[b];
   const bool dead = !(nl < INFINITY) || gs == 0.f;          // zero_infinity / nothing to propagate
   // rows >= T and classes >= K receive no gradient
-  for (long e = tid; e < (long)Tq * Tk; e += 256) {
+  for (long e = tid; e < (long)Tq * Tk; e += nthr) {
     const int t = (int)(e / Tk), k = (int)(e - (long)t * Tk);
     if (dead || t >= T || k >= K) G[e] = 0.f;
   }
   if (dead) return;
-  for (int t = tid; t < T; t += 256) s_lse[t] = lse[(long)b * Tq + t];
+  for (int t = tid; t < T; t += nthr) s_lse[t] = lse[(long)b * Tq + t];
   __syncthreads();
   float nxa[FS_CH][NS], nxl[FS_CH][NS];
   auto load_chunk = [&](int c0) {               // chunk element r is frame t = T-1-(c0+r)
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256) void forward_sum_bwd_kernel(const float* __res
     for (int r = 0; r < FS_CH; ++r)
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
-        const int t = T - 1 - (c0 + r), st = tid + 256 * q;
+        const int t = T - 1 - (c0 + r), st = tid + nthr * q;
         const bool ok = t >= 0 && st < S;
         nxa[r][q] = (ok && (st & 1)) ? A[(long)t * Tk + (st >> 1)] : blank;
         nxl[r][q] = ok ? AL[(long)t * SM + st] : -INFINITY;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256) void forward_sum_bwd_kernel(const float* __res
       const float norm = s_lse[t];
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
-        const int st = tid + 256 * q;
+        const int st = tid + nthr * q;
         if (st < S) {
           const float lp = ca[r][q] - norm;
           float v;
@@ -331,8 +337,8 @@ __global__ __launch_bounds__(256) void forward_sum_bwd_kernel(const float* __res
           }
           now[st] = v;
           if (st & 1) {
-            const float occ = expf(cl[r][q] + v - lp + nl);
-            G[(long)t * Tk + (st >> 1)] = gs * (expf(lp) - occ);
+            const float occ = __expf(cl[r][q] + v - lp + nl);
+            G[(long)t * Tk + (st >> 1)] = gs * (__expf(lp) - occ);
           }
         }
       }
@@ -360,10 +366,13 @@ extern "C" int ctts_mas(const float* attn, const int32_t* in_lens, const int32_t
   if (B == 0) return 0;
   const size_t lds = (size_t)Tq * ((Tk + 63) / 64) * 8 + (size_t)2 * Tk * 4 + (size_t)Tk * 4 + (size_t)Tq * 2;
   if (lds <= 60 * 1024 && Tk <= 512 && Tk < 32768) {       // back-pointer bits fit in LDS: fast path
+    const long total = (long)B * Tq * Tk;
+    hipLaunchKernelGGL(mas_log_kernel, dim3((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, attn, opt, total);
     if (Tk <= 256)
-      hipLaunchKernelGGL((mas_lds_kernel<1>), dim3(B), dim3(256), lds, (hipStream_t)stream, attn, in_lens, out_lens, opt, dur, Tq, Tk);
+      hipLaunchKernelGGL((mas_lds_kernel<1>), dim3(B), dim3(256), lds, (hipStream_t)stream, in_lens, out_lens, opt, dur, Tq, Tk);
     else
-      hipLaunchKernelGGL((mas_lds_kernel<2>), dim3(B), dim3(256), lds, (hipStream_t)stream, attn, in_lens, out_lens, opt, dur, Tq, Tk);
+      hipLaunchKernelGGL((mas_lds_kernel<2>), dim3(B), dim3(256), lds, (hipStream_t)stream, in_lens, out_lens, opt, dur, Tq, Tk);
   } else {
     hipLaunchKernelGGL(mas_kernel, dim3(B), dim3(256), (size_t)2 * Tk * sizeof(float), (hipStream_t)stream, attn, in_lens, out_lens,
                        opt, dur, back, Tq, Tk);
@@ -372,20 +381,22 @@ extern "C" int ctts_mas(const float* attn, const int32_t* in_lens, const int32_t
   return 0;
 }
 
-static int fs_ns(int Tk) { return (2 * Tk + 1 + 255) / 256; }
+static int fs_threads(int Tk) { const int S = 2 * Tk + 1; return S >= 1024 ? 1024 : (S + 63) / 64 * 64; }
+static int fs_ns(int Tk) { return (2 * Tk + 1 + fs_threads(Tk) - 1) / fs_threads(Tk); }
 
 extern "C" int ctts_forward_sum_fwd(const float* attn_logprob, const int32_t* in_lens, const int32_t* out_lens, float blank_logprob,
                                     float* lse, float* alpha, float* nll, int B, int Tq, int Tk, void* stream) {
   CTTS_REQUIRE(attn_logprob && in_lens && out_lens && lse && alpha && nll && Tq > 0 && Tk > 0, "ctts_forward_sum_fwd: bad arguments");
   const size_t lds = ((size_t)Tq + 2 * (2 * (size_t)Tk + 1)) * sizeof(float);
-  CTTS_REQUIRE(lds <= 60 * 1024 && fs_ns(Tk) <= 5, "ctts_forward_sum_fwd: Tq=%d / Tk=%d beyond the LDS row buffers (Tk <= 639)", Tq, Tk);
+  CTTS_REQUIRE(lds <= 60 * 1024 && fs_ns(Tk) <= 2, "ctts_forward_sum_fwd: Tq=%d / Tk=%d beyond the LDS row buffers (Tk <= 1023)", Tq, Tk);
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-#define CTTS_FS_FWD(NS) hipLaunchKernelGGL((forward_sum_fwd_kernel<NS>), dim3(B), dim3(256), lds, st, attn_logprob, in_lens, out_lens, \
-                                           blank_logprob, lse, alpha, nll, Tq, Tk)
-  switch (fs_ns(Tk)) { case 1: CTTS_FS_FWD(1); break; case 2: CTTS_FS_FWD(2); break; case 3: CTTS_FS_FWD(3); break;
-                       case 4: CTTS_FS_FWD(4); break; default: CTTS_FS_FWD(5); }
-#undef CTTS_FS_FWD
+  if (fs_ns(Tk) == 1)
+    hipLaunchKernelGGL((forward_sum_fwd_kernel<1>), dim3(B), dim3(fs_threads(Tk)), lds, st, attn_logprob, in_lens, out_lens,
+                       blank_logprob, lse, alpha, nll, Tq, Tk);
+  else
+    hipLaunchKernelGGL((forward_sum_fwd_kernel<2>), dim3(B), dim3(fs_threads(Tk)), lds, st, attn_logprob, in_lens, out_lens,
+                       blank_logprob, lse, alpha, nll, Tq, Tk);
   CTTS_CHECK_LAUNCH("ctts_forward_sum_fwd");
   return 0;
 }
@@ -396,14 +407,15 @@ extern "C" int ctts_forward_sum_bwd(const float* attn_logprob, const int32_t* in
   CTTS_REQUIRE(attn_logprob && in_lens && out_lens && lse && alpha && nll && gscale && grad && Tq > 0 && Tk > 0,
                "ctts_forward_sum_bwd: bad arguments");
   const size_t lds = ((size_t)Tq + 2 * (2 * (size_t)Tk + 1)) * sizeof(float);
-  CTTS_REQUIRE(lds <= 60 * 1024 && fs_ns(Tk) <= 5, "ctts_forward_sum_bwd: Tq=%d / Tk=%d beyond the LDS row buffers (Tk <= 639)", Tq, Tk);
+  CTTS_REQUIRE(lds <= 60 * 1024 && fs_ns(Tk) <= 2, "ctts_forward_sum_bwd: Tq=%d / Tk=%d beyond the LDS row buffers (Tk <= 1023)", Tq, Tk);
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-#define CTTS_FS_BWD(NS) hipLaunchKernelGGL((forward_sum_bwd_kernel<NS>), dim3(B), dim3(256), lds, st, attn_logprob, in_lens, out_lens, \
-                                           blank_logprob, lse, alpha, nll, gscale, grad, Tq, Tk)
-  switch (fs_ns(Tk)) { case 1: CTTS_FS_BWD(1); break; case 2: CTTS_FS_BWD(2); break; case 3: CTTS_FS_BWD(3); break;
-                       case 4: CTTS_FS_BWD(4); break; default: CTTS_FS_BWD(5); }
-#undef CTTS_FS_BWD
+  if (fs_ns(Tk) == 1)
+    hipLaunchKernelGGL((forward_sum_bwd_kernel<1>), dim3(B), dim3(fs_threads(Tk)), lds, st, attn_logprob, in_lens, out_lens,
+                       blank_logprob, lse, alpha, nll, gscale, grad, Tq, Tk);
+  else
+    hipLaunchKernelGGL((forward_sum_bwd_kernel<2>), dim3(B), dim3(fs_threads(Tk)), lds, st, attn_logprob, in_lens, out_lens,
+                       blank_logprob, lse, alpha, nll, gscale, grad, Tq, Tk);
   CTTS_CHECK_LAUNCH("ctts_forward_sum_bwd");
   return 0;
 }
