@@ -68,6 +68,12 @@ class TrainStep:
         self.params = self.arena.params
         self.flat_grad = self.arena.flat
         self.use_graph = use_graph
+        self.fadam = None
+        if os.environ.get("CTTS_TORCH_ADAM", "0") != "1":    # default: fused clip + Adam over flat arenas (csrc/optim.hip)
+            from ctts_amd.dp import FlatAdam
+            oc = optim._optimizer.defaults
+            self.fadam = FlatAdam(self.arena, optim._optimizer.param_groups[0]["lr"], betas=tuple(oc["betas"]), eps=oc["eps"],
+                                  weight_decay=oc["weight_decay"], max_norm=1.0, current_step=0)
         self.g_fb = self.g_opt = None
         self.loss_val = None
 
@@ -86,6 +92,9 @@ class TrainStep:
         self.arena.all_reduce_mean(self.world)
 
     def clip_and_step(self):
+        if self.fadam is not None:
+            self.fadam.step()
+            return
         torch.nn.utils.clip_grad_norm_(self.params, 1.0, foreach=True)
         self.optim._optimizer.step()
 

@@ -1,0 +1,91 @@
+// Fused global-norm clip + Adam over ONE flat fp32 parameter arena (reference train.py:118-125 =
+// nn.utils.clip_grad_norm_(model.parameters(), 1.0) + ScheduledOptim/torch.optim.Adam step, model/optimizer.py:22-53).
+//
+// The reference walks ~170 parameter tensors three times (norm, scale, Adam).  Here parameters, gradients and both moments are flat
+// arenas (views handed to torch), so the whole update is two streaming passes: (1) sum of squares of the gradient arena,
+// (2) one kernel that applies the clip coefficient and the Adam update (reads g,p,m,v, writes p,m,v: 28 B per parameter - HBM bound).
+// Step counter, learning rate and the norm accumulator live in device memory so the launches replay inside a hipGraph.
+#include "ctts_common.h"
+
+namespace {
+
+// state[0] = sum of squares accumulator (must be 0 on entry; re-zeroed by finalize), state[1] = step count (float), state[2] = last
+// total gradient norm (output, for logging like clip_grad_norm_'s return value)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float4* __restrict__ g, long n4, const float* __restrict__ gtail, int ntail,
+                                                      float* __restrict__ state) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = g[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) acc += gtail[threadIdx.x] * gtail[threadIdx.x];
+  acc = ctts_wave_sum(acc);
+  __shared__ float s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(state, s[0] + s[1] + s[2] + s[3]);
+}
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float coef, float wd, float b1, float b2, float eps,
+                                         float step_size, float inv_sqrt_bc2) {
+  g = g * coef + wd * p;
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p -= step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, const float* __restrict__ lr, float b1, float b2,
+                                                    float eps, float wd, float max_norm, const float* __restrict__ state) {
+  const float total = sqrtf(state[0]);
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(1.f, max_norm / (total + 1e-6f));        // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
+  const float step = state[1] + 1.f;
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  const float step_size = lr[0] / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  const long n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 pp = p4[i], mm = m4[i], vv = v4[i];
+    const float4 gg = g4[i];
+    adam_one(pp.x, gg.x, mm.x, vv.x, coef, wd, b1, b2, eps, step_size, inv_sqrt_bc2);
+    adam_one(pp.y, gg.y, mm.y, vv.y, coef, wd, b1, b2, eps, step_size, inv_sqrt_bc2);
+    adam_one(pp.z, gg.z, mm.z, vv.z, coef, wd, b1, b2, eps, step_size, inv_sqrt_bc2);
+    adam_one(pp.w, gg.w, mm.w, vv.w, coef, wd, b1, b2, eps, step_size, inv_sqrt_bc2);
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  if (blockIdx.x == 0) {
+    const long i = (n4 << 2) + threadIdx.x;
+    if (i < n) adam_one(p[i], g[i], m[i], v[i], coef, wd, b1, b2, eps, step_size, inv_sqrt_bc2);
+  }
+}
+
+__global__ void adam_finalize_kernel(float* __restrict__ state) {
+  state[2] = sqrtf(state[0]);
+  state[0] = 0.f;
+  state[1] += 1.f;
+}
+
+}  // namespace
+
+extern "C" int ctts_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, float beta1, float beta2,
+                                   float eps, float weight_decay, float max_norm, float* state, void* stream) {
+  CTTS_REQUIRE(p && g && m && v && lr && state && n >= 0, "ctts_adam_clip_step: bad arguments");
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  CTTS_REQUIRE(al16(p) && al16(g) && al16(m) && al16(v), "ctts_adam_clip_step: arenas must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const long n4 = n >> 2;
+  const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : ((n4 + 255) / 256 < 1 ? 1 : (n4 + 255) / 256));
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)g, n4, g + (n4 << 2), (int)(n - (n4 << 2)), state);
+  CTTS_CHECK_LAUNCH("ctts_adam_clip_step(sqnorm)");
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, max_norm, state);
+  CTTS_CHECK_LAUNCH("ctts_adam_clip_step(adam)");
+  hipLaunchKernelGGL(adam_finalize_kernel, dim3(1), dim3(1), 0, st, state);
+  CTTS_CHECK_LAUNCH("ctts_adam_clip_step(finalize)");
+  return 0;
+}

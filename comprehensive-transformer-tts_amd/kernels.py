@@ -440,3 +440,11 @@ def forward_sum_bwd(attn_logprob, in32, out32, blank, lse, alpha, nll, gscale):
     _lib.check(lib.ctts_forward_sum_bwd(_p(attn_logprob), _p(in32), _p(out32), float(blank), _p(lse), _p(alpha), _p(nll),
                                         _p(_f32c(gscale, "gscale")), _p(grad), B, Tq, Tk, _stream()), "ctts_forward_sum_bwd")
     return grad
+
+
+def adam_clip_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, max_norm, state):
+    """fused clip_grad_norm_ + Adam on flat fp32 arenas (csrc/optim.hip); lr / state are device tensors (graph-replayable)"""
+    lib = _lib.load()
+    _lib.check(lib.ctts_adam_clip_step(_p(_f32c(p, "p")), _p(_f32c(g, "g")), _p(_f32c(m, "m")), _p(_f32c(v, "v")), p.numel(), _p(lr),
+                                       float(beta1), float(beta2), float(eps), float(weight_decay), float(max_norm), _p(state),
+                                       _stream()), "ctts_adam_clip_step")

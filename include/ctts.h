@@ -207,6 +207,17 @@ int ctts_softmax_rect_fwd(float* S, const int32_t* klens, const int32_t* qlens, 
 int ctts_softmax_rect_bwd(const float* P, float* dP, const int32_t* klens, const int32_t* qlens, int nb, int Tq, int Tk,
                           void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Fused gradient clipping + Adam over flat fp32 arenas (train.py:118-125, model/optimizer.py:22-53):
+ *   total = ||g||_2 ; g <- g * min(1, max_norm / (total + 1e-6))  (nn.utils.clip_grad_norm_; max_norm <= 0: no clipping)
+ *   g <- g + weight_decay * p ; m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2
+ *   p <- p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)           (torch.optim.Adam, amsgrad off)
+ * p, g, m, v: n floats each, 16-byte aligned.  lr: device scalar.  state: 3 device floats {sum-of-squares accumulator (0 on first
+ * call, re-zeroed here), step count t-1 (incremented here), total norm of this call (output)} - all device resident so that the three
+ * launches replay inside a hipGraph. */
+int ctts_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, float beta1, float beta2, float eps,
+                        float weight_decay, float max_norm, float* state, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

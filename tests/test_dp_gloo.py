@@ -43,7 +43,7 @@ def _worker(rank, world, port, q):
     # rank 1 does not use the last layer -> its gradient there is all zeros on that rank
     _loss(m, X[idx], Y[idx], use_last=(rank == 0)).backward()
     arena.all_reduce_mean()
-    q.put((rank, arena.flat.clone()))
+    q.put((rank, torch.cat([p.grad.flatten() for p in arena.params])))      # the arena's per-tensor views, alignment gaps dropped
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,7 +82,8 @@ def test_arena_views_alias_param_grads():
     arena = FlatGradArena(m.parameters())
     m(torch.ones(2, 12)).sum().backward()
     assert arena.flat.abs().sum() > 0
-    o = 0
-    for p in m.parameters():
+    for p, o in zip(arena.params, arena.offsets):
+        assert o % 64 == 0                                   # 256-byte aligned starts (16-byte aligned GEMM operands)
         assert p.grad.data_ptr() == arena.flat[o:o + p.numel()].data_ptr()
-        o += p.numel()
+    used = sum(p.numel() for p in arena.params)
+    assert abs(float(arena.flat.sum()) - float(sum(p.grad.sum() for p in arena.params))) < 1e-4 and arena.flat.numel() >= used

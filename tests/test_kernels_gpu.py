@@ -493,3 +493,31 @@ def test_forward_sum_kernel_vs_torch_ctc(B, Tm, Ts):
     loss.backward()
     close(ad.grad, a.grad, 2e-5, "forward-sum grad")
     assert torch.isfinite(ad.grad).all()
+
+
+def test_fused_adam_clip_matches_torch():
+    """ctts_adam_clip_step (flat arenas) against nn.utils.clip_grad_norm_ + torch.optim.Adam on the same tensors, 4 steps,
+    with and without the clip being active."""
+    from ctts_amd.dp import FlatGradArena, FlatAdam
+    torch.manual_seed(3)
+    shapes = [(257, 33), (1024,), (7,), (3, 5, 9), (1,)]
+    ref = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    opt = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.98), eps=1e-9)
+    arena = FlatGradArena(mine)
+    fa = FlatAdam(arena, 3e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=1.0)
+    for it in range(4):
+        scale = 0.01 if it == 2 else 5.0                      # step 2: total norm below max_norm -> no clipping
+        gs = [torch.randn(*s) * scale for s in shapes]
+        for p, g in zip(ref, gs):
+            p.grad = g.clone()
+        total = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt.step()
+        for p, g in zip(mine, gs):
+            p.grad.copy_(g.to(DEV))
+        fa.step()
+        assert abs(float(fa.total_norm) - float(total)) <= 1e-5 * max(1.0, float(total))
+        for p, q in zip(ref, mine):
+            close(q, p, 2e-6, f"param after step {it}")
+    assert float(fa.state[1]) == 4.0 and float(fa.state[0]) == 0.0
+    assert mine[0].data_ptr() == fa.flat_param.data_ptr()     # parameters are views of the flat arena
