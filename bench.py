@@ -137,9 +137,11 @@ def measure_dominant_kernel(dev, batch, iters=20):
     seed = torch.zeros(1, dtype=torch.int64, device=dev)
     lens = batch["mel_lens"].to(torch.int32).to(dev)          # padded-row skipping exactly as the decoder passes it (model.py FFTBlocks.run)
 
+    tmap = K.row_tile_map(lens, T, 0, M)                      # device-built m-tile schedule, as ops.PadRows hands it to every layer
+
     def launch():
         K.gemm(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, conv=(T, ks // 2, cin), alpha=ks ** -0.5, bias=bias,
-               Z=Z, ldz=cout, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1, row_lens=lens, row_T=T, row_halo=0)
+               Z=Z, ldz=cout, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1, row_lens=lens, row_T=T, row_halo=0, tile_map=tmap)
     for _ in range(3):
         launch()
     st = torch.cuda.current_stream()

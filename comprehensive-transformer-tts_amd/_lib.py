@@ -34,12 +34,14 @@ class GemmDesc(C.Structure):
         ("R", _vp), ("ldr", _i64),
         ("rowscale", _vp),
         ("row_lens", _vp), ("row_T", _i32), ("row_halo", _i32),
+        ("tile_map", _vp),
     ]
 
 
 # name -> argtypes (every function returns int status except the two listed below)
 _SIGNATURES = {
     "ctts_gemm": [C.POINTER(GemmDesc), _vp],
+    "ctts_row_tile_map": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "ctts_conv_weight_repack": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_lr_index": [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
     "ctts_lr_gather_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],

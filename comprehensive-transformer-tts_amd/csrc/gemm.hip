@@ -602,18 +602,26 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   }
   const int tiles_n = (d.N + BN - 1) / BN;
   const int nwg = gridDim.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int tiles_m = nwg / tiles_n;
-  int tm = wg / tiles_n;
-  {
+  int wg, tm;
+  bool scheduled_active = false;
+  if (BM == 64 && A_KC && d.tile_map) {
+    // device-built schedule: active m-tiles first, natural workgroup order (round-robin over the XCDs)
+    wg = blockIdx.x;
+    const int r = wg / tiles_n;
+    tm = d.tile_map[1 + r];
+    scheduled_active = r < d.tile_map[0];
+  } else {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int tiles_m = nwg / tiles_n;
+    tm = wg / tiles_n;
     const int P = (tiles_m % 37) ? 37 : ((tiles_m % 41) ? 41 : 43);
     tm = (int)(((long)tm * P) % tiles_m);
   }
   const int row0 = tm * BM, col0 = (wg % tiles_n) * BN;
   if (row0 >= Mv || col0 >= Nv) return;
   float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
-  if (A_KC && d.row_lens) {
+  if (A_KC && d.row_lens && !scheduled_active) {
     const int last = min(row0 + BM, Mv) - 1;
     const int b0 = row0 / d.row_T, b1 = last / d.row_T;
     if (b0 == b1 && (row0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo) {
@@ -767,6 +775,43 @@ bool vec_ok(const ctts_gemm_desc& d) {
 }
 
 }  // namespace
+
+namespace {
+// one wave: stable partition of the m-tiles into active (first) and inactive, count in map[0]
+__global__ __launch_bounds__(64) void row_tile_map_kernel(const int32_t* __restrict__ row_lens, int row_T, int row_halo, int M,
+                                                            int32_t* __restrict__ map) {
+  const int tiles = (M + 63) / 64, lane = threadIdx.x;
+  auto inactive = [&](int tm) -> bool {
+    const int row0 = tm * 64, last = min(row0 + 64, M) - 1;
+    const int b0 = row0 / row_T, b1 = last / row_T;
+    return b0 == b1 && (row0 - b0 * row_T) >= row_lens[b0] + row_halo;
+  };
+  int n_act = 0;
+  for (int base = 0; base < tiles; base += 64) {
+    const int tm = base + lane;
+    const bool a = tm < tiles && !inactive(tm);
+    const unsigned long long m = __ballot(a);
+    if (a) map[1 + n_act + __popcll(m & ((1ULL << lane) - 1ULL))] = tm;
+    n_act += __popcll(m);
+  }
+  int n_in = 0;
+  for (int base = 0; base < tiles; base += 64) {
+    const int tm = base + lane;
+    const bool a = tm < tiles && inactive(tm);
+    const unsigned long long m = __ballot(a);
+    if (a) map[1 + n_act + n_in + __popcll(m & ((1ULL << lane) - 1ULL))] = tm;
+    n_in += __popcll(m);
+  }
+  if (lane == 0) map[0] = n_act;
+}
+}  // namespace
+
+extern "C" int ctts_row_tile_map(const int32_t* row_lens, int row_T, int row_halo, int M, int32_t* tile_map, void* stream) {
+  CTTS_REQUIRE(row_lens && tile_map && row_T > 0 && M >= 0, "ctts_row_tile_map: bad arguments");
+  hipLaunchKernelGGL(row_tile_map_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, row_lens, row_T, row_halo, M, tile_map);
+  CTTS_CHECK_LAUNCH("ctts_row_tile_map");
+  return 0;
+}
 
 extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   CTTS_REQUIRE(dp != nullptr, "ctts_gemm: null descriptor");

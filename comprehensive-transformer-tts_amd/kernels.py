@@ -58,7 +58,7 @@ class DropCtx:
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_off=0, c_off=0, nb0=1, nb1=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), lens=None, lim=(0, 0, 0), conv=None, conv_on_b=False, split_k=1, alpha=1.0,
          bias=None, Z=None, ldz=0, act=ACT_NONE, p_drop=0.0, seed=None, drop_offset=0, R=None, ldr=0, rowscale=None,
-         row_lens=None, row_T=0, row_halo=0):
+         row_lens=None, row_T=0, row_halo=0, tile_map=None):
     """C = epi(alpha * (opA @ opB + bias)); see include/ctts.h ctts_gemm_desc."""
     d = GemmDesc()
     d.A, d.B, d.C = _p(A, a_off), _p(B, b_off), _p(Cout, c_off)
@@ -86,9 +86,18 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_of
     d.rowscale = _p(rowscale)
     if row_lens is not None:
         d.row_lens, d.row_T, d.row_halo = _p(row_lens), int(row_T), int(row_halo)
+        d.tile_map = _p(tile_map)
     lib = _lib.load()
     _lib.check(lib.ctts_gemm(C.byref(d), _stream()), "ctts_gemm")
     return Cout
+
+
+def row_tile_map(row_lens, row_T, row_halo, M):
+    """m-tile schedule (active 64-row tiles first) for GEMMs over padded (b,t) rows; int32 [1 + ceil(M/64)]"""
+    tm = torch.empty(1 + (M + 63) // 64, dtype=torch.int32, device=row_lens.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_row_tile_map(_p(row_lens), int(row_T), int(row_halo), int(M), _p(tm), _stream()), "ctts_row_tile_map")
+    return tm
 
 
 def conv_weight_repack(src, dst, cout, cin, k, mode):

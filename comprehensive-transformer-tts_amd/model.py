@@ -151,7 +151,7 @@ class FFTBlocks(nn.Module):
         else:
             x = ops.rowscale_dropout(x, nonpad, 0.0, None)
         alpha = self.ksize ** -0.5
-        pr = (lens, T)      # rows t >= len are padding: every sub-layer output is re-masked (transformer_fs2.py:190,199)
+        pr = ops.PadRows(lens, T)      # rows t >= len are padding: every sub-layer output is re-masked (transformer_fs2.py:190,199)
         for layer in self.layers:
             op = layer.op
             h = ops.layer_norm(x, op.layer_norm1.weight, op.layer_norm1.bias, 1e-12)

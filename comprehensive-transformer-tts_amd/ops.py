@@ -99,7 +99,7 @@ class _LinearConv(torch.autograd.Function):
     modules.py:140-148,1299-1356 and CompTransTTS.py:133 (fwd, dgrad, wgrad all on MFMA)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, rowscale, act, alpha, p_drop, seed, drop_offset, ksize, row_lens, row_T):
+    def forward(ctx, x, w, b, residual, rowscale, act, alpha, p_drop, seed, drop_offset, ksize, row_lens, row_T, pr=None):
         x = x.contiguous()
         Cin = x.shape[-1]
         M = x.numel() // Cin
@@ -118,9 +118,10 @@ class _LinearConv(torch.autograd.Function):
             residual = residual.contiguous()
         K.gemm(x, wf, out, M, N, Kdim, Cin, Kdim, N, True, True, conv=conv, alpha=alpha, bias=b, Z=Z, ldz=N, act=act,
                p_drop=p_drop, seed=seed, drop_offset=drop_offset, R=residual, ldr=N, rowscale=rowscale,
-               row_lens=row_lens, row_T=row_T, row_halo=0)
+               row_lens=row_lens, row_T=row_T, row_halo=0, tile_map=pr.tile_map(0, M) if pr is not None else None)
         ctx.save_for_backward(x, w, Z, rowscale, seed, row_lens, b)
         ctx.cfg = (act, alpha, p_drop, drop_offset, ksize, b is not None, residual is not None, row_T)
+        ctx.pr = pr
         return out
 
     @staticmethod
@@ -128,6 +129,7 @@ class _LinearConv(torch.autograd.Function):
         x, w, Z, rowscale, seed, row_lens, b = ctx.saved_tensors
         act, alpha, p_drop, drop_offset, ksize, has_bias, has_res, row_T = ctx.cfg
         rl = dict(row_lens=row_lens, row_T=row_T) if row_lens is not None else {}
+        pr = ctx.pr
         dY = dY.contiguous()
         Cin = x.shape[-1]
         M = x.numel() // Cin
@@ -151,7 +153,8 @@ class _LinearConv(torch.autograd.Function):
                 wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
                 K.conv_weight_repack(w.contiguous(), wd, N, Cin, ksize, 1)
                 dX = torch.empty_like(x)
-                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, conv=(T, pad, N), alpha=alpha, row_halo=pad, **rl)
+                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, conv=(T, pad, N), alpha=alpha, row_halo=pad,
+                       tile_map=pr.tile_map(pad, M) if pr is not None else None, **rl)
             if ctx.needs_input_grad[1]:
                 Kd = ksize * Cin
                 fused = _fusable(w)
@@ -167,7 +170,8 @@ class _LinearConv(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[0]:
                 dX = torch.empty_like(x)
-                K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha, **rl)
+                K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha,
+                       tile_map=pr.tile_map(0, M) if pr is not None else None, **rl)
             if ctx.needs_input_grad[1]:
                 fused = _fusable(w)
                 dW = w.grad if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
@@ -176,27 +180,48 @@ class _LinearConv(torch.autograd.Function):
                            **rl)
                 if fused:
                     dW = None
-        return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None
+        return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None
+
+
+class PadRows:
+    """Padding description of activations whose rows are (b, t) pairs: `lens` int32 [B] valid lengths, `T` padded length.
+    Besides the per-tile skipping predicate the GEMM gets a device-built m-tile SCHEDULE (kernels.row_tile_map: active 64-row
+    tiles first) per row halo - built once per forward/backward and shared by every layer of the stack (the lengths live on the
+    device, so the host cannot order the tiles itself without a sync)."""
+
+    def __init__(self, lens, T):
+        self.lens, self.T = lens, int(T)
+        self._maps = {}
+
+    def tile_map(self, halo, M):
+        key = (int(halo), int(M))
+        if key not in self._maps:
+            self._maps[key] = K.row_tile_map(self.lens, self.T, halo, M)
+        return self._maps[key]
 
 
 def _pad_rows(pad_rows):
-    return (pad_rows[0], int(pad_rows[1])) if pad_rows is not None else (None, 0)
+    if pad_rows is None:
+        return None, 0, None
+    if isinstance(pad_rows, PadRows):
+        return pad_rows.lens, pad_rows.T, pad_rows
+    return pad_rows[0], int(pad_rows[1]), PadRows(pad_rows[0], pad_rows[1])
 
 
 def linear(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None, pad_rows=None):
-    """pad_rows=(lens int32 [B], T): rows (b,t) with t >= lens[b] are padding - their outputs are don't-care
+    """pad_rows=(lens int32 [B], T) or an ops.PadRows: rows (b,t) with t >= lens[b] are padding - their outputs are don't-care
     (written as zero) and the incoming gradient there is zero, so whole padded tiles / K-blocks are skipped."""
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
-    rl, rT = _pad_rows(pad_rows)
-    return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off, 0, rl, rT)
+    rl, rT, pr = _pad_rows(pad_rows)
+    return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off, 0, rl, rT, pr)
 
 
 def conv1d(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None, pad_rows=None):
     """x [B,T,Cin], w [Cout,Cin,k] (nn.Conv1d layout), 'same' zero padding, stride 1."""
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
-    rl, rT = _pad_rows(pad_rows)
+    rl, rT, pr = _pad_rows(pad_rows)
     return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off,
-                             w.shape[2], rl, rT)
+                             w.shape[2], rl, rT, pr)
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -61,9 +61,19 @@ typedef struct ctts_gemm_desc {
    * whole output tiles of such rows are zero-filled without touching the operands (a_kc=1), and K-blocks
    * of such rows are skipped in weight-gradient reductions (a_kc=0, b_kc=0).  NULL = off.               */
   const int32_t* row_lens; int32_t row_T; int32_t row_halo;
+  /* Optional m-tile schedule for row_lens launches (ctts_row_tile_map, 64-row tiles): tile_map[0] = number of ACTIVE m-tiles,
+   * tile_map[1..] = m-tile indices, active ones first.  Workgroup b then works on m-tile tile_map[1 + b / tiles_n] and n-tile
+   * b % tiles_n: the active tiles occupy the first workgroup ids, so the hardware's round-robin placement spreads them evenly over
+   * the 8 XCDs (a fixed permutation leaves a +-10 % imbalance of active tiles per XCD), and each XCD only sees tiles_n / 8 weight
+   * panels.  NULL = built-in scrambled order. */
+  const int32_t* tile_map;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
+
+/* m-tile schedule for padded-row skipping (see ctts_gemm_desc.tile_map): a 64-row tile is inactive when all its rows (b,t) belong to one
+ * utterance b and t >= row_lens[b] + row_halo.  tile_map: 1 + ceil(M/64) int32. */
+int ctts_row_tile_map(const int32_t* row_lens, int row_T, int row_halo, int M, int32_t* tile_map, void* stream);
 
 /* Conv1d weight repack: w[Cout][Cin][K] (reference nn.Conv1d layout) ->
  *   mode 0: wf[Cout][K][Cin]                 (forward implicit-GEMM B operand)

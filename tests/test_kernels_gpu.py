@@ -521,3 +521,19 @@ def test_fused_adam_clip_matches_torch():
             close(q, p, 2e-6, f"param after step {it}")
     assert float(fa.state[1]) == 4.0 and float(fa.state[0]) == 0.0
     assert mine[0].data_ptr() == fa.flat_param.data_ptr()     # parameters are views of the flat arena
+
+
+def test_row_tile_map_schedule():
+    """ctts_row_tile_map: stable partition of the 64-row tiles into active (first) / wholly-padded, for two halos."""
+    T, lens = 300, [300, 10, 0, 129, 64]
+    M = T * len(lens)
+    lt = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    for halo in (0, 4):
+        tm = K.row_tile_map(lt, T, halo, M).cpu().numpy()
+        tiles = (M + 63) // 64
+        act, ina = [], []
+        for t in range(tiles):
+            r0, last = t * 64, min(t * 64 + 64, M) - 1
+            b0, b1 = r0 // T, last // T
+            (ina if (b0 == b1 and r0 - b0 * T >= lens[b0] + halo) else act).append(t)
+        assert tm[0] == len(act) and list(tm[1:]) == act + ina

@@ -36,3 +36,30 @@ for name, ep, rl in [("dense bare", False, False), ("dense epilogue", True, Fals
     us = t(lambda: K.gemm(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, **kw))
     rows = valid if rl else M
     print(f"{name:16s} {us:8.1f} us   {2 * rows * cout * ks * cin / us / 1e6:7.1f} TFLOP/s (rows credited: {rows})")
+
+# how much of the ragged-batch time is the skipping mechanism itself?  dense GEMM over exactly the rows the skipping version executes
+rows_exec = int(sum((int(l) + 63) // 64 * 64 for l in lens.tolist()))
+xd = torch.randn(1, rows_exec, cin, device=dev); outd = torch.empty(1, rows_exec, cout, device=dev); Zd = torch.empty_like(outd)
+for name, ep in [("dense-compact bare", False), ("dense-compact epilogue", True)]:
+    kw = dict(conv=(rows_exec, ks // 2, cin))
+    if ep:
+        kw.update(alpha=ks ** -0.5, bias=bias, Z=Zd, ldz=cout, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1)
+    us = t(lambda: K.gemm(xd, wf, outd, rows_exec, cout, ks * cin, cin, ks * cin, cout, True, True, **kw))
+    print(f"{name:24s} {us:8.1f} us   rows executed {rows_exec}  -> {2 * rows_exec * cout * ks * cin / us / 1e6:7.1f} TFLOP/s dense")
+for name, ep, rl in [("skip epilogue (again)", True, True), ("dense epilogue (again)", True, False)]:
+    kw = dict(conv=(T, ks // 2, cin), alpha=ks ** -0.5, bias=bias, Z=Z, ldz=cout, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1)
+    if rl:
+        kw.update(row_lens=lens, row_T=T, row_halo=0)
+    us = t(lambda: K.gemm(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, **kw), iters=50)
+    print(f"{name:24s} {us:8.1f} us")
+
+tmap = K.row_tile_map(lens, T, 0, M)
+kw = dict(conv=(T, ks // 2, cin), alpha=ks ** -0.5, bias=bias, Z=Z, ldz=cout, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1,
+          row_lens=lens, row_T=T, row_halo=0)
+out2 = torch.empty_like(out)
+K.gemm(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, **kw)
+K.gemm(x, wf, out2, M, cout, ks * cin, cin, ks * cin, cout, True, True, tile_map=tmap, **kw)
+print("tile-map result identical:", bool(torch.equal(out, out2)), "active tiles", int(tmap[0]), "of", tmap.numel() - 1)
+for name, tm_ in [("skip epilogue", None), ("skip+schedule epilogue", tmap), ("skip epilogue", None), ("skip+schedule epilogue", tmap)]:
+    us = t(lambda: K.gemm(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, tile_map=tm_, **kw), iters=50)
+    print(f"{name:24s} {us:8.1f} us   {2 * valid * cout * ks * cin / us / 1e6:7.1f} TFLOP/s algorithmic")
