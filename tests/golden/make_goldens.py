@@ -294,6 +294,36 @@ def main():
     run_case(model_c, cb, "train", "g4_conformer_train_nodrop", with_grads=True)
 
 
+from tests.util import synthetic_samples  # noqa: E402  (shared with tests/test_data_cpu.py)
+
+
+def golden_collate():
+    """G11: Dataset.collate_fn / reprocess (dataset.py:166-248) + to_device (utils/tools.py:69-134) on in-memory samples."""
+    from dataset import Dataset
+    from utils.tools import to_device
+
+    arrs = {}
+    for tag, la in (("sup", False), ("unsup", True)):
+        ds = Dataset.__new__(Dataset)
+        ds.pitch_type, ds.learn_alignment, ds.load_spker_embed, ds.batch_size, ds.sort, ds.drop_last = "cwt", la, False, 4, True, False
+        samples = synthetic_samples(10, 5 + int(la), la)
+        batches = ds.collate_fn(samples)
+        arrs[f"{tag}.n_batches"] = np.asarray(len(batches))
+        for bi, b in enumerate(batches):
+            dev = to_device(b, "cpu")
+            arrs[f"{tag}.b{bi}.ids"] = np.array(b[0])
+            flat = {"speakers": dev[2], "texts": dev[3], "src_lens": dev[4], "max_src_len": torch.tensor(int(dev[5])), "mels": dev[6],
+                    "mel_lens": dev[7], "max_mel_len": torch.tensor(int(dev[8])), "energies": dev[10], "durations": dev[11],
+                    "attn_priors": dev[12]}
+            flat.update({"pitch." + k: v for k, v in dev[9].items()})
+            for k, v in flat.items():
+                if v is not None:
+                    arrs[f"{tag}.b{bi}.{k}"] = v.numpy()
+    path = os.path.join(OUT, "g11_collate.npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, len(arrs), "arrays")
+
+
 def main_liu2021():
     """G10: prosody_modeling.model_type = liu2021, supervised and with learn_alignment=True (config C5)."""
     torch.manual_seed(0)
@@ -311,6 +341,9 @@ def main_liu2021():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "liu2021":
         main_liu2021()
+    elif len(sys.argv) > 1 and sys.argv[1] == "collate":
+        golden_collate()
     else:
         main()
         main_liu2021()
+        golden_collate()

@@ -415,3 +415,27 @@ def test_g10_liu2021_prosody_matches_reference(gname, unsup, training):
         n += 1
     print(f"{gname}: worst relative gradient error", worst, "over", n)
     assert n > 250, n
+
+
+def test_packed_batch_upload_and_prefetcher_feed_the_model():
+    """one pinned buffer -> one async H2D -> zero-copy views; the Prefetcher yields reference-style batches in order and
+    the model trains on them (batch[2:] positional, as train.py:106)."""
+    from ctts_amd import data as D
+    from tests.util import synthetic_samples
+    samples = synthetic_samples(10, 5, False)
+    batches = D.collate(samples, 4, sort=True)
+    host = [D.PackedBatch.pack(b).host_views() for b in batches]
+    got = list(D.Prefetcher(batches, DEV, depth=2))
+    assert len(got) == len(batches)
+    for h, d in zip(host, got):
+        assert h[0] == d[0] and h[5] == d[5] and h[8] == d[8]
+        for a, b_ in zip(h, d):
+            if torch.is_tensor(a):
+                assert b_.is_cuda and b_.dtype == a.dtype and torch.equal(a, b_.cpu())
+        for k in h[9]:
+            assert torch.equal(h[9][k], d[9][k].cpu())
+    m, _ = build()
+    m.train()
+    batch = got[0]
+    out = m(*batch[2:], step=1)                      # speakers, texts, src_lens, max_src_len, mels, mel_lens, max_mel_len, pitch dict, ...
+    assert out[0].shape == batch[6].shape and torch.isfinite(out[1]).all()

@@ -54,3 +54,21 @@ def batch_from_golden(g):
         p_targets=p_targets or None, e_targets=t("in.e_targets"), d_targets=t("in.d_targets"),
         spker_embeds=t("in.spker_embeds"), attn_priors=t("in.attn_priors"),
     )
+
+
+def synthetic_samples(n, seed, learn_alignment):
+    """in-memory stand-ins for Dataset.__getitem__ outputs (dataset.py:52-146): ragged text / mel lengths, reference dtypes"""
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        P = int(rng.randint(3, 20))
+        dur = rng.randint(1, 6, size=P)
+        M = int(dur.sum())
+        s = {"id": f"utt{i:03d}", "speaker": int(rng.randint(0, 4)), "text": rng.randint(1, 360, size=P), "raw_text": f"raw {i}",
+             "mel": rng.randn(M, 80).astype(np.float32), "pitch": rng.randn(M).astype(np.float64), "f0": rng.randn(M),
+             "uv": (rng.rand(M) > 0.7).astype(np.float64), "cwt_spec": rng.randn(M, 10).astype(np.float32),
+             "f0_mean": float(rng.randn()), "f0_std": float(abs(rng.randn())), "energy": rng.randn(P if not learn_alignment else M).astype(np.float32),
+             "duration": None if learn_alignment else dur, "mel2ph": None if learn_alignment else np.repeat(np.arange(1, P + 1), dur),
+             "attn_prior": rng.rand(P, M).astype(np.float32) if learn_alignment else None, "spker_embed": None}
+        out.append(s)
+    return out
