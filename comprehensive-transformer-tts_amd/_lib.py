@@ -76,8 +76,8 @@ _SIGNATURES = {
     "ctts_adam_clip_step": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     "ctts_im2col_3x3s2": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_col2im_3x3s2": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "ctts_gru_fwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "ctts_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_gru_fwd": [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_softmax_rect_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_softmax_rect_bwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
 }

@@ -72,11 +72,12 @@ constexpr int GRU_CH = 8;   // time steps per prefetch chunk: global loads are i
 template <int H>
 __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
                                                                          const float* __restrict__ bhh, float* __restrict__ out,
-                                                                         float* __restrict__ gates, int T, int ndir) {
+                                                                         float* __restrict__ gates, int T, int ndir, int rev_mask) {
   __shared__ float s_h[H];
   __shared__ float s_gh[3 * H];
   __shared__ float s_gi[2][GRU_CH][3 * H];       // double-buffered chunk of input projections
   const int b = blockIdx.x, dir = blockIdx.y, g = threadIdx.x;
+  const bool rev = (rev_mask >> dir) & 1;          // this sequence runs t = T-1 .. 0
   const bool act = g < 3 * H;
   float w[H];
   float bias = 0.f;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_fwd_kernel(const f
 #pragma unroll
     for (int i = 0; i < GRU_CH; ++i) {
       const int s = c0 + i;
-      nx[i] = (act && s < T) ? gib[(long)(dir ? T - 1 - s : s) * gs + g] : 0.f;
+      nx[i] = (act && s < T) ? gib[(long)(rev ? T - 1 - s : s) * gs + g] : 0.f;
     }
   };
   load_chunk(0);
@@ -110,7 +111,7 @@ __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_fwd_kernel(const f
     for (int i = 0; i < GRU_CH; ++i) {
       const int s = c0 + i;
       if (s >= T) break;
-      const int t = dir ? T - 1 - s : s;
+      const int t = rev ? T - 1 - s : s;
       if (act) {
         float acc = bias;
 #pragma unroll
@@ -146,11 +147,12 @@ template <int H>
 __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                                          const float* __restrict__ gates, const float* __restrict__ whh,
                                                                          float* __restrict__ dgi, float* __restrict__ dgh,
-                                                                         float* __restrict__ hprev, int T, int ndir) {
+                                                                         float* __restrict__ hprev, int T, int ndir, int rev_mask) {
   __shared__ float s_dgh[3 * H];
   __shared__ float s_part[3 * H];
   __shared__ float s_in[2][GRU_CH][6 * H];       // per step: r|z|n|ghn (4H) | dout (H) | h_{prev} (H)
   const int b = blockIdx.x, dir = blockIdx.y, id = threadIdx.x;
+  const bool rev = (rev_mask >> dir) & 1;
   const bool act = id < 3 * H;
   const int p = id / H, j = id - p * H;
   float wc[H];
@@ -168,11 +170,11 @@ __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_bwd_kernel(const f
         const int v = id + q * 3 * H;
         float val = 0.f;
         if (act && s >= 0) {
-          const int t = dir ? T - 1 - s : s;
+          const int t = rev ? T - 1 - s : s;
           const long o = ((long)b * T + t) * ndir + dir;
           if (v < 4 * H) val = gates[o * 4 * H + v];
           else if (v < 5 * H) val = dout[o * H + (v - 4 * H)];
-          else if (s > 0) val = out[(((long)b * T + (dir ? t + 1 : t - 1)) * ndir + dir) * H + (v - 5 * H)];
+          else if (s > 0) val = out[(((long)b * T + (rev ? t + 1 : t - 1)) * ndir + dir) * H + (v - 5 * H)];
         }
         nx[i][q] = val;
       }
@@ -192,7 +194,7 @@ __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_bwd_kernel(const f
     for (int i = 0; i < GRU_CH; ++i) {
       const int s = T - 1 - (c0 + i);
       if (s < 0) break;
-      const int t = dir ? T - 1 - s : s;
+      const int t = rev ? T - 1 - s : s;
       float dcarry = 0.f;
       if (id < H) {
         const float* in = s_in[buf][i];
@@ -264,16 +266,17 @@ __global__ __launch_bounds__(256) void softmax_rect_kernel(float* __restrict__ S
 }
 
 template <int H>
-int launch_gru_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* gates, int B, int T, int ndir, hipStream_t st) {
-  hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3(B, ndir), dim3((3 * H + 63) / 64 * 64), 0, st, gi, whh, bhh, out, gates, T, ndir);
+int launch_gru_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* gates, int B, int T, int ndir, int rev_mask,
+                   hipStream_t st) {
+  hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3(B, ndir), dim3((3 * H + 63) / 64 * 64), 0, st, gi, whh, bhh, out, gates, T, ndir, rev_mask);
   CTTS_CHECK_LAUNCH("ctts_gru_fwd");
   return 0;
 }
 template <int H>
 int launch_gru_bwd(const float* dout, const float* out, const float* gates, const float* whh, float* dgi, float* dgh, float* hprev,
-                   int B, int T, int ndir, hipStream_t st) {
+                   int B, int T, int ndir, int rev_mask, hipStream_t st) {
   hipLaunchKernelGGL((gru_bwd_kernel<H>), dim3(B, ndir), dim3((3 * H + 63) / 64 * 64), 0, st, dout, out, gates, whh, dgi, dgh, hprev, T,
-                     ndir);
+                     ndir, rev_mask);
   CTTS_CHECK_LAUNCH("ctts_gru_bwd");
   return 0;
 }
@@ -303,15 +306,15 @@ extern "C" int ctts_col2im_3x3s2(const float* dcol, float* dx, int B, int T, int
 }
 
 extern "C" int ctts_gru_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* gates, int B, int T, int H, int ndir,
-                            void* stream) {
-  CTTS_REQUIRE(gi && whh && bhh && out && B >= 0 && T >= 0 && (ndir == 1 || ndir == 2), "ctts_gru_fwd: bad arguments");
+                            int rev_mask, void* stream) {
+  CTTS_REQUIRE(gi && whh && bhh && out && B >= 0 && T >= 0 && ndir >= 1 && ndir <= 8, "ctts_gru_fwd: bad arguments");
   if (B == 0 || T == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   switch (H) {
-    case 16: return launch_gru_fwd<16>(gi, whh, bhh, out, gates, B, T, ndir, st);
-    case 32: return launch_gru_fwd<32>(gi, whh, bhh, out, gates, B, T, ndir, st);
-    case 64: return launch_gru_fwd<64>(gi, whh, bhh, out, gates, B, T, ndir, st);
-    case 128: return launch_gru_fwd<128>(gi, whh, bhh, out, gates, B, T, ndir, st);
+    case 16: return launch_gru_fwd<16>(gi, whh, bhh, out, gates, B, T, ndir, rev_mask, st);
+    case 32: return launch_gru_fwd<32>(gi, whh, bhh, out, gates, B, T, ndir, rev_mask, st);
+    case 64: return launch_gru_fwd<64>(gi, whh, bhh, out, gates, B, T, ndir, rev_mask, st);
+    case 128: return launch_gru_fwd<128>(gi, whh, bhh, out, gates, B, T, ndir, rev_mask, st);
     default:
       ctts_set_error("ctts_gru_fwd: hidden size %d is not instantiated (16, 32, 64, 128: W_hh rows live in registers)", H);
       return -1;
@@ -319,16 +322,16 @@ extern "C" int ctts_gru_fwd(const float* gi, const float* whh, const float* bhh,
 }
 
 extern "C" int ctts_gru_bwd(const float* dout, const float* out, const float* gates, const float* whh, float* dgi, float* dgh,
-                            float* hprev, int B, int T, int H, int ndir, void* stream) {
-  CTTS_REQUIRE(dout && out && gates && whh && dgi && dgh && hprev && B >= 0 && T >= 0 && (ndir == 1 || ndir == 2),
+                            float* hprev, int B, int T, int H, int ndir, int rev_mask, void* stream) {
+  CTTS_REQUIRE(dout && out && gates && whh && dgi && dgh && hprev && B >= 0 && T >= 0 && ndir >= 1 && ndir <= 8,
                "ctts_gru_bwd: bad arguments");
   if (B == 0 || T == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   switch (H) {
-    case 16: return launch_gru_bwd<16>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, st);
-    case 32: return launch_gru_bwd<32>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, st);
-    case 64: return launch_gru_bwd<64>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, st);
-    case 128: return launch_gru_bwd<128>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, st);
+    case 16: return launch_gru_bwd<16>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, rev_mask, st);
+    case 32: return launch_gru_bwd<32>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, rev_mask, st);
+    case 64: return launch_gru_bwd<64>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, rev_mask, st);
+    case 128: return launch_gru_bwd<128>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, rev_mask, st);
     default:
       ctts_set_error("ctts_gru_bwd: hidden size %d is not instantiated (16, 32, 64, 128)", H);
       return -1;

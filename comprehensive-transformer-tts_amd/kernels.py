@@ -390,26 +390,28 @@ def col2im_3x3s2(dcol, B, T, W, Cc):
     return dx
 
 
-def gru_fwd(gi, whh, bhh, H, ndir, save_gates=True):
+def gru_fwd(gi, whh, bhh, H, ndir, save_gates=True, rev_mask=None):
     """gi [B,T,ndir*3H], whh [ndir,3H,H], bhh [ndir,3H] -> (out [B,T,ndir*H], gates [B,T,ndir*4H] or None)"""
     B, T = gi.shape[0], gi.shape[1]
     out = torch.empty(B, T, ndir * H, dtype=torch.float32, device=gi.device)
     gates = torch.empty(B, T, ndir * 4 * H, dtype=torch.float32, device=gi.device) if save_gates else None
+    rev_mask = (2 if ndir == 2 else 0) if rev_mask is None else int(rev_mask)       # default: nn.GRU(bidirectional) = fwd | bwd
     lib = _lib.load()
     _lib.check(lib.ctts_gru_fwd(_p(_f32c(gi, "gi")), _p(_f32c(whh, "whh")), _p(_f32c(bhh, "bhh")), _p(out), _p(gates), B, T, H, ndir,
-                                _stream()), "ctts_gru_fwd")
+                                rev_mask, _stream()), "ctts_gru_fwd")
     return out, gates
 
 
-def gru_bwd(dout, out, gates, whh, H, ndir):
+def gru_bwd(dout, out, gates, whh, H, ndir, rev_mask=None):
     """-> (dgi, dgh [B,T,ndir*3H], hprev [B,T,ndir*H])"""
     B, T = out.shape[0], out.shape[1]
     dgi = torch.empty(B, T, ndir * 3 * H, dtype=torch.float32, device=out.device)
     dgh = torch.empty_like(dgi)
     hprev = torch.empty_like(out)
+    rev_mask = (2 if ndir == 2 else 0) if rev_mask is None else int(rev_mask)
     lib = _lib.load()
     _lib.check(lib.ctts_gru_bwd(_p(_f32c(dout, "dout")), _p(out), _p(gates), _p(_f32c(whh, "whh")), _p(dgi), _p(dgh), _p(hprev), B, T, H,
-                                ndir, _stream()), "ctts_gru_bwd")
+                                ndir, rev_mask, _stream()), "ctts_gru_bwd")
     return dgi, dgh, hprev
 
 

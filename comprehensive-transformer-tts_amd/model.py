@@ -419,9 +419,12 @@ class VarianceAdaptor(nn.Module):
             assert mel is not None and mel_mask is not None, "liu2021 prosody encoders need the reference mel in training"
             mel_nonpad = (~mel_mask).to(torch.float32).reshape(-1).contiguous()
             src_nonpad = (~src_mask).to(torch.float32).reshape(-1).contiguous()
-            up_emb = self.utterance_prosody_encoder(mel, mel_nonpad)
-            pp_emb, pp_attn = self.phoneme_prosody_encoder(x, src_len.to(torch.int32), src_nonpad, mel, mel_len.to(torch.int32),
-                                                           mel_nonpad)
+            ue, pe = self.utterance_prosody_encoder, self.phoneme_prosody_encoder
+            gi_u, whh_u, bhh_u = ue.encoder.features(mel, mel_nonpad)
+            gi_p, whh_p, bhh_p = pe.encoder.features(mel, mel_nonpad)
+            mem_u, mem_p = ops.gru_group([gi_u, gi_p], [whh_u, whh_p], [bhh_u, bhh_p])    # both Tm-step recurrences in one launch
+            up_emb = ue.head(mem_u)
+            pp_emb, pp_attn = pe.head(x, src_len.to(torch.int32), src_nonpad, mel_len.to(torch.int32), mem_p)
         up_vec = self.utterance_prosody_predictor(x)
         u = up_emb if self.training else up_vec
         x = x + ops.linear(u, self.utterance_prosody_prj.weight, self.utterance_prosody_prj.bias)      # [N,1,H] broadcast over Ts

@@ -660,27 +660,35 @@ class _GRU(torch.autograd.Function):
     `linear` (so W_ih / b_ih / input gradients are ordinary GEMMs)."""
 
     @staticmethod
-    def forward(ctx, gi, whh, bhh, H, ndir):
+    def forward(ctx, gi, whh, bhh, H, ndir, rev_mask=None):
         gi, whh, bhh = gi.contiguous(), whh.contiguous(), bhh.contiguous()
         need = gi.requires_grad or whh.requires_grad or bhh.requires_grad
-        out, gates = K.gru_fwd(gi, whh, bhh, H, ndir, save_gates=need)
+        out, gates = K.gru_fwd(gi, whh, bhh, H, ndir, save_gates=need, rev_mask=rev_mask)
         ctx.save_for_backward(out, gates, whh)
-        ctx.cfg = (H, ndir)
+        ctx.cfg = (H, ndir, rev_mask)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         out, gates, whh = ctx.saved_tensors
-        H, ndir = ctx.cfg
+        H, ndir, rev_mask = ctx.cfg
         B, T = out.shape[0], out.shape[1]
-        dgi, dgh, hprev = K.gru_bwd(dout.contiguous(), out, gates, whh, H, ndir)
+        dgi, dgh, hprev = K.gru_bwd(dout.contiguous(), out, gates, whh, H, ndir, rev_mask)
         rows = B * T
         dwhh = torch.zeros_like(whh)
         for d in range(ndir):              # dW_hh[d] = dgh_d^T h_prev_d : [3H, H], reduction over all B*T steps (split-K on MFMA)
             K.gemm(dgh, hprev, dwhh, 3 * H, H, rows, ndir * 3 * H, ndir * H, H, False, False, a_off=d * 3 * H, b_off=d * H,
                    c_off=d * 3 * H * H, split_k=max(2, _split_k_for(3 * H, H, rows)))
         dbhh = K.colsum(dgh.view(rows, ndir * 3 * H)).view(ndir, 3 * H)
-        return dgi, dwhh, dbhh, None, None
+        return dgi, dwhh, dbhh, None, None, None
+
+
+def gru_group(gis, w_hhs, b_hhs):
+    """Several independent forward-in-time GRUs of equal hidden size and length in ONE launch (the recurrence is latency bound and
+    one GRU fills 16 of 256 CUs, so a second one rides along for free): gis[i] [B,T,3H] -> list of outputs [B,T,H]."""
+    n, H = len(gis), w_hhs[0].shape[1]
+    out = _GRU.apply(torch.stack(gis, 2).flatten(2), torch.stack(w_hhs, 0), torch.stack(b_hhs, 0), H, n, 0)
+    return [out[..., i * H:(i + 1) * H] for i in range(n)]
 
 
 def gru(x, w_ih, w_hh, b_ih, b_hh, w_ih_r=None, w_hh_r=None, b_ih_r=None, b_hh_r=None):

@@ -84,6 +84,12 @@ class ReferenceEncoder(nn.Module):
 
     def forward(self, mel, nonpad_rows):
         """mel [N,T,n_mel] (device), nonpad_rows float [N*T] -> memory [N,T,G] (G = gru size); last state = memory[:, -1]"""
+        gi, w_hh, b_hh = self.features(mel, nonpad_rows)
+        return ops.gru_group([gi], [w_hh], [b_hh])[0]
+
+    def features(self, mel, nonpad_rows):
+        """conv stack + GRU input projection: -> (gi [N,T,3G], W_hh, b_hh).  The recurrence itself is left to the caller so that the
+        two reference encoders of the variance adaptor share ONE launch (ops.gru_group)."""
         N, T, W = mel.shape
         if self._coords is None or self._coords.shape[:2] != (T, W) or self._coords.device != mel.device:
             self._coords = coord_planes(T, W, mel.device)
@@ -98,7 +104,7 @@ class ReferenceEncoder(nn.Module):
         g = self.gru
         # reference feature order is (c, w); ours is (w, c): permute W_ih's columns once per call (96 x 256, autograd un-permutes)
         w_ih = g.weight_ih_l0.view(-1, C, Wo).transpose(1, 2).reshape(-1, Wo * C)
-        return g.run(x, w_ih)
+        return ops.linear(x, w_ih, g.bias_ih_l0), g.weight_hh_l0, g.bias_hh_l0
 
 
 class StyleEmbedAttention(nn.Module):
@@ -146,7 +152,9 @@ class UtteranceLevelProsodyEncoder(nn.Module):
         self.drop_ctx = None
 
     def forward(self, mel, nonpad_rows):
-        mem = self.encoder(mel, nonpad_rows)
+        return self.head(self.encoder(mel, nonpad_rows))
+
+    def head(self, mem):
         last = mem[:, -1, :].contiguous()                                    # final hidden state after ALL padded steps
         ep = ops.linear(last, self.encoder_prj.weight, self.encoder_prj.bias)
         out = ops.linear(self.stl(ep), self.encoder_bottleneck.weight, self.encoder_bottleneck.bias)
@@ -178,9 +186,11 @@ class PhonemeLevelProsodyEncoder(nn.Module):
 
     def forward(self, x, src_len_i32, src_nonpad_rows, mel, mel_len_i32, mel_nonpad_rows):
         """x [N,Ts,E] -> (out [N,Ts,bottleneck_p], attn [N,Ts,Tm])"""
+        return self.head(x, src_len_i32, src_nonpad_rows, mel_len_i32, self.encoder(mel, mel_nonpad_rows))
+
+    def head(self, x, src_len_i32, src_nonpad_rows, mel_len_i32, mem):
         E = self.E
-        mem = self.encoder(mel, mel_nonpad_rows)
-        ep = ops.linear(mem, self.encoder_prj.weight, self.encoder_prj.bias)                      # [N,Tm,2E]
+        ep = ops.linear(mem.contiguous(), self.encoder_prj.weight, self.encoder_prj.bias)         # [N,Tm,2E]
         k, v = ep[..., :E], ep[..., E:]
         q = ops.linear(x, self.linears[0].linear.weight)
         k = ops.linear(k.contiguous(), self.linears[1].linear.weight)

@@ -198,10 +198,12 @@ int ctts_forward_sum_bwd(const float* attn_logprob, const int32_t* in_lens, cons
  * ctts_im2col_3x3s2: patch matrix of Conv2d(3x3, stride (1,2), padding (1,1)) (ReferenceEncoder convs, modules.py:351-361) on
  *   channel-last x[B,T,W,C]: col[(b,t,wo)][(kh*3+kw)*C + c] = x[b, t+kh-1, 2*wo-1+kw, c] (0 outside), Wo = (W-1)/2+1, C % 4 == 0.
  *   The convolution itself is ctts_gemm(col, w[Cout][kh][kw][Cin]).  ctts_col2im_3x3s2 is the adjoint (dx from dcol).
- * ctts_gru_fwd / ctts_gru_bwd: recurrent part of a one-layer nn.GRU, batch_first, zero initial state, ndir = 1 or 2
+ * ctts_gru_fwd / ctts_gru_bwd: recurrent part of `ndir` independent one-layer nn.GRU sequences per utterance (1..8: the two directions
+ *   of a bidirectional GRU, or several GRUs of equal H and T sharing one launch), batch_first, zero initial state; sequence d runs
+ *   t = T-1..0 iff bit d of rev_mask is set
  *   (modules.py:359-361,391 ReferenceEncoder; :618-621,637 ParallelProsodyPredictor).  gate order r|z|n,
  *   n = tanh(gi_n + r * (W_hn h + b_hn)), h' = (1-z) n + z h.  The sequence runs over all T steps (the reference never packs).
- *   gi [B,T,ndir,3H] = W_ih x + b_ih (caller's GEMM); whh [ndir,3H,H]; bhh [ndir,3H]; out [B,T,ndir,H] (direction 1 runs t = T-1..0);
+ *   gi [B,T,ndir,3H] = W_ih x + b_ih (caller's GEMM); whh [ndir,3H,H]; bhh [ndir,3H]; out [B,T,ndir,H];
  *   gates [B,T,ndir,4H] <- r|z|n|(W_hn h + b_hn) saved for backward (NULL in inference).
  *   bwd: dout [B,T,ndir,H] -> dgi, dgh [B,T,ndir,3H] (gradients w.r.t. the input / hidden pre-activations) and hprev [B,T,ndir,H]
  *   (h_{t-1}); the caller forms dW_hh = dgh^T hprev and db_hh = colsum(dgh).  H in {16,32,64,128}.
@@ -210,9 +212,9 @@ int ctts_forward_sum_bwd(const float* attn_logprob, const int32_t* in_lens, cons
 int ctts_im2col_3x3s2(const float* x, float* col, int B, int T, int W, int C, void* stream);
 int ctts_col2im_3x3s2(const float* dcol, float* dx, int B, int T, int W, int C, void* stream);
 int ctts_gru_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* gates, int B, int T, int H, int ndir,
-                 void* stream);
+                 int rev_mask, void* stream);
 int ctts_gru_bwd(const float* dout, const float* out, const float* gates, const float* whh, float* dgi, float* dgh, float* hprev,
-                 int B, int T, int H, int ndir, void* stream);
+                 int B, int T, int H, int ndir, int rev_mask, void* stream);
 int ctts_softmax_rect_fwd(float* S, const int32_t* klens, const int32_t* qlens, int nb, int Tq, int Tk, void* stream);
 int ctts_softmax_rect_bwd(const float* P, float* dP, const int32_t* klens, const int32_t* qlens, int nb, int Tq, int Tk,
                           void* stream);

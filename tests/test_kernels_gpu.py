@@ -537,3 +537,27 @@ def test_row_tile_map_schedule():
             b0, b1 = r0 // T, last // T
             (ina if (b0 == b1 and r0 - b0 * T >= lens[b0] + halo) else act).append(t)
         assert tm[0] == len(act) and list(tm[1:]) == act + ina
+
+
+def test_gru_group_matches_separate_grus():
+    """ops.gru_group: two independent forward GRUs in one launch == the same GRUs run one by one (values and gradients)."""
+    B, T, In, H = 3, 29, 64, 32
+    ps = []
+    for i in range(2):
+        torch.manual_seed(40 + i)
+        ps.append([t.to(DEV).requires_grad_(True) for t in (rnd(3 * H, In, seed=i, scale=0.2), rnd(3 * H, H, seed=9 + i, scale=0.3),
+                                                           rnd(3 * H, seed=20 + i), rnd(3 * H, seed=30 + i))])
+    xs = [rnd(B, T, In, seed=50 + i).to(DEV).requires_grad_(True) for i in range(2)]
+    gy = [rnd(B, T, H, seed=60 + i).to(DEV) for i in range(2)]
+    sep = [ops.gru(xs[i], ps[i][0], ps[i][1], ps[i][2], ps[i][3]) for i in range(2)]
+    (sep[0] * gy[0]).sum().backward(); (sep[1] * gy[1]).sum().backward()
+    ref = [[t.grad.clone() for t in ps[i]] + [xs[i].grad.clone()] for i in range(2)]
+    for t in ps[0] + ps[1] + xs:
+        t.grad = None
+    gis = [ops.linear(xs[i], ps[i][0], ps[i][2]) for i in range(2)]
+    grp = ops.gru_group(gis, [ps[0][1], ps[1][1]], [ps[0][3], ps[1][3]])
+    ((grp[0] * gy[0]).sum() + (grp[1] * gy[1]).sum()).backward()
+    for i in range(2):
+        close(grp[i], sep[i], 1e-6, f"gru_group out {i}")
+        for a, b in zip([t.grad for t in ps[i]] + [xs[i].grad], ref[i]):
+            close(a, b, 1e-5, f"gru_group grad {i}")
