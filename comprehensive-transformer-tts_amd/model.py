@@ -317,8 +317,6 @@ class AlignmentEncoder(nn.Module):
 
     def __init__(self, n_mel, n_att, n_text, temperature, multi_speaker):
         super().__init__()
-        if multi_speaker:
-            raise NotImplementedError("AlignmentEncoder speaker projections (multi_speaker + learn_alignment) are not built yet")
         self.temperature = temperature
         self.key_proj = nn.Module()
         self.key_proj.add_module("0", _ConvNormK(n_text, 2 * n_text, 3))
@@ -327,9 +325,17 @@ class AlignmentEncoder(nn.Module):
         self.query_proj.add_module("0", _ConvNormK(n_mel, 2 * n_mel, 3))
         self.query_proj.add_module("2", _ConvNormK(2 * n_mel, n_mel, 1))
         self.query_proj.add_module("4", _ConvNormK(n_mel, n_att, 1))
+        if multi_speaker:                     # modules.py:1172-1174 (bias-free LinearNorm)
+            self.key_spk_proj = nn.Module()
+            self.key_spk_proj.linear = _Linear(n_text, n_text, bias=False)
+            self.query_spk_proj = nn.Module()
+            self.query_spk_proj.linear = _Linear(n_text, n_mel, bias=False)
 
-    def forward(self, mel, text_emb, src_pad, attn_prior):
+    def forward(self, mel, text_emb, src_pad, attn_prior, speaker_embedding=None):
         """mel [B,Tm,80], text_emb [B,Ts,256], src_pad [B,Ts] bool, attn_prior [B,Tm,Ts] -> (soft, logprob) [B,1,Tm,Ts]"""
+        if speaker_embedding is not None:     # the projected speaker vector is added to every key / query position (:1188-1194)
+            text_emb = text_emb + ops.linear(speaker_embedding, self.key_spk_proj.linear.weight).unsqueeze(1)
+            mel = mel + ops.linear(speaker_embedding, self.query_spk_proj.linear.weight).unsqueeze(1)
         kp, qp = self.key_proj, self.query_proj
         k0, k2 = getattr(kp, "0").conv, getattr(kp, "2").conv
         q0, q2, q4 = getattr(qp, "0").conv, getattr(qp, "2").conv, getattr(qp, "4").conv
@@ -447,7 +453,7 @@ class VarianceAdaptor(nn.Module):
         attn_out = (None, None, None, None)
         if attn_prior is not None:      # training of unsupervised duration modelling (modules.py:1031-1053)
             assert self.learn_alignment and duration_target is None and mel is not None
-            attn_soft, attn_logprob = self.aligner(mel, text_embedding, src_mask, attn_prior.transpose(1, 2))
+            attn_soft, attn_logprob = self.aligner(mel, text_embedding, src_mask, attn_prior.transpose(1, 2), speaker_embedding)
             attn_hard, attn_hard_dur = ops.mas_binarize(attn_soft, src_len, mel_len)
             attn_out = (attn_soft, attn_hard, attn_hard_dur, attn_logprob)
             if step < self.binarization_start_steps:
@@ -596,6 +602,8 @@ class CompTransTTS(nn.Module):
                 nn.init.xavier_uniform_(p)
             elif name.endswith("ffn_2.bias"):
                 nn.init.zeros_(p)
+            elif name.startswith("variance_adaptor.aligner.") and name.endswith("_spk_proj.linear.weight"):
+                nn.init.xavier_uniform_(p)
             elif name.startswith("variance_adaptor.aligner.") and name.endswith("conv.weight"):
                 relu = name.endswith("key_proj.0.conv.weight") or name.endswith("query_proj.0.conv.weight")
                 nn.init.xavier_uniform_(p, gain=nn.init.calculate_gain("relu" if relu else "linear"))

@@ -261,10 +261,14 @@ def binarize_attention(attn_soft, in_lens, out_lens):
     return torch.from_numpy(out)
 
 
-def alignment_encoder(sd, mel, text_emb, src_pad, attn_prior, temperature):
-    """model/modules.py:1176-1213 AlignmentEncoder.forward (single speaker).  mel [B,Tm,80], text_emb [B,Ts,256],
-    attn_prior [B,Tm,Ts] -> (attn_soft [B,1,Tm,Ts], attn_logprob [B,1,Tm,Ts])."""
+def alignment_encoder(sd, mel, text_emb, src_pad, attn_prior, temperature, speaker_embedding=None):
+    """model/modules.py:1176-1213 AlignmentEncoder.forward.  mel [B,Tm,80], text_emb [B,Ts,256], attn_prior [B,Tm,Ts]
+    -> (attn_soft [B,1,Tm,Ts], attn_logprob [B,1,Tm,Ts]).  multi_speaker: bias-free projections of the speaker embedding are added
+    to every key / query position (:1188-1194)."""
     a = "variance_adaptor.aligner."
+    if speaker_embedding is not None:
+        text_emb = text_emb + (speaker_embedding @ sd[a + "key_spk_proj.linear.weight"].t())[:, None, :]
+        mel = mel + (speaker_embedding @ sd[a + "query_spk_proj.linear.weight"].t())[:, None, :]
     k = torch.relu(conv1d_btc(text_emb, sd[a + "key_proj.0.conv.weight"], sd[a + "key_proj.0.conv.bias"], 1))
     k = conv1d_btc(k, sd[a + "key_proj.2.conv.weight"], sd[a + "key_proj.2.conv.bias"], 0)
     q = torch.relu(conv1d_btc(mel, sd[a + "query_proj.0.conv.weight"], sd[a + "query_proj.0.conv.bias"], 1))
@@ -442,7 +446,7 @@ def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pa
     mel2ph_inf = None
     if attn_prior is not None:         # unsupervised duration modelling (modules.py:1031-1053)
         attn_soft, attn_logprob = alignment_encoder(sd, mel, text_embedding, src_pad, attn_prior.transpose(1, 2),
-                                                    cfg["duration_modeling"]["aligner_temperature"])
+                                                    cfg["duration_modeling"]["aligner_temperature"], speaker_embedding)
         attn_hard = binarize_attention(attn_soft, src_lens, mel_lens)
         attn_hard_dur = attn_hard.sum(2)[:, 0, :]
         if attn_out is not None:

@@ -248,9 +248,9 @@ def golden_stft():
     print("wrote", path, mel.shape, energy.shape)
 
 
-def make_unsup_batch(src_lens, fpp, seed):
+def make_unsup_batch(src_lens, fpp, seed, **kw):
     """learn_alignment=True inputs: no durations, frame-level energy targets, attention prior [B,Ts,Tm]."""
-    b = make_batch(src_lens, fpp, seed=seed)
+    b = make_batch(src_lens, fpp, seed=seed, **kw)
     g = torch.Generator().manual_seed(seed + 1)
     B, Ts, Tm = b["texts"].shape[0], b["texts"].shape[1], b["mels"].shape[1]
     prior = torch.zeros(B, Ts, Tm)
@@ -324,6 +324,14 @@ def golden_collate():
     print("wrote", path, len(arrs), "arrays")
 
 
+def main_vctk_unsup():
+    """G12: the reference's DEFAULT VCTK yaml - multi_speaker + learn_alignment=True (aligner with speaker projections)."""
+    torch.manual_seed(0)
+    model, cfgs = build("VCTK", "transformer_fs2", learn_alignment=True)
+    vb = make_unsup_batch([21, 24, 9], 5, seed=78, multi_speaker=True)
+    run_case(model, vb, "train", "g12_vctk_unsup_step60000", with_grads=True, extra_kwargs=dict(step=60000))
+
+
 def main_liu2021():
     """G10: prosody_modeling.model_type = liu2021, supervised and with learn_alignment=True (config C5)."""
     torch.manual_seed(0)
@@ -343,7 +351,10 @@ if __name__ == "__main__":
         main_liu2021()
     elif len(sys.argv) > 1 and sys.argv[1] == "collate":
         golden_collate()
+    elif len(sys.argv) > 1 and sys.argv[1] == "vctk_unsup":
+        main_vctk_unsup()
     else:
         main()
         main_liu2021()
         golden_collate()
+        main_vctk_unsup()

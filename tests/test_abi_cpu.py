@@ -94,6 +94,18 @@ def test_liu2021_state_dict_schema_matches_reference(unsup):
         ctts_amd.CompTransTTS(pre, mc, tc)
 
 
+def test_vctk_default_yaml_schema_matches_reference():
+    """config/VCTK/model.yaml as shipped: multi_speaker + learn_alignment=True (aligner incl. key/query speaker projections)."""
+    pre, mc, tc = get_configs("VCTK")
+    mc["duration_modeling"]["learn_alignment"] = True
+    m = ctts_amd.CompTransTTS(pre, mc, tc)
+    sd, sch = m.state_dict(), schema("VCTK", "transformer_fs2", True)
+    assert set(sd) == set(sch), (set(sd) ^ set(sch))
+    for k, (shape, dtype, is_param) in sch.items():
+        assert list(sd[k].shape) == shape, k
+        assert torch.isfinite(sd[k].float()).all(), k
+
+
 def test_unsupported_block_types_raise():
     pre, mc, tc = get_configs()
     mc["block_type"] = "reformer"

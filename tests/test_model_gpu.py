@@ -439,3 +439,44 @@ def test_packed_batch_upload_and_prefetcher_feed_the_model():
     batch = got[0]
     out = m(*batch[2:], step=1)                      # speakers, texts, src_lens, max_src_len, mels, mel_lens, max_mel_len, pitch dict, ...
     assert out[0].shape == batch[6].shape and torch.isfinite(out[1]).all()
+
+
+def test_g12_vctk_multispeaker_unsupervised_matches_reference():
+    """reference default VCTK yaml (multi_speaker + learn_alignment): aligner speaker projections, device MAS, gradients."""
+    g = load_golden("g12_vctk_unsup_step60000")
+    pre, mc, tc = get_configs("VCTK")
+    mc["duration_modeling"]["learn_alignment"] = True
+    m = ctts_amd.CompTransTTS(pre, mc, tc)
+    m.load_state_dict(closed_form_sd("VCTK", unsup=True))
+    m = m.to(DEV)
+    m.train()
+    no_dropout(m)
+    b = to_device(batch_from_golden(g), DEV)
+    out = m(b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"], b["max_mel_len"], b["p_targets"],
+            b["e_targets"], None, b["attn_priors"], b["spker_embeds"], step=60000)
+    a_soft, a_hard, a_dur, a_logp = out[10]
+    assert maxerr(a_soft, g["out.attn_soft"]) < 1e-5 and maxerr(a_logp, g["out.attn_logprob"]) < 1e-3
+    assert np.array_equal(a_hard.cpu().numpy(), g["out.attn_hard"]) and np.array_equal(a_dur.cpu().numpy(), g["out.attn_hard_dur"])
+    for name, i in (("mel", 0), ("postnet_mel", 1), ("log_d", 4), ("e_pred", 3)):
+        assert maxerr(out[i], g["out." + name]) <= MEL_TOL, name
+
+    def pseudo(name, shape):
+        return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float().to(DEV)
+    mel, post, p_pred, e_pred, log_d = out[:5]
+    loss = ((post * pseudo("post", post.shape)).sum() + (mel * pseudo("mel", mel.shape)).sum()
+            + (log_d * pseudo("logd", log_d.shape)).sum() + (e_pred * pseudo("e", e_pred.shape)).sum()
+            + (p_pred["cwt"] * pseudo("cwt", p_pred["cwt"].shape)).sum()
+            + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum()
+            + (a_soft * pseudo("asoft", a_soft.shape)).sum() * 10 + (a_logp * pseudo("alogp", a_logp.shape)).sum() * 0.1)
+    loss.backward()
+    n = 0
+    for k, p in m.named_parameters():
+        if "grad.stat." + k not in g:
+            continue
+        gs = g["grad.stat." + k]
+        gr = p.grad.flatten() if p.grad is not None else torch.zeros(p.numel(), device=DEV)
+        scale = max(1.0, float(gs[1]))
+        e = max(maxerr(gr[:64], g["grad.head." + k]) / scale, abs(float(gr.double().pow(2).sum().sqrt()) - gs[1]) / scale)
+        assert e < 2e-3, (k, e)
+        n += 1
+    assert n > 170 and any("spk_proj" in k for k in dict(m.named_parameters()) if "grad.stat." + k in g)

@@ -234,3 +234,21 @@ def test_g10_liu2021_prosody(gname, unsup, training):
         assert abs(float(gr.double().pow(2).sum().sqrt()) - gs[1]) <= tol, k
         n += 1
     assert n > 80, n
+
+
+def test_g12_vctk_multispeaker_unsupervised():
+    """the reference's default VCTK yaml: multi_speaker + learn_alignment=True - aligner with speaker projections (modules.py:1188-1194)."""
+    g = load_golden("g12_vctk_unsup_step60000")
+    sd = closed_form_sd("VCTK", unsup=True)
+    pre, mc, tc = get_configs("VCTK")
+    mc["duration_modeling"]["learn_alignment"] = True
+    b = batch_from_golden(g)
+    out = R.comp_trans_tts_forward(sd, mc, pre, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"],
+                                   b["max_mel_len"], b["p_targets"], b["e_targets"], None, b["attn_priors"], b["spker_embeds"],
+                                   step=60000, training=True)
+    a_soft, a_hard, a_dur, a_logp = out[10]
+    _close(a_soft, g["out.attn_soft"], 1e-6, "attn_soft")
+    _close(a_logp, g["out.attn_logprob"], 1e-4, "attn_logprob")
+    assert np.array_equal(a_hard.numpy(), g["out.attn_hard"]) and np.array_equal(a_dur.numpy(), g["out.attn_hard_dur"])
+    _close(out[0], g["out.mel"], name="mel")
+    _close(out[1], g["out.postnet_mel"], 5e-5, name="postnet_mel")
