@@ -325,6 +325,35 @@ extern "C" int ctts_colstats(const float* x, double* sums, int rows, int C, void
   return 0;
 }
 
+namespace {
+// batch statistics from the double column sums + nn.BatchNorm running-stat update (momentum, unbiased variance), one launch
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int rows, int C, float eps, float momentum, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ num_batches) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const double mu = sums[c] / rows;
+    double var = sums[C + c] / rows - mu * mu;
+    var = var < 0.0 ? 0.0 : var;
+    const float m = (float)mu, v = (float)var;
+    mean[c] = m;
+    rstd[c] = rsqrtf(v + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (v * ((float)rows / (float)max(rows - 1, 1)));
+  }
+  if (c == 0 && num_batches) *num_batches += 1;
+}
+}  // namespace
+
+extern "C" int ctts_bn_finalize(const double* sums, int rows, int C, float eps, float momentum, float* mean, float* rstd,
+                                float* running_mean, float* running_var, int64_t* num_batches, void* stream) {
+  CTTS_REQUIRE(sums && mean && rstd && rows > 0 && C > 0, "ctts_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, rows, C, eps, momentum, mean, rstd,
+                     running_mean, running_var, (long long*)num_batches);
+  CTTS_CHECK_LAUNCH("ctts_bn_finalize");
+  return 0;
+}
+
 extern "C" int ctts_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                              float* y, int rows, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset,
                              void* stream) {

@@ -190,6 +190,18 @@ def colstats(x2d):
     return sums
 
 
+def bn_batch_stats(x2d, eps, momentum, running_mean, running_var, num_batches):
+    """train-mode BatchNorm statistics of x2d [rows,C] (+ running-stat update) -> (mean, rstd) float32 [C]; two launches"""
+    rows, Cc = x2d.shape
+    sums = colstats(x2d)
+    mean = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty_like(mean)
+    lib = _lib.load()
+    _lib.check(lib.ctts_bn_finalize(_p(sums), rows, Cc, float(eps), float(momentum), _p(mean), _p(rstd), _p(running_mean),
+                                    _p(running_var), _p(num_batches), _stream()), "ctts_bn_finalize")
+    return mean, rstd
+
+
 def bn_apply(x2d, mean, rstd, gamma, beta, act, p_drop=0.0, seed=None, drop_offset=0):
     rows, Cc = x2d.shape
     y = torch.empty_like(x2d)

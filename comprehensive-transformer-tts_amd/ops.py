@@ -366,14 +366,7 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracke
     rows = x2d.shape[0]
     if training:
         with torch.no_grad():
-            sums = K.colstats(x2d)
-            mean64 = sums[:C] / rows
-            var64 = (sums[C:] / rows - mean64 * mean64).clamp_(min=0)
-            mean, var = mean64.float(), var64.float()
-            rstd = torch.rsqrt(var + eps)
-            running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-            running_var.mul_(1 - momentum).add_(var * (rows / max(rows - 1, 1)), alpha=momentum)
-            num_batches_tracked.add_(1)
+            mean, rstd = K.bn_batch_stats(x2d, eps, momentum, running_mean, running_var, num_batches_tracked)
     else:
         mean = running_mean
         rstd = torch.rsqrt(running_var + eps)

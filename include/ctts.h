@@ -117,6 +117,10 @@ int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
  * bwd_reduce: sums[0..C) = sum dt, sums[C..2C) = sum dt*xhat with dt = dy*dropmask*act'(u).
  * bwd_apply: dx = gamma*rstd*(dt - sum_dt/rows - xhat*sum_dtxhat/rows); dgamma/dbeta from sums. */
 int ctts_colstats(const float* x, double* sums, int rows, int C, void* stream);
+/* mean / rstd of the batch from ctts_colstats sums, plus the nn.BatchNorm train-mode bookkeeping (running_mean / running_var with
+ * momentum and the unbiased variance, num_batches_tracked += 1; NULL pointers skip) - one launch instead of a dozen [C]-sized ops. */
+int ctts_bn_finalize(const double* sums, int rows, int C, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                     float* running_var, int64_t* num_batches, void* stream);
 int ctts_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   float* y, int rows, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset,
                   void* stream);
