@@ -181,7 +181,7 @@ class TextEncoder(_ConformerStack):
         self.src_word_emb = nn.Embedding(N_SYMBOLS + 1, self.d_model, padding_idx=0)
 
     def forward(self, src_seq, mask):
-        emb = self.src_word_emb(src_seq)
+        emb = ops.embedding(src_seq, self.src_word_emb.weight, 0)
         pos = self._pos(src_seq.shape[1], emb.device)
         return self.run(emb + pos.unsqueeze(0), mask, pos), emb
 

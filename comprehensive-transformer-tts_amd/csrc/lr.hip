@@ -171,3 +171,79 @@ extern "C" int ctts_positions(const void* src, int src_is_float, int64_t stride,
   CTTS_CHECK_LAUNCH("ctts_positions");
   return 0;
 }
+
+// ---------------------------------------------------------------- embedding lookup (blocks.py:10-15 Embedding, modules.py:779-788,
+// 947,958 pitch / energy embeddings): forward gather; backward without a sort: one wave per (vocabulary row, 64-id chunk) ballots the
+// chunk for its row, sums the selected gradient rows in registers and issues one atomicAdd per channel (most waves exit at once).
+namespace {
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __restrict__ ids, const float4* __restrict__ w,
+                                                             float4* __restrict__ out, int C4, int V, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / C4;
+    const int c = (int)(e - r * C4);
+    const long long id = ids[r];
+    out[e] = (id >= 0 && id < V) ? w[id * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int NC>   // floats per lane: C <= 64 * NC
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dy,
+                                                             float* __restrict__ dw, long n, int C, int V, int padding_idx) {
+  // wave = (vocabulary row v, 64-id chunk): a popular row (e.g. the unvoiced pitch bin, ~30 % of all frames) is spread over n/64 waves
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= V || v == padding_idx) return;
+  const long base = (long)blockIdx.y * 64;
+  const long p = base + lane;
+  unsigned long long m = __ballot(p < n && ids[p] == (long long)v);
+  if (!m) return;
+  float acc[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) acc[i] = 0.f;
+  while (m) {
+    const int b = __builtin_ctzll(m);
+    m &= m - 1;
+    const float* row = dy + (base + b) * C;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) acc[i] += row[c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) atomicAdd(dw + (long)v * C + c, acc[i]);
+  }
+}
+}  // namespace
+
+extern "C" int ctts_embedding_fwd(const int64_t* ids, const float* weight, float* out, int64_t n, int C, int V, void* stream) {
+  CTTS_REQUIRE(ids && weight && out && n >= 0 && C > 0 && (C % 4) == 0 && V > 0, "ctts_embedding_fwd: bad arguments (C %% 4 must be 0)");
+  const long total = (long)n * (C / 4);
+  if (total == 0) return 0;
+  const int blocks = (int)min((total + 255) / 256, (long)4096);
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, (const float4*)weight,
+                     (float4*)out, C / 4, V, total);
+  CTTS_CHECK_LAUNCH("ctts_embedding_fwd");
+  return 0;
+}
+
+extern "C" int ctts_embedding_bwd(const int64_t* ids, const float* dy, float* dweight, int64_t n, int C, int V, int padding_idx,
+                                  int accumulate, void* stream) {
+  CTTS_REQUIRE(ids && dy && dweight && n >= 0 && C > 0 && C <= 512 && V > 0, "ctts_embedding_bwd: bad arguments (C <= 512)");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)V * C, st) != hipSuccess) {
+    ctts_set_error("ctts_embedding_bwd: memset failed");
+    return -2;
+  }
+  if (n == 0) return 0;
+  CTTS_REQUIRE((n + 63) / 64 <= 65535, "ctts_embedding_bwd: more than 4 M ids per call");
+  const dim3 grid((V + 3) / 4, (unsigned)((n + 63) / 64)), block(256);
+  const long long* idp = (const long long*)ids;
+  if (C <= 64) hipLaunchKernelGGL((embedding_bwd_kernel<1>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx);
+  else if (C <= 256) hipLaunchKernelGGL((embedding_bwd_kernel<4>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx);
+  else hipLaunchKernelGGL((embedding_bwd_kernel<8>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx);
+  CTTS_CHECK_LAUNCH("ctts_embedding_bwd");
+  return 0;
+}

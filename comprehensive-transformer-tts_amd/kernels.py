@@ -471,3 +471,22 @@ def adam_clip_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, max_norm, st
     _lib.check(lib.ctts_adam_clip_step(_p(_f32c(p, "p")), _p(_f32c(g, "g")), _p(_f32c(m, "m")), _p(_f32c(v, "v")), p.numel(), _p(lr),
                                        float(beta1), float(beta2), float(eps), float(weight_decay), float(max_norm), _p(state),
                                        _stream()), "ctts_adam_clip_step")
+
+
+def embedding_fwd(ids, weight):
+    """ids int64 [...], weight [V,C] -> [..., C]"""
+    V, Cc = weight.shape
+    ids = ids.contiguous()
+    out = torch.empty(*ids.shape, Cc, dtype=torch.float32, device=weight.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_embedding_fwd(_p(ids), _p(_f32c(weight, "weight")), _p(out), ids.numel(), Cc, V, _stream()), "ctts_embedding_fwd")
+    return out
+
+
+def embedding_bwd(ids, dy, V, padding_idx=-1, acc_into=None):
+    Cc = dy.shape[-1]
+    dw = torch.empty(V, Cc, dtype=torch.float32, device=dy.device) if acc_into is None else acc_into
+    lib = _lib.load()
+    _lib.check(lib.ctts_embedding_bwd(_p(ids), _p(_f32c(dy, "dy")), _p(dw), ids.numel(), Cc, V, int(padding_idx),
+                                      int(acc_into is not None), _stream()), "ctts_embedding_bwd")
+    return dw

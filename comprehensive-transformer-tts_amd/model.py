@@ -184,7 +184,7 @@ class TextEncoder(FFTBlocks):
         self.d_model = c["encoder_hidden"]
 
     def forward(self, txt_tokens, encoder_padding_mask):
-        emb = self.embed_scale * self.embed_tokens(txt_tokens)
+        emb = self.embed_scale * ops.embedding(txt_tokens, self.embed_tokens.weight, 0)
         x = emb + self.embed_positions.lookup(txt_tokens.contiguous(), 1)
         p = self.dropout if self.training else 0.0
         x = ops.rowscale_dropout(x, None, p, self.drop_ctx if p > 0 else None)
@@ -494,7 +494,7 @@ class VarianceAdaptor(nn.Module):
             f0_denorm = 2 ** f0
             f0_denorm = torch.where(uv > 0, torch.zeros_like(f0_denorm), f0_denorm)
             pitch_ids = f0_to_coarse(f0_denorm)
-        pitch_embedding = self.pitch_embed(pitch_ids)
+        pitch_embedding = ops.embedding(pitch_ids, self.pitch_embed.weight, 0)
         pitch_prediction = {"pitch_pred": None, "f0_denorm": f0_denorm, "cwt": cwt, "f0_mean": f0_mean, "f0_std": f0_std}
         # ---- energy (phoneme level)   modules.py:950-960,1095-1099 (no gradient scaling: :951 is a no-op)
         energy_prediction = self.energy_predictor(x_org, squeeze=True)
@@ -503,7 +503,7 @@ class VarianceAdaptor(nn.Module):
         else:
             energy_prediction = energy_prediction * e_control
             e_ids = torch.bucketize(energy_prediction.detach(), self.energy_bins)
-        energy_embedding = self.energy_embedding(e_ids)
+        energy_embedding = ops.embedding(e_ids, self.energy_embedding.weight, 0)
         e_frames, _, _ = ops.length_regulate(energy_embedding, d_rounded, max_len)
         x = x + pitch_embedding + e_frames
         return (x, pitch_target, pitch_prediction, energy_target, energy_prediction, log_d, d_rounded, mel_len, mel_mask,

@@ -638,8 +638,8 @@ class _Im2Col3x3s2(torch.autograd.Function):
 
 def conv2d_3x3s2(x, w, b):
     """nn.Conv2d(kernel 3x3, stride (1,2), padding (1,1)) of ReferenceEncoder (modules.py:351-361) on channel-last x [B,T,W,Cin];
-    w [Cout,Cin,3,3] (reference layout), b [Cout] -> [B,T,Wo,Cout].  Patch matrix (csrc/prosody.hip) + implicit... explicit GEMM on
-    MFMA: forward, dgrad (then col2im) and wgrad all go through ctts_gemm."""
+    w [Cout,Cin,3,3] (reference layout), b [Cout] -> [B,T,Wo,Cout].  Patch matrix (csrc/prosody.hip) + GEMM on MFMA: forward,
+    dgrad (then col2im) and wgrad all go through ctts_gemm."""
     B, T, W, Cin = x.shape
     Cout = w.shape[0]
     col = _Im2Col3x3s2.apply(x) if x.requires_grad else K.im2col_3x3s2(x.contiguous())
@@ -772,3 +772,26 @@ def forward_sum_nll(attn_logprob, in_lens, out_lens, blank_logprob=-1.0):
     """attn_logprob [B,Tm,Ts] (device) -> nll [B]: -log p(1..K_b | frames) with a blank of log-prob `blank_logprob` prepended
     to every frame's logits and the log-softmax taken over [blank, first K_b tokens]."""
     return _ForwardSum.apply(attn_logprob, in_lens, out_lens, float(blank_logprob))
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, weight, padding_idx):
+        ids = ids.contiguous()
+        ctx.save_for_backward(ids, weight)
+        ctx.padding_idx = padding_idx
+        return K.embedding_fwd(ids, weight.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, weight = ctx.saved_tensors
+        if _fusable(weight):
+            K.embedding_bwd(ids, dy.contiguous(), weight.shape[0], ctx.padding_idx, acc_into=weight.grad)
+            return None, None, None
+        return None, K.embedding_bwd(ids, dy.contiguous(), weight.shape[0], ctx.padding_idx), None
+
+
+def embedding(ids, weight, padding_idx=-1):
+    """nn.Embedding(padding_idx=...) lookup (blocks.py:10-15; pitch / energy embeddings modules.py:947,958): gather forward, sort-free
+    backward (torch sorts the ids and runs a 110 us kernel for the 16 k pitch ids)."""
+    return _Embedding.apply(ids, weight, -1 if padding_idx is None else int(padding_idx))

@@ -177,6 +177,14 @@ int ctts_relpos_softmax_bwd(const float* P, float* dPd, int nbatch, int T, float
                             uint32_t drop_offset, void* stream);
 int ctts_relshift_bwd(const float* dS, float* dPS, int nbatch, int T, void* stream);
 
+/* Embedding lookup (model/transformers/blocks.py:10-15, model/modules.py:779-788,947,958).
+ * fwd: out[r,:] = weight[ids[r],:] (ids int64 [n], weight [V,C], C % 4 == 0).
+ * bwd: dweight[v,:] (+)= sum over r with ids[r] == v of dy[r,:], row padding_idx forced to zero (nn.Embedding(padding_idx=..));
+ *      one wave per (vocabulary row, 64-id chunk), register partial sums + one atomicAdd per channel.  padding_idx < 0: none. */
+int ctts_embedding_fwd(const int64_t* ids, const float* weight, float* out, int64_t n, int C, int V, void* stream);
+int ctts_embedding_bwd(const int64_t* ids, const float* dy, float* dweight, int64_t n, int C, int V, int padding_idx, int accumulate,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Unsupervised duration modelling.
  * ctts_neg_sqdist: AlignmentEncoder scores out[b,t,s] = -temp * sum_c (q[b,t,c]-k[b,s,c])^2  (model/modules.py:1199-1200), channel-last.

@@ -561,3 +561,21 @@ def test_gru_group_matches_separate_grus():
         close(grp[i], sep[i], 1e-6, f"gru_group out {i}")
         for a, b in zip([t.grad for t in ps[i]] + [xs[i].grad], ref[i]):
             close(a, b, 1e-5, f"gru_group grad {i}")
+
+
+@pytest.mark.parametrize("V,C,shape", [(300, 256, (16, 1024)), (361, 256, (3, 50)), (17, 64, (5,)), (9, 384, (4, 7))])
+def test_embedding_fwd_bwd_vs_torch(V, C, shape):
+    """ctts_embedding_fwd/bwd against F.embedding with padding_idx=0 (zero gradient row), heavy index repetition included."""
+    g = torch.Generator().manual_seed(V + C)
+    ids = torch.randint(0, V, shape, generator=g)
+    ids.view(-1)[::3] = 1                                   # one very popular row
+    w = rnd(V, C, seed=5).requires_grad_(True)
+    gy = rnd(*shape, C, seed=6)
+    ref = F.embedding(ids, w.double(), padding_idx=0)
+    ref.backward(gy.double())
+    wd = w.detach().to(DEV).requires_grad_(True)
+    out = ops.embedding(ids.to(DEV), wd, 0)
+    assert torch.equal(out.cpu(), F.embedding(ids, w.detach()))
+    out.backward(gy.to(DEV))
+    close(wd.grad, w.grad, 1e-5, "embedding grad")
+    assert float(wd.grad[0].abs().max()) == 0.0
