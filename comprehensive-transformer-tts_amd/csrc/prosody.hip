@@ -232,6 +232,155 @@ __global__ __launch_bounds__((3 * H + 63) / 64 * 64) void gru_bwd_kernel(const f
   }
 }
 
+// ---- H = 32 in ONE wave (the Tm-step reference-encoder GRUs): no workgroup barriers at all.  Lane l < 32 owns unit j = l: gate rows
+// r_j and n_j; lane 32 + j owns row z_j.  h is broadcast through LDS (in-order within a wave), z crosses the halves by one shuffle, each
+// lane prefetches its own gi rows 8 steps ahead in registers.
+__global__ __launch_bounds__(64) void gru_fwd_wave32_kernel(const float* __restrict__ gi, const float* __restrict__ whh,
+                                                             const float* __restrict__ bhh, float* __restrict__ out,
+                                                             float* __restrict__ gates, int T, int ndir, int rev_mask) {
+  constexpr int H = 32;
+  __shared__ __attribute__((aligned(16))) float s_h[H];
+  const int b = blockIdx.x, dir = blockIdx.y, l = threadIdx.x, half = l >> 5, j = l & 31;
+  const bool rev = (rev_mask >> dir) & 1;
+  const int row0 = half ? H + j : j, row1 = 2 * H + j;          // lanes >= 32 compute row1 redundantly (never used)
+  float w0[H], w1[H];
+  {
+    const float* a = whh + ((long)dir * 3 * H + row0) * H;
+    const float* c = whh + ((long)dir * 3 * H + row1) * H;
+#pragma unroll
+    for (int k = 0; k < H; ++k) { w0[k] = a[k]; w1[k] = c[k]; }
+  }
+  const float b0 = bhh[dir * 3 * H + row0], b1 = bhh[dir * 3 * H + row1];
+  const long gs = (long)ndir * 3 * H;
+  const float* gib = gi + (long)b * T * gs + (long)dir * 3 * H;
+  float n0[GRU_CH], n1[GRU_CH];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i) {
+      const int s = c0 + i;
+      const float* p = gib + (long)(rev ? T - 1 - s : s) * gs;
+      n0[i] = s < T ? p[row0] : 0.f;
+      n1[i] = s < T ? p[row1] : 0.f;
+    }
+  };
+  load_chunk(0);
+  float h = 0.f;
+  for (int c0 = 0; c0 < T; c0 += GRU_CH) {
+    float g0[GRU_CH], g1[GRU_CH];
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i) { g0[i] = n0[i]; g1[i] = n1[i]; }
+    if (c0 + GRU_CH < T) load_chunk(c0 + GRU_CH);
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i) {
+      const int s = c0 + i;
+      if (s >= T) break;
+      const int t = rev ? T - 1 - s : s;
+      if (half == 0) s_h[j] = h;
+      __builtin_amdgcn_wave_barrier();                       // one wave: LDS executes in order, this only pins the compiler's order
+      float a0 = b0, a1 = b1, c0_ = 0.f, c1_ = 0.f, d0_ = 0.f, d1_ = 0.f, e0_ = 0.f, e1_ = 0.f;   // 8 independent FMA chains of 8
+#pragma unroll
+      for (int k = 0; k < H; k += 4) {
+        const float4 hv = *reinterpret_cast<const float4*>(s_h + k);          // same address in all lanes: LDS broadcast
+        a0 = fmaf(w0[k], hv.x, a0); c0_ = fmaf(w0[k + 1], hv.y, c0_); d0_ = fmaf(w0[k + 2], hv.z, d0_); e0_ = fmaf(w0[k + 3], hv.w, e0_);
+        a1 = fmaf(w1[k], hv.x, a1); c1_ = fmaf(w1[k + 1], hv.y, c1_); d1_ = fmaf(w1[k + 2], hv.z, d1_); e1_ = fmaf(w1[k + 3], hv.w, e1_);
+      }
+      a0 = (a0 + c0_) + (d0_ + e0_);
+      a1 = (a1 + c1_) + (d1_ + e1_);
+      const float sg = sigmoidf_(g0[i] + a0);            // r_j in lane j, z_j in lane 32 + j
+      const float z = __shfl(sg, j + 32, 64);
+      if (half == 0) {
+        const float n = tanhf_(g1[i] + sg * a1);
+        h = (1.0f - z) * n + z * h;
+        const long o = ((long)b * T + t) * ndir + dir;
+        out[o * H + j] = h;
+        if (gates) {
+          float* gp = gates + o * 4 * H;
+          gp[j] = sg; gp[H + j] = z; gp[2 * H + j] = n; gp[3 * H + j] = a1;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// BPTT, one wave: lane j < 32 owns unit j (elementwise part) and the W_hh column-j segments of the r and n rows; lane 32 + j the z rows.
+__global__ __launch_bounds__(64) void gru_bwd_wave32_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                             const float* __restrict__ gates, const float* __restrict__ whh,
+                                                             float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ hprev,
+                                                             int T, int ndir, int rev_mask) {
+  constexpr int H = 32;
+  __shared__ __attribute__((aligned(16))) float s_dgh[3 * H];
+  const int b = blockIdx.x, dir = blockIdx.y, l = threadIdx.x, half = l >> 5, j = l & 31;
+  const bool rev = (rev_mask >> dir) & 1;
+  const int p0 = half ? 1 : 0;                               // gate block whose rows this lane contracts first (r | z), then n (lanes < 32)
+  float wa[H], wn[H];
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    wa[k] = whh[((long)dir * 3 * H + p0 * H + k) * H + j];
+    wn[k] = whh[((long)dir * 3 * H + 2 * H + k) * H + j];
+  }
+  float nx[GRU_CH][6];
+  auto load_chunk = [&](int c0) {                            // chunk element i is processing step s = T-1-(c0+i); lanes < 32 only
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i) {
+      const int s = T - 1 - (c0 + i);
+      const bool ok = half == 0 && s >= 0;
+      const int t = rev ? T - 1 - s : s;
+      const long o = ((long)b * T + (ok ? t : 0)) * ndir + dir;
+      const float* gp = gates + o * 4 * H;
+      nx[i][0] = ok ? gp[j] : 0.f; nx[i][1] = ok ? gp[H + j] : 0.f; nx[i][2] = ok ? gp[2 * H + j] : 0.f; nx[i][3] = ok ? gp[3 * H + j] : 0.f;
+      nx[i][4] = ok ? dout[o * H + j] : 0.f;
+      nx[i][5] = (ok && s > 0) ? out[(((long)b * T + (rev ? t + 1 : t - 1)) * ndir + dir) * H + j] : 0.f;
+    }
+  };
+  load_chunk(0);
+  float dh = 0.f;
+  for (int c0 = 0; c0 < T; c0 += GRU_CH) {
+    float cur[GRU_CH][6];
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) cur[i][q] = nx[i][q];
+    if (c0 + GRU_CH < T) load_chunk(c0 + GRU_CH);
+#pragma unroll
+    for (int i = 0; i < GRU_CH; ++i) {
+      const int s = T - 1 - (c0 + i);
+      if (s < 0) break;
+      const int t = rev ? T - 1 - s : s;
+      float dcarry = 0.f;
+      if (half == 0) {
+        const float r = cur[i][0], z = cur[i][1], n = cur[i][2], ghn = cur[i][3], hp = cur[i][5];
+        const float d = dh + cur[i][4];
+        const float dn = d * (1.0f - z);
+        const float dz = d * (hp - n);
+        dcarry = d * z;
+        const float dnp = dn * (1.0f - n * n);
+        const float dzp = dz * z * (1.0f - z);
+        const float drp = dnp * ghn * r * (1.0f - r);
+        const long o = ((long)b * T + t) * ndir + dir;
+        float* a = dgi + o * 3 * H;
+        a[j] = drp; a[H + j] = dzp; a[2 * H + j] = dnp;
+        float* c = dgh + o * 3 * H;
+        c[j] = drp; c[H + j] = dzp; c[2 * H + j] = dnp * r;
+        s_dgh[j] = drp; s_dgh[H + j] = dzp; s_dgh[2 * H + j] = dnp * r;
+        hprev[o * H + j] = hp;
+      }
+      __builtin_amdgcn_wave_barrier();
+      float pa = 0.f, pn = 0.f;
+#pragma unroll
+      for (int k = 0; k < H; k += 4) {
+        const float4 va = *reinterpret_cast<const float4*>(s_dgh + p0 * H + k);       // r block (lanes < 32) / z block (lanes >= 32)
+        const float4 vn = *reinterpret_cast<const float4*>(s_dgh + 2 * H + k);
+        pa = fmaf(wa[k], va.x, pa); pa = fmaf(wa[k + 1], va.y, pa); pa = fmaf(wa[k + 2], va.z, pa); pa = fmaf(wa[k + 3], va.w, pa);
+        pn = fmaf(wn[k], vn.x, pn); pn = fmaf(wn[k + 1], vn.y, pn); pn = fmaf(wn[k + 2], vn.z, pn); pn = fmaf(wn[k + 3], vn.w, pn);
+      }
+      const float pz = __shfl(pa, j + 32, 64);
+      dh = dcarry + pa + pn + pz;                            // meaningful in lanes < 32
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void softmax_rect_kernel(float* __restrict__ S, const float* __restrict__ P,
                                                             const int32_t* __restrict__ klens, const int32_t* __restrict__ qlens,
@@ -312,7 +461,11 @@ extern "C" int ctts_gru_fwd(const float* gi, const float* whh, const float* bhh,
   hipStream_t st = (hipStream_t)stream;
   switch (H) {
     case 16: return launch_gru_fwd<16>(gi, whh, bhh, out, gates, B, T, ndir, rev_mask, st);
-    case 32: return launch_gru_fwd<32>(gi, whh, bhh, out, gates, B, T, ndir, rev_mask, st);
+    case 32:
+      if (getenv("CTTS_GRU_MULTIWAVE")) return launch_gru_fwd<32>(gi, whh, bhh, out, gates, B, T, ndir, rev_mask, st);
+      hipLaunchKernelGGL(gru_fwd_wave32_kernel, dim3(B, ndir), dim3(64), 0, st, gi, whh, bhh, out, gates, T, ndir, rev_mask);
+      CTTS_CHECK_LAUNCH("ctts_gru_fwd(wave32)");
+      return 0;
     case 64: return launch_gru_fwd<64>(gi, whh, bhh, out, gates, B, T, ndir, rev_mask, st);
     case 128: return launch_gru_fwd<128>(gi, whh, bhh, out, gates, B, T, ndir, rev_mask, st);
     default:
@@ -329,7 +482,11 @@ extern "C" int ctts_gru_bwd(const float* dout, const float* out, const float* ga
   hipStream_t st = (hipStream_t)stream;
   switch (H) {
     case 16: return launch_gru_bwd<16>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, rev_mask, st);
-    case 32: return launch_gru_bwd<32>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, rev_mask, st);
+    case 32:
+      if (getenv("CTTS_GRU_MULTIWAVE")) return launch_gru_bwd<32>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, rev_mask, st);
+      hipLaunchKernelGGL(gru_bwd_wave32_kernel, dim3(B, ndir), dim3(64), 0, st, dout, out, gates, whh, dgi, dgh, hprev, T, ndir, rev_mask);
+      CTTS_CHECK_LAUNCH("ctts_gru_bwd(wave32)");
+      return 0;
     case 64: return launch_gru_bwd<64>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, rev_mask, st);
     case 128: return launch_gru_bwd<128>(dout, out, gates, whh, dgi, dgh, hprev, B, T, ndir, rev_mask, st);
     default:
