@@ -82,6 +82,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// Backward of the GEMM epilogue y = rowscale * (R + drop(act(alpha * (acc + bias)))) in ONE pass over dY:
+//   gm = dY * rowscale (the residual's gradient, optional output), dZ = gm * drop * act'(Z), dbias (+)= bias_scale * colsum(dZ).
+// Replaces the rowscale_dropout -> act_dropout_bwd -> colsum chain (three reads of a [rows, C] tensor, two intermediate writes).
+__global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ rowscale,
+                                                            const float* __restrict__ z, float* __restrict__ dz, float* __restrict__ gm,
+                                                            float* __restrict__ dbias, long rows, int C, int act, float p_drop,
+                                                            const uint64_t* seed, uint32_t drop_offset, float bias_scale) {
+  __shared__ float s[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+  const long stripe = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = blockIdx.y * stripe, r1 = min(rows, r0 + stripe);
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  float a = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (long r = r0 + ty; r < r1; r += 4) {
+      const long e = r * C + c;
+      float g = dy[e];
+      if (rowscale) g *= rowscale[r];
+      if (gm) gm[e] = g;
+      if (do_drop) g *= ctts_drop_scale(dkey, (uint32_t)e, p_drop, inv_keep);
+      if (z) g *= ctts_act_grad(z[e], act);
+      dz[e] = g;
+      a += g;
+    }
+  }
+  if (!dbias) return;
+  s[ty][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    const int l = threadIdx.x;
+    atomicAdd(dbias + c, bias_scale * (s[0][l] + s[1][l] + s[2][l] + s[3][l]));
+  }
+}
+
 // w[Cout][Cin][K] <-> GEMM-friendly layouts
 __global__ void conv_weight_repack_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int k,
                                           int mode, long total) {
@@ -190,6 +227,24 @@ extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int6
   const int gy = (int)max((long)1, min((long)max(1, 1024 / gx), Rv / 64));
   hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, out, Rv, Cv, C, (long)ld * k, scale);
   CTTS_CHECK_LAUNCH("ctts_colsum");
+  return 0;
+}
+
+extern "C" int ctts_epilogue_bwd(const float* dy, const float* rowscale, const float* z, float* dz, float* gm, float* dbias,
+                                 int64_t rows, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, float bias_scale,
+                                 int accumulate_bias, void* stream) {
+  CTTS_REQUIRE(dy && dz && rows >= 0 && C > 0 && p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed), "ctts_epilogue_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dbias && !accumulate_bias && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) {
+    ctts_set_error("ctts_epilogue_bwd: memset failed");
+    return -2;
+  }
+  if (rows == 0) return 0;
+  const int gx = (C + 63) / 64;
+  const int gy = (int)max((long)1, min((long)max(1, 2048 / gx), (long)rows / 32));
+  hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(gx, gy), dim3(256), 0, st, dy, rowscale, act ? z : nullptr, dz, gm, dbias, (long)rows, C, act,
+                     p_drop, seed, drop_offset, bias_scale);
+  CTTS_CHECK_LAUNCH("ctts_epilogue_bwd");
   return 0;
 }
 

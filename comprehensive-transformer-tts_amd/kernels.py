@@ -490,3 +490,20 @@ def embedding_bwd(ids, dy, V, padding_idx=-1, acc_into=None):
     _lib.check(lib.ctts_embedding_bwd(_p(ids), _p(_f32c(dy, "dy")), _p(dw), ids.numel(), Cc, V, int(padding_idx),
                                       int(acc_into is not None), _stream()), "ctts_embedding_bwd")
     return dw
+
+
+def epilogue_bwd(dy, rowscale=None, z=None, act=0, p_drop=0.0, seed=None, drop_offset=0, want_gm=False, want_bias=False,
+                 bias_scale=1.0, bias_acc_into=None):
+    """one-pass backward of the GEMM epilogue -> (dZ, gm or None, dbias or None); see include/ctts.h ctts_epilogue_bwd"""
+    Cc = dy.shape[-1]
+    rows = dy.numel() // Cc
+    dz = torch.empty_like(dy)
+    gm = torch.empty_like(dy) if want_gm else None
+    dbias = None
+    if want_bias:
+        dbias = bias_acc_into if bias_acc_into is not None else torch.empty(Cc, dtype=torch.float32, device=dy.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_epilogue_bwd(_p(_f32c(dy, "dy")), _p(rowscale), _p(z if act else None), _p(dz), _p(gm), _p(dbias), rows, Cc,
+                                     int(act), float(p_drop), _p(seed), int(drop_offset), float(bias_scale),
+                                     int(bias_acc_into is not None), _stream()), "ctts_epilogue_bwd")
+    return dz, gm, dbias

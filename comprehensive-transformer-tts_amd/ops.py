@@ -134,18 +134,23 @@ class _LinearConv(torch.autograd.Function):
         Cin = x.shape[-1]
         M = x.numel() // Cin
         N = w.shape[0]
-        gm = K.rowscale_dropout(dY, rowscale) if rowscale is not None else dY
-        d_res = gm if has_res else None
-        if act == ACT_NONE:
-            dZ = K.rowscale_dropout(dY, rowscale, p_drop, seed, drop_offset) if p_drop > 0 else gm
-        else:
-            dZ = K.act_dropout_bwd(gm, Z, act, p_drop, seed, drop_offset)
         dX = dW = dB = None
-        if has_bias and ctx.needs_input_grad[2]:
-            if _fusable(b):
-                K.colsum(dZ.view(M, N), scale=alpha, acc_into=b.grad)
-            else:
-                dB = K.colsum(dZ.view(M, N), scale=alpha)
+        want_bias = has_bias and ctx.needs_input_grad[2]
+        fuse_bias = want_bias and _fusable(b)
+        if rowscale is None and act == ACT_NONE and p_drop == 0:
+            dZ, d_res = dY, (dY if has_res else None)          # plain linear: nothing to undo
+            if want_bias:
+                if fuse_bias:
+                    K.colsum(dZ.view(M, N), scale=alpha, acc_into=b.grad)
+                else:
+                    dB = K.colsum(dZ.view(M, N), scale=alpha)
+        else:
+            # one pass: gm = dY * rowscale (gradient of the residual), dZ = gm * drop * act'(Z), bias gradient = alpha * colsum(dZ)
+            dZ, gm, dBn = K.epilogue_bwd(dY, rowscale, Z, act, p_drop, seed, drop_offset, want_gm=has_res and rowscale is not None,
+                                         want_bias=want_bias, bias_scale=alpha, bias_acc_into=b.grad if fuse_bias else None)
+            d_res = (gm if rowscale is not None else dY) if has_res else None
+            if want_bias and not fuse_bias:
+                dB = dBn
         if ksize:
             T = x.shape[-2]
             pad = (ksize - 1) // 2

@@ -71,6 +71,13 @@ typedef struct ctts_gemm_desc {
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
 
+/* Backward of the ctts_gemm epilogue in one pass over dY [rows,C]:  gm = dY * rowscale[row] (optional output = gradient of the
+ * residual R), dZ = gm * dropout_mask(seed, drop_offset, element) / (1-p) * act'(Z) (act as in ctts_gemm_desc; Z NULL or act 0: factor 1),
+ * dbias[c] (+)= bias_scale * sum_rows dZ[.,c] (optional; bias_scale = the epilogue's alpha).  Any of rowscale, z, gm, dbias may be NULL. */
+int ctts_epilogue_bwd(const float* dy, const float* rowscale, const float* z, float* dz, float* gm, float* dbias, int64_t rows, int C,
+                      int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, float bias_scale, int accumulate_bias,
+                      void* stream);
+
 /* m-tile schedule for padded-row skipping (see ctts_gemm_desc.tile_map): a 64-row tile is inactive when all its rows (b,t) belong to one
  * utterance b and t >= row_lens[b] + row_halo.  tile_map: 1 + ceil(M/64) int32. */
 int ctts_row_tile_map(const int32_t* row_lens, int row_T, int row_halo, int M, int32_t* tile_map, void* stream);
