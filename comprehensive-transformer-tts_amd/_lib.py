@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("rowscale", _vp),
         ("row_lens", _vp), ("row_T", _i32), ("row_halo", _i32),
         ("tile_map", _vp),
+        ("tile_group_n", _i32),
     ]
 
 

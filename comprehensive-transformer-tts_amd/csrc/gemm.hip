@@ -607,7 +607,13 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   if (BM == 64 && A_KC && d.tile_map && d.tile_map != reinterpret_cast<const int32_t*>(1)) {
     // device-built schedule: active m-tiles first, natural workgroup order (round-robin over the XCDs)
     wg = blockIdx.x;
-    const int r = wg / tiles_n;
+    int r = wg / tiles_n;
+    if (d.tile_group_n > 0) {                     // XCD-grouped order (validated on the host): see ctts_gemm_desc.tile_group_n
+      const int g = d.tile_group_n, ngroups = tiles_n / g, mways = 8 / ngroups;
+      const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+      r = (i / g) * mways + x / ngroups;
+      wg = r * tiles_n + (x % ngroups) * g + i % g;
+    }
     tm = d.tile_map[1 + r];
     scheduled_active = r < d.tile_map[0];
   } else if (d.tile_map == reinterpret_cast<const int32_t*>(1)) {      // tuning knob CTTS_NATURAL_ORDER: plain blockIdx order
@@ -834,6 +840,18 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : d.nb0 * d.nb1);
   static const int force_tile = getenv("CTTS_FORCE_TILE") ? atoi(getenv("CTTS_FORCE_TILE")) : 0;   // tuning knob
   static const bool natural = getenv("CTTS_NATURAL_ORDER") != nullptr;
+  // XCD-grouped order for scheduled launches: default 4 n-groups (XCD x: n-group x % 4, every second scheduled m-tile) - halves the
+  // L2-miss traffic of the FFN conv (FETCH_SIZE 441 -> 195 MB per launch) at unchanged time; CTTS_TILE_GROUP=<g> overrides, 0 = off.
+  static const int tile_group = getenv("CTTS_TILE_GROUP") ? atoi(getenv("CTTS_TILE_GROUP")) : -1;
+  d.tile_group_n = 0;
+  if (tile_group != 0 && d.tile_map && d.tile_map != reinterpret_cast<const int32_t*>(1)) {
+    const int tn = (d.N + 63) / 64, tmn = (d.M + 63) / 64;
+    const int g = tile_group > 0 ? tile_group : ((tn >= 8 && tn % 4 == 0) ? tn / 4 : 0);
+    if (g > 0 && tn % g == 0) {
+      const int ng = tn / g;
+      if ((ng == 1 || ng == 2 || ng == 4 || ng == 8) && tmn % (8 / ng) == 0 && ((long)tmn * tn) % 8 == 0) d.tile_group_n = g;
+    }
+  }
   // CTTS_TN_NATURAL: plain blockIdx order for the weight-gradient (TN, split-K) launches only.  4-12 % faster in the isolated
   // micro-benchmark (96.6 -> 86 us FFN linear, 711 -> 683 us FFN conv) - in-step effect measured separately, off by default.
   static const bool tn_natural = getenv("CTTS_TN_NATURAL") != nullptr;

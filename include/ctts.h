@@ -67,6 +67,10 @@ typedef struct ctts_gemm_desc {
    * the 8 XCDs (a fixed permutation leaves a +-10 % imbalance of active tiles per XCD), and each XCD only sees tiles_n / 8 weight
    * panels.  NULL = built-in scrambled order. */
   const int32_t* tile_map;
+  /* with tile_map: n-tiles per XCD group (0 = plain order).  g > 0 (tiles_n % g == 0, tiles_n / g in {1,2,4,8}): XCD x works on the g
+   * n-tiles of group x % (tiles_n/g) and on every (8*g/tiles_n)-th scheduled m-tile - trades weight-panel against activation-tile
+   * footprint in the XCD's 4 MiB L2. */
+  int32_t tile_group_n;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
