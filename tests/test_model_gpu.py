@@ -480,3 +480,42 @@ def test_g12_vctk_multispeaker_unsupervised_matches_reference():
         assert e < 2e-3, (k, e)
         n += 1
     assert n > 170 and any("spk_proj" in k for k in dict(m.named_parameters()) if "grad.stat." + k in g)
+
+
+@pytest.mark.parametrize("src_lens,fpp", [([1], 1), ([1, 1], 3), ([2, 1, 3], 1), ([128], 8)])
+def test_edge_shapes_vs_oracle(src_lens, fpp):
+    """degenerate and extreme shapes: single phoneme / single frame / batch of one / one full-length utterance (train-mode BN
+    statistics over as few as one row), HIP forward + backward against the CPU oracle."""
+    torch.manual_seed(11)
+    m, (pre, mc, tc) = build()
+    m.train()
+    no_dropout(m)
+    batch = make_batch(src_lens, fpp, seed=5)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    out = m(*as_model_args(to_device(batch, DEV)))
+    ref = R.comp_trans_tts_forward(sd, mc, pre, *as_model_args(batch), training=True)
+    rows = batch["mels"].shape[0] * batch["mels"].shape[1]
+    tol = MEL_TOL if rows > 4 else 5e-2          # BatchNorm over <= 4 rows divides by a near-zero variance: ill-conditioned in any arithmetic
+    assert maxerr(out[0], ref[0].detach().numpy()) <= MEL_TOL
+    assert maxerr(out[1], ref[1].detach().numpy()) <= tol
+    assert torch.equal(out[9].cpu(), ref[9]) and torch.equal(out[7].cpu(), ref[7])
+    (out[0].abs().mean() + out[1].abs().mean() + out[4].pow(2).mean()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_conformer_decoder_crops_to_max_seq_len_in_training():
+    """conformer.py:148-154: the decoder (and its mask) is cropped to max_seq_len in training; the returned mel is shorter than
+    the padded targets - reproduced with max_seq_len shrunk to 40 so that the crop is exercised on a small batch."""
+    torch.manual_seed(12)
+    pre, mc, tc = get_configs()
+    mc["block_type"] = "conformer"
+    mc["max_seq_len"] = 40
+    m = ctts_amd.CompTransTTS(pre, mc, tc).to(DEV)
+    m.train()
+    no_dropout(m)
+    batch = make_batch([9, 7], 6, seed=6)            # mel lengths 54 / 42 > 40
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    out = m(*as_model_args(to_device(batch, DEV)))
+    ref = R.comp_trans_tts_forward_conformer(sd, mc, pre, *as_model_args(batch), training=True)
+    assert out[0].shape[1] == 40 == ref[0].shape[1] and out[7].shape[1] == 40
+    assert maxerr(out[0], ref[0].detach().numpy()) <= MEL_TOL and maxerr(out[1], ref[1].detach().numpy()) <= MEL_TOL
