@@ -396,6 +396,22 @@ __device__ __forceinline__ void gemm_epilogue(const ctts_gemm_desc& d, floatx16 
   float inv_keep = 1.f;
   if (do_drop) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
   const uint32_t zoff = (uint32_t)z * (uint32_t)d.M * (uint32_t)d.N;
+  if (d.E) {           // fused softmax backward: dS = P * (dP - D)
+    const float* Eb = d.E + (Cb - d.C);
+    const float* rs = d.rowsub + (long)z * d.M;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = col0 + wn0 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < Mv && n < Nv) Cb[(long)m * d.ldc + n] = Eb[(long)m * d.ldc + n] * (alpha * acc[i][j][r] - rs[m]);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -836,6 +852,8 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
     CTTS_REQUIRE(d.conv_on_b ? (!d.a_kc && !d.b_kc) : (d.a_kc != 0), "ctts_gemm: conv view on an unsupported operand layout");
   }
   CTTS_REQUIRE(d.p_drop >= 0.f && d.p_drop < 1.f, "ctts_gemm: p_drop out of range");
+  CTTS_REQUIRE(!d.E || (d.rowsub && d.split_k <= 1 && !d.bias && !d.act && d.p_drop == 0.f && !d.R && !d.rowscale && !d.Z),
+               "ctts_gemm: the E/rowsub epilogue excludes bias, activation, dropout, residual, rowscale and split-K");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : d.nb0 * d.nb1);
   static const int force_tile = getenv("CTTS_FORCE_TILE") ? atoi(getenv("CTTS_FORCE_TILE")) : 0;   // tuning knob

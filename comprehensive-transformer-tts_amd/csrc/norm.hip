@@ -394,6 +394,34 @@ extern "C" int ctts_bn_bwd_apply(const float* dy, const float* x, const float* m
   return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void rowdot_heads_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ out, int T, int H, int dh, long nrows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long row = (long)blockIdx.x * 4 + wave; row < nrows; row += (long)gridDim.x * 4) {     // row = (b*H + h)*T + t
+    const int t = (int)(row % T);
+    const long bh = row / T;
+    const int hh = (int)(bh % H);
+    const long bb = bh / H;
+    const long base = ((bb * T + t) * H + hh) * (long)dh;
+    float s = 0.f;
+    for (int d = lane; d < dh; d += 64) s += a[base + d] * b[base + d];
+    s = ctts_wave_sum(s);
+    if (lane == 0) out[row] = s;
+  }
+}
+}  // namespace
+
+extern "C" int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, int H, int dh, void* stream) {
+  CTTS_REQUIRE(a && b && out && B >= 0 && T > 0 && H > 0 && dh > 0, "ctts_rowdot_heads: bad arguments");
+  const long nrows = (long)B * H * T;
+  if (nrows == 0) return 0;
+  const int blocks = (int)min((nrows + 3) / 4, (long)8192);
+  hipLaunchKernelGGL(rowdot_heads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, T, H, dh, nrows);
+  CTTS_CHECK_LAUNCH("ctts_rowdot_heads");
+  return 0;
+}
+
 extern "C" int ctts_softmax_fwd(float* S, const int32_t* lens, int nb0, int nb1, int T, int64_t ld, void* stream) {
   CTTS_REQUIRE(S && nb0 > 0 && nb1 > 0 && T > 0, "ctts_softmax_fwd: bad arguments");
   const long nrows = (long)nb0 * nb1 * T;

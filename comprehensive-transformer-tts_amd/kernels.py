@@ -58,7 +58,7 @@ class DropCtx:
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_off=0, c_off=0, nb0=1, nb1=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), lens=None, lim=(0, 0, 0), conv=None, conv_on_b=False, split_k=1, alpha=1.0,
          bias=None, Z=None, ldz=0, act=ACT_NONE, p_drop=0.0, seed=None, drop_offset=0, R=None, ldr=0, rowscale=None,
-         row_lens=None, row_T=0, row_halo=0, tile_map=None):
+         row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None):
     """C = epi(alpha * (opA @ opB + bias)); see include/ctts.h ctts_gemm_desc."""
     d = GemmDesc()
     d.A, d.B, d.C = _p(A, a_off), _p(B, b_off), _p(Cout, c_off)
@@ -87,6 +87,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_of
     if row_lens is not None:
         d.row_lens, d.row_T, d.row_halo = _p(row_lens), int(row_T), int(row_halo)
         d.tile_map = _p(tile_map)
+    d.E, d.rowsub = _p(E), _p(rowsub)
     lib = _lib.load()
     _lib.check(lib.ctts_gemm(C.byref(d), _stream()), "ctts_gemm")
     return Cout
@@ -507,3 +508,13 @@ def epilogue_bwd(dy, rowscale=None, z=None, act=0, p_drop=0.0, seed=None, drop_o
                                      int(act), float(p_drop), _p(seed), int(drop_offset), float(bias_scale),
                                      int(bias_acc_into is not None), _stream()), "ctts_epilogue_bwd")
     return dz, gm, dbias
+
+
+def rowdot_heads(a, b, n_heads):
+    """a, b [B,T,C] -> [B,H,T]: per-head dot products along the channel slices (D = rowsum(dO * O) of the fused softmax backward)"""
+    B, T, Cc = a.shape
+    out = torch.empty(B, n_heads, T, dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_rowdot_heads(_p(_f32c(a, "a")), _p(_f32c(b, "b")), _p(out), B, T, n_heads, Cc // n_heads, _stream()),
+               "ctts_rowdot_heads")
+    return out

@@ -277,13 +277,13 @@ class _SelfAttention(torch.autograd.Function):
         out = torch.zeros(B, T, C, dtype=torch.float32, device=qkv.device)
         K.gemm(S, qkv, out, T, dh, T, T, C3, C, True, False, b_off=2 * C, nb0=B, nb1=n_heads,
                sA=(n_heads * T * T, T * T), sB=(T * C3, dh), sC=(T * C, dh), lens=lens, lim=(1, 0, 1))
-        ctx.save_for_backward(qkv, S, lens)
+        ctx.save_for_backward(qkv, S, lens, out)
         ctx.n_heads = n_heads
         return out
 
     @staticmethod
     def backward(ctx, dO):
-        qkv, P, lens = ctx.saved_tensors
+        qkv, P, lens, O = ctx.saved_tensors
         H = ctx.n_heads
         dO = dO.contiguous()
         B, T, C3 = qkv.shape
@@ -295,11 +295,12 @@ class _SelfAttention(torch.autograd.Function):
         # dV[key,d] = sum_q P[q,key] dO[q,d]
         K.gemm(P, dO, dqkv, T, dh, T, T, C, C3, False, False, c_off=2 * C, nb0=B, nb1=H, sA=sP, sB=(T * C, dh),
                sC=(T * C3, dh), lens=lens, lim=(1, 0, 1))
-        # dP[q,key] = sum_d dO[q,d] V[key,d]
+        # dS[q,key] = P * (dO V^T - D),  D[q] = sum_key dP P = sum_d dO[q,d] O[q,d]: the softmax backward rides in the epilogue of the
+        # dP GEMM (one read of P) instead of a separate pass that re-reads P and dP and rewrites dS
+        Dv = K.rowdot_heads(dO, O, H)
         dP = torch.empty_like(P)
         K.gemm(dO, qkv, dP, T, T, dh, C, C3, T, True, True, b_off=2 * C, nb0=B, nb1=H, sA=(T * C, dh), sB=(T * C3, dh),
-               sC=sP, lens=lens, lim=(1, 1, 0))
-        K.softmax_bwd(P, dP, lens, B, H, T)  # dP <- dS
+               sC=sP, lens=lens, lim=(1, 1, 0), E=P, rowsub=Dv)
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d]
         K.gemm(dP, qkv, dqkv, T, dh, T, T, C3, C3, True, False, b_off=C, c_off=0, nb0=B, nb1=H, sA=sP, sB=(T * C3, dh),
                sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale)

@@ -71,9 +71,16 @@ typedef struct ctts_gemm_desc {
    * n-tiles of group x % (tiles_n/g) and on every (8*g/tiles_n)-th scheduled m-tile - trades weight-panel against activation-tile
    * footprint in the XCD's 4 MiB L2. */
   int32_t tile_group_n;
+  /* Optional softmax-backward fusion (attention): C = E * (alpha * acc - rowsub[row]) with E laid out exactly like C (same ldc and
+   * batch strides) and rowsub indexed [batch * M + row]:  dS = P * (dP - D), D = rowsum(dO * O), straight out of the dP = dO V^T GEMM -
+   * no separate pass over the [T,T] maps.  NULL = off; not combinable with bias / act / dropout / R / rowscale / split_k. */
+  const float* E; const float* rowsub;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
+
+/* out[b,h,t] = sum_d a[b,t,h*dh+d] * b[b,t,h*dh+d]   (a, b [B,T,H*dh] channel-last; the D vector of the fused softmax backward). */
+int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, int H, int dh, void* stream);
 
 /* Backward of the ctts_gemm epilogue in one pass over dY [rows,C]:  gm = dY * rowscale[row] (optional output = gradient of the
  * residual R), dZ = gm * dropout_mask(seed, drop_offset, element) / (1-p) * act'(Z) (act as in ctts_gemm_desc; Z NULL or act 0: factor 1),
