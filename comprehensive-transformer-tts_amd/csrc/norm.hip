@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int rows, int C, float p_drop,
                                                              const uint64_t* seed, uint32_t drop_offset,
-                                                             const float* __restrict__ rowscale) {
+                                                             const float* __restrict__ rowscale, const float* __restrict__ dres) {
   __shared__ float s_red[2][4][LN_MAXV * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
@@ -111,12 +111,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     const float c1 = ctts_wave_sum(s1) * invC, c2 = ctts_wave_sum(s2) * invC;
     float4* dxr = reinterpret_cast<float4*>(dx + (long)row * C);
+    const float4* rr = dres ? reinterpret_cast<const float4*>(dres + (long)row * C) : nullptr;   // gradient of the residual branch
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane + 64 * i;
-      if (c < nvec)
-        dxr[c] = make_float4(rs * (g[i][0] - c1 - xh[i][0] * c2), rs * (g[i][1] - c1 - xh[i][1] * c2),
-                             rs * (g[i][2] - c1 - xh[i][2] * c2), rs * (g[i][3] - c1 - xh[i][3] * c2));
+      if (c < nvec) {
+        float4 o = make_float4(rs * (g[i][0] - c1 - xh[i][0] * c2), rs * (g[i][1] - c1 - xh[i][1] * c2),
+                               rs * (g[i][2] - c1 - xh[i][2] * c2), rs * (g[i][3] - c1 - xh[i][3] * c2));
+        if (rr) { const float4 a = rr[c]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+        dxr[c] = o;
+      }
     }
   }
   // block reduce of the per-wave dgamma/dbeta partials, then one atomic per channel per block
@@ -290,7 +294,7 @@ extern "C" int ctts_layernorm_fwd(const float* x, const float* gamma, const floa
 extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
                                   float p_drop, const uint64_t* seed, uint32_t drop_offset, const float* rowscale,
-                                  int accumulate, void* stream) {
+                                  int accumulate, const float* dres, void* stream) {
   CTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "ctts_layernorm_bwd: null pointer");
   CTTS_REQUIRE((C % 4) == 0 && C <= 1024 && C > 0, "ctts_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
   hipStream_t st = (hipStream_t)stream;
@@ -301,7 +305,7 @@ extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* 
   if (rows == 0) return 0;
   const int blocks = min((rows + 3) / 4, 256);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
-                     C, p_drop, seed, drop_offset, rowscale);
+                     C, p_drop, seed, drop_offset, rowscale, dres);
   CTTS_CHECK_LAUNCH("ctts_layernorm_bwd");
   return 0;
 }

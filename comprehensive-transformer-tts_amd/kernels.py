@@ -166,7 +166,7 @@ def layernorm_fwd(x, gamma, beta, eps, p_drop=0.0, seed=None, drop_offset=0, row
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, p_drop=0.0, seed=None, drop_offset=0, rowscale=None, acc_into=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, p_drop=0.0, seed=None, drop_offset=0, rowscale=None, acc_into=None, dres=None):
     """acc_into=(dgamma_buf, dbeta_buf): accumulate the parameter gradients into existing buffers (param.grad)."""
     Cc = x.shape[-1]
     rows = x.numel() // Cc
@@ -179,7 +179,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, p_drop=0.0, seed=None, drop_offset=0
     lib = _lib.load()
     _lib.check(lib.ctts_layernorm_bwd(_p(_f32c(dy, "dy")), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
                                       _p(dbeta), rows, Cc, p_drop, _p(seed), drop_offset, _p(rowscale), int(acc_into is not None),
-                                      _stream()), "ctts_layernorm_bwd")
+                                      _p(dres), _stream()), "ctts_layernorm_bwd")
     return dx, dgamma, dbeta
 
 

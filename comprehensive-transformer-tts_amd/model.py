@@ -154,14 +154,14 @@ class FFTBlocks(nn.Module):
         pr = ops.PadRows(lens, T)      # rows t >= len are padding: every sub-layer output is re-masked (transformer_fs2.py:190,199)
         for layer in self.layers:
             op = layer.op
-            h = ops.layer_norm(x, op.layer_norm1.weight, op.layer_norm1.bias, 1e-12)
+            h, xr = ops.layer_norm_res(x, op.layer_norm1.weight, op.layer_norm1.bias, 1e-12)
             qkv = ops.linear(h, op.self_attn.in_proj_weight, pad_rows=pr)
             a = ops.self_attention(qkv, lens, self.num_heads)
-            x = ops.linear(a, op.self_attn.out_proj.weight, None, residual=x, rowscale=nonpad, p_drop=p, drop=drop, pad_rows=pr)
-            h = ops.layer_norm(x, op.layer_norm2.weight, op.layer_norm2.bias, 1e-12)
+            x = ops.linear(a, op.self_attn.out_proj.weight, None, residual=xr, rowscale=nonpad, p_drop=p, drop=drop, pad_rows=pr)
+            h, xr = ops.layer_norm_res(x, op.layer_norm2.weight, op.layer_norm2.bias, 1e-12)
             g = ops.conv1d(h, op.ffn.ffn_1.weight, op.ffn.ffn_1.bias, act=ops.ACT_GELU, alpha=alpha, p_drop=p, drop=drop,
                            pad_rows=pr)
-            x = ops.linear(g, op.ffn.ffn_2.weight, op.ffn.ffn_2.bias, residual=x, rowscale=nonpad, p_drop=p, drop=drop,
+            x = ops.linear(g, op.ffn.ffn_2.weight, op.ffn.ffn_2.bias, residual=xr, rowscale=nonpad, p_drop=p, drop=drop,
                            pad_rows=pr)
         return ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, 1e-5, rowscale=nonpad)
 

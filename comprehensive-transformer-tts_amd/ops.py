@@ -250,6 +250,35 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None
 
 
+class _LayerNormRes(torch.autograd.Function):
+    """(LN(x), x): the second output is x itself, handed to the caller as the residual operand of the sub-layer's last GEMM.  Both
+    gradient paths then arrive HERE, and the LN backward kernel adds the residual one while it writes dx - no separate autograd add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        y, mean, rstd = K.layernorm_fwd(x, gamma, beta, eps, 0.0, None, 0, None)
+        ctx.save_for_backward(x, gamma, mean, rstd, beta)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, gamma, mean, rstd, beta = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        dres = dres.contiguous() if dres is not None else None
+        if _fusable(gamma) and _fusable(beta):
+            dx, _, _ = K.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, acc_into=(gamma.grad, beta.grad), dres=dres)
+            return dx, None, None, None
+        dx, dg, db = K.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dres=dres)
+        return dx, dg, db, None
+
+
+def layer_norm_res(x, gamma, beta, eps):
+    """-> (LayerNorm(x), x_res): use x_res as the `residual=` of the GEMM that closes the pre-LN sub-layer (transformer_fs2.py:186-199)."""
+    return _LayerNormRes.apply(x, gamma, beta, eps)
+
+
 def layer_norm(x, gamma, beta, eps, rowscale=None, p_drop=0.0, drop=None):
     """y = rowscale * drop(LayerNorm(x)) over the last dim."""
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)

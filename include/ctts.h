@@ -125,8 +125,10 @@ int ctts_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
                        const float* rowscale, void* stream);
 int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx, float* dgamma, float* dbeta, int rows, int C, float p_drop, const uint64_t* seed,
-                       uint32_t drop_offset, const float* rowscale, int accumulate, void* stream);
-/* accumulate != 0: dgamma / dbeta (and ctts_colsum's out) are ADDED to - gradient-accumulation fusion straight into param.grad */
+                       uint32_t drop_offset, const float* rowscale, int accumulate, const float* dres, void* stream);
+/* accumulate != 0: dgamma / dbeta (and ctts_colsum's out) are ADDED to - gradient-accumulation fusion straight into param.grad.
+ * dres (optional, [rows,C]): added to dx - the gradient arriving through the residual connection around the pre-LN sub-layer
+ * (x -> LN -> f -> + x), so the autograd sum of the two paths costs no extra pass. */
 
 /* BatchNorm1d over [rows, C] (channel-last view of nn.BatchNorm1d, modules.py:105,140-148),
  * fused with tanh (act=3) / none and inverted dropout.
