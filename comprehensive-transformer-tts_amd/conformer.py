@@ -108,9 +108,9 @@ class ConformerBlock(nn.Module):
     def _ff(self, x, res, p, drop):
         s = res.module.sequential
         ln, l1, l2 = getattr(s, "0"), getattr(s, "1").linear, getattr(s, "4").linear
-        h = ops.layer_norm(x, ln.weight, ln.bias, 1e-5)
+        h, xr = ops.layer_norm_res(x, ln.weight, ln.bias, 1e-5)
         h = ops.linear(h, l1.weight, l1.bias, act=ops.ACT_SWISH, p_drop=p, drop=drop)
-        return ops.linear(h, l2.weight, l2.bias, alpha=self.ff_factor, residual=x, p_drop=p, drop=drop)
+        return ops.linear(h, l2.weight, l2.bias, alpha=self.ff_factor, residual=xr, p_drop=p, drop=drop)
 
     def forward(self, x, nonpad, pos_table):
         """x [B,T,C]; nonpad float [B*T]; pos_table [T,C] (rows of the sinusoid table)"""
@@ -122,24 +122,24 @@ class ConformerBlock(nn.Module):
         # ---- relative-position multi-head self-attention (mask deliberately NOT applied, conformer.py:243)
         m = getattr(seq, "1").module
         at = m.attention
-        h = ops.layer_norm(x, m.layer_norm.weight, m.layer_norm.bias, 1e-5)
+        h, xr = ops.layer_norm_res(x, m.layer_norm.weight, m.layer_norm.bias, 1e-5)
         w_qkv = torch.cat([at.query_proj.linear.weight, at.key_proj.linear.weight, at.value_proj.linear.weight], 0)
         qkv = ops.linear(h, w_qkv)                                       # one [768,256] GEMM for q | k | v
         q, kv = qkv[..., :C], qkv[..., C:]
         pos = ops.linear(pos_table, at.pos_proj.linear.weight)           # [T,C], batch independent
         ctxv = ops.relpos_attention(q + at.u_bias.reshape(1, 1, C), q + at.v_bias.reshape(1, 1, C), kv, pos, self.n_heads,
                                     1.0 / math.sqrt(C), p_drop=p, drop=drop)
-        x = ops.linear(ctxv, at.out_proj.linear.weight, None, residual=x, p_drop=p, drop=drop)
+        x = ops.linear(ctxv, at.out_proj.linear.weight, None, residual=xr, p_drop=p, drop=drop)
         # ---- convolution module
         s = getattr(seq, "2").module.sequential
         ln, pw1, dw, bn, pw2 = getattr(s, "0"), getattr(s, "2").conv, getattr(s, "4").conv, getattr(s, "5"), getattr(s, "7").conv
-        h = ops.layer_norm(x, ln.weight, ln.bias, 1e-5)
+        h, xr = ops.layer_norm_res(x, ln.weight, ln.bias, 1e-5)
         h = ops.linear(h, pw1.weight.view(2 * C, C), pw1.bias)
         h = ops.glu(h)
         h = ops.depthwise_conv1d(h, dw.weight)
         h = ops.batch_norm_act(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, self.training,
                                act=ops.ACT_SWISH)
-        x = ops.linear(h, pw2.weight.view(C, C), pw2.bias, residual=x, p_drop=p, drop=drop)
+        x = ops.linear(h, pw2.weight.view(C, C), pw2.bias, residual=xr, p_drop=p, drop=drop)
         x = self._ff(x, getattr(seq, "3"), p, drop)
         fin = getattr(seq, "4")
         return ops.layer_norm(x, fin.weight, fin.bias, 1e-5, rowscale=nonpad)   # LN then masked_fill(pad, 0)
