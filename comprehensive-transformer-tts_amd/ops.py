@@ -85,10 +85,15 @@ def _wgrad_scope(fused, *operands):
     return _OnWgradStream(*operands) if (fused and _WGRAD["stream"] is not None) else _Inline()
 
 
+import os as _os
+_DGRAD_SPLIT_K = int(_os.environ.get("CTTS_DGRAD_SPLIT_K", "1"))     # tuning knob; 0 = never split the data-gradient reduction
+_WGRAD_SPLIT_MULT = float(_os.environ.get("CTTS_WGRAD_SPLIT_MULT", "1"))
+
+
 def _split_k_for(Mo, No, Kred):
     """split-K factor for weight-gradient GEMMs (small output, long reduction)."""
     t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
-    want = max(1, -(-512 // t128))
+    want = max(1, int(-(-512 // t128) * _WGRAD_SPLIT_MULT))
     return int(max(1, min(want, max(1, Kred // 512))))
 
 
@@ -157,9 +162,13 @@ class _LinearConv(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
                 K.conv_weight_repack(w.contiguous(), wd, N, Cin, ksize, 1)
-                dX = torch.empty_like(x)
+                # few output tiles but a long reduction (FFN conv dgrad: 1024 tiles, K = 9216): split K so that the launch fills
+                # all 256 CUs x 6 workgroups (atomic accumulation into a zero-filled dX)
+                tiles = -(-M // 64) * -(-Cin // 64)
+                sk = min(4, max(2, -(-2304 // tiles))) if (_DGRAD_SPLIT_K and tiles < 1536 and ksize * N >= 4096) else 1
+                dX = torch.zeros_like(x) if sk > 1 else torch.empty_like(x)
                 K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, conv=(T, pad, N), alpha=alpha, row_halo=pad,
-                       tile_map=pr.tile_map(pad, M) if pr is not None else None, **rl)
+                       split_k=sk, tile_map=pr.tile_map(pad, M) if pr is not None else None, **rl)
             if ctx.needs_input_grad[1]:
                 Kd = ksize * Cin
                 fused = _fusable(w)
