@@ -447,8 +447,8 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
 
   // ---- batch / split decode
   const int z = blockIdx.z;
-  int z0 = 0, z1 = 0, split = 0;
-  if (d.split_k > 1) split = z; else { z0 = z / d.nb1; z1 = z - z0 * d.nb1; }
+  const int split = blockIdx.y;                         // K split (grid.y = split_k, 1 when off); z = batch index
+  const int z0 = z / d.nb1, z1 = z - z0 * d.nb1;
   int Mv = d.M, Nv = d.N, Kv = d.K;
   if (d.lens) {
     const int L = d.lens[z0];
@@ -588,8 +588,8 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool VEC>
 int launch(const ctts_gemm_desc& d, hipStream_t st) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-  const int nz = d.split_k > 1 ? d.split_k : d.nb0 * d.nb1;
-  dim3 grid(tiles, 1, nz);
+  const int nz = d.nb0 * d.nb1, ny = d.split_k > 1 ? d.split_k : 1;
+  dim3 grid(tiles, ny, nz);
   hipLaunchKernelGGL((gemm_kernel<BM, BN, A_KC, B_KC, CONV, VEC>), grid, dim3(256), 0, st, d);
   CTTS_CHECK_LAUNCH("ctts_gemm");
   return 0;
@@ -607,8 +607,8 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   float* sA = smem;
   float* sB = smem + A_SZ;
   const int z = blockIdx.z;
-  int z0 = 0, z1 = 0, split = 0;
-  if (d.split_k > 1) split = z; else { z0 = z / d.nb1; z1 = z - z0 * d.nb1; }
+  const int split = blockIdx.y;                         // K split (grid.y = split_k, 1 when off); z = batch index
+  const int z0 = z / d.nb1, z1 = z - z0 * d.nb1;
   int Mv = d.M, Nv = d.N, Kv = d.K;
   if (PARTIAL && d.lens) {                // per-batch valid lengths (attention over non-padded tokens only)
     const int L = d.lens[z0];
@@ -746,10 +746,10 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
 int launch_buf(const ctts_gemm_desc& d, hipStream_t st) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-  const int nz = d.split_k > 1 ? d.split_k : d.nb0 * d.nb1;
+  const int nz = d.nb0 * d.nb1, ny = d.split_k > 1 ? d.split_k : 1;
   if (d.lens && (d.lim_m || d.lim_n || d.lim_k)) {
     if constexpr (!CONV) {
-      hipLaunchKernelGGL((gemm_buf_kernel<BM, BN, A_KC, B_KC, false, true>), dim3(tiles, 1, nz), dim3(256), 0, st, d);
+      hipLaunchKernelGGL((gemm_buf_kernel<BM, BN, A_KC, B_KC, false, true>), dim3(tiles, ny, nz), dim3(256), 0, st, d);
       CTTS_CHECK_LAUNCH("ctts_gemm(buf,partial)");
       return 0;
     } else {
@@ -757,7 +757,7 @@ int launch_buf(const ctts_gemm_desc& d, hipStream_t st) {
       return -1;
     }
   }
-  hipLaunchKernelGGL((gemm_buf_kernel<BM, BN, A_KC, B_KC, CONV, false>), dim3(tiles, 1, nz), dim3(256), 0, st, d);
+  hipLaunchKernelGGL((gemm_buf_kernel<BM, BN, A_KC, B_KC, CONV, false>), dim3(tiles, ny, nz), dim3(256), 0, st, d);
   CTTS_CHECK_LAUNCH("ctts_gemm(buf)");
   return 0;
 }
@@ -846,7 +846,6 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   if (d.M == 0 || d.N == 0) return 0;
   if (d.nb0 < 1) d.nb0 = 1;
   if (d.nb1 < 1) d.nb1 = 1;
-  CTTS_REQUIRE(!(d.split_k > 1 && d.nb0 * d.nb1 > 1), "ctts_gemm: split_k and batching are exclusive");
   if (d.conv_T > 0) {
     CTTS_REQUIRE(d.conv_cin > 0 && (d.conv_cin % 4) == 0, "ctts_gemm: conv view needs cin %% 4 == 0 (got %d)", d.conv_cin);
     CTTS_REQUIRE(d.conv_on_b ? (!d.a_kc && !d.b_kc) : (d.a_kc != 0), "ctts_gemm: conv view on an unsupported operand layout");
@@ -855,7 +854,7 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   CTTS_REQUIRE(!d.E || (d.rowsub && d.split_k <= 1 && !d.bias && !d.act && d.p_drop == 0.f && !d.R && !d.rowscale && !d.Z),
                "ctts_gemm: the E/rowsub epilogue excludes bias, activation, dropout, residual, rowscale and split-K");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : d.nb0 * d.nb1);
+  const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : 1) * d.nb0 * d.nb1;
   static const int force_tile = getenv("CTTS_FORCE_TILE") ? atoi(getenv("CTTS_FORCE_TILE")) : 0;   // tuning knob
   static const bool natural = getenv("CTTS_NATURAL_ORDER") != nullptr;
   // XCD-grouped order for scheduled launches: default 4 n-groups (XCD x: n-group x % 4, every second scheduled m-tile) - halves the

@@ -294,6 +294,17 @@ def layer_norm(x, gamma, beta, eps, rowscale=None, p_drop=0.0, drop=None):
     return _LayerNorm.apply(x, gamma, beta, eps, rowscale, p_drop if seed is not None else 0.0, seed, off)
 
 
+_ATTN_SPLIT_K = int(_os.environ.get("CTTS_ATTN_SPLIT_K", "2"))      # tuning knob; 1 = off
+
+
+def _attn_split_k(nbatch, T, dh):
+    """The [T, d_h] outputs of attention (P V, dV, dQ, dK) are only ceil(T/64) x ceil(d_h/64) tiles per (batch, head) - 1,024 workgroups
+    for 1,536 slots at the canonical batch - but reduce over T keys / queries: split that reduction (atomic accumulation into the
+    zero-initialised outputs) until the launch fills the machine."""
+    tiles = -(-T // 64) * -(-dh // 64) * nbatch
+    return _ATTN_SPLIT_K if (_ATTN_SPLIT_K > 1 and tiles < 1536 and T >= 512) else 1
+
+
 class _SelfAttention(torch.autograd.Function):
     """Multi-head self-attention core on the packed projection qkv [B,T,3C] with a key-padding
     mask given as valid lengths (F.multi_head_attention_forward semantics,
@@ -313,8 +324,9 @@ class _SelfAttention(torch.autograd.Function):
                sA=(T * C3, dh), sB=(T * C3, dh), sC=(n_heads * T * T, T * T), lens=lens, lim=(1, 1, 0), alpha=scale)
         K.softmax_fwd(S, lens, B, n_heads, T)
         out = torch.zeros(B, T, C, dtype=torch.float32, device=qkv.device)
+        sk = _attn_split_k(B * n_heads, T, dh)
         K.gemm(S, qkv, out, T, dh, T, T, C3, C, True, False, b_off=2 * C, nb0=B, nb1=n_heads,
-               sA=(n_heads * T * T, T * T), sB=(T * C3, dh), sC=(T * C, dh), lens=lens, lim=(1, 0, 1))
+               sA=(n_heads * T * T, T * T), sB=(T * C3, dh), sC=(T * C, dh), lens=lens, lim=(1, 0, 1), split_k=sk)
         ctx.save_for_backward(qkv, S, lens, out)
         ctx.n_heads = n_heads
         return out
@@ -330,9 +342,10 @@ class _SelfAttention(torch.autograd.Function):
         scale = dh ** -0.5
         sP = (H * T * T, T * T)
         dqkv = torch.zeros_like(qkv)
+        sk = _attn_split_k(B * H, T, dh)
         # dV[key,d] = sum_q P[q,key] dO[q,d]
         K.gemm(P, dO, dqkv, T, dh, T, T, C, C3, False, False, c_off=2 * C, nb0=B, nb1=H, sA=sP, sB=(T * C, dh),
-               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1))
+               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), split_k=sk)
         # dS[q,key] = P * (dO V^T - D),  D[q] = sum_key dP P = sum_d dO[q,d] O[q,d]: the softmax backward rides in the epilogue of the
         # dP GEMM (one read of P) instead of a separate pass that re-reads P and dP and rewrites dS
         Dv = K.rowdot_heads(dO, O, H)
@@ -341,10 +354,10 @@ class _SelfAttention(torch.autograd.Function):
                sC=sP, lens=lens, lim=(1, 1, 0), E=P, rowsub=Dv)
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d]
         K.gemm(dP, qkv, dqkv, T, dh, T, T, C3, C3, True, False, b_off=C, c_off=0, nb0=B, nb1=H, sA=sP, sB=(T * C3, dh),
-               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale)
+               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale, split_k=sk)
         # dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
         K.gemm(dP, qkv, dqkv, T, dh, T, T, C3, C3, False, False, b_off=0, c_off=C, nb0=B, nb1=H, sA=sP, sB=(T * C3, dh),
-               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale)
+               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale, split_k=sk)
         return dqkv, None, None
 
 
