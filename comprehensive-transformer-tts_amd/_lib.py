@@ -44,6 +44,7 @@ class GemmDesc(C.Structure):
 _SIGNATURES = {
     "ctts_gemm": [C.POINTER(GemmDesc), _vp],
     "ctts_rowdot_heads": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_weighted_colsum": [_vp, _vp, _vp, _i64, C.c_int, _f32, C.c_int, _vp],
     "ctts_epilogue_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _u32, _f32, C.c_int, _vp],
     "ctts_row_tile_map": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "ctts_conv_weight_repack": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],

@@ -214,6 +214,41 @@ extern "C" int ctts_rowscale_dropout(const float* x, float* y, int64_t rows, int
   return 0;
 }
 
+namespace {
+// out[c] (+)= scale * sum_r w[r] * x[r,c]: weight gradient of a one-output Linear (N = 1 heads of the duration / energy predictors)
+__global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ out, long rows, int C, float scale) {
+  __shared__ float s[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+  const long stripe = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = blockIdx.y * stripe, r1 = min(rows, r0 + stripe);
+  float a = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (long r = r0 + ty; r < r1; r += 4) a = fmaf(w[r], x[r * C + c], a);
+  }
+  s[ty][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    const int l = threadIdx.x;
+    atomicAdd(out + c, scale * (s[0][l] + s[1][l] + s[2][l] + s[3][l]));
+  }
+}
+}  // namespace
+
+extern "C" int ctts_weighted_colsum(const float* x, const float* w, float* out, int64_t rows, int C, float scale, int accumulate,
+                                    void* stream) {
+  CTTS_REQUIRE(x && w && out && C > 0, "ctts_weighted_colsum: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { ctts_set_error("ctts_weighted_colsum: memset failed"); return -2; }
+  if (rows == 0) return 0;
+  const int gx = (C + 63) / 64;
+  const int gy = (int)max((long)1, min((long)max(1, 1024 / gx), (long)rows / 64));
+  hipLaunchKernelGGL(weighted_colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, w, out, (long)rows, C, scale);
+  CTTS_CHECK_LAUNCH("ctts_weighted_colsum");
+  return 0;
+}
+
 extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* stream) {
   CTTS_REQUIRE(x && out && C > 0, "ctts_colsum: bad arguments");
   hipStream_t st = (hipStream_t)stream;

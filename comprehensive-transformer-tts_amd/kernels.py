@@ -518,3 +518,13 @@ def rowdot_heads(a, b, n_heads):
     _lib.check(lib.ctts_rowdot_heads(_p(_f32c(a, "a")), _p(_f32c(b, "b")), _p(out), B, T, n_heads, Cc // n_heads, _stream()),
                "ctts_rowdot_heads")
     return out
+
+
+def weighted_colsum(x2d, w, scale=1.0, acc_into=None):
+    """out[c] = scale * sum_r w[r] * x[r,c]"""
+    rows, Cc = x2d.shape
+    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device) if acc_into is None else acc_into
+    lib = _lib.load()
+    _lib.check(lib.ctts_weighted_colsum(_p(_f32c(x2d, "x")), _p(_f32c(w, "w")), _p(out), rows, Cc, float(scale),
+                                        int(acc_into is not None), _stream()), "ctts_weighted_colsum")
+    return out

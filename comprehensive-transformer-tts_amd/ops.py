@@ -186,7 +186,12 @@ class _LinearConv(torch.autograd.Function):
                 dX = torch.empty_like(x)
                 K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha,
                        tile_map=pr.tile_map(0, M) if pr is not None else None, **rl)
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and N == 1 and row_lens is None:
+                # one-output head: dW[0,:] = alpha * sum_r dZ[r] x[r,:] - a weighted column sum, not a 1 x C GEMM
+                fused = _fusable(w)
+                got = K.weighted_colsum(x.view(M, Cin), dZ.reshape(M), scale=alpha, acc_into=w.grad.view(-1) if fused else None)
+                dW = None if fused else got.view(1, Cin)
+            elif ctx.needs_input_grad[1]:
                 fused = _fusable(w)
                 dW = w.grad if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
                 with _wgrad_scope(fused, dZ, x):

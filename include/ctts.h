@@ -82,6 +82,10 @@ int ctts_gemm(const ctts_gemm_desc* d, void* stream);
 /* out[b,h,t] = sum_d a[b,t,h*dh+d] * b[b,t,h*dh+d]   (a, b [B,T,H*dh] channel-last; the D vector of the fused softmax backward). */
 int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, int H, int dh, void* stream);
 
+/* out[c] (+)= scale * sum_r w[r] * x[r,c] (x [rows,C] dense): the weight gradient of a one-output Linear - the N = 1 heads of the
+ * duration / energy predictors (modules.py:1296,1349) - as one streaming pass instead of a degenerate 1 x C GEMM. */
+int ctts_weighted_colsum(const float* x, const float* w, float* out, int64_t rows, int C, float scale, int accumulate, void* stream);
+
 /* Backward of the ctts_gemm epilogue in one pass over dY [rows,C]:  gm = dY * rowscale[row] (optional output = gradient of the
  * residual R), dZ = gm * dropout_mask(seed, drop_offset, element) / (1-p) * act'(Z) (act as in ctts_gemm_desc; Z NULL or act 0: factor 1),
  * dbias[c] (+)= bias_scale * sum_rows dZ[.,c] (optional; bias_scale = the epilogue's alpha).  Any of rowscale, z, gm, dbias may be NULL. */
