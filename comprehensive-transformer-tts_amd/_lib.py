@@ -81,6 +81,8 @@ _SIGNATURES = {
     "ctts_mas": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_forward_sum_fwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_forward_sum_bwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_mel_l1_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp],
+    "ctts_mel_l1_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp],
     "ctts_adam_clip_step": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     "ctts_im2col_3x3s2": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_col2im_3x3s2": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],

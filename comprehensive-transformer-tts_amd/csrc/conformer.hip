@@ -214,7 +214,7 @@ extern "C" int ctts_dwconv_fwd(const float* x, const float* wT, float* y, int B,
 extern "C" int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, int B, int T, int C, int K, void* stream) {
   CTTS_REQUIRE(dy && x && dw && K <= DW_MAXK && (K & 1), "ctts_dwconv_wgrad: need odd K <= 32");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * K, st) != hipSuccess) { ctts_set_error("ctts_dwconv_wgrad: memset failed"); return -2; }
+  if (ctts_zero_async(dw, sizeof(float) * (size_t)C * K, st) != 0) { ctts_set_error("ctts_dwconv_wgrad: memset failed"); return -2; }
   if (B == 0 || T == 0) return 0;
   const int chunk = 32;                       // = DW_CH
   dim3 grid((T + chunk - 1) / chunk, B, (C + 255) / 256);

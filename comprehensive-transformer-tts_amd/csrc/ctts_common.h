@@ -8,6 +8,10 @@
 #define CTTS_WAVE 64
 
 void ctts_set_error(const char* fmt, ...);
+// Zero-fill `bytes` (multiple of 4) on `st` with a KERNEL.  hipMemsetAsync must not be used in this library: memset nodes captured into
+// a hipGraph re-execute incorrectly on this ROCm stack (from the second replay on, bytes 8..11 of the buffer keep stale data - measured
+// with tools/check_graph_memset.py), which silently corrupts accumulators when a train step is replayed.
+int ctts_zero_async(void* p, size_t bytes, hipStream_t st);
 
 #define CTTS_CHECK_LAUNCH(name)                                                     \
   do {                                                                              \

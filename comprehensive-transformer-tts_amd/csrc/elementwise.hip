@@ -3,6 +3,20 @@
 #include "ctts_common.h"
 
 namespace {
+__global__ void zero_u32_kernel(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+
+int ctts_zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  const size_t n = (bytes + 3) / 4;
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(zero_u32_kernel, dim3(blocks), dim3(256), 0, st, (uint32_t*)p, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+namespace {
 
 __global__ void act_dropout_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ z, float* __restrict__ dz,
                                        long total, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset) {
@@ -240,7 +254,7 @@ extern "C" int ctts_weighted_colsum(const float* x, const float* w, float* out, 
                                     void* stream) {
   CTTS_REQUIRE(x && w && out && C > 0, "ctts_weighted_colsum: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { ctts_set_error("ctts_weighted_colsum: memset failed"); return -2; }
+  if (!accumulate && ctts_zero_async(out, sizeof(float) * C, st) != 0) { ctts_set_error("ctts_weighted_colsum: memset failed"); return -2; }
   if (rows == 0) return 0;
   const int gx = (C + 63) / 64;
   const int gy = (int)max((long)1, min((long)max(1, 1024 / gx), (long)rows / 64));
@@ -252,7 +266,7 @@ extern "C" int ctts_weighted_colsum(const float* x, const float* w, float* out, 
 extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* stream) {
   CTTS_REQUIRE(x && out && C > 0, "ctts_colsum: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) { ctts_set_error("ctts_colsum: memset failed"); return -2; }
+  if (!accumulate && ctts_zero_async(out, sizeof(float) * C, st) != 0) { ctts_set_error("ctts_colsum: memset failed"); return -2; }
   if (rows == 0) return 0;
   int k = 1;                                   // fold narrow dense matrices so that a wave reads 64 useful floats per row
   if (ld == C)
@@ -270,7 +284,7 @@ extern "C" int ctts_epilogue_bwd(const float* dy, const float* rowscale, const f
                                  int accumulate_bias, void* stream) {
   CTTS_REQUIRE(dy && dz && rows >= 0 && C > 0 && p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed), "ctts_epilogue_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (dbias && !accumulate_bias && hipMemsetAsync(dbias, 0, sizeof(float) * C, st) != hipSuccess) {
+  if (dbias && !accumulate_bias && ctts_zero_async(dbias, sizeof(float) * C, st) != 0) {
     ctts_set_error("ctts_epilogue_bwd: memset failed");
     return -2;
   }

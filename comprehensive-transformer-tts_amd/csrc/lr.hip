@@ -233,7 +233,7 @@ extern "C" int ctts_embedding_bwd(const int64_t* ids, const float* dy, float* dw
                                   int accumulate, void* stream) {
   CTTS_REQUIRE(ids && dy && dweight && n >= 0 && C > 0 && C <= 512 && V > 0, "ctts_embedding_bwd: bad arguments (C <= 512)");
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)V * C, st) != hipSuccess) {
+  if (!accumulate && ctts_zero_async(dweight, sizeof(float) * (size_t)V * C, st) != 0) {
     ctts_set_error("ctts_embedding_bwd: memset failed");
     return -2;
   }

@@ -298,7 +298,7 @@ extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* 
   CTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "ctts_layernorm_bwd: null pointer");
   CTTS_REQUIRE((C % 4) == 0 && C <= 1024 && C > 0, "ctts_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate && (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)) {
+  if (!accumulate && (ctts_zero_async(dgamma, sizeof(float) * C, st) != 0 || ctts_zero_async(dbeta, sizeof(float) * C, st) != 0)) {
     ctts_set_error("ctts_layernorm_bwd: memset failed");
     return -2;
   }
@@ -321,7 +321,7 @@ static int colreduce_grid_y(int rows, int gx) { return max(1, min(max(1, 1024 / 
 extern "C" int ctts_colstats(const float* x, double* sums, int rows, int C, void* stream) {
   CTTS_REQUIRE(x && sums && rows > 0 && C > 0, "ctts_colstats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { ctts_set_error("ctts_colstats: memset failed"); return -2; }
+  if (ctts_zero_async(sums, sizeof(double) * 2 * C, st) != 0) { ctts_set_error("ctts_colstats: memset failed"); return -2; }
   const int k = colreduce_fold(rows, C), Cv = C * k, Rv = rows / k, gx = (Cv + 63) / 64;
   hipLaunchKernelGGL((colreduce_kernel<0>), dim3(gx, colreduce_grid_y(Rv, gx)), dim3(256), 0, st, x, nullptr, nullptr,
                      nullptr, nullptr, nullptr, sums, Rv, Cv, C, 0, 0.f, nullptr, 0u);
@@ -376,7 +376,7 @@ extern "C" int ctts_bn_bwd_reduce(const float* dy, const float* x, const float* 
                                   const uint64_t* seed, uint32_t drop_offset, void* stream) {
   CTTS_REQUIRE(dy && x && mean && rstd && gamma && beta && sums && rows > 0, "ctts_bn_bwd_reduce: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) { ctts_set_error("ctts_bn_bwd_reduce: memset failed"); return -2; }
+  if (ctts_zero_async(sums, sizeof(double) * 2 * C, st) != 0) { ctts_set_error("ctts_bn_bwd_reduce: memset failed"); return -2; }
   const int k = colreduce_fold(rows, C), Cv = C * k, Rv = rows / k, gx = (Cv + 63) / 64;
   hipLaunchKernelGGL((colreduce_kernel<1>), dim3(gx, colreduce_grid_y(Rv, gx)), dim3(256), 0, st, x, dy, mean, rstd,
                      gamma, beta, sums, Rv, Cv, C, act, p_drop, seed, drop_offset);

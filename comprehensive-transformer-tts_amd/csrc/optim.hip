@@ -89,3 +89,69 @@ extern "C" int ctts_adam_clip_step(float* p, const float* g, float* m, float* v,
   CTTS_CHECK_LAUNCH("ctts_adam_clip_step(finalize)");
   return 0;
 }
+
+// ---------------------------------------------------------------- masked L1 of the two mel predictions
+// CompTransTTSLoss.get_mel_loss (model/loss.py:130-138, as l1_loss of transformer_fs2): with target rows zeroed at padded frames,
+//   weights w = (sum_c |target[row,c]| != 0), loss = sum |pred - target| * w / (n_mel * sum w)   (per prediction; pads contribute 0).
+// One pass over (mel, postnet_mel, target) produces both numerators and the shared denominator; the backward writes both gradients.
+namespace {
+__global__ __launch_bounds__(256) void mel_l1_fwd_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                          const float* __restrict__ tgt, const unsigned char* __restrict__ pad,
+                                                          float* __restrict__ sums, float* __restrict__ roww, long rows, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float a1 = 0.f, a2 = 0.f, aw = 0.f;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const bool is_pad = pad[r] != 0;
+    float s_t = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float t = is_pad ? 0.f : tgt[r * C + c];
+      const float x1 = is_pad ? 0.f : p1[r * C + c], x2 = is_pad ? 0.f : p2[r * C + c];
+      s_t += fabsf(t); s1 += fabsf(x1 - t); s2 += fabsf(x2 - t);
+    }
+    s_t = ctts_wave_sum(s_t); s1 = ctts_wave_sum(s1); s2 = ctts_wave_sum(s2);
+    const float w = s_t != 0.f ? 1.f : 0.f;
+    if (lane == 0) roww[r] = w;
+    a1 += s1 * w; a2 += s2 * w; aw += w;
+  }
+  __shared__ float s[3][4];
+  if (lane == 0) { s[0][wave] = a1; s[1][wave] = a2; s[2][wave] = aw; }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicAdd(sums + threadIdx.x, s[threadIdx.x][0] + s[threadIdx.x][1] + s[threadIdx.x][2] + s[threadIdx.x][3]);
+}
+
+// d loss_k / d p_k = g_k * sign(p_k - t) * w[row] / (C * sum w)
+__global__ void mel_l1_bwd_kernel(const float* __restrict__ p1, const float* __restrict__ p2, const float* __restrict__ tgt,
+                                  const float* __restrict__ roww, const float* __restrict__ sums, const float* __restrict__ g,
+                                  float* __restrict__ d1, float* __restrict__ d2, long total, int C) {
+  const float inv = 1.f / ((float)C * sums[2]);
+  const float g1 = g[0] * inv, g2 = g[1] * inv;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const float w = roww[e / C], t = tgt[e];
+    const float x1 = p1[e] - t, x2 = p2[e] - t;
+    d1[e] = w * g1 * (x1 > 0.f ? 1.f : (x1 < 0.f ? -1.f : 0.f));
+    d2[e] = w * g2 * (x2 > 0.f ? 1.f : (x2 < 0.f ? -1.f : 0.f));
+  }
+}
+}  // namespace
+
+extern "C" int ctts_mel_l1_fwd(const float* p1, const float* p2, const float* tgt, const uint8_t* pad, float* sums, float* roww,
+                               int64_t rows, int C, void* stream) {
+  CTTS_REQUIRE(p1 && p2 && tgt && pad && sums && roww && rows >= 0 && C > 0, "ctts_mel_l1_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (rows == 0) return 0;
+  const int blocks = (int)((rows + 3) / 4 > 1024 ? 1024 : (rows + 3) / 4);
+  hipLaunchKernelGGL(mel_l1_fwd_kernel, dim3(blocks), dim3(256), 0, st, p1, p2, tgt, pad, sums, roww, (long)rows, C);
+  CTTS_CHECK_LAUNCH("ctts_mel_l1_fwd");
+  return 0;
+}
+
+extern "C" int ctts_mel_l1_bwd(const float* p1, const float* p2, const float* tgt, const float* roww, const float* sums, const float* g,
+                               float* d1, float* d2, int64_t rows, int C, void* stream) {
+  CTTS_REQUIRE(p1 && p2 && tgt && roww && sums && g && d1 && d2 && rows >= 0 && C > 0, "ctts_mel_l1_bwd: bad arguments");
+  const long total = (long)rows * C;
+  if (total == 0) return 0;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(mel_l1_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p1, p2, tgt, roww, sums, g, d1, d2, total, C);
+  CTTS_CHECK_LAUNCH("ctts_mel_l1_bwd");
+  return 0;
+}

@@ -528,3 +528,25 @@ def weighted_colsum(x2d, w, scale=1.0, acc_into=None):
     _lib.check(lib.ctts_weighted_colsum(_p(_f32c(x2d, "x")), _p(_f32c(w, "w")), _p(out), rows, Cc, float(scale),
                                         int(acc_into is not None), _stream()), "ctts_weighted_colsum")
     return out
+
+
+def mel_l1_fwd(p1, p2, tgt, pad_u8):
+    """-> (sums [3] = {sum w|p1-t|, sum w|p2-t|, sum w}, roww [rows])"""
+    Cc = tgt.shape[-1]
+    rows = tgt.numel() // Cc
+    sums = torch.zeros(3, dtype=torch.float32, device=tgt.device)        # accumulated into by the kernel
+    roww = torch.empty(rows, dtype=torch.float32, device=tgt.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_mel_l1_fwd(_p(_f32c(p1, "p1")), _p(_f32c(p2, "p2")), _p(_f32c(tgt, "tgt")), _p(pad_u8), _p(sums), _p(roww), rows,
+                                   Cc, _stream()), "ctts_mel_l1_fwd")
+    return sums, roww
+
+
+def mel_l1_bwd(p1, p2, tgt, roww, sums, g):
+    Cc = tgt.shape[-1]
+    rows = tgt.numel() // Cc
+    d1, d2 = torch.empty_like(p1), torch.empty_like(p2)
+    lib = _lib.load()
+    _lib.check(lib.ctts_mel_l1_bwd(_p(p1), _p(p2), _p(tgt), _p(roww), _p(sums), _p(_f32c(g, "g")), _p(d1), _p(d2), rows, Cc, _stream()),
+               "ctts_mel_l1_bwd")
+    return d1, d2

@@ -8,6 +8,8 @@ energy L1 uses a masked mean instead of `masked_select` (loss.py:236-243) - neit
 device->host sync.  learn_alignment=True adds ForwardSumLoss (one batched CTC call) and BinLoss;
 prosody_modeling.model_type == "liu2021" adds the prosody L1 terms (loss.py:319-324).
 """
+import os as _os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -111,8 +113,13 @@ class CompTransTTSLoss(nn.Module):
         src_nonpad = (~src_masks)
         mel_nonpad = (~mel_masks)
         mel_targets = mel_targets[:, : mel_masks.shape[1], :]
-        mel_loss = self._masked_l1_mel(mel_pred, mel_targets, mel_masks)
-        postnet_mel_loss = self._masked_l1_mel(post_pred, mel_targets, mel_masks)
+        if mel_pred.is_cuda and not _os.environ.get("CTTS_TORCH_MEL_L1"):          # device path: both masked L1 terms in one kernel pass (csrc/optim.hip)
+            from . import ops
+            both = ops.mel_l1_pair(mel_pred, post_pred, mel_targets, mel_masks)
+            mel_loss, postnet_mel_loss = both[0], both[1]
+        else:                         # host tensors (loss-arithmetic tests, cpu_baseline): stock torch ops
+            mel_loss = self._masked_l1_mel(mel_pred, mel_targets, mel_masks)
+            postnet_mel_loss = self._masked_l1_mel(post_pred, mel_targets, mel_masks)
         zero = torch.zeros(1, device=mel_targets.device)
         ctc_loss = bin_loss = zero
         if self.learn_alignment:

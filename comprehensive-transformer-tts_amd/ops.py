@@ -857,3 +857,25 @@ def embedding(ids, weight, padding_idx=-1):
     """nn.Embedding(padding_idx=...) lookup (blocks.py:10-15; pitch / energy embeddings modules.py:947,958): gather forward, sort-free
     backward (torch sorts the ids and runs a 110 us kernel for the 16 k pitch ids)."""
     return _Embedding.apply(ids, weight, -1 if padding_idx is None else int(padding_idx))
+
+
+class _MelL1(torch.autograd.Function):
+    """both masked mel L1 terms of CompTransTTSLoss (loss.py:130-138,303-304) in one pass - csrc/optim.hip"""
+
+    @staticmethod
+    def forward(ctx, p1, p2, tgt, pad_mask):
+        p1, p2, tgt = p1.contiguous(), p2.contiguous(), tgt.contiguous()
+        sums, roww = K.mel_l1_fwd(p1, p2, tgt, pad_mask.contiguous().view(torch.uint8))
+        ctx.save_for_backward(p1, p2, tgt, roww, sums)
+        return sums[:2] / (tgt.shape[-1] * sums[2])
+
+    @staticmethod
+    def backward(ctx, g):
+        p1, p2, tgt, roww, sums = ctx.saved_tensors
+        d1, d2 = K.mel_l1_bwd(p1, p2, tgt, roww, sums, g.contiguous())
+        return d1, d2, None, None
+
+
+def mel_l1_pair(mel_pred, postnet_pred, target, pad_mask):
+    """-> tensor [2] = (mel_loss, postnet_mel_loss)"""
+    return _MelL1.apply(mel_pred, postnet_pred, target, pad_mask)

@@ -266,6 +266,16 @@ int ctts_softmax_rect_bwd(const float* P, float* dP, const int32_t* klens, const
 int ctts_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, float beta1, float beta2, float eps,
                         float weight_decay, float max_norm, float* state, void* stream);
 
+/* Masked L1 of the two mel predictions in one pass (CompTransTTSLoss mel / postnet-mel terms, model/loss.py:130-138,
+ * 303-304): rows with pad[row] != 0 count as zeros, w[row] = (sum_c |target[row,c]| != 0),
+ *   sums = { sum w |p1 - t|, sum w |p2 - t|, sum w }  ->  loss_k = sums[k] / (C * sums[2]);   roww [rows] <- w (kept for backward);
+ *   sums must be ZERO on entry (the kernel accumulates into it)
+ * bwd: d1, d2 = g[k] * sign(p_k - t) * w / (C * sums[2]) with g the two upstream scalars (device). */
+int ctts_mel_l1_fwd(const float* p1, const float* p2, const float* tgt, const uint8_t* pad, float* sums, float* roww, int64_t rows,
+                    int C, void* stream);
+int ctts_mel_l1_bwd(const float* p1, const float* p2, const float* tgt, const float* roww, const float* sums, const float* g, float* d1,
+                    float* d2, int64_t rows, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
