@@ -13,6 +13,10 @@ value = valid mel frames of all ranks / max-over-ranks wall time.
 Adds `roofline` (dominant kernel: the implicit-GEMM Conv1d k=9 of the decoder FFN, fp32 MFMA peak
 157.3 TFLOP/s) and `cpu_baseline` (oracle restatement of the reference's CPU PyTorch path, timed on
 this host on a bounded sample) to the JSON line.
+
+Other BASELINE configurations: --block conformer (configs[2]); --learn-alignment / --prosody liu2021
+(together: configs[4] = SURVEY C5).  The step is two hipGraphs (fwd+loss+bwd | fused clip+Adam) with the
+RCCL all-reduce of the flat gradient arena between them; --no-graph launches eagerly.
 """
 import argparse
 import json
