@@ -876,14 +876,14 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   if (!vec_ok(d)) return dispatch_layout<64, 64, false>(d, st);
 #ifndef CTTS_NO_BUF
   if (buf_ok(d)) {
-    // 64x64 tiles (6 waves/SIMD) match the 128x128 kernel on every measured shape (109 / 119 / 108 / 107 TFLOP/s on FFN conv fwd,
+    // 64x64 tiles (64 VGPRs: 8 waves/SIMD) match the 128x128 kernel on every measured shape (109 / 119 / 108 / 107 TFLOP/s on FFN conv fwd,
     // 4096^3, conv dgrad, conv wgrad) and make padded-row skipping effective: 64-row granularity and many waves per CU instead of two
     // rounds of 128-row tiles (fs2 train step 33.3 -> 29.8 ms).  CTTS_FORCE_TILE=128 keeps the big-tile kernel reachable for A/B runs.
     if (force_tile == 128) return dispatch_buf<128, 128>(d, st);
     return dispatch_buf<64, 64>(d, st);
   }
 #endif
-  // weight-gradient (TN) reductions measured faster on 64x64 tiles (6 waves/SIMD): 92.6 vs 84.6 TFLOP/s on the FFN conv wgrad
+  // weight-gradient (TN) reductions measured faster on 64x64 tiles (64 VGPRs: 8 waves/SIMD): 92.6 vs 84.6 TFLOP/s on the FFN conv wgrad
   if (tiles128 >= 256 && d.N > 64 && (d.a_kc || d.b_kc)) return dispatch_layout<128, 128, true>(d, st);
   return dispatch_layout<64, 64, true>(d, st);
 }

@@ -163,7 +163,7 @@ class _LinearConv(torch.autograd.Function):
                 wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
                 K.conv_weight_repack(w.contiguous(), wd, N, Cin, ksize, 1)
                 # few output tiles but a long reduction (FFN conv dgrad: 1024 tiles, K = 9216): split K so that the launch fills
-                # all 256 CUs x 6 workgroups (atomic accumulation into a zero-filled dX)
+                # all 256 CUs x 8 resident workgroups (atomic accumulation into a zero-filled dX)
                 tiles = -(-M // 64) * -(-Cin // 64)
                 sk = min(4, max(2, -(-2304 // tiles))) if (_DGRAD_SPLIT_K and tiles < 1536 and ksize * N >= 4096) else 1
                 dX = torch.zeros_like(x) if sk > 1 else torch.empty_like(x)
@@ -304,7 +304,7 @@ _ATTN_SPLIT_K = int(_os.environ.get("CTTS_ATTN_SPLIT_K", "2"))      # tuning kno
 
 def _attn_split_k(nbatch, T, dh):
     """The [T, d_h] outputs of attention (P V, dV, dQ, dK) are only ceil(T/64) x ceil(d_h/64) tiles per (batch, head) - 1,024 workgroups
-    for 1,536 slots at the canonical batch - but reduce over T keys / queries: split that reduction (atomic accumulation into the
+    for 2,048 slots (256 CUs x 8 resident workgroups) at the canonical batch - but reduce over T keys / queries: split that reduction (atomic accumulation into the
     zero-initialised outputs) until the launch fills the machine."""
     tiles = -(-T // 64) * -(-dh // 64) * nbatch
     return _ATTN_SPLIT_K if (_ATTN_SPLIT_K > 1 and tiles < 1536 and T >= 512) else 1
