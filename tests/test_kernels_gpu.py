@@ -618,3 +618,27 @@ def test_accumulators_are_rezeroed_on_every_graph_replay(Cc):
         g.replay()
         torch.cuda.synchronize()
         close(res, x.double().sum(0), 1e-5, "colsum under graph replay")
+
+
+def test_c_abi_rejects_bad_arguments_with_messages():
+    """int status + thread-local error string (include/ctts.h conventions): every wrapper raises CttsError carrying ctts_last_error()."""
+    from ctts_amd._lib import CttsError
+    x = torch.zeros(4, 8, 6, device=DEV)                 # C = 6 is not a multiple of 4
+    with pytest.raises(CttsError, match="C % 4"):
+        K.im2col_3x3s2(x.view(1, 4, 8, 6))
+    with pytest.raises(CttsError, match="conv view needs cin"):
+        K.gemm(torch.zeros(8, 6, device=DEV), torch.zeros(4, 18, device=DEV), torch.zeros(8, 4, device=DEV), 8, 4, 18, 6, 18, 4, True, True,
+               conv=(8, 1, 6))
+    with pytest.raises(CttsError, match="p_drop"):
+        K.gemm(torch.zeros(8, 8, device=DEV), torch.zeros(8, 8, device=DEV), torch.zeros(8, 8, device=DEV), 8, 8, 8, 8, 8, 8, True, True,
+               p_drop=1.5)
+    with pytest.raises(CttsError, match="excludes bias"):
+        K.gemm(torch.zeros(8, 8, device=DEV), torch.zeros(8, 8, device=DEV), torch.zeros(8, 8, device=DEV), 8, 8, 8, 8, 8, 8, True, True,
+               bias=torch.zeros(8, device=DEV), E=torch.zeros(8, 8, device=DEV), rowsub=torch.zeros(8, device=DEV))
+    with pytest.raises(CttsError, match="Tk"):
+        K.forward_sum_fwd(torch.zeros(1, 4, 2000, device=DEV), torch.ones(1, dtype=torch.int32, device=DEV),
+                          torch.ones(1, dtype=torch.int32, device=DEV), -1.0)
+    with pytest.raises(CttsError, match="CPU tensor"):
+        K.colsum(torch.zeros(4, 4))
+    # a failed call does not poison the library: the next valid call works
+    assert float(K.colsum(torch.ones(5, 3, device=DEV)).sum()) == 15.0
