@@ -113,14 +113,19 @@ class TrainStep:
         self.g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fb):
             self.fwd_bwd()
-        self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt):
-            self.clip_and_step()
+        if self.fadam is not None:           # the fused clip+Adam kernels are capture-safe; torch's foreach clip + Adam (CTTS_TORCH_ADAM=1)
+            self.g_opt = torch.cuda.CUDAGraph()   # mis-replays on the strided (GEMM-major) Conv1d parameters and stays eager
+            with torch.cuda.graph(self.g_opt):
+                self.clip_and_step()
 
     def __call__(self):
         self.optim.update_learning_rate()            # host scalar -> device lr tensor (outside the graphs)
         if self.g_fb is not None:
-            self.g_fb.replay(); self.reduce(); self.g_opt.replay()
+            self.g_fb.replay(); self.reduce()
+            if self.g_opt is not None:
+                self.g_opt.replay()
+            else:
+                self.clip_and_step()
         else:
             self.fwd_bwd(); self.reduce(); self.clip_and_step()
         self.step_no += 1
@@ -186,7 +191,7 @@ def cpu_baseline(seconds_budget=30.0):
     torch.manual_seed(1234)
     model = ctts_amd.CompTransTTS(pre, mc, tc)            # parameters only (reference initialisers); never run on CPU
     trainable = {k for k, p in model.named_parameters() if p.requires_grad}
-    sd = {k: (v.detach().clone().requires_grad_(True) if k in trainable else v.detach().clone())
+    sd = {k: (v.detach().contiguous().clone().requires_grad_(True) if k in trainable else v.detach().clone())
           for k, v in model.state_dict().items()}
     params = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9)

@@ -143,6 +143,9 @@ __global__ void conv_weight_repack_kernel(const float* __restrict__ src, float* 
     } else if (mode == 1) {  // dst[ci][kk][co] = src[co][ci][k-1-kk]
       const int co = (int)(e % cout); const long t = e / cout; const int kk = (int)(t % k); const int ci = (int)(t / k);
       dst[e] = src[((long)co * cin + ci) * k + (k - 1 - kk)];
+    } else if (mode == 4) {  // dst[ci][kk][co] = src[co][k-1-kk][ci]      (src already in the GEMM-major forward layout)
+      const int co = (int)(e % cout); const long t = e / cout; const int kk = (int)(t % k); const int ci = (int)(t / k);
+      dst[e] = src[((long)co * k + (k - 1 - kk)) * cin + ci];
     } else {                 // dst[co][ci][kk] (+)= src[co][kk][ci]      (mode 3 accumulates)
       const int kk = (int)(e % k); const long t = e / k; const int ci = (int)(t % cin); const int co = (int)(t / cin);
       const float v = src[((long)co * k + kk) * cin + ci];
@@ -298,7 +301,7 @@ extern "C" int ctts_epilogue_bwd(const float* dy, const float* rowscale, const f
 }
 
 extern "C" int ctts_conv_weight_repack(const float* src, float* dst, int cout, int cin, int k, int mode, void* stream) {
-  CTTS_REQUIRE(src && dst && mode >= 0 && mode <= 3, "ctts_conv_weight_repack: bad arguments");
+  CTTS_REQUIRE(src && dst && mode >= 0 && mode <= 4, "ctts_conv_weight_repack: bad arguments");
   const long total = (long)cout * cin * k;
   if (total == 0) return 0;
   hipLaunchKernelGGL(conv_weight_repack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, cout, cin, k,

@@ -23,13 +23,20 @@ def arena_offsets(params):
     return offs, o
 
 
+def _strided_like(flat_slice, p):
+    """view of a flat slice with p's shape AND strides (parameters may be dense permuted views, e.g. the GEMM-major Conv1d weights)"""
+    if p.is_contiguous():
+        return flat_slice.view_as(p)
+    return flat_slice.as_strided(p.size(), p.stride())
+
+
 class FlatGradArena:
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.offsets, n = arena_offsets(self.params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)     # alignment gaps stay zero forever
         for p, o in zip(self.params, self.offsets):
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            p.grad = _strided_like(self.flat[o:o + p.numel()], p)
 
     def zero_(self):
         self.flat.zero_()
@@ -66,8 +73,9 @@ class FlatAdam:
         self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)      # same (aligned) layout as the gradient arena
         with torch.no_grad():
             for p, o in zip(params, grad_arena.offsets):
-                self.flat_param[o:o + p.numel()].copy_(p.detach().reshape(-1))
-                p.data = self.flat_param[o:o + p.numel()].view_as(p)
+                v = _strided_like(self.flat_param[o:o + p.numel()], p)
+                v.copy_(p.detach())
+                p.data = v
         self.m = torch.zeros_like(self.flat_param)
         self.v = torch.zeros_like(self.flat_param)
         self.lr = lr if torch.is_tensor(lr) else torch.tensor(float(lr), dtype=torch.float32, device=dev)

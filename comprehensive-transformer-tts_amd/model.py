@@ -41,9 +41,13 @@ class _Linear(nn.Module):
 
 
 class _Conv(nn.Module):
+    """Conv1d parameters with the reference's shape [Cout, Cin, K] (state-dict / optimizer compatible) but GEMM-major MEMORY
+    [Cout][K][Cin] behind permuted strides: the implicit-GEMM forward reads the weight as is, the weight-gradient GEMM accumulates
+    straight into `.grad` (same strides), only the data-gradient operand is repacked (ops._LinearConv)."""
+
     def __init__(self, cin, cout, k):
         super().__init__()
-        self.weight = nn.Parameter(torch.empty(cout, cin, k))
+        self.weight = nn.Parameter(torch.empty(cout, k, cin).permute(0, 2, 1))
         self.bias = nn.Parameter(torch.empty(cout))
 
 

@@ -28,8 +28,18 @@ def set_grad_accumulation_fusion(flag):
 
 
 def _fusable(p):
-    return (_FUSE_GRAD_ACCUM and p is not None and p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_contiguous()
-            and p.grad.dtype == torch.float32)
+    return (_FUSE_GRAD_ACCUM and p is not None and p.is_leaf and p.requires_grad and p.grad is not None
+            and p.grad.dtype == torch.float32 and (p.grad.is_contiguous() or p.grad.stride() == p.stride()))
+
+
+def _gemm_major(w):
+    """[Cout, K*Cin] view of a Conv1d weight whose memory is already [Cout][K][Cin] (model._Conv), else None"""
+    if w.dim() != 3:
+        return None
+    N, Cin, k = w.shape
+    if w.stride() == (k * Cin, 1, Cin) or (k == 1 and w.is_contiguous()):
+        return w.permute(0, 2, 1).view(N, k * Cin)
+    return None
 
 
 # ---- weight-gradient side stream -------------------------------------------------------------------------------
@@ -113,8 +123,10 @@ class _LinearConv(torch.autograd.Function):
         Z = torch.empty_like(out) if act != ACT_NONE else None
         if ksize:
             T = x.shape[-2]
-            wf = torch.empty(N, ksize * Cin, dtype=torch.float32, device=x.device)
-            K.conv_weight_repack(w.contiguous(), wf, N, Cin, ksize, 0)
+            wf = _gemm_major(w)
+            if wf is None:
+                wf = torch.empty(N, ksize * Cin, dtype=torch.float32, device=x.device)
+                K.conv_weight_repack(w.contiguous(), wf, N, Cin, ksize, 0)
             conv = (T, (ksize - 1) // 2, Cin)
             Kdim = ksize * Cin
         else:
@@ -161,7 +173,11 @@ class _LinearConv(torch.autograd.Function):
             pad = (ksize - 1) // 2
             if ctx.needs_input_grad[0]:
                 wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
-                K.conv_weight_repack(w.contiguous(), wd, N, Cin, ksize, 1)
+                wmaj = _gemm_major(w)
+                if wmaj is not None:
+                    K.conv_weight_repack(wmaj, wd, N, Cin, ksize, 4)
+                else:
+                    K.conv_weight_repack(w.contiguous(), wd, N, Cin, ksize, 1)
                 # few output tiles but a long reduction (FFN conv dgrad: 1024 tiles, K = 9216): split K so that the launch fills
                 # all 256 CUs x 8 resident workgroups (atomic accumulation into a zero-filled dX)
                 tiles = -(-M // 64) * -(-Cin // 64)
@@ -172,15 +188,23 @@ class _LinearConv(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 Kd = ksize * Cin
                 fused = _fusable(w)
-                dwf = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
-                with _wgrad_scope(fused, dZ, x, dwf):
-                    K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                           split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
-                    if fused:
-                        K.conv_weight_repack(dwf, w.grad, N, Cin, ksize, 3)
-                    else:
-                        dW = torch.empty_like(w)
-                        K.conv_weight_repack(dwf, dW, N, Cin, ksize, 2)
+                gmaj = _gemm_major(w.grad) if fused else None
+                if gmaj is not None:             # GEMM-major parameter: the split-K partials are added straight into param.grad
+                    with _wgrad_scope(True, dZ, x):
+                        K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
+                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
+                else:
+                    dwf = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
+                    with _wgrad_scope(fused, dZ, x, dwf):
+                        K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
+                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
+                        if fused:
+                            K.conv_weight_repack(dwf, w.grad, N, Cin, ksize, 3)
+                        elif _gemm_major(w) is not None:
+                            dW = dwf.view(N, ksize, Cin).permute(0, 2, 1)      # a view with the parameter's own strides: no repack
+                        else:
+                            dW = torch.empty_like(w)
+                            K.conv_weight_repack(dwf, dW, N, Cin, ksize, 2)
         else:
             if ctx.needs_input_grad[0]:
                 dX = torch.empty_like(x)

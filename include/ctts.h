@@ -101,7 +101,9 @@ int ctts_row_tile_map(const int32_t* row_lens, int row_T, int row_halo, int M, i
  *   mode 0: wf[Cout][K][Cin]                 (forward implicit-GEMM B operand)
  *   mode 1: wd[Cin][K][Cout], taps flipped   (data-gradient implicit-GEMM B operand)
  *   mode 2: inverse of mode 0 (wgrad result [Cout][K][Cin] -> [Cout][Cin][K])
- *   mode 3: as mode 2 but ADDED to dst (gradient accumulation straight into param.grad)      */
+ *   mode 3: as mode 2 but ADDED to dst (gradient accumulation straight into param.grad)
+ *   mode 4: wd from a weight that is already stored GEMM-major, src = wf[Cout][K][Cin] (the layout this package keeps its own Conv1d
+ *           parameters in - exposed with reference shape [Cout,Cin,K] through strides - so that forward and wgrad need no repack)  */
 int ctts_conv_weight_repack(const float* src, float* dst, int cout, int cin, int k, int mode, void* stream);
 
 /* ---------------------------------------------------------------------------------------
