@@ -102,7 +102,10 @@ _WGRAD_SPLIT_MULT = float(_os.environ.get("CTTS_WGRAD_SPLIT_MULT", "1"))
 
 def _split_k_for(Mo, No, Kred):
     """split-K factor for weight-gradient GEMMs (small output, long reduction)."""
+    forced = int(_os.environ.get("CTTS_WGRAD_SPLIT", "0"))
     t128 = ((Mo + 127) // 128) * ((No + 127) // 128)
+    if forced and t128 >= 64:
+        return forced
     want = max(1, int(-(-512 // t128) * _WGRAD_SPLIT_MULT))
     return int(max(1, min(want, max(1, Kred // 512))))
 
