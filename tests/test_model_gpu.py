@@ -553,3 +553,22 @@ def test_hipgraph_replay_matches_eager_training():
     print("eager", eager, "graph", graph)
     for a, b in zip(eager, graph):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (eager, graph)       # observed ~1e-7: same kernels, same dropout stream
+
+
+def test_bench_two_rank_data_parallel_path_runs():
+    """bench.py --gpus 2 launched exactly as the driver does (torch.distributed.run, one process per rank), with both ranks sharing this
+    GPU and gloo standing in for RCCL (test hooks CTTS_BENCH_SAME_DEVICE / CTTS_BENCH_BACKEND): flat-arena all-reduce between the two
+    graphs, max-over-ranks timing, one JSON line from rank 0 with the aggregate value."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CTTS_BENCH_SAME_DEVICE="1", CTTS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--batch", "c1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2" and np.isfinite(d["config"]["final_loss"])
