@@ -180,9 +180,9 @@ def cpu_baseline(seconds_budget=30.0):
     timed on this host: C1 batch (B=4, 3,032 valid frames), full train step with dropout."""
     import ctts_amd
     from ctts_amd.configs import get_configs
-    from ctts_amd.loss import CompTransTTSLoss
     from ctts_amd.synthetic import make_batch, as_model_args, C1_SRC_LENS
     from oracle import restate as R           # checker / baseline only
+    from oracle.loss_restate import RefLoss as CompTransTTSLoss
 
     pre, mc, tc = get_configs()
     ncores = os.cpu_count() or 1
@@ -262,8 +262,6 @@ def main():
     # conformer decoders crop to max_seq_len = 1000 in training (conformer.py:148-154): cap mel length
     mk = make_unsup_batch if a.learn_alignment else make_batch
     batch_cpu = mk(src_lens, seed=1234 + rank, max_mel_cap=1000 if a.block == "conformer" else None)
-    if a.learn_alignment:         # host copies of the lengths keep F.ctc_loss free of device->host syncs (graph capture)
-        loss_fn.host_lens = (batch_cpu["src_lens"].tolist(), batch_cpu["mel_lens"].tolist())
     batch = to_device(batch_cpu, dev)
     valid_frames = int(batch_cpu["mel_lens"].sum())
     padded_frames = batch_cpu["mels"].shape[0] * batch_cpu["mels"].shape[1]

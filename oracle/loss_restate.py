@@ -1,24 +1,19 @@
-"""`CompTransTTSLoss` and `ScheduledOptim` (reference: model/loss.py:10-347, model/optimizer.py:5-53).
+"""TEST INFRASTRUCTURE - CPU restatement of the reference's loss (model/loss.py:10-386) in stock torch ops.
 
-SURVEY.md section 8(f1): the loss runs inside the timed train step, on the HIP device only: the two masked mel-L1 terms are one
-fused kernel pair (csrc/optim.hip), ForwardSumLoss is the device CTC recursion (csrc/align.hip); the [B,Ts]-sized duration / pitch /
-energy terms are stock PyTorch-ROCm ops on device tensors.  Two changes make the step
-hipGraph-capturable without changing any value: the word-duration scatter uses the static bound
-Ts+1 instead of `word_id.max()+1` (loss.py:156-157: the extra bins are zero and masked), and the
-energy L1 uses a masked mean instead of `masked_select` (loss.py:236-243) - neither needs a
-device->host sync.  learn_alignment=True adds ForwardSumLoss and BinLoss;
-prosody_modeling.model_type == "liu2021" adds the prosody L1 terms (loss.py:319-324).
+Checker only (tests/, bench.py's cpu_baseline): the product loss (comprehensive-transformer-tts_amd/loss.py) runs on the HIP device and
+raises on host tensors.  Pinned against the reference's own 9-tuple on goldens G9 / G6-loss / G10-loss (tests/test_loss_cpu.py).
+Two formulation changes that do not alter any value: the word-duration scatter uses the static bound Ts+1 instead of `word_id.max()+1`
+(loss.py:156-157) and the energy L1 is a masked mean instead of `masked_select` (loss.py:236-243); ForwardSumLoss is one batched
+`F.ctc_loss` call with the classes beyond each utterance's key length masked to -inf (the reference loops over utterances).
 """
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
-from .configs import SIL_PHONEME_IDS
+SIL_PHONEME_IDS = (357, 358, 359)        # "@sp", "@spn", "@sil" of text/symbols.py (the silence tokens loss.py:30-33 looks up)
 
 
-class CompTransTTSLoss(nn.Module):
+class RefLoss(nn.Module):
     def __init__(self, preprocess_config, model_config, train_config):
         super().__init__()
         self.learn_alignment = model_config["duration_modeling"]["learn_alignment"]
@@ -32,6 +27,13 @@ class CompTransTTSLoss(nn.Module):
         self.model_type = model_config["prosody_modeling"]["model_type"]
         self.prosody_loss_enable_steps = train_config["prosody"]["prosody_loss_enable_steps"]
         self.sil_ph_ids = SIL_PHONEME_IDS
+
+    @staticmethod
+    def _masked_l1_mel(pred, target, pad_mask):
+        pred = pred.masked_fill(pad_mask.unsqueeze(-1), 0)
+        target = target.masked_fill(pad_mask.unsqueeze(-1), 0)
+        w = target.abs().sum(-1, keepdim=True).ne(0).float().expand_as(target)
+        return ((pred - target).abs() * w).sum() / w.sum()
 
     def _duration_loss(self, dur_pred, dur_gt, txt_tokens, nonpad):
         losses = {}
@@ -73,17 +75,20 @@ class CompTransTTSLoss(nn.Module):
         return losses
 
     @staticmethod
-    def forward_sum_loss(attn_logprob, in_lens, out_lens, blank_logprob=-1.0):
-        """ForwardSumLoss (loss.py:350-377): mean over utterances of the CTC negative log-likelihood of the text sequence (per token),
-        the log-softmax taken over [blank, first key_len tokens] - all utterances in one launch on the device."""
-        B = attn_logprob.shape[0]
-        if not attn_logprob.is_cuda:
-            raise _lib.CttsError("CompTransTTSLoss runs on the HIP device only (ForwardSum kernels, csrc/align.hip); got host tensors")
-        from . import ops
-        # the alpha/beta recursions of all utterances in one launch each, no host round trip
-        per = ops.forward_sum_nll(attn_logprob[:, 0], in_lens, out_lens, blank_logprob)
-        per = torch.where(torch.isinf(per), torch.zeros_like(per), per)                # zero_infinity=True
-        return (per / in_lens.clamp(min=1).to(per.dtype)).sum() / B
+    def forward_sum_loss(attn_logprob, in_lens, out_lens, blank_logprob=-1.0, host_lens=None):
+        """ForwardSumLoss (loss.py:350-377) as ONE batched CTC call instead of a per-sample Python loop: classes beyond
+        key_len are excluded from each sample's log-softmax (the reference slices them away) by masking them to -inf.
+        `host_lens=(in_list, out_list)`: the same lengths as Python ints - F.ctc_loss otherwise copies the device tensors
+        to the host (a sync that a hipGraph capture cannot contain)."""
+        B, _, Tm, Ts = attn_logprob.shape
+        logits = F.pad(attn_logprob[:, 0], (1, 0), value=blank_logprob)                     # [B,Tm,Ts+1], class 0 = blank
+        cls = torch.arange(Ts + 1, device=logits.device)[None, None, :]
+        logits = logits.masked_fill(cls > in_lens[:, None, None], float("-inf"))
+        logp = torch.log_softmax(logits, dim=-1).transpose(0, 1)                             # [Tm,B,Ts+1]
+        targets = torch.arange(1, Ts + 1, device=logits.device)[None, :].expand(B, -1)
+        ctc_in, ctc_tgt = (list(host_lens[1]), list(host_lens[0])) if host_lens is not None else (out_lens, in_lens)
+        per = F.ctc_loss(logp, targets, ctc_in, ctc_tgt, blank=0, reduction="none", zero_infinity=True)
+        return (per / in_lens.clamp(min=1).to(per.dtype)).sum() / B          # nn.CTCLoss 'mean' per sample, then / batch
 
     @staticmethod
     def bin_loss(hard, soft):
@@ -96,17 +101,14 @@ class CompTransTTSLoss(nn.Module):
         src_nonpad = (~src_masks)
         mel_nonpad = (~mel_masks)
         mel_targets = mel_targets[:, : mel_masks.shape[1], :]
-        if not mel_pred.is_cuda:
-            raise _lib.CttsError("CompTransTTSLoss runs on the HIP device only: there is no CPU path in the product")
-        from . import ops
-        both = ops.mel_l1_pair(mel_pred, post_pred, mel_targets, mel_masks)     # both masked L1 terms in one kernel pass (csrc/optim.hip)
-        mel_loss, postnet_mel_loss = both[0], both[1]
+        mel_loss = self._masked_l1_mel(mel_pred, mel_targets, mel_masks)
+        postnet_mel_loss = self._masked_l1_mel(post_pred, mel_targets, mel_masks)
         zero = torch.zeros(1, device=mel_targets.device)
         ctc_loss = bin_loss = zero
         if self.learn_alignment:
             attn_soft, attn_hard, attn_hard_dur, attn_logprob = attn_outs
             duration_targets = attn_hard_dur
-            ctc_loss = self.forward_sum_loss(attn_logprob, src_lens, mel_lens)
+            ctc_loss = self.forward_sum_loss(attn_logprob, src_lens, mel_lens, host_lens=None)
             if step < self.binarization_loss_enable_steps:
                 w = 0.0
             else:
@@ -132,53 +134,3 @@ class CompTransTTSLoss(nn.Module):
                 energy_loss = ((e_pred - energy_targets).abs() * m).sum() / m.sum()
             total = total + sum(duration_loss.values()) + sum(pitch_loss.values()) + energy_loss
         return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, prosody_loss)
-
-
-class ScheduledOptim:
-    """Adam(betas, eps) + Noam warm-up with step annealing (model/optimizer.py:5-53).
-    `capturable=True` keeps the learning rate in a device tensor so the step can live in a hipGraph."""
-
-    def __init__(self, model, train_config, model_config, current_step, capturable=False):
-        oc = train_config["optimizer"]
-        dev = next(model.parameters()).device
-        self.capturable = capturable and dev.type == "cuda"
-        lr0 = torch.tensor(1e-3, device=dev) if self.capturable else 1e-3
-        self._optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr0, betas=tuple(oc["betas"]),
-                                           eps=oc["eps"], weight_decay=oc["weight_decay"],
-                                           capturable=self.capturable, fused=True if dev.type == "cuda" else None)
-        self.n_warmup_steps = oc["warm_up_step"]
-        self.anneal_steps = oc["anneal_steps"]
-        self.anneal_rate = oc["anneal_rate"]
-        self.current_step = current_step
-        self.init_lr = np.power(model_config["transformer"]["encoder_hidden"], -0.5)
-
-    def _get_lr_scale(self):
-        lr = np.min([np.power(self.current_step, -0.5), np.power(self.n_warmup_steps, -1.5) * self.current_step])
-        for s in self.anneal_steps:
-            if self.current_step > s:
-                lr = lr * self.anneal_rate
-        return lr
-
-    def update_learning_rate(self):
-        self.current_step += 1
-        lr = float(self.init_lr * self._get_lr_scale())
-        for g in self._optimizer.param_groups:
-            if torch.is_tensor(g["lr"]):
-                g["lr"].fill_(lr)
-            else:
-                g["lr"] = lr
-        return lr
-
-    def step_and_update_lr(self, scaler=None):
-        lr = self.update_learning_rate()
-        if scaler is not None:
-            scaler.step(self._optimizer)
-        else:
-            self._optimizer.step()
-        return lr
-
-    def zero_grad(self):
-        self._optimizer.zero_grad()
-
-    def load_state_dict(self, sd):
-        self._optimizer.load_state_dict(sd)

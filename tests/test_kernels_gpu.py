@@ -584,7 +584,7 @@ def test_embedding_fwd_bwd_vs_torch(V, C, shape):
 def test_fused_mel_l1_pair_matches_torch_formula():
     """ctts_mel_l1_fwd/bwd against CompTransTTSLoss._masked_l1_mel (the reference's masked l1, loss.py:130-138), incl. an all-zero target
     row inside the valid region (weight 0) and padded rows."""
-    from ctts_amd.loss import CompTransTTSLoss
+    from oracle.loss_restate import RefLoss as CompTransTTSLoss
     B, T, C = 3, 37, 80
     g = torch.Generator().manual_seed(9)
     tgt = torch.randn(B, T, C, generator=g)

@@ -1,10 +1,11 @@
-"""CPU: the restated CompTransTTSLoss reproduces the reference's 9-tuple (golden G9, captured from
-model/loss.py on the G2 train-mode outputs)."""
+"""CPU: the oracle's loss restatement (oracle/loss_restate.py) reproduces the reference's 9-tuple (goldens G9 / G6-loss / G10-loss,
+captured from model/loss.py); the product loss is device-only and is checked against the same goldens in tests/test_model_gpu.py."""
 import numpy as np
 import torch
 
 from ctts_amd.configs import get_configs
-from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
+from ctts_amd.loss import ScheduledOptim
+from oracle.loss_restate import RefLoss as CompTransTTSLoss
 from oracle import restate as R
 from tests.util import load_golden, closed_form_sd, batch_from_golden
 

@@ -572,3 +572,46 @@ def test_bench_two_rank_data_parallel_path_runs():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "dp2" and np.isfinite(d["config"]["final_loss"])
+
+
+@pytest.mark.parametrize("gname,lname,unsup,prosody", [
+    ("g2_fs2_train_nodrop", "g9_loss", False, "none"),
+    ("g6_unsup_hard_step60000", "g6_unsup_loss_step60000", True, "none"),
+    ("g10_liu2021_train_nodrop", "g10_liu2021_loss", False, "liu2021"),
+    ("g10_liu2021_unsup_step60000", "g10_liu2021_unsup_loss_step100001", True, "liu2021")])
+def test_product_loss_matches_reference_goldens(gname, lname, unsup, prosody):
+    """The device-only CompTransTTSLoss (fused mel-L1 pair, device ForwardSum, Bin and prosody terms) on the product model's own outputs
+    against the 9-tuples captured from the reference's model/loss.py (goldens G9, G6-loss, G10-loss)."""
+    from ctts_amd.loss import CompTransTTSLoss
+    g, gl = load_golden(gname), load_golden(lname)
+    pre, mc, tc = get_configs()
+    mc["duration_modeling"]["learn_alignment"] = unsup
+    mc["prosody_modeling"]["model_type"] = prosody
+    m = ctts_amd.CompTransTTS(pre, mc, tc)
+    m.load_state_dict(closed_form_sd(unsup=unsup, prosody=prosody))
+    m = m.to(DEV)
+    m.train()
+    no_dropout(m)
+    b = to_device(batch_from_golden(g), DEV)
+    args = [b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"], b["max_mel_len"], b["p_targets"],
+            b["e_targets"], b["d_targets"], b["attn_priors"] if unsup else None, None]
+    step_fwd = 60000 if unsup else None
+    out = m(*args, step=step_fwd)
+    inputs = [None, None] + list(args)
+    inputs[9:11] = out[-2:]
+    L = CompTransTTSLoss(pre, mc, tc).to(DEV)
+    step = int(gl["step"])
+    total, mel, post, pitch, energy, dur, ctc, binl, pros = L(inputs, out[:-2], step)
+    got = {"total": total, "mel": mel, "postnet_mel": post, "energy": energy, "pitch.C": pitch["C"], "pitch.uv": pitch["uv"],
+           "duration.pdur": dur["pdur"], "duration.wdur": dur["wdur"], "duration.sdur": dur["sdur"], "ctc": ctc, "bin": binl, "prosody": pros}
+    for k, v in got.items():
+        if "loss." + k not in gl:
+            continue
+        ref = float(np.asarray(gl["loss." + k]).reshape(-1)[0])
+        val = float(v.reshape(-1)[0])
+        assert abs(val - ref) <= 5e-4 * max(1.0, abs(ref)), (k, val, ref)
+    total.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    with pytest.raises(Exception):
+        L([None, None] + [a.cpu() if torch.is_tensor(a) else a for a in args], tuple(o.cpu() if torch.is_tensor(o) else o for o in out[:-2]),
+          step)
