@@ -521,7 +521,8 @@ def test_conformer_decoder_crops_to_max_seq_len_in_training():
     assert maxerr(out[0], ref[0].detach().numpy()) <= MEL_TOL and maxerr(out[1], ref[1].detach().numpy()) <= MEL_TOL
 
 
-def test_hipgraph_replay_matches_eager_training():
+@pytest.mark.parametrize("c5", [False, True])
+def test_hipgraph_replay_matches_eager_training(c5):
     """Five full train steps (fwd + loss + bwd + fused clip/Adam, dropout on) replayed from the two hipGraphs vs launched eagerly
     from the same initial state and dropout seed: the loss trajectories must agree (this is the check that exposed the stale-bytes
     problem of memset nodes inside replayed graphs)."""
@@ -533,12 +534,18 @@ def test_hipgraph_replay_matches_eager_training():
     def run(use_graph):
         torch.manual_seed(1234)
         pre, mc, tc = get_configs()
+        if c5:                        # SURVEY config C5: liu2021 prosody + learn_alignment (GRU, MAS, ForwardSum kernels inside the graph)
+            from ctts_amd.synthetic import make_unsup_batch
+            mc["prosody_modeling"]["model_type"] = "liu2021"
+            mc["duration_modeling"]["learn_alignment"] = True
         model = ctts_amd.CompTransTTS(pre, mc, tc).to(DEV)
         model.train()
         loss_fn = CompTransTTSLoss(pre, mc, tc).to(DEV)
         optim = ScheduledOptim(model, tc, mc, 50000, capturable=True)
-        batch = to_device(make_batch([60, 41, 33, 17], 8, seed=3), DEV)
+        batch = to_device((make_unsup_batch if c5 else make_batch)([60, 41, 33, 17], 8, seed=3), DEV)
         step = bench.TrainStep(model, loss_fn, optim, batch, 1, use_graph)
+        if c5:
+            step.step_no = 100001
         if use_graph:
             step.capture()            # 2 warm-up steps + capture: do the same number of eager steps on the other side
         else:
