@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--batch", default="canonical", choices=["canonical", "c1"])
     ap.add_argument("--block", default="transformer_fs2", choices=["transformer_fs2", "conformer"],
                     help="block_type plugin; the headline metric (BASELINE configs[1]) is transformer_fs2, conformer = configs[2]")
+    ap.add_argument("--dataset", default="LJSpeech", choices=["LJSpeech", "VCTK"],
+                    help="VCTK = multi-speaker yaml (external 512-d speaker embeddings, lambda_word_dur 0); with 8 utterances per GPU this "
+                         "is the per-GPU slice of BASELINE configs[3] / SURVEY C4 (global batch 64 over 8 GPUs)")
     ap.add_argument("--prosody", default="none", choices=["none", "liu2021"], help="prosody_modeling.model_type (SURVEY a17)")
     ap.add_argument("--learn-alignment", action="store_true",
                     help="unsupervised durations: aligner + device MAS + ForwardSum/Bin losses (SURVEY a16); with --prosody liu2021 "
@@ -249,7 +252,7 @@ def main():
     from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
     from ctts_amd.synthetic import make_batch, make_unsup_batch, to_device, C1_SRC_LENS
 
-    pre, mc, tc = get_configs()
+    pre, mc, tc = get_configs(a.dataset)
     mc["block_type"] = a.block
     mc["prosody_modeling"]["model_type"] = a.prosody
     mc["duration_modeling"]["learn_alignment"] = a.learn_alignment
@@ -259,9 +262,14 @@ def main():
     loss_fn = CompTransTTSLoss(pre, mc, tc).to(dev)
     optim = ScheduledOptim(model, tc, mc, 50000, capturable=True)
     src_lens = None if a.batch == "canonical" else C1_SRC_LENS
+    extra = {}
+    if a.dataset == "VCTK":          # C4: 8 utterances per GPU (every second canonical length), speaker embeddings ~ N(0,1)[B,512]
+        from ctts_amd.synthetic import CANONICAL_SRC_LENS
+        src_lens = CANONICAL_SRC_LENS[rank % 2::2] if a.batch == "canonical" else src_lens
+        extra = dict(multi_speaker=True)
     # conformer decoders crop to max_seq_len = 1000 in training (conformer.py:148-154): cap mel length
     mk = make_unsup_batch if a.learn_alignment else make_batch
-    batch_cpu = mk(src_lens, seed=1234 + rank, max_mel_cap=1000 if a.block == "conformer" else None)
+    batch_cpu = mk(src_lens, seed=1234 + rank, max_mel_cap=1000 if a.block == "conformer" else None, **extra)
     batch = to_device(batch_cpu, dev)
     valid_frames = int(batch_cpu["mel_lens"].sum())
     padded_frames = batch_cpu["mels"].shape[0] * batch_cpu["mels"].shape[1]
@@ -304,7 +312,8 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = total_valid * a.steps / elapsed
     if rank == 0:
-        headline = a.batch == "canonical" and a.block == "transformer_fs2" and a.prosody == "none" and not a.learn_alignment
+        headline = (a.batch == "canonical" and a.block == "transformer_fs2" and a.prosody == "none" and not a.learn_alignment
+                    and a.dataset == "LJSpeech")
         roof = measure_dominant_kernel(dev, batch_cpu) if headline else None
         # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
         step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
@@ -313,8 +322,10 @@ def main():
             "metric": "mel-frames/sec (train step) LJSpeech batch=16, 1/2/4/8 MI355X", "value": value, "unit": "mel-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"LJSpeech {a.block} batch={len(batch_cpu['src_lens'])}/GPU, seq<=128 -> mel<={batch_cpu['mels'].shape[1]}x80, "
-                                    + (f"supervised durations (BASELINE configs[{1 if a.block == 'transformer_fs2' else 2}])"
+            "config": {"workload": (f"{a.dataset} {a.block} batch={len(batch_cpu['src_lens'])}/GPU, seq<=128 -> mel<={batch_cpu['mels'].shape[1]}x80, "
+                                    + ("supervised durations, multi-speaker (per-GPU slice of BASELINE configs[3] = 64 utterances over 8 GPUs)"
+                                       if (a.dataset == "VCTK" and not a.learn_alignment and a.prosody == "none") else
+                                       f"supervised durations (BASELINE configs[{1 if a.block == 'transformer_fs2' else 2}])"
                                        if not (a.learn_alignment or a.prosody != "none") else
                                        f"learn_alignment={a.learn_alignment} prosody={a.prosody} (BASELINE configs[4] / SURVEY C5 family)")
                                     + "; full train step fwd+loss+bwd+clip+Adam, dropout on"),

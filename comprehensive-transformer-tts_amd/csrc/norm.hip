@@ -1,6 +1,7 @@
 // LayerNorm / BatchNorm1d (channel-last) / masked softmax kernels.  All HBM-bound: one pass over
 // the activation per direction, row statistics in registers (one wavefront per row).
 #include "ctts_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -303,7 +304,8 @@ extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* 
     return -2;
   }
   if (rows == 0) return 0;
-  const int blocks = min((rows + 3) / 4, 256);
+  static const int ln_blocks = getenv("CTTS_LN_BWD_BLOCKS") ? atoi(getenv("CTTS_LN_BWD_BLOCKS")) : 256;     // tuning knob
+  const int blocks = min((rows + 3) / 4, ln_blocks);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
                      C, p_drop, seed, drop_offset, rowscale, dres);
   CTTS_CHECK_LAUNCH("ctts_layernorm_bwd");
