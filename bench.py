@@ -317,7 +317,7 @@ def main():
         roof = measure_dominant_kernel(dev, batch_cpu) if headline else None
         # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
         step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
-        cpu = None if a.no_cpu_baseline else cpu_baseline()
+        cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline()      # reported baseline: rank 0 at N = 1 only
         line = {
             "metric": "mel-frames/sec (train step) LJSpeech batch=16, 1/2/4/8 MI355X", "value": value, "unit": "mel-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
