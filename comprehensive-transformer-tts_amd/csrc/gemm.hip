@@ -632,7 +632,9 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
     }
     tm = d.tile_map[1 + r];
     scheduled_active = r < d.tile_map[0];
-  } else if (d.tile_map == reinterpret_cast<const int32_t*>(1)) {      // tuning knob CTTS_NATURAL_ORDER: plain blockIdx order
+  } else if (PARTIAL || d.tile_map == reinterpret_cast<const int32_t*>(1)) {
+    // plain blockIdx order.  Always for per-batch length limits (attention): the valid tiles of a short utterance are its FIRST
+    // rows / columns, and the XCD-contiguous remap below would put all of them on the first XCDs.  Also the CTTS_NATURAL_ORDER knob.
     wg = blockIdx.x;
     tm = wg / tiles_n;
   } else {
