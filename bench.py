@@ -1,26 +1,32 @@
 """bench.py - mel-frames/sec of one full CompTransTTS train step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-Step (train.py:102-125 of the reference): forward -> CompTransTTSLoss (step > var_start_steps, all
-terms active) -> backward -> [DP: all-reduce(sum)/world of the flat gradient arena over RCCL] ->
-clip_grad_norm_(1.0) -> Adam (Noam LR) -> zero_grad, fp32, dropout ON, synthetic LJSpeech-shaped
-canonical batch (B=16, src<=128, mel<=1024, 11,992 valid frames) resident in HBM.
-Weak scaling: every rank runs its own canonical batch (what the reference de facto does).
-value = valid mel frames of all ranks / max-over-ranks wall time.
+N > 1 without a launcher: bench.py starts the N ranks itself (one process per GPU, like the reference's
+`mp.spawn(train, nprocs=num_gpus)`, train.py:251-252).  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N` it picks RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment instead.  Rank 0 prints ONE JSON line.
 
-Adds `roofline` (dominant kernel: the implicit-GEMM Conv1d k=9 of the decoder FFN, fp32 MFMA peak
-157.3 TFLOP/s) and `cpu_baseline` (oracle restatement of the reference's CPU PyTorch path, timed on
-this host on a bounded sample) to the JSON line.
+Step (train.py:102-125 of the reference): forward -> CompTransTTSLoss (step > var_start_steps, all terms active) -> backward
+[-> DP: bucketed all-reduce(sum)/world of the flat gradient arena over RCCL, overlapped with the remaining backward stages] ->
+clip_grad_norm_(1.0) -> Adam (Noam LR) -> zero_grad, fp32, dropout ON, synthetic LJSpeech-shaped canonical batch (SURVEY.md 8(d):
+B=16, src<=128, mel<=1024, 11,992 valid frames) resident in HBM.
+  --scaling weak   (default): every rank runs its own canonical batch of 16 (what the reference de facto does)
+  --scaling strong : ONE global canonical batch of 16, rank r takes utterances r, r+N, ... (DistributedSampler, train.py:44)
+value = valid mel frames of all ranks per step / max-over-ranks wall time per step.
 
-Other BASELINE configurations: --block conformer (configs[2]); --learn-alignment / --prosody liu2021
-(together: configs[4] = SURVEY C5).  The step is two hipGraphs (fwd+loss+bwd | fused clip+Adam) with the
-RCCL all-reduce of the flat gradient arena between them; --no-graph launches eagerly.
+Adds `roofline` (dominant kernel: the implicit-GEMM Conv1d k=9 of the decoder FFN, fp32 MFMA peak 157.3 TFLOP/s), `cpu_baseline`
+(oracle restatement of the reference's CPU PyTorch path timed on this host on a bounded sample: C2 = the same B=16 batch, and C1 =
+B=4, at n = physical cores and n = 8 threads) and `pcie_inclusive` (the same step fed by the host data path: collate layout ->
+one pinned buffer -> one async H2D per step -> one D2D refresh of the graph inputs) to the JSON line.
+
+Other BASELINE configurations: --block conformer (configs[2]); --dataset VCTK (per-GPU slice of configs[3]); --learn-alignment /
+--prosody liu2021 (together: configs[4] = SURVEY C5).  --no-graph launches eagerly; --no-overlap uses one blocking all-reduce.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,8 +43,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: 16 utterances per GPU; strong: 16 utterances in total, sharded r::N")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-overlap", action="store_true", help="DP: one blocking all-reduce of the whole arena after backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="full", choices=["full", "primary"],
+                    help="primary: only C2 at physical cores; full: C1 and C2 at physical cores and at 8 threads")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the second timed loop with the host data path inside")
     ap.add_argument("--batch", default="canonical", choices=["canonical", "c1"])
     ap.add_argument("--block", default="transformer_fs2", choices=["transformer_fs2", "conformer"],
                     help="block_type plugin; the headline metric (BASELINE configs[1]) is transformer_fs2, conformer = configs[2]")
@@ -52,88 +64,48 @@ def parse():
     return ap.parse_args()
 
 
-class TrainStep:
-    """forward/loss/backward [+ gradient all-reduce] + clip + Adam, optionally as two hipGraphs
-    (fwd+bwd, clip+Adam) with the RCCL all-reduce issued eagerly between them."""
-
-    def __init__(self, model, loss_fn, optim, batch, world, use_graph):
-        from ctts_amd.synthetic import as_model_args
-
-        self.model, self.loss_fn, self.optim, self.world = model, loss_fn, optim, world
-        self.args = as_model_args(batch)
-        self.loss_inputs = [None, None] + list(self.args)
-        self.step_no = 50001
-        from ctts_amd.dp import FlatGradArena
-        from ctts_amd import ops
-        ops.set_grad_accumulation_fusion(True)     # kernels accumulate straight into the flat gradient arena
-        if os.environ.get("CTTS_WGRAD_STREAM", "0") == "1":
-            # opt-in A/B knob: wgrad GEMMs on a side stream.  Measured SLOWER on MI355X (31.1 vs 29.9 ms/step): the
-            # co-scheduled GEMMs evict each other's L2 working set, which costs more than the tail rounds they fill.
-            ops.set_wgrad_stream(torch.cuda.Stream())
-        # flat fp32 gradient arena: p.grad are views -> one all-reduce, no bucket copies
-        self.arena = FlatGradArena(model.parameters())
-        self.params = self.arena.params
-        self.flat_grad = self.arena.flat
-        self.use_graph = use_graph
-        self.fadam = None
-        if os.environ.get("CTTS_TORCH_ADAM", "0") != "1":    # default: fused clip + Adam over flat arenas (csrc/optim.hip)
-            from ctts_amd.dp import FlatAdam
-            oc = optim._optimizer.defaults
-            self.fadam = FlatAdam(self.arena, optim._optimizer.param_groups[0]["lr"], betas=tuple(oc["betas"]), eps=oc["eps"],
-                                  weight_decay=oc["weight_decay"], max_norm=1.0, current_step=0)
-        self.g_fb = self.g_opt = None
-        self.loss_val = None
-
-    def fwd_bwd(self):
-        args = list(self.args)
-        args[7] = dict(args[7])                      # the model mutates p_targets like the reference does
-        out = self.model(*args, step=self.step_no)
-        inputs = list(self.loss_inputs)
-        inputs[9:11] = out[-2:]
-        losses = self.loss_fn(inputs, out[:-2], self.step_no)
-        self.flat_grad.zero_()
-        losses[0].backward()
-        self.loss_val = losses[0].detach()
-
-    def reduce(self):
-        self.arena.all_reduce_mean(self.world)
-
-    def clip_and_step(self):
-        if self.fadam is not None:
-            self.fadam.step()
-            return
-        torch.nn.utils.clip_grad_norm_(self.params, 1.0, foreach=True)
-        self.optim._optimizer.step()
-
-    def capture(self):
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                self.fwd_bwd(); self.reduce(); self.optim.update_learning_rate(); self.clip_and_step()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
-            self.fwd_bwd()
-        if self.fadam is not None:           # the fused clip+Adam kernels are capture-safe; torch's foreach clip + Adam (CTTS_TORCH_ADAM=1)
-            self.g_opt = torch.cuda.CUDAGraph()   # mis-replays on the strided (GEMM-major) Conv1d parameters and stays eager
-            with torch.cuda.graph(self.g_opt):
-                self.clip_and_step()
-
-    def __call__(self):
-        self.optim.update_learning_rate()            # host scalar -> device lr tensor (outside the graphs)
-        if self.g_fb is not None:
-            self.g_fb.replay(); self.reduce()
-            if self.g_opt is not None:
-                self.g_opt.replay()
-            else:
-                self.clip_and_step()
-        else:
-            self.fwd_bwd(); self.reduce(); self.clip_and_step()
-        self.step_no += 1
+# ---------------------------------------------------------------------------------------------------------------- launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
+def spawn_ranks(n):
+    """one process per GPU (train.py:29-35,251-252): re-run this script N times with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set;
+    rank 0 inherits stdout (the JSON line), the others only stderr.  Returns the first non-zero exit code (0 if all succeeded)."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                        for q in pending:
+                            procs[q].terminate()          # exact PIDs we started, never a pattern
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------- measurement
 def measure_dominant_kernel(dev, batch, iters=20):
     """HIP-event timing (on the launch stream) of the dominant kernel at its train-step arguments:
     decoder FFN Conv1d(256->1024, k=9) as implicit GEMM, M=B*Tm rows, N=1024, K=2304."""
@@ -174,22 +146,30 @@ def measure_dominant_kernel(dev, batch, iters=20):
             traffic = json.load(f).get("traffic_bytes_per_launch")
     return {"bound": "mfma", "achieved": algo_flops / dt / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": algo_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-            "kernel": "gemm_buf_kernel<64,64,true,true,true,false> (decoder FFN Conv1d k=9 fwd as implicit GEMM, train-step arguments incl. padded-row skipping)", "launch_us": dt * 1e6,
-            "padded_tflops": padded_flops / dt / 1e12}
+            "kernel": "ctts_gemm conv fwd (decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments incl. padded-row skipping)",
+            "launch_us": dt * 1e6, "padded_tflops": padded_flops / dt / 1e12}
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """Reference CPU PyTorch path, restated (oracle/restate.py; parity vs the reference <= 2e-5 on the goldens),
-    timed on this host: C1 batch (B=4, 3,032 valid frames), full train step with dropout."""
+def _physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:      # noqa: BLE001
+        pass
+    return os.cpu_count() or 1
+
+
+def _cpu_train_steps(src_lens, nthreads, n_timed, warm):
+    """oracle restatement of the reference's CPU PyTorch train step (dropout on) -> (median seconds per step, valid frames)"""
     import ctts_amd
     from ctts_amd.configs import get_configs
-    from ctts_amd.synthetic import make_batch, as_model_args, C1_SRC_LENS
+    from ctts_amd.synthetic import make_batch, as_model_args
     from oracle import restate as R           # checker / baseline only
     from oracle.loss_restate import RefLoss as CompTransTTSLoss
 
     pre, mc, tc = get_configs()
-    ncores = os.cpu_count() or 1
-    nthreads = min(ncores, 64)
     torch.set_num_threads(nthreads)
     torch.manual_seed(1234)
     model = ctts_amd.CompTransTTS(pre, mc, tc)            # parameters only (reference initialisers); never run on CPU
@@ -199,12 +179,11 @@ def cpu_baseline(seconds_budget=30.0):
     params = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
     loss_fn = CompTransTTSLoss(pre, mc, tc)
-    batch = make_batch(C1_SRC_LENS)
+    batch = make_batch(src_lens)
     args = as_model_args(batch)
     valid = int(batch["mel_lens"].sum())
     times = []
-    t_start = time.perf_counter()
-    for it in range(4):
+    for it in range(warm + n_timed):
         t0 = time.perf_counter()
         a = list(args); a[7] = dict(a[7])
         stats = {}
@@ -219,25 +198,52 @@ def cpu_baseline(seconds_budget=30.0):
         with torch.no_grad():
             for k, v in stats.items():
                 sd[k].copy_(v)
-        dt = time.perf_counter() - t0
-        if it > 0:
-            times.append(dt)
-        if time.perf_counter() - t_start > seconds_budget and times:
-            break
-    med = sorted(times)[len(times) // 2]
-    return {"value": valid / med, "unit": "mel-frames/s", "cores": nthreads, "kind": "port",
-            "sample": f"C1 batch B=4 ({valid} valid frames), {len(times)} train steps after 1 warm-up, median {med:.2f} s/step, "
-                      f"torch CPU fp32 {nthreads} threads of {ncores} cores"}
+        if it >= warm:
+            times.append(time.perf_counter() - t0)
+    return sorted(times)[len(times) // 2], valid
+
+
+def cpu_baseline(mode="full"):
+    """Reference CPU PyTorch path, restated (oracle/restate.py; parity vs the live reference: tests/golden/reference_vs_oracle_full_size.json),
+    timed on this host.  BASELINE.md section 4: C2 (the canonical B=16 batch, i.e. the SAME workload as `value`) and C1 (B=4), at
+    n = physical cores and n = 8 threads.  The headline `value` of this object is C2 at the faster of the two thread counts."""
+    from ctts_amd.synthetic import C1_SRC_LENS
+    phys = _physical_cores()
+    runs = []
+    plan = [("C2", None, phys, 1, 1)] if mode == "primary" else \
+           [("C1", C1_SRC_LENS, phys, 2, 1), ("C1", C1_SRC_LENS, 8, 1, 1), ("C2", None, phys, 1, 1), ("C2", None, 8, 1, 0)]
+    for name, lens, nt, n_timed, warm in plan:
+        sec, valid = _cpu_train_steps(lens, nt, n_timed, warm)
+        runs.append({"config": name, "threads": nt, "valid_frames": valid, "s_per_step": sec, "frames_per_s": valid / sec,
+                     "timed_steps": n_timed, "warmup_steps": warm})
+    c2 = [r for r in runs if r["config"] == "C2"]
+    best = max(c2, key=lambda r: r["frames_per_s"])
+    ratio = None
+    rj = os.path.join(ROOT, "tests", "golden", "reference_vs_oracle_full_size.json")
+    if os.path.exists(rj):
+        with open(rj) as f:
+            ratio = json.load(f).get("speed_ratio_reference_over_oracle")
+    return {"value": best["frames_per_s"], "unit": "mel-frames/s", "cores": best["threads"], "kind": "port",
+            "sample": f"C2 = canonical batch B=16 ({best['valid_frames']} valid frames), full train step with dropout, "
+                      f"{best['timed_steps']} timed step(s) after {best['warmup_steps']} warm-up, {best['s_per_step']:.2f} s/step, torch CPU fp32 "
+                      f"{best['threads']} threads ({phys} physical / {os.cpu_count()} logical cores on this host)",
+            "runs": runs, "reference_over_port_time_ratio": ratio}
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with --gpus equal to the number of ranks")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path in the product)"
     if os.environ.get("CTTS_BENCH_SAME_DEVICE"):              # test hook: all ranks share cuda:0 (gloo backend)
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -249,8 +255,10 @@ def main():
             dist.init_process_group(backend)
     import ctts_amd
     from ctts_amd.configs import get_configs
+    from ctts_amd.data import PackedBatch, Prefetcher
     from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
-    from ctts_amd.synthetic import make_batch, make_unsup_batch, to_device, C1_SRC_LENS
+    from ctts_amd.synthetic import make_batch, make_unsup_batch, as_collated_tuple, shard, C1_SRC_LENS, CANONICAL_SRC_LENS
+    from ctts_amd.trainer import TrainStep
 
     pre, mc, tc = get_configs(a.dataset)
     mc["block_type"] = a.block
@@ -264,46 +272,63 @@ def main():
     src_lens = None if a.batch == "canonical" else C1_SRC_LENS
     extra = {}
     if a.dataset == "VCTK":          # C4: 8 utterances per GPU (every second canonical length), speaker embeddings ~ N(0,1)[B,512]
-        from ctts_amd.synthetic import CANONICAL_SRC_LENS
         src_lens = CANONICAL_SRC_LENS[rank % 2::2] if a.batch == "canonical" else src_lens
         extra = dict(multi_speaker=True)
     # conformer decoders crop to max_seq_len = 1000 in training (conformer.py:148-154): cap mel length
     mk = make_unsup_batch if a.learn_alignment else make_batch
-    batch_cpu = mk(src_lens, seed=1234 + rank, max_mel_cap=1000 if a.block == "conformer" else None, **extra)
-    batch = to_device(batch_cpu, dev)
+    cap = 1000 if a.block == "conformer" else None
+    if a.scaling == "strong":        # ONE global batch, utterances rank::world (identical on every rank before sharding)
+        batch_cpu = shard(mk(src_lens, seed=1234, max_mel_cap=cap, **extra), rank, world)
+    else:                            # weak: a full batch per rank, different data on every rank
+        batch_cpu = mk(src_lens, seed=1234 + rank, max_mel_cap=cap, **extra)
     valid_frames = int(batch_cpu["mel_lens"].sum())
     padded_frames = batch_cpu["mels"].shape[0] * batch_cpu["mels"].shape[1]
+    # host data path: collate layout -> ONE pinned buffer -> ONE H2D copy; the model inputs are views of the device buffer
+    collated = as_collated_tuple(batch_cpu)
+    packed = PackedBatch.pack(collated)
+    views, ev = packed.to_device(dev)
+    torch.cuda.current_stream().wait_event(ev)
+    model_args = views[2:]
 
-    step = TrainStep(model, loss_fn, optim, batch, world, not a.no_graph)
+    step = TrainStep(model, loss_fn, optim, model_args, world=world, use_graph=not a.no_graph, overlap=not a.no_overlap,
+                     adam_step=optim.current_step)   # steady state: both the Noam schedule and Adam's bias correction at step 50,000
+    step.bind_static_buffer(packed.device_buffer)
     if a.prosody != "none" or a.learn_alignment:
         step.step_no = 100001                                 # every loss term on: bin-loss weight 1, prosody loss enabled
     mode = "eager"
     if not a.no_graph:
         try:
             step.capture()
-            mode = "hipgraph(fwd+bwd | clip+adam)"
+            mode = (f"hipgraph({step.n_stages} backward stages, bucketed all-reduce between replays | clip+adam)" if step.staged
+                    else "hipgraph(fwd+bwd | clip+adam)")
         except Exception as e:                                # noqa: BLE001
-            if rank == 0:
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            step.g_fb = step.g_opt = None
+            if world > 1:
+                raise                                         # ranks must not diverge in launch mode
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            step.graphs = step.g_opt = None
+
+    def timed(fn, n):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t)
+        return el
+
     for _ in range(a.warmup):
         step()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(step, a.steps)
     loss_final = float(step.loss_val)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
         vf = torch.tensor([valid_frames], device=dev, dtype=torch.float64)
         dist.all_reduce(vf)
         total_valid = float(vf)
@@ -311,31 +336,56 @@ def main():
         total_valid = float(valid_frames)
     ms_per_step = elapsed / a.steps * 1e3
     value = total_valid * a.steps / elapsed
+
+    # second loop, PCIe inclusive: a prefetch thread packs + uploads one batch per step; the step starts with ONE D2D refresh
+    pcie = None
+    if not a.no_pcie:
+        n_feed = a.steps + 2
+        pf = Prefetcher((collated for _ in range(n_feed)), dev, depth=2)
+
+        def fed_step():
+            next(pf)
+            step.feed(pf.last_buffer)
+            step()
+        for _ in range(2):
+            fed_step()
+        el2 = timed(fed_step, a.steps)
+        pcie = {"value": total_valid * a.steps / el2, "unit": "mel-frames/s", "ms_per_step": el2 / a.steps * 1e3,
+                "h2d_bytes_per_step": int(packed.host.numel()),
+                "path": "collate-layout tuple -> PackedBatch (one pinned buffer) -> one async H2D on a copy stream (prefetch depth 2) -> "
+                        "one D2D copy into the graph's static inputs"}
+
     if rank == 0:
         headline = (a.batch == "canonical" and a.block == "transformer_fs2" and a.prosody == "none" and not a.learn_alignment
                     and a.dataset == "LJSpeech")
-        roof = measure_dominant_kernel(dev, batch_cpu) if headline else None
+        roof = measure_dominant_kernel(dev, make_batch(None, seed=1234)) if headline else None
         # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
         step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
-        cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline()      # reported baseline: rank 0 at N = 1 only
+        cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.cpu_baseline)      # reported baseline: rank 0 at N = 1 only
+        nb = len(batch_cpu["src_lens"])
+        what = ("supervised durations, multi-speaker (per-GPU slice of BASELINE configs[3] = 64 utterances over 8 GPUs)"
+                if (a.dataset == "VCTK" and not a.learn_alignment and a.prosody == "none") else
+                f"supervised durations (BASELINE configs[{1 if a.block == 'transformer_fs2' else 2}])"
+                if not (a.learn_alignment or a.prosody != "none") else
+                f"learn_alignment={a.learn_alignment} prosody={a.prosody} (BASELINE configs[4] / SURVEY C5 family)")
         line = {
             "metric": "mel-frames/sec (train step) LJSpeech batch=16, 1/2/4/8 MI355X", "value": value, "unit": "mel-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{a.dataset} {a.block} batch={len(batch_cpu['src_lens'])}/GPU, seq<=128 -> mel<={batch_cpu['mels'].shape[1]}x80, "
-                                    + ("supervised durations, multi-speaker (per-GPU slice of BASELINE configs[3] = 64 utterances over 8 GPUs)"
-                                       if (a.dataset == "VCTK" and not a.learn_alignment and a.prosody == "none") else
-                                       f"supervised durations (BASELINE configs[{1 if a.block == 'transformer_fs2' else 2}])"
-                                       if not (a.learn_alignment or a.prosody != "none") else
-                                       f"learn_alignment={a.learn_alignment} prosody={a.prosody} (BASELINE configs[4] / SURVEY C5 family)")
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"{a.dataset} {a.block} batch={nb}/GPU"
+                                    + (f" (global batch {nb * world}, weak scaling)" if a.scaling == "weak" else
+                                       " (global batch 16 sharded r::N, strong scaling)")
+                                    + f", seq<=128 -> mel<={batch_cpu['mels'].shape[1]}x80, " + what
                                     + "; full train step fwd+loss+bwd+clip+Adam, dropout on"),
                        "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
-                       "parallelism": f"dp{world}", "final_loss": loss_final},
+                       "parallelism": f"dp{world}", "final_loss": loss_final,
+                       "grad_buckets_bytes": step.reducer.bucket_bytes() if world > 1 else None},
             "roofline": roof, "step_model_tflops_per_gpu": step_tflops,
             "step_frac_of_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
+            "pcie_inclusive": pcie,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

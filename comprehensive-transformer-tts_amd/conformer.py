@@ -153,6 +153,8 @@ class _ConformerStack(nn.Module):
         self.max_seq_len = config["max_seq_len"]
         self.position_enc = nn.Parameter(interleaved_sinusoid_table(self.max_seq_len + 1, self.d_model).unsqueeze(0),
                                          requires_grad=False)
+        if which == "encoder":      # registered BEFORE layer_stack like the reference (conformer.py:41-48): `parameters()` order is what
+            self.src_word_emb = nn.Embedding(N_SYMBOLS + 1, self.d_model, padding_idx=0)     # index-based Adam state is keyed on
         self.layer_stack = nn.ModuleList([
             ConformerBlock(self.d_model, c[f"{which}_head"], c["feed_forward_expansion_factor"], c["conv_expansion_factor"],
                            c["conv_kernel_size"], c[f"{which}_dropout"], c["half_step_residual"], self.position_enc)
@@ -168,7 +170,10 @@ class _ConformerStack(nn.Module):
     def run(self, x, mask, pos_table):
         nonpad = (~mask).to(torch.float32).reshape(-1).contiguous()
         pos_table = pos_table.contiguous()
-        for blk in self.layer_stack:
+        cut = getattr(self, "_cut_prefix", None)
+        for li, blk in enumerate(self.layer_stack):
+            if cut is not None:
+                x = ops.stage_cut(x, f"{cut}.{li}")
             x = blk(x, nonpad, pos_table)
         return x
 
@@ -178,7 +183,6 @@ class TextEncoder(_ConformerStack):
 
     def __init__(self, config):
         super().__init__(config, "encoder")
-        self.src_word_emb = nn.Embedding(N_SYMBOLS + 1, self.d_model, padding_idx=0)
 
     def forward(self, src_seq, mask):
         emb = ops.embedding(src_seq, self.src_word_emb.weight, 0)

@@ -178,6 +178,7 @@ class Prefetcher:
                 raise self.err
             raise StopIteration
         batch, ev, dev = item
+        self.last_buffer = dev            # the packed device buffer behind `batch` (trainer.TrainStep.feed copies it in one piece)
         cur = torch.cuda.current_stream()
         cur.wait_event(ev)
         dev.record_stream(cur)            # the buffer was allocated on the copy stream: keep the allocator from recycling it early

@@ -1,12 +1,21 @@
 """Data-parallel plumbing (reference: train.py:29-35,44,58 = mp.spawn + DDP over NCCL).
 
-One process per GPU, parameters / Adam state / BN running stats replicated (identical seed), each
-rank its own batch, BatchNorm statistics local (the reference does not use SyncBatchNorm).  The only
-exchange per step is the gradient average.  Instead of DDP's 25 MiB bucket copies the gradients live
-in ONE flat fp32 arena (`p.grad` are views into it), reduced by a single RCCL all-reduce over xGMI
-(140.4 MB for fs2) and consumed in place by the fused clip + Adam.  Parameters that received no
-gradient contribute zeros (needed before var_start_steps).  Device-agnostic: the same
-code runs on gloo/CPU tensors in tests/test_dp_gloo.py.
+One process per GPU, parameters / Adam state replicated (identical seed), each rank its own batch, BatchNorm statistics
+local (the reference does not use SyncBatchNorm).  The only exchange per step is the gradient average.
+
+Layout: the gradients live in ONE flat fp32 arena (`p.grad` are views into it), so nothing is copied into buckets.  The arena is
+cut into a few BUCKETS by backward *stage*: the model's forward is severed at a handful of activations (`ops.stage_cut`), the
+backward pass then runs as S separate `backward()` calls (stage 0 = loss -> last cut, stage s = cut s-1 -> cut s), and after
+stage s every parameter that lives downstream of cut s has its final gradient.  Its arena range is all-reduced on a side
+stream while the next stage computes - the role DDP's 25 MiB bucket hooks play in the reference (train.py:58), but with
+boundaries that survive hipGraph capture: each stage is its own graph, the collectives stay eager launches between replays.
+
+Collective choice (xGMI is point-to-point, 7 links x ~153 GB/s per GPU): every bucket is a single large RCCL all-reduce
+(35-55 MB fp32), i.e. large enough that RCCL's multi-ring / direct schedules use all links; the per-link-bound single ring would
+need 2*(7/8)*140 MB / 153 GB/s = 1.6 ms per step, a 7-link reduce-scatter + all-gather 0.23 ms.  Either way
+only the LAST bucket (encoder + variance adaptor, finished by the final stage) is exposed; the others hide under the remaining
+backward stages.  Parameters that received no gradient contribute zeros (needed before var_start_steps).
+Device-agnostic: the same code runs on gloo/CPU tensors in tests/test_dp_gloo.py.
 """
 import torch
 import torch.distributed as dist
@@ -31,18 +40,39 @@ def _strided_like(flat_slice, p):
 
 
 class FlatGradArena:
+    """`params`: iterable of parameters, or of (name, parameter) pairs (names are kept for state dicts and stage plans)."""
+
     def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+        items = list(params)
+        if items and isinstance(items[0], tuple):
+            named = [(n, p) for n, p in items if p.requires_grad]
+        else:
+            named = [(str(i), p) for i, p in enumerate(items) if p.requires_grad]
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
         self.offsets, n = arena_offsets(self.params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)     # alignment gaps stay zero forever
+        self.bind()
+
+    def bind(self):
+        """(re)point every p.grad at its arena slice"""
         for p, o in zip(self.params, self.offsets):
             p.grad = _strided_like(self.flat[o:o + p.numel()], p)
+
+    def check_bound(self):
+        """raise if some p.grad no longer aliases the arena (e.g. after `zero_grad(set_to_none=True)`): the all-reduce and the fused
+        optimizer would silently run on stale zeros otherwise"""
+        base = self.flat.data_ptr()
+        for n, p, o in zip(self.names, self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != base + 4 * o:
+                raise RuntimeError(f"FlatGradArena: the gradient of '{n}' no longer aliases the flat arena (zero_grad(set_to_none=True)?) "
+                                   "- call arena.zero_() / arena.bind() instead")
 
     def zero_(self):
         self.flat.zero_()
 
     def all_reduce_mean(self, world=None, group=None):
-        """all-reduce(sum) / world == DDP gradient averaging."""
+        """blocking path: one all-reduce(sum) / world of the whole arena == DDP gradient averaging."""
         if world is None:
             world = dist.get_world_size(group) if dist.is_initialized() else 1
         if world > 1:
@@ -50,18 +80,117 @@ class FlatGradArena:
             self.flat.div_(world)
         return self.flat
 
+    def ranges_of(self, selected):
+        """merged [start, end) arena ranges (in floats, alignment gaps included) covering the parameters whose index is in `selected`"""
+        out = []
+        sel = sorted(selected)
+        ends = self.offsets[1:] + [self.flat.numel()]
+        for i in sel:
+            a, b = self.offsets[i], ends[i]
+            if out and out[-1][1] == a:
+                out[-1][1] = b
+            else:
+                out.append([a, b])
+        return [tuple(r) for r in out]
+
 
 def shard_batch_indices(n_items, rank, world):
     """DistributedSampler-like strided shard (train.py:44): rank r takes items r, r+world, ..."""
     return list(range(rank, n_items, world))
 
 
+# ---- staged backward + bucketed, overlapped gradient all-reduce -------------------------------------------------------------
+def stage_plan(model, n_cuts=3):
+    """Where to sever the forward of a CompTransTTS and which parameters are final after each backward stage.
+
+    -> (cut_names, stage_of) : `cut_names` in BACKWARD order (first = closest to the loss); `stage_of(param_name)` = index of the
+    stage after which that parameter's gradient is complete (0 .. len(cut_names)).
+    The decoder dominates the backward pass (75 % of the FLOPs), so the cuts sit between decoder layers and at the
+    decoder input: stage 0 = PostNet + mel_linear + upper decoder layers, ..., last stage = variance adaptor + encoder."""
+    dec = model.decoder
+    stack_name = "layers" if hasattr(dec, "layers") else "layer_stack"
+    L = len(getattr(dec, stack_name))
+    n_cuts = max(1, min(int(n_cuts), L))
+    # layer indices at whose INPUT the forward is severed, descending; the last cut is always the decoder input
+    inner = sorted({(L * k) // n_cuts for k in range(1, n_cuts)} - {0}, reverse=True)
+    cut_names = [f"decoder.{stack_name}.{i}" for i in inner] + ["decoder.in"]
+    bounds = inner                                    # stage s (< len(inner)) owns decoder layers >= inner[s] (and < inner[s-1])
+
+    def stage_of(name):
+        if name.startswith("postnet.") or name.startswith("mel_linear."):
+            return 0
+        if name.startswith(f"decoder.{stack_name}."):
+            li = int(name.split(".")[2])
+            for s, lo in enumerate(bounds):
+                if li >= lo:
+                    return s
+            return len(bounds)
+        if name.startswith("decoder."):
+            # final LayerNorm of the fs2 stack is applied after the last layer (stage 0); everything applied before the first
+            # layer (pos_embed_alpha) belongs to the stage that ends at the decoder input
+            return 0 if name.startswith("decoder.layer_norm.") else len(bounds)
+        return len(bounds) + 1                        # encoder, variance adaptor, speaker embedding: complete after the last stage
+    return cut_names, stage_of
+
+
+class BucketedReducer:
+    """All-reduce(sum)/world of the arena, one bucket per backward stage, on a side stream (overlaps the following stages).
+
+    launch(s): call right after backward stage s has been ISSUED on the current stream; finish(): current stream waits for all
+    buckets.  With world == 1 both are no-ops."""
+
+    def __init__(self, arena, stage_of, n_stages, world=None, group=None):
+        self.arena, self.group = arena, group
+        self.world = (dist.get_world_size(group) if dist.is_initialized() else 1) if world is None else int(world)
+        by_stage = [[] for _ in range(n_stages)]
+        for i, n in enumerate(arena.names):
+            by_stage[stage_of(n)].append(i)
+        self.ranges = [arena.ranges_of(ix) for ix in by_stage]
+        self.is_cuda = arena.flat.is_cuda
+        self.comm = torch.cuda.Stream(device=arena.flat.device) if (self.is_cuda and self.world > 1) else None
+        self.launched = 0
+
+    def bucket_bytes(self):
+        return [sum(b - a for a, b in r) * 4 for r in self.ranges]
+
+    def _reduce(self, s):
+        inv = 1.0 / self.world
+        for a, b in self.ranges[s]:
+            seg = self.arena.flat[a:b]
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+            seg.mul_(inv)
+
+    def launch(self, s):
+        self.launched += 1
+        if self.world <= 1 or not self.ranges[s]:
+            return
+        if self.comm is None:
+            self._reduce(s)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ev)
+            self._reduce(s)
+
+    def finish(self):
+        assert self.launched == len(self.ranges), f"BucketedReducer: {self.launched} of {len(self.ranges)} stages were launched"
+        self.launched = 0
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+
+
 class FlatAdam:
     """`clip_grad_norm_(params, max_norm)` + `torch.optim.Adam.step()` (train.py:118-125, model/optimizer.py:22-53) as ONE fused
     streaming update (csrc/optim.hip): parameters are re-homed into a flat fp32 arena (the tensors torch sees become
     views, state_dict()/load_state_dict() keep working), the gradients are the FlatGradArena, the moments are flat too.
-    `lr` is a device scalar tensor (share ScheduledOptim's capturable lr so the Noam schedule keeps driving it); the step counter
-    lives on the device, so `step()` replays inside a hipGraph."""
+    `lr` is a device scalar tensor (share ScheduledOptim's capturable lr - `ScheduledOptim.lr_tensor` - so the Noam schedule keeps
+    driving it); the step counter lives on the device, so `step()` replays inside a hipGraph.
+
+    `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format (state: {index: {step, exp_avg, exp_avg_sq}}, indices in
+    arena order = `model.parameters()` order restricted to trainable tensors), so the optimizer half of a reference checkpoint
+    (`train.py:190-200`: {"model": ..., "optimizer": adam.state_dict()}) round-trips; frozen parameters the reference also hands to
+    Adam (energy_bins) never get state there either."""
 
     def __init__(self, grad_arena, lr, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0, max_norm=1.0, current_step=0):
         from . import kernels
@@ -90,3 +219,43 @@ class FlatAdam:
     @property
     def total_norm(self):
         return self.state[2]
+
+    # ---- checkpointing in torch.optim.Adam's format
+    def state_dict(self):
+        step = float(self.state[1])
+        st = {}
+        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+            sl = slice(o, o + p.numel())
+            st[i] = {"step": torch.tensor(step), "exp_avg": _strided_like(self.m[sl], p).detach().clone(),
+                     "exp_avg_sq": _strided_like(self.v[sl], p).detach().clone()}
+        group = {"lr": float(self.lr), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "params": list(range(len(self.arena.params)))}
+        return {"state": st, "param_groups": [group]}
+
+    def load_state_dict(self, sd, param_index=None):
+        """`param_index`: optional list mapping arena position -> index in the checkpoint's param list (use it when the checkpoint's
+        Adam was built over ALL `model.parameters()` including frozen ones, as the reference does)."""
+        n = len(self.arena.params)
+        idx = list(range(n)) if param_index is None else list(param_index)
+        if len(idx) != n:
+            raise ValueError(f"FlatAdam.load_state_dict: need {n} parameter indices, got {len(idx)}")
+        steps = set()
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+                s = sd["state"].get(idx[i])
+                sl = slice(o, o + p.numel())
+                if s is None:                                           # parameter never stepped in the checkpoint
+                    self.m[sl].zero_(); self.v[sl].zero_()
+                    continue
+                if tuple(s["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"FlatAdam.load_state_dict: state {idx[i]} has shape {tuple(s['exp_avg'].shape)}, parameter "
+                                     f"'{self.arena.names[i]}' has {tuple(p.shape)}")
+                _strided_like(self.m[sl], p).copy_(s["exp_avg"])
+                _strided_like(self.v[sl], p).copy_(s["exp_avg_sq"])
+                steps.add(float(s["step"]))
+            if len(steps) > 1:
+                raise ValueError(f"FlatAdam.load_state_dict: per-parameter step counts differ ({sorted(steps)}); the fused update keeps one")
+            if steps:
+                self.state[1] = steps.pop()
+        g = sd["param_groups"][0]
+        self.betas, self.eps, self.weight_decay = tuple(g["betas"]), g["eps"], g["weight_decay"]

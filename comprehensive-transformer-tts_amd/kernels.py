@@ -33,6 +33,14 @@ def _f32c(t, name):
     return t
 
 
+def _dp_rank():
+    import os
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    return int(os.environ.get("RANK", "0"))
+
+
 class DropCtx:
     """Dropout bookkeeping: device-resident 64-bit seed + per-call-site offsets.
 
@@ -40,8 +48,12 @@ class DropCtx:
     hipGraph draws fresh masks on every replay; offsets are plain host constants assigned
     in program order, identical between eager and captured runs."""
 
-    def __init__(self, device, seed=1234):
-        self.seed = torch.tensor([seed * 0x9E3779B1 + 0x7F4A7C15], dtype=torch.int64, device=device)
+    def __init__(self, device, seed=None):
+        if seed is None:
+            # follows torch.manual_seed (like nn.Dropout would) and differs per data-parallel rank: ranks that were seeded identically
+            # for identical initial weights must still draw different masks
+            seed = (torch.initial_seed() + 0x51ED27 * _dp_rank()) & 0x3FFFFFFFFFFF
+        self.seed = torch.tensor([(int(seed) * 0x9E3779B1 + 0x7F4A7C15) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
         self.counter = 0
 
     def next_offset(self):

@@ -143,7 +143,9 @@ class ScheduledOptim:
         dev = next(model.parameters()).device
         self.capturable = capturable and dev.type == "cuda"
         lr0 = torch.tensor(1e-3, device=dev) if self.capturable else 1e-3
-        self._optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=lr0, betas=tuple(oc["betas"]),
+        # ALL model.parameters(), frozen ones included, exactly like the reference (optimizer.py:8-14): the optimizer half of a
+        # checkpoint is keyed on positions in this list (utils/model.py:22-26)
+        self._optimizer = torch.optim.Adam(list(model.parameters()), lr=lr0, betas=tuple(oc["betas"]),
                                            eps=oc["eps"], weight_decay=oc["weight_decay"],
                                            capturable=self.capturable, fused=True if dev.type == "cuda" else None)
         self.n_warmup_steps = oc["warm_up_step"]
@@ -177,8 +179,16 @@ class ScheduledOptim:
             self._optimizer.step()
         return lr
 
+    @property
+    def lr_tensor(self):
+        """the learning rate as the optimizer holds it: a device scalar tensor when `capturable` (hand it to dp.FlatAdam so the Noam
+        schedule keeps driving the fused update inside a hipGraph), else a float"""
+        return self._optimizer.param_groups[0]["lr"]
+
     def zero_grad(self):
-        self._optimizer.zero_grad()
+        # set_to_none=False: gradients that are views of a dp.FlatGradArena must stay bound to it (the reference's loop calls this
+        # every step, train.py:125); values are identical, None gradients stay None
+        self._optimizer.zero_grad(set_to_none=False)
 
     def load_state_dict(self, sd):
         self._optimizer.load_state_dict(sd)

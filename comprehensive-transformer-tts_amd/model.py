@@ -11,9 +11,11 @@ Contract kept from the reference:
   * the `block_type` plugin surface: `TextEncoder(config)`, `Decoder(config)`, `.d_model`.
 
 Not a module-tree translation: activations stay [B,T,C]; each reference sub-layer maps to one
-or two fused kernel launches (see ops.py).  Supported here: block_type transformer_fs2 and conformer
-(conformer.py), learn_alignment False, pitch_type cwt, phoneme-level energy, prosody model "none"
-(BASELINE.json configs 1-4); anything else raises NotImplementedError loudly.
+or two fused kernel launches (see ops.py).  Supported here (= every BASELINE.json config): block_type transformer_fs2 and
+conformer (conformer.py); learn_alignment False and True (aligner + device MAS, single- and multi-speaker); prosody_modeling
+"none" and "liu2021" (prosody.py); pitch_type cwt with pitch_norm log and use_uv; phoneme-level energy; ffn_act gelu,
+ffn_padding SAME, use_pitch_embed / use_energy_embed True (the shipped yaml values).  Any other value of these switches raises
+NotImplementedError in the constructor - nothing is silently ignored.
 """
 import json
 import math
@@ -141,6 +143,7 @@ class FFTBlocks(nn.Module):
         self.layers = nn.ModuleList([_Layer(hidden, ksize) for _ in range(n_layers)])
         self.layer_norm = _Norm(hidden)
         self.drop_ctx = None  # set by the owning model
+        self._cut_prefix = None   # "decoder.layers" when owned by CompTransTTS: names of the staged-backward cut points (dp.stage_plan)
 
     def run(self, x, pad_mask):
         """x [B,T,C] float32, pad_mask [B,T] bool (True = pad) -> [B,T,C]"""
@@ -156,8 +159,10 @@ class FFTBlocks(nn.Module):
             x = ops.rowscale_dropout(x, nonpad, 0.0, None)
         alpha = self.ksize ** -0.5
         pr = ops.PadRows(lens, T)      # rows t >= len are padding: every sub-layer output is re-masked (transformer_fs2.py:190,199)
-        for layer in self.layers:
+        for li, layer in enumerate(self.layers):
             op = layer.op
+            if self._cut_prefix is not None:
+                x = ops.stage_cut(x, f"{self._cut_prefix}.{li}")
             h, xr = ops.layer_norm_res(x, op.layer_norm1.weight, op.layer_norm1.bias, 1e-12)
             qkv = ops.linear(h, op.self_attn.in_proj_weight, pad_rows=pr)
             a = ops.self_attention(qkv, lens, self.num_heads)
@@ -175,11 +180,21 @@ class FFTBlocks(nn.Module):
         return self.run(x, padding_mask), padding_mask
 
 
+def _check_ffn_switches(config):
+    """transformer_fs2.py:87-88,131-132 hand variance_predictor.ffn_padding / ffn_act to every FFN; only the shipped values are built"""
+    vp = config.get("variance_predictor", {})
+    if vp.get("ffn_act", "gelu") != "gelu":
+        raise NotImplementedError(f"variance_predictor.ffn_act '{vp['ffn_act']}': the fused FFN epilogue is built for 'gelu' only")
+    if vp.get("ffn_padding", "SAME") != "SAME":
+        raise NotImplementedError(f"variance_predictor.ffn_padding '{vp['ffn_padding']}': only 'SAME' is built")
+
+
 class TextEncoder(FFTBlocks):
     """plugin contract: TextEncoder(config).forward(tokens[B,Ts], pad_mask[B,Ts]) -> (enc, word_emb)."""
 
     def __init__(self, config):
         c = config["transformer_fs2"]
+        _check_ffn_switches(config)
         super().__init__(c["encoder_hidden"], c["encoder_layer"], c["ffn_kernel_size"], c["encoder_dropout"],
                          c["encoder_head"], use_pos_embed=False)
         self.embed_tokens = nn.Embedding(N_SYMBOLS + 1, c["encoder_hidden"], padding_idx=0)
@@ -200,6 +215,7 @@ class Decoder(FFTBlocks):
 
     def __init__(self, config):
         c = config["transformer_fs2"]
+        _check_ffn_switches(config)
         super().__init__(c["decoder_hidden"], c["decoder_layer"], c["ffn_kernel_size"], c["decoder_dropout"],
                          c["decoder_head"], use_pos_embed=True)
         self.d_model = c["decoder_hidden"]
@@ -387,6 +403,11 @@ class VarianceAdaptor(nn.Module):
             raise NotImplementedError("only phoneme_level energy (the shipped configs)")
         self.pitch_cfg = pitch
         vp = model_config["variance_predictor"]
+        ve = model_config["variance_embedding"]
+        if not (ve.get("use_pitch_embed", True) and ve.get("use_energy_embed", True)):
+            raise NotImplementedError("variance_embedding.use_pitch_embed / use_energy_embed = False are not built (shipped configs: True)")
+        if vp.get("ffn_padding", "SAME") != "SAME":
+            raise NotImplementedError(f"variance_predictor.ffn_padding '{vp['ffn_padding']}': only 'SAME' is built")
         self.predictor_grad = vp["predictor_grad"]
         self.cwt_std_scale = vp["cwt_std_scale"]
         hidden = model_config["transformer"]["encoder_hidden"]  # sic: modules.py:739 reads the 'transformer' section
@@ -568,6 +589,7 @@ class CompTransTTS(nn.Module):
         self.encoder = enc_cls(model_config)
         self.variance_adaptor = VarianceAdaptor(preprocess_config, model_config, train_config, self.encoder.d_model)
         self.decoder = dec_cls(model_config)
+        self.decoder._cut_prefix = "decoder.layers" if hasattr(self.decoder, "layers") else "decoder.layer_stack"
         self.mel_linear = _Linear(self.decoder.d_model, preprocess_config["preprocessing"]["mel"]["n_mel_channels"])
         self.postnet = PostNet()
         self.speaker_emb = None
@@ -658,7 +680,7 @@ class CompTransTTS(nn.Module):
          attn_outs, prosody_info) = self.variance_adaptor(
             speaker_embeds, enc, text_embeds, src_lens, src_masks, mels, mel_lens, mel_masks, max_mel_len, p_targets,
             e_targets, d_targets, attn_priors, p_control, e_control, d_control, step)
-        output, mel_masks = self.decoder(output, mel_masks)
+        output, mel_masks = self.decoder(ops.stage_cut(output, "decoder.in"), mel_masks)
         output = ops.linear(output, self.mel_linear.weight, self.mel_linear.bias)
         postnet_output = self.postnet(output) + output
         return (output, postnet_output, p_predictions, e_predictions, log_d_predictions, d_rounded, src_masks, mel_masks,

@@ -32,6 +32,59 @@ def _fusable(p):
             and p.grad.dtype == torch.float32 and (p.grad.is_contiguous() or p.grad.stride() == p.stride()))
 
 
+# ---- staged backward (dp.py): named cut points in the forward ---------------------------------------------------------------
+_CUTS = None
+
+
+class CutRecorder:
+    """While active, `stage_cut(x, name)` with `name` in `names` severs the autograd graph at x: the forward continues on a detached
+    leaf copy, and (x, leaf) is recorded so that the backward pass can be run in stages - `loss.backward()` stops at the leaves,
+    `x.backward(leaf.grad)` continues upstream.  Each stage can then be captured as its own hipGraph with the gradient all-reduce
+    of the finished parameters launched between the replays (dp.BucketedReducer)."""
+
+    def __init__(self, names):
+        self.names = list(names)
+        self.pairs = {}
+
+    def __enter__(self):
+        global _CUTS
+        assert _CUTS is None, "CutRecorder is not re-entrant"
+        _CUTS = self
+        self.pairs = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _CUTS
+        _CUTS = None
+        return False
+
+    def backward_stages(self, loss):
+        """generator: runs backward stage 0 (from `loss`), yields 0, then stage s for every cut in backward order, yielding s."""
+        missing = [n for n in self.names if n not in self.pairs]
+        if missing:
+            raise RuntimeError(f"staged backward: the forward never reached the cut point(s) {missing}")
+        loss.backward()
+        yield 0
+        for s, name in enumerate(self.names, 1):
+            x, leaf = self.pairs[name]
+            g, leaf.grad = leaf.grad, None
+            if g is None:
+                raise RuntimeError(f"staged backward: no gradient arrived at cut '{name}'")
+            x.backward(g)
+            yield s
+        self.pairs = {}
+
+
+def stage_cut(x, name):
+    """identity unless a CutRecorder asks for `name` (and x is part of an autograd graph)"""
+    rec = _CUTS
+    if rec is None or name not in rec.names or not x.requires_grad:
+        return x
+    leaf = x.detach().requires_grad_(True)
+    rec.pairs[name] = (x, leaf)
+    return leaf
+
+
 def _gemm_major(w):
     """[Cout, K*Cin] view of a Conv1d weight whose memory is already [Cout][K][Cin] (model._Conv), else None"""
     if w.dim() != 3:

@@ -95,3 +95,44 @@ def as_model_args(batch):
     return (batch["speakers"], batch["texts"], batch["src_lens"], batch["max_src_len"], batch["mels"],
             batch["mel_lens"], batch["max_mel_len"], batch["p_targets"], batch["e_targets"], batch["d_targets"],
             batch.get("attn_priors"), batch["spker_embeds"])
+
+
+def as_collated_tuple(batch):
+    """The same batch in the layout `Dataset.collate_fn` hands to the train loop (dataset.py:166-228: a 20-tuple of numpy arrays and
+    lists) - the input of `data.PackedBatch.pack`, i.e. of the host data path."""
+    def n(t):
+        return None if t is None else t.numpy()
+    p = batch["p_targets"]
+    B = batch["texts"].shape[0]
+    return ([f"syn{i:04d}" for i in range(B)], [""] * B, n(batch["speakers"]), n(batch["texts"]), n(batch["src_lens"]),
+            int(batch["max_src_len"]), n(batch["mels"]), n(batch["mel_lens"]), int(batch["max_mel_len"]), n(p["pitch"]), n(p["f0"]),
+            n(p["uv"]), n(p["cwt_spec"]), n(p["f0_mean"]), n(p["f0_std"]), n(batch["e_targets"]), n(batch.get("d_targets")),
+            n(p.get("mel2ph")) if batch.get("d_targets") is not None else None, n(batch.get("attn_priors")), n(batch.get("spker_embeds")))
+
+
+def shard(batch, rank, world):
+    """DistributedSampler-like shard of a CPU batch (train.py:44): utterances rank, rank+world, ...; padded widths shrink to the
+    shard's own maxima exactly as a per-rank `collate_fn` would produce them."""
+    idx = list(range(rank, batch["texts"].shape[0], world))
+    src, mel = batch["src_lens"][idx], batch["mel_lens"][idx]
+    Ts, Tm = int(src.max()), int(mel.max())
+
+    def cut(t, widths):
+        if t is None:
+            return None
+        t = t[idx]
+        for d, w in widths:
+            t = t.narrow(d, 0, min(w, t.shape[d]))
+        return t.contiguous()
+    p = batch["p_targets"]
+    frame_e = batch["e_targets"] is not None and batch["e_targets"].shape[1] == batch["mels"].shape[1] and batch.get("d_targets") is None
+    out = {
+        "speakers": batch["speakers"][idx], "texts": cut(batch["texts"], [(1, Ts)]), "src_lens": src, "max_src_len": Ts,
+        "mels": cut(batch["mels"], [(1, Tm)]), "mel_lens": mel, "max_mel_len": Tm,
+        "p_targets": {k: (cut(v, [(1, Tm)]) if v.dim() > 1 else v[idx]) for k, v in p.items()},
+        "e_targets": cut(batch["e_targets"], [(1, Tm if frame_e else Ts)]), "d_targets": cut(batch.get("d_targets"), [(1, Ts)]),
+        "spker_embeds": cut(batch.get("spker_embeds"), []),
+    }
+    if batch.get("attn_priors") is not None:
+        out["attn_priors"] = cut(batch["attn_priors"], [(1, Ts), (2, Tm)])
+    return out

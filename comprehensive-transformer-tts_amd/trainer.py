@@ -1,0 +1,137 @@
+"""The train step of the reference's `train.py:102-125` as the product runs it on an MI355X:
+
+    forward -> CompTransTTSLoss -> backward [-> gradient all-reduce] -> clip_grad_norm_(1.0) -> Adam (Noam lr) -> zero_grad
+
+Host orchestration only; every kernel is behind `ops` / `kernels`.  What this module adds over a literal loop:
+
+  * gradients live in `dp.FlatGradArena` (kernels accumulate straight into it), the optimizer is `dp.FlatAdam` (fused clip + Adam);
+  * the step is replayed from hipGraphs (the model has no host syncs in training);
+  * data parallel (world > 1): the backward pass is STAGED (`ops.CutRecorder`, cuts from `dp.stage_plan`), one hipGraph per stage,
+    and after each stage the finished bucket of the arena is all-reduced on a side stream by `dp.BucketedReducer` while the next
+    stage replays - DDP's bucketed overlap (train.py:58) without autograd hooks, so it survives graph capture;
+  * `feed(device_buffer)`: the inputs can be views of one packed device buffer (`data.PackedBatch`), refreshed by a single
+    device-to-device copy per step, so a prefetching loader (`data.Prefetcher`) can sit inside the timed loop.
+"""
+import torch
+
+from . import ops
+from .dp import FlatGradArena, FlatAdam, BucketedReducer, stage_plan
+
+
+class TrainStep:
+    def __init__(self, model, loss_fn, optim, model_args, world=1, group=None, use_graph=True, overlap=True, n_cuts=3,
+                 step_no=50001, fused_optimizer=True, max_norm=1.0, adam_step=0, force_staged=False):
+        """`model_args`: positional arguments of CompTransTTS.forward (static device tensors; the graphs read them in place).
+        `optim`: loss.ScheduledOptim(..., capturable=True) - owns the Noam schedule and the device-resident lr.
+        `adam_step`: Adam's bias-correction step count to start from (a resumed run: the restore step; `FlatAdam.load_state_dict`
+        sets it from a checkpoint).  `force_staged`: stage the backward pass even with world == 1 (tests)."""
+        self.model, self.loss_fn, self.optim, self.world = model, loss_fn, optim, int(world)
+        self.args = list(model_args)
+        self.loss_inputs = [None, None] + list(self.args)
+        self.step_no = step_no
+        ops.set_grad_accumulation_fusion(True)          # kernels accumulate straight into the flat gradient arena
+        self.arena = FlatGradArena(model.named_parameters())
+        self.params = self.arena.params
+        self.flat_grad = self.arena.flat
+        self.use_graph = bool(use_graph)
+        self.max_norm = max_norm
+        self.fadam = None
+        if fused_optimizer:
+            oc = optim._optimizer.defaults
+            self.fadam = FlatAdam(self.arena, optim.lr_tensor, betas=tuple(oc["betas"]), eps=oc["eps"],
+                                  weight_decay=oc["weight_decay"], max_norm=max_norm, current_step=adam_step)
+        self.staged = (self.world > 1 and overlap) or force_staged
+        self.cut_names, stage_of = stage_plan(model, n_cuts)
+        self.n_stages = len(self.cut_names) + 1
+        if not self.staged:
+            self.cut_names, self.n_stages = [], 1
+            stage_of = lambda name: 0                                         # noqa: E731
+        self.reducer = BucketedReducer(self.arena, stage_of, self.n_stages, world=self.world, group=group)
+        self.graphs = None              # [stage graphs], then the optimizer graph
+        self.g_opt = None
+        self.loss_val = None
+        self.static_buffer = None
+
+    # ---- pieces
+    def _forward_loss(self):
+        args = list(self.args)
+        if isinstance(args[7], dict):
+            args[7] = dict(args[7])                     # the model mutates p_targets like the reference does
+        out = self.model(*args, step=self.step_no)
+        inputs = list(self.loss_inputs)
+        inputs[9:11] = out[-2:]
+        losses = self.loss_fn(inputs, out[:-2], self.step_no)
+        self.loss_val = losses[0].detach()
+        return losses[0]
+
+    def _stages(self):
+        """generator over backward stages; forward + loss + stage 0 run on the first next()"""
+        rec = ops.CutRecorder(self.cut_names)
+        with rec:
+            loss = self._forward_loss()
+        self.flat_grad.zero_()
+        yield from rec.backward_stages(loss)
+
+    def _optimizer_step(self):
+        if self.fadam is not None:
+            self.fadam.step()
+            return
+        self.arena.check_bound()
+        torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
+        self.optim._optimizer.step()
+
+    def _eager(self):
+        for s in self._stages():
+            self.reducer.launch(s)
+        self.reducer.finish()
+        self._optimizer_step()
+
+    # ---- graph capture
+    def capture(self, warmup=2):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.optim.update_learning_rate()
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # every stage is captured on the SAME stream (autograd runs a node's backward on the stream of its forward) and into one pool
+        graphs, gen, pool = [], self._stages(), None
+        for s in range(self.n_stages):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=side):
+                got = next(gen)
+            assert got == s
+            pool = g.pool()
+            graphs.append(g)
+        for _ in gen:                                     # exhaust (clears the recorder)
+            raise AssertionError("more backward stages than planned")
+        self.graphs = graphs
+        if self.fadam is not None:                        # torch's foreach clip + Adam are not capture-safe on strided parameters: eager
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=pool, stream=side):
+                self._optimizer_step()
+
+    # ---- inputs as views of one packed device buffer (data.PackedBatch layout)
+    def bind_static_buffer(self, buf):
+        self.static_buffer = buf
+
+    def feed(self, device_buffer):
+        """refresh every model input with ONE device-to-device copy (same PackedBatch layout as the static buffer)"""
+        self.static_buffer.copy_(device_buffer, non_blocking=True)
+
+    def __call__(self):
+        self.optim.update_learning_rate()               # host scalar -> device lr tensor (outside the graphs)
+        if self.graphs is not None:
+            for s, g in enumerate(self.graphs):
+                g.replay()
+                self.reducer.launch(s)
+            self.reducer.finish()
+            if self.g_opt is not None:
+                self.g_opt.replay()
+            else:
+                self._optimizer_step()
+        else:
+            self._eager()
+        self.step_no += 1

@@ -87,3 +87,138 @@ def test_arena_views_alias_param_grads():
         assert p.grad.data_ptr() == arena.flat[o:o + p.numel()].data_ptr()
     used = sum(p.numel() for p in arena.params)
     assert abs(float(arena.flat.sum()) - float(sum(p.grad.sum() for p in arena.params))) < 1e-4 and arena.flat.numel() >= used
+
+
+# ---- the product's arena / stage plan / bucketed reducer over the REAL CompTransTTS parameter set --------------------------------
+def _real_model(block="transformer_fs2"):
+    import ctts_amd
+    from ctts_amd.configs import get_configs
+    pre, mc, tc = get_configs()
+    mc["block_type"] = block
+    torch.manual_seed(1234)
+    return ctts_amd.CompTransTTS(pre, mc, tc)
+
+
+def _standin_grad(n, rank):
+    """deterministic per-rank stand-in for a backward pass (the product's kernels do not run on the CPU)"""
+    i = torch.arange(n, dtype=torch.float32)
+    return torch.sin(i * 1e-3) * (rank + 1) + (rank == 1) * 0.25
+
+
+def _real_worker(rank, world, port, q):
+    from ctts_amd.dp import BucketedReducer, stage_plan
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _real_model()
+    arena = FlatGradArena(m.named_parameters())
+    cuts, stage_of = stage_plan(m, 3)
+    red = BucketedReducer(arena, stage_of, len(cuts) + 1)
+    arena.flat.copy_(_standin_grad(arena.flat.numel(), rank))
+    if rank == 1:      # a parameter that received no gradient on this rank contributes zeros (SURVEY B15)
+        m.variance_adaptor.energy_predictor.linear.weight.grad.zero_()
+    for s in range(len(cuts) + 1):     # backward order: stage 0 first
+        red.launch(s)
+    red.finish()
+    probe = {n: p.grad.flatten()[:5].clone() for n, p in zip(arena.names, arena.params)
+             if n in ("postnet.convolutions.4.0.conv.weight", "decoder.layers.3.op.ffn.ffn_1.weight", "decoder.pos_embed_alpha",
+                      "encoder.embed_tokens.weight", "variance_adaptor.energy_predictor.linear.weight")}
+    q.put((rank, float(arena.flat.double().sum()), probe, red.bucket_bytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_real_model_bucketed_allreduce_two_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, tot, probe, bb = q.get(timeout=300)
+        res[r] = (tot, probe, bb)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process expectation on the same arena layout
+    m = _real_model()
+    arena = FlatGradArena(m.named_parameters())
+    n = arena.flat.numel()
+    g0, g1 = _standin_grad(n, 0), _standin_grad(n, 1)
+    arena.flat.copy_(g1)
+    m.variance_adaptor.energy_predictor.linear.weight.grad.zero_()
+    g1 = arena.flat.clone()
+    mask = torch.zeros(n, dtype=torch.bool)                    # reduced positions = parameter storage + its alignment tail
+    ends = arena.offsets[1:] + [n]
+    for o, e in zip(arena.offsets, ends):
+        mask[o:e] = True
+    assert bool(mask.all())                                    # the buckets tile the whole arena
+    expect = (g0 + g1) / 2
+    assert abs(res[0][0] - float(expect.double().sum())) < 1e-3 * max(1.0, abs(float(expect.double().sum())))
+    assert res[0][0] == res[1][0]
+    arena.flat.copy_(expect)
+    for name, v in res[0][1].items():
+        p = dict(zip(arena.names, arena.params))[name]
+        assert torch.allclose(v, p.grad.flatten()[:5], atol=1e-6), name
+        assert torch.equal(v, res[1][1][name]), name
+    bb = res[0][2]
+    assert len(bb) == 4 and sum(bb) == 4 * n and min(bb) > 20e6 and max(bb) < 60e6     # ~25-55 MB buckets, nothing dropped
+
+
+@__import__("pytest").mark.parametrize("block", ["transformer_fs2", "conformer"])
+def test_stage_plan_partitions_parameters_in_backward_order(block):
+    from ctts_amd.dp import stage_plan, BucketedReducer
+    m = _real_model(block)
+    arena = FlatGradArena(m.named_parameters())
+    cuts, stage_of = stage_plan(m, 3)
+    assert cuts[-1] == "decoder.in" and len(cuts) == 3
+    st = {n: stage_of(n) for n in arena.names}
+    assert st["postnet.convolutions.0.0.conv.weight"] == 0 and st["mel_linear.weight"] == 0
+    assert all(v == 3 for k, v in st.items() if k.startswith("encoder.") or k.startswith("variance_adaptor."))
+    stack = "layers" if block == "transformer_fs2" else "layer_stack"
+    lay = {int(k.split(".")[2]): v for k, v in st.items() if k.startswith(f"decoder.{stack}.")}
+    assert [lay[i] for i in range(6)] == [2, 2, 1, 1, 0, 0]
+    red = BucketedReducer(arena, stage_of, 4, world=1)
+    covered = sorted(r for rs in red.ranges for r in rs)
+    assert covered[0][0] == 0 and covered[-1][1] == arena.flat.numel()
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))          # contiguous, disjoint, complete
+
+
+def test_flat_adam_state_dict_roundtrips_in_torch_adam_format():
+    from ctts_amd.dp import FlatAdam
+    m = _model()
+    arena = FlatGradArena(m.named_parameters())
+    fa = FlatAdam(arena, 1e-3, current_step=7)
+    fa.m.copy_(torch.arange(fa.m.numel(), dtype=torch.float32) * 0.5)
+    fa.v.copy_(torch.arange(fa.v.numel(), dtype=torch.float32) * 0.25)
+    sd = fa.state_dict()
+    # torch.optim.Adam accepts it as its own state
+    ref = torch.optim.Adam(arena.params, lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    ref.load_state_dict(sd)
+    assert float(ref.state[arena.params[0]]["step"]) == 7.0
+    assert torch.equal(ref.state[arena.params[1]]["exp_avg"], sd["state"][1]["exp_avg"])
+    m2 = _model()
+    fb = FlatAdam(FlatGradArena(m2.named_parameters()), 1e-3)
+    fb.load_state_dict(ref.state_dict())
+    for p, o in zip(arena.params, arena.offsets):             # per parameter (the alignment gaps between them carry no state)
+        sl = slice(o, o + p.numel())
+        assert torch.equal(fb.m[sl], fa.m[sl]) and torch.equal(fb.v[sl], fa.v[sl])
+    assert float(fb.state[1]) == 7.0
+    # parameters were re-homed into the flat arena without changing their values or the module's state_dict
+    for (k, a), (_, b) in zip(m.state_dict().items(), _model().state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_zero_grad_set_to_none_is_detected():
+    import pytest
+    m = _model()
+    arena = FlatGradArena(m.named_parameters())
+    arena.check_bound()
+    torch.optim.SGD(m.parameters(), lr=0.1).zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        arena.check_bound()
+    arena.bind()
+    arena.check_bound()
