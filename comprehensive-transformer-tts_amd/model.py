@@ -676,11 +676,14 @@ class CompTransTTS(nn.Module):
             else:
                 assert spker_embeds is not None, "Speaker embedding should not be None"
                 speaker_embeds = ops.linear(spker_embeds, self.speaker_emb.weight, self.speaker_emb.bias)
-        (output, p_targets, p_predictions, e_targets, e_predictions, log_d_predictions, d_rounded, mel_lens, mel_masks,
-         attn_outs, prosody_info) = self.variance_adaptor(
+        va_out = self.variance_adaptor(
             speaker_embeds, enc, text_embeds, src_lens, src_masks, mels, mel_lens, mel_masks, max_mel_len, p_targets,
             e_targets, d_targets, attn_priors, p_control, e_control, d_control, step)
-        output, mel_masks = self.decoder(ops.stage_cut(output, "decoder.in"), mel_masks)
+        # staged backward (dp.py): everything that leaves the variance adaptor - the decoder input and the predictions the loss
+        # reads - is one cut, so the encoder + adaptor region is back-propagated once, after the decoder stages
+        (output, p_targets, p_predictions, e_targets, e_predictions, log_d_predictions, d_rounded, mel_lens, mel_masks,
+         attn_outs, prosody_info) = ops.stage_cut_tree(va_out, "decoder.in")
+        output, mel_masks = self.decoder(output, mel_masks)
         output = ops.linear(output, self.mel_linear.weight, self.mel_linear.bias)
         postnet_output = self.postnet(output) + output
         return (output, postnet_output, p_predictions, e_predictions, log_d_predictions, d_rounded, src_masks, mel_masks,

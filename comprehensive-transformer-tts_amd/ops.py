@@ -66,11 +66,15 @@ class CutRecorder:
         loss.backward()
         yield 0
         for s, name in enumerate(self.names, 1):
-            x, leaf = self.pairs[name]
-            g, leaf.grad = leaf.grad, None
-            if g is None:
+            xs, gs = [], []
+            for x, leaf in self.pairs[name]:
+                g, leaf.grad = leaf.grad, None
+                if g is not None:                    # a severed tensor the loss does not use (e.g. before var_start_steps)
+                    xs.append(x)
+                    gs.append(g)
+            if not xs:
                 raise RuntimeError(f"staged backward: no gradient arrived at cut '{name}'")
-            x.backward(g)
+            torch.autograd.backward(xs, gs)          # ONE traversal of the upstream graph for all tensors of the cut
             yield s
         self.pairs = {}
 
@@ -81,8 +85,32 @@ def stage_cut(x, name):
     if rec is None or name not in rec.names or not x.requires_grad:
         return x
     leaf = x.detach().requires_grad_(True)
-    rec.pairs[name] = (x, leaf)
+    rec.pairs.setdefault(name, []).append((x, leaf))
     return leaf
+
+
+def stage_cut_tree(obj, name):
+    """`stage_cut` for EVERY differentiable tensor inside a nested tuple / list / dict (a module boundary that several tensors
+    cross: the variance adaptor hands the decoder input AND the predictions the loss reads).  All of them are severed under one
+    name, so the region upstream is back-propagated exactly once, from all of them together.  Containers without a differentiable
+    tensor keep their identity (the reference mutates and returns the caller's `p_targets` dict)."""
+    rec = _CUTS
+    if rec is None or name not in rec.names:
+        return obj
+
+    def walk(o):
+        if torch.is_tensor(o):
+            return stage_cut(o, name) if (o.requires_grad and o.is_floating_point()) else o
+        if isinstance(o, dict):
+            new = {k: walk(v) for k, v in o.items()}
+            return new if any(new[k] is not o[k] for k in o) else o
+        if isinstance(o, (tuple, list)):
+            new = [walk(v) for v in o]
+            if all(a is b for a, b in zip(new, o)):
+                return o
+            return type(o)(new)
+        return o
+    return walk(obj)
 
 
 def _gemm_major(w):

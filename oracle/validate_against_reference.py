@@ -1,0 +1,171 @@
+"""TEST INFRASTRUCTURE (build container only - needs /root/reference): full-size pin of the oracle against the LIVE reference.
+
+The committed goldens are small (B <= 3, Tm <= 144).  This script runs the imported reference (oracle/ref_import.py) and the
+restatement (oracle/restate.py) side by side at the BASELINE shapes and records
+
+  * eval forward, canonical fs2 batch (B=16, Ts<=128, Tm<=1024): max-abs of mel / postnet mel / log-duration / cwt / energy;
+  * train-mode forward + backward of the reference's loss, dropout patched to identity on both sides: max-abs of the outputs and
+    the worst per-tensor relative error over all parameter gradients;
+  * conformer, B=4 canonical lengths capped at T = 1000 (rel-shift index arithmetic at full length): eval forward max-abs;
+  * wall time of one full train step (dropout on, same thread count) of both -> r = t_reference / t_restatement, the factor that
+    converts bench.py's `cpu_baseline` (restatement timed on the GPU host) into "reference CPU PyTorch path" time.
+
+Output: tests/golden/reference_vs_oracle_full_size.json (data, committed).      python oracle/validate_against_reference.py
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden", "reference_vs_oracle_full_size.json")
+
+import ctts_amd  # noqa: E402,F401
+from ctts_amd.synthetic import make_batch, as_model_args, CANONICAL_SRC_LENS  # noqa: E402
+from oracle import ref_import, restate as R  # noqa: E402
+from oracle.loss_restate import RefLoss  # noqa: E402
+from oracle.weights import closed_form_state_dict  # noqa: E402
+
+ref_import.install()
+import torch.nn.functional as F  # noqa: E402
+
+_real_dropout = F.dropout
+
+
+def maxabs(a, b):
+    return float((a.detach().double() - b.detach().double()).abs().max())
+
+
+def build(block):
+    from model import CompTransTTS, CompTransTTSLoss
+    pre, mc, tc = ref_import.load_configs("LJSpeech")
+    mc["block_type"] = block
+    mc["duration_modeling"]["learn_alignment"] = False          # BASELINE configs[1] / [2]: supervised durations
+    mc["prosody_modeling"]["model_type"] = "none"
+    model = CompTransTTS(pre, mc, tc)
+    sd = closed_form_state_dict(model.state_dict())
+    model.load_state_dict(sd)
+    return model, CompTransTTSLoss(pre, mc, tc), (pre, mc, tc), sd
+
+
+def ref_step(model, loss_fn, batch, step=50001):
+    a = list(as_model_args(batch))
+    a[7] = dict(a[7])
+    out = model(*a, step=step)
+    inputs = [None, None] + a
+    inputs[9:11], out = out[-2:], out[:-2]
+    return out, loss_fn(inputs, out, step=step)
+
+
+def oracle_step(sd, cfgs, batch, fwd, train_dropout, step=50001):
+    pre, mc, tc = cfgs
+    a = list(as_model_args(batch))
+    a[7] = dict(a[7])
+    out = fwd(sd, mc, pre, *a, step=step, training=True, train_dropout=train_dropout, new_stats={})
+    inputs = [None, None] + a
+    inputs[9:11] = out[-2:]
+    return out[:-2], RefLoss(pre, mc, tc)(inputs, out[:-2], step)
+
+
+def main():
+    nthreads = int(os.environ.get("CTTS_VALIDATE_THREADS", str(os.cpu_count() or 1)))
+    torch.set_num_threads(nthreads)
+    rec = {"threads": nthreads, "torch": torch.__version__, "host": "build container (CPU only)"}
+
+    # ---------------- fs2, canonical batch
+    model, loss_fn, cfgs, sd = build("transformer_fs2")
+    batch = make_batch()
+    model.eval()
+    with torch.no_grad():
+        a = list(as_model_args(batch)); a[7] = dict(a[7])
+        ref = model(*a)
+        a = list(as_model_args(batch)); a[7] = dict(a[7])
+        ora = R.comp_trans_tts_forward(sd, cfgs[1], cfgs[0], *a)
+    rec["fs2_eval_B16_Tm1024"] = {"mel": maxabs(ref[0], ora[0]), "postnet_mel": maxabs(ref[1], ora[1]), "log_d": maxabs(ref[4], ora[4]),
+                                 "cwt": maxabs(ref[2]["cwt"], ora[2]["cwt"]), "e_pred": maxabs(ref[3], ora[3])}
+    print("fs2 eval", rec["fs2_eval_B16_Tm1024"], flush=True)
+
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x           # train mode, dropout off on both sides
+    model.train()
+    model.zero_grad()
+    out_r, loss_r = ref_step(model, loss_fn, batch)
+    loss_r[0].backward()
+    g_ref = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    sdg = {k: (v.clone().requires_grad_(True) if k in trainable else v.clone()) for k, v in sd.items()}
+    out_o, loss_o = oracle_step(sdg, cfgs, batch, R.comp_trans_tts_forward, False)
+    loss_o[0].backward()
+    worst, worst_k = 0.0, None
+    for k, g in g_ref.items():
+        e = float((sdg[k].grad - g).abs().max() / (g.abs().max() + 1e-20))
+        if e > worst:
+            worst, worst_k = e, k
+    rec["fs2_train_nodropout_B16_Tm1024"] = {"mel": maxabs(out_r[0], out_o[0]), "postnet_mel": maxabs(out_r[1], out_o[1]),
+                                            "total_loss_ref": float(loss_r[0]), "total_loss_oracle": float(loss_o[0]),
+                                            "n_grad_tensors": len(g_ref), "worst_grad_rel_max_err": worst, "worst_grad_tensor": worst_k}
+    print("fs2 train", rec["fs2_train_nodropout_B16_Tm1024"], flush=True)
+    F.dropout = _real_dropout
+
+    # ---------------- timing: one full train step, dropout on (C2 and C1)
+    def time_ref(b, n):
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
+        ts = []
+        for _ in range(n + 1):
+            t0 = time.perf_counter()
+            _, l = ref_step(model, loss_fn, b)
+            opt.zero_grad()
+            l[0].backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts[1:])[len(ts[1:]) // 2]
+
+    def time_oracle(b, n):
+        params = [v for v in sdg.values() if v.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9)
+        ts = []
+        for _ in range(n + 1):
+            t0 = time.perf_counter()
+            _, l = oracle_step(sdg, cfgs, b, R.comp_trans_tts_forward, True)
+            opt.zero_grad()
+            l[0].backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts[1:])[len(ts[1:]) // 2]
+
+    from ctts_amd.synthetic import C1_SRC_LENS
+    c1 = make_batch(C1_SRC_LENS)
+    t_r1, t_o1 = time_ref(c1, 3), time_oracle(c1, 3)
+    t_r2, t_o2 = time_ref(batch, 2), time_oracle(batch, 2)
+    rec["timing_train_step_dropout_on"] = {
+        "C1_B4": {"reference_s": t_r1, "oracle_s": t_o1, "valid_frames": int(c1["mel_lens"].sum())},
+        "C2_B16": {"reference_s": t_r2, "oracle_s": t_o2, "valid_frames": int(batch["mel_lens"].sum())}}
+    rec["speed_ratio_reference_over_oracle"] = t_r2 / t_o2
+    rec["speed_ratio_reference_over_oracle_C1"] = t_r1 / t_o1
+    print("timing", rec["timing_train_step_dropout_on"], flush=True)
+
+    # ---------------- conformer, B=4, T capped at 1000
+    del model, sdg
+    model, _, cfgs, sd = build("conformer")
+    b4 = make_batch(CANONICAL_SRC_LENS[:4], max_mel_cap=1000)
+    model.eval()
+    with torch.no_grad():
+        a = list(as_model_args(b4)); a[7] = dict(a[7])
+        ref = model(*a)
+        a = list(as_model_args(b4)); a[7] = dict(a[7])
+        ora = R.comp_trans_tts_forward_conformer(sd, cfgs[1], cfgs[0], *a)
+    rec["conformer_eval_B4_T1000"] = {"mel": maxabs(ref[0], ora[0]), "postnet_mel": maxabs(ref[1], ora[1]), "log_d": maxabs(ref[4], ora[4]),
+                                      "T": int(ref[0].shape[1])}
+    print("conformer eval", rec["conformer_eval_B4_T1000"], flush=True)
+    os.chdir(ROOT)
+    with open(OUT, "w") as f:
+        json.dump(rec, f, indent=1)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,200 @@
+"""GPU: the data-parallel train step as bench.py runs it - staged backward, one hipGraph per stage, bucketed all-reduce between the
+replays - against (a) the monolithic single-graph / eager step and (b) a single process on the global batch.  RCCL needs one GPU
+per rank; on the 1-GPU test box both ranks share cuda:0 and gloo stands in (same host code path, collectives between replays)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import ctts_amd
+from ctts_amd.configs import get_configs
+from ctts_amd.synthetic import make_batch, make_unsup_batch, to_device, as_model_args, shard
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else None
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(c5=False, block="transformer_fs2"):
+    from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
+    torch.manual_seed(1234)
+    pre, mc, tc = get_configs()
+    mc["block_type"] = block
+    if c5:                        # SURVEY config C5: liu2021 prosody + learn_alignment (GRU, MAS, ForwardSum kernels inside the graph)
+        mc["prosody_modeling"]["model_type"] = "liu2021"
+        mc["duration_modeling"]["learn_alignment"] = True
+    model = ctts_amd.CompTransTTS(pre, mc, tc).to(DEV)
+    model.train()
+    return model, CompTransTTSLoss(pre, mc, tc).to(DEV), ScheduledOptim(model, tc, mc, 50000, capturable=True)
+
+
+def _trajectory(c5, block, use_graph, staged, n=5):
+    from ctts_amd.trainer import TrainStep
+    model, loss_fn, optim = _make(c5, block)
+    cap = 1000 if block == "conformer" else None
+    batch = to_device((make_unsup_batch if c5 else make_batch)([60, 41, 33, 17], 8, seed=3, max_mel_cap=cap), DEV)
+    step = TrainStep(model, loss_fn, optim, as_model_args(batch), world=1, use_graph=use_graph, force_staged=staged)
+    if c5:
+        step.step_no = 100001
+    if use_graph:
+        step.capture(warmup=2)    # 2 warm-up steps + capture: do the same number of eager steps on the other side
+    else:
+        for _ in range(2):
+            step.optim.update_learning_rate()
+            step._eager()
+    losses = []
+    for _ in range(n):
+        step()
+        losses.append(float(step.loss_val))
+    return losses, step
+
+
+@pytest.mark.parametrize("c5", [False, True])
+def test_hipgraph_replay_matches_eager_training(c5):
+    """Five full train steps (fwd + loss + bwd + fused clip/Adam, dropout on) replayed from the two hipGraphs vs launched eagerly
+    from the same initial state and dropout seed: the loss trajectories must agree (this is the check that exposed the stale-bytes
+    problem of memset nodes inside replayed graphs)."""
+    eager, _ = _trajectory(c5, "transformer_fs2", False, False)
+    graph, _ = _trajectory(c5, "transformer_fs2", True, False)
+    print("eager", eager, "graph", graph)
+    for a, b in zip(eager, graph):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (eager, graph)       # observed ~1e-7: same kernels, same dropout stream
+
+
+@pytest.mark.parametrize("block,c5", [("transformer_fs2", False), ("conformer", False), ("transformer_fs2", True)])
+def test_staged_backward_graphs_match_monolithic_eager(block, c5):
+    """The DP step's structure with world = 1: forward severed at 3 cut points, 4 backward stages, each its own hipGraph (plus the
+    optimizer graph) - same loss trajectory as one eager backward() over the unsevered graph, dropout on."""
+    mono, _ = _trajectory(c5, block, False, False)
+    staged, st = _trajectory(c5, block, True, True)
+    assert st.staged and st.n_stages == 4 and len(st.graphs) == 4 and st.g_opt is not None
+    print("mono", mono, "staged", staged)
+    for a, b in zip(mono, staged):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (mono, staged)
+
+
+def _run_ranks(world, block, n_steps, use_graph, tmp_path):
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"rank{r}.pt")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, block, str(n_steps),
+                                       "1" if use_graph else "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-3000:]
+    return [torch.load(o) for o in outs]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_rank_step_equals_single_process_on_the_global_batch(tmp_path, use_graph):
+    """after one step (graph path: one eager + one replayed step) from identical init, the 2-rank parameters equal the 1-rank parameters on the same global batch
+    (DDP semantics: mean of the per-rank gradients; BatchNorm with local-batch statistics, as the reference - no SyncBN).
+    Ranks run tests/dp_worker.py: trainer.TrainStep with the staged backward and the bucketed all-reduce (gloo, both on cuda:0)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker
+    from ctts_amd.dp import FlatGradArena, FlatAdam
+    from ctts_amd import ops
+    world = 2
+    res = _run_ranks(world, "transformer_fs2", 1, use_graph, tmp_path)
+    assert torch.equal(res[0]["params"], res[1]["params"])            # replicas stay bit-identical
+    assert torch.equal(res[0]["grads"], res[1]["grads"])
+    # single process: per-shard gradients (local BN statistics) averaged, then ONE fused clip + Adam step
+    model, loss_fn, optim = dp_worker.build("transformer_fs2", DEV)
+    ops.set_grad_accumulation_fusion(True)
+    arena = FlatGradArena(model.named_parameters())
+    fadam = FlatAdam(arena, optim.lr_tensor, betas=(0.9, 0.98), eps=1e-9)
+    gb = dp_worker.global_batch()
+    total_steps = 2 if use_graph else 1       # the graph path takes one eager warm-up step before capture, then one replayed step
+    for it in range(total_steps):
+        acc = torch.zeros_like(arena.flat)
+        for r in range(world):
+            args = list(as_model_args(to_device(shard(gb, r, world), DEV)))
+            args[7] = dict(args[7])
+            out = model(*args, step=50001 + it)
+            inputs = [None, None] + args
+            inputs[9:11] = out[-2:]
+            loss = loss_fn(inputs, out[:-2], 50001 + it)[0]
+            arena.zero_()
+            loss.backward()
+            acc += arena.flat / world
+        arena.flat.copy_(acc)
+        optim.update_learning_rate()
+        fadam.step()
+    torch.cuda.synchronize()
+    g_ref, p_ref = acc.cpu(), fadam.flat_param.cpu()
+    gerr = float((res[0]["grads"] - g_ref).abs().max() / g_ref.abs().max())
+    dp_ = (res[0]["params"] - p_ref).abs()
+    perr, frac_off = float(dp_.max()), float((dp_ > 5e-6).float().mean())
+    lr = float(optim.lr_tensor)
+    print(f"2-rank vs single process: grad rel-max err {gerr:.2e}, param max-abs err {perr:.2e} (lr {lr:.2e}), "
+          f"fraction of weights off by > 5e-6: {frac_off:.2e}, |g| {float(res[0]['norm']):.3f}")
+    assert gerr <= 2e-5, gerr                 # fp32 reduction order only (split-K atomics, (a+b)/2 vs a/2+b/2)
+    # Adam's first steps move every weight by ~lr * g / (|g| + 1e-9): where a gradient is pure cancellation noise (|g| ~ eps) the
+    # reduction order decides the direction, so a handful of weights may differ by up to 2 lr per step; all others agree to rounding
+    assert frac_off <= 1e-4 and perr <= 2.02 * lr * total_steps, (frac_off, perr)
+
+
+def _bench(args, env_extra, timeout=600):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_gpus_2_spawns_two_ranks_itself(scaling):
+    """`python bench.py --gpus 2` with NO launcher: bench.py starts both ranks (the reference's mp.spawn, train.py:251-252), the step is
+    4 stage graphs + bucketed all-reduce between the replays + the optimizer graph, rank 0 prints one line with n_gpus 2.  Both ranks
+    share this GPU and gloo stands in for RCCL (test hooks CTTS_BENCH_SAME_DEVICE / CTTS_BENCH_BACKEND)."""
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--batch", "c1", "--scaling", scaling],
+               {"CTTS_BENCH_SAME_DEVICE": "1", "CTTS_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2" and np.isfinite(d["config"]["final_loss"])
+    assert "4 backward stages" in d["config"]["launch_mode"] and len(d["config"]["grad_buckets_bytes"]) == 4
+    per = d["config"]["valid_frames_per_gpu"]
+    assert per == (3032 if scaling == "weak" else (128 + 78) * 8)            # strong: rank 0 takes utterances 0 and 2 of C1
+    assert d["pcie_inclusive"]["value"] > 0
+
+
+def test_bench_under_torch_distributed_run():
+    """the driver's launch line: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2"""
+    env = dict(os.environ, CTTS_BENCH_SAME_DEVICE="1", CTTS_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-pcie", "--batch", "c1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+
+
+def test_bench_rejects_gpus_world_mismatch():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"],
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_single_gpu_bench_line_has_roofline_and_pcie_rates():
+    d = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert d["n_gpus"] == 1 and d["roofline"]["frac"] > 0.3 and d["roofline"]["bound"] == "mfma"
+    assert d["pcie_inclusive"]["value"] > 0.8 * d["value"]                  # one 8 MB H2D per step hides behind the previous step

@@ -1,0 +1,159 @@
+"""GPU: the drop-in claim as evidence - the reference's own training loop, literally, on the product
+model, and the reference's DistributedDataParallel wrap over the strided Conv1d parameters."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import ctts_amd
+from ctts_amd import ops
+from ctts_amd.configs import get_configs
+from ctts_amd.data import PackedBatch
+from ctts_amd.synthetic import make_batch, as_collated_tuple, as_model_args, to_device, shard
+from oracle import restate as R
+from oracle.loss_restate import RefLoss
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else None
+
+
+def _no_dropout(m):
+    for sub in m.modules():
+        if hasattr(sub, "dropout"):
+            sub.dropout = 0.0
+
+
+def test_reference_train_loop_runs_literally_on_the_product_and_tracks_the_oracle():
+    """train.py:102-125, statement by statement, with the product's CompTransTTS / CompTransTTSLoss / ScheduledOptim standing where the
+    reference's classes stand (plain torch.optim.Adam over the strided parameters, GradScaler(enabled=False), clip_grad_norm_,
+    step_and_update_lr(scaler), zero_grad) for 3 steps - against the same loop on the CPU oracle from identical weights."""
+    from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
+    ops.set_grad_accumulation_fusion(False)            # an unchanged train.py knows nothing about arenas
+    pre, mc, tc = get_configs()
+    torch.manual_seed(11)
+    model = ctts_amd.CompTransTTS(pre, mc, tc)
+    _no_dropout(model)
+    sd0 = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    model.train()
+    grad_acc_step, grad_clip_thresh = tc["optimizer"]["grad_acc_step"], tc["optimizer"]["grad_clip_thresh"]
+    Loss = CompTransTTSLoss(pre, mc, tc).to(DEV)
+    optimizer = ScheduledOptim(model, tc, mc, 50000)
+    scaler = torch.amp.GradScaler("cuda", enabled=False)
+    cpu_batch = make_batch([31, 24, 17, 9], 6, seed=21)
+    packed = PackedBatch.pack(as_collated_tuple(cpu_batch))
+    step, prod_losses, lrs = 50001, [], []
+    for _ in range(3):
+        batch, ev = packed.to_device(DEV)              # = utils/tools.py to_device(batch, device): the 14-list
+        torch.cuda.current_stream().wait_event(ev)
+        # ---- train.py:104-125 ----
+        output = model(*(batch[2:]), step=step)
+        batch[9:11], output = output[-2:], output[:-2]
+        losses = Loss(batch, output, step=step)
+        total_loss = losses[0]
+        total_loss = total_loss / grad_acc_step
+        scaler.scale(total_loss).backward()
+        if step % grad_acc_step == 0:
+            scaler.unscale_(optimizer._optimizer)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip_thresh)
+        lr = optimizer.step_and_update_lr(scaler)
+        scaler.update()
+        optimizer.zero_grad()
+        # --------------------------
+        prod_losses.append([float(losses[0])] + [float(l) for l in losses[1:3]])
+        lrs.append(lr)
+        step += 1
+    # the same loop on the oracle (functional restatement over a state dict)
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    sd = {k: (v.clone().requires_grad_(True) if k in trainable else v.clone()) for k, v in sd0.items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, betas=tuple(tc["optimizer"]["betas"]), eps=tc["optimizer"]["eps"],
+                           weight_decay=tc["optimizer"]["weight_decay"])
+    ref_loss = RefLoss(pre, mc, tc)
+    step, ref_losses = 50001, []
+    for it in range(3):
+        a = list(as_model_args(cpu_batch))
+        a[7] = dict(a[7])
+        stats = {}
+        out = R.comp_trans_tts_forward(sd, mc, pre, *a, step=step, training=True, train_dropout=False, new_stats=stats)
+        inputs = [None, None] + a
+        inputs[9:11] = out[-2:]
+        losses = ref_loss(inputs, out[:-2], step)
+        losses[0].backward()
+        torch.nn.utils.clip_grad_norm_(params, grad_clip_thresh)
+        for g in opt.param_groups:
+            g["lr"] = lrs[it]
+        opt.step()
+        opt.zero_grad()
+        with torch.no_grad():
+            for k, v in stats.items():
+                sd[k].copy_(v)
+        ref_losses.append([float(losses[0])] + [float(l) for l in losses[1:3]])
+        step += 1
+    print("product", prod_losses, "oracle", ref_losses)
+    for p_, r_ in zip(prod_losses, ref_losses):
+        for a_, b_ in zip(p_, r_):
+            assert abs(a_ - b_) <= 2e-4 * max(1.0, abs(b_)), (prod_losses, ref_losses)
+    assert ref_losses[2][0] < ref_losses[0][0]                      # and it trains
+    # weights after 3 Adam steps (|step| ~ lr): all but a cancellation-noise handful agree to rounding
+    lr = lrs[-1]
+    worst, off, n = 0.0, 0, 0
+    psd = model.state_dict()
+    for k in trainable:
+        d = (psd[k].detach().cpu() - sd[k].detach()).abs()
+        worst, off, n = max(worst, float(d.max())), off + int((d > 0.05 * lr).sum()), n + d.numel()
+    print(f"weights after 3 steps: max-abs diff {worst:.2e}, {off}/{n} beyond 5% of lr ({lr:.2e})")
+    assert worst <= 6.1 * lr and off / n <= 2e-3
+    # BatchNorm running statistics took the same three updates
+    for k in ("postnet.convolutions.0.1.running_mean", "postnet.convolutions.4.1.running_var"):
+        assert float((psd[k].cpu() - sd[k]).abs().max()) <= 1e-4, k
+    assert int(psd["postnet.convolutions.0.1.num_batches_tracked"]) == 3
+
+
+def test_distributed_data_parallel_wraps_the_strided_parameters(tmp_path):
+    """train.py:58: DistributedDataParallel(model) over the product (2 processes, gloo, both on this GPU): construction broadcasts
+    rank 0's weights, the bucketed gradient hooks average the per-rank gradients of the dense-but-strided Conv1d weights, and the
+    result equals the single-process mean of the two shards' gradients."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs, outs = [], []
+    for r in range(2):
+        out = str(tmp_path / f"ddp{r}.pt")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-3000:]
+    res = [torch.load(o) for o in outs]
+    assert res[0]["strides_kept"] and res[1]["strides_kept"]
+    assert torch.equal(res[0]["mel_w"], res[1]["mel_w"])                        # rank 1's perturbed weight was overwritten by rank 0's
+    for k in res[0]["grads"]:
+        assert torch.equal(res[0]["grads"][k], res[1]["grads"][k]), k            # every rank holds the averaged gradient
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker
+    ops.set_grad_accumulation_fusion(False)
+    model, loss_fn, _ = dp_worker.build("transformer_fs2", DEV)
+    ref = {}
+    for r in range(2):
+        model.zero_grad(set_to_none=True)
+        args = list(as_model_args(to_device(shard(dp_worker.global_batch(), r, 2), DEV)))
+        out = model(*args, step=50001)
+        inputs = [None, None] + args
+        inputs[9:11] = out[-2:]
+        loss_fn(inputs, out[:-2], 50001)[0].backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                ref[n] = ref.get(n, 0) + p.grad.detach().cpu().contiguous() / 2
+    assert set(ref) == set(res[0]["grads"])
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    # per-tensor relative error, the scale floored at 1e-4 of the model's largest gradient entry (conv biases in front of a train-mode
+    # BatchNorm have a true gradient of zero: pure cancellation noise on both sides)
+    worst = max(float((res[0]["grads"][k] - ref[k]).abs().max() / max(float(ref[k].abs().max()), 1e-4 * gmax)) for k in ref)
+    print(f"DDP-averaged gradients vs single-process mean: worst per-tensor rel-max err {worst:.2e} over {len(ref)} tensors")
+    assert worst <= 1e-4

@@ -137,8 +137,9 @@ def test_linear_tiny_heads():
         close(bg.grad, br.grad, 2e-5, f"head{N} db")
 
 
-@pytest.mark.parametrize("B,T,H,C", [(3, 70, 2, 256), (2, 130, 2, 256), (2, 33, 8, 256)])
+@pytest.mark.parametrize("B,T,H,C", [(3, 70, 2, 256), (2, 130, 2, 256), (2, 33, 8, 256), (3, 1024, 2, 256), (2, 600, 2, 256)])
 def test_self_attention_fwd_bwd(B, T, H, C):
+    """incl. the canonical decoder shape T = 1024 with ragged lengths (long-sequence code paths: split reductions / key tiling)"""
     qkv = rnd(B, T, 3 * C, seed=50)
     lens = torch.tensor([T, max(1, T // 2), max(1, T - 7)][:B], dtype=torch.int32)
     dh = C // H
