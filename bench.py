@@ -324,10 +324,22 @@ def main():
             el = float(t)
         return el
 
+    trace = [] if os.environ.get("CTTS_BENCH_TRACE") else None
+    run_step = step
+    if trace is not None:                                     # debugging aid: device-side copies of the loss of every step (no host sync)
+        def run_step():
+            step()
+            flat = []
+            for t in step.loss_terms:
+                flat += [v for v in t.values()] if isinstance(t, dict) else [t]
+            trace.append(torch.stack([v.detach().reshape(()).float() for v in flat]))
     for _ in range(a.warmup):
-        step()
-    elapsed = timed(step, a.steps)
+        run_step()
+    elapsed = timed(run_step, a.steps)
     loss_final = float(step.loss_val)
+    if trace is not None and rank == 0:
+        for i, t in enumerate(trace):
+            print(f"[bench] step {i}: " + " ".join(f"{float(v):.4g}" for v in t), file=sys.stderr)
     if world > 1:
         vf = torch.tensor([valid_frames], device=dev, dtype=torch.float64)
         dist.all_reduce(vf)

@@ -44,6 +44,11 @@ class GemmDesc(C.Structure):
 _SIGNATURES = {
     "ctts_gemm": [C.POINTER(GemmDesc), _vp],
     "ctts_rowdot_heads": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_mha_fwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _vp],
+    "ctts_mha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp],
+    "ctts_relmha_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
+    "ctts_relmha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                        _f32, _f32, _vp, _u32, _vp],
     "ctts_weighted_colsum": [_vp, _vp, _vp, _i64, C.c_int, _f32, C.c_int, _vp],
     "ctts_epilogue_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _u32, _f32, C.c_int, _vp],
     "ctts_row_tile_map": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
@@ -81,6 +86,10 @@ _SIGNATURES = {
     "ctts_mas": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_forward_sum_fwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_forward_sum_bwd": [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_var_loss_fwd": [_vp] * 2 + [C.c_int] + [_vp] * 12 + [C.c_int] * 3 + [_vp, C.c_int, _vp] + [_vp] * 4 + [_vp],
+    "ctts_var_loss_bwd": [_vp] * 2 + [C.c_int] + [_vp] * 12 + [C.c_int] * 3 + [_vp, C.c_int, _vp] + [_vp] * 4 + [_vp] * 5 + [_vp],
+    "ctts_bin_loss_fwd": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "ctts_bin_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "ctts_mel_l1_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp],
     "ctts_mel_l1_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp],
     "ctts_adam_clip_step": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
@@ -91,7 +100,8 @@ _SIGNATURES = {
     "ctts_softmax_rect_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_softmax_rect_bwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version"])
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version", "ctts_mha_supported", "ctts_relmha_workspace_floats"])
+ADAM_STATE_FLOATS = 3 + 2048          # CTTS_ADAM_STATE_FLOATS of include/ctts.h
 
 _lib = None
 
@@ -119,6 +129,10 @@ def load():
     lib.ctts_last_error.argtypes = []
     lib.ctts_version.restype = C.c_int
     lib.ctts_version.argtypes = []
+    lib.ctts_mha_supported.restype = C.c_int
+    lib.ctts_mha_supported.argtypes = [C.c_int, C.c_int]
+    lib.ctts_relmha_workspace_floats.restype = C.c_size_t
+    lib.ctts_relmha_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     _lib = lib
     return lib
 

@@ -9,8 +9,10 @@
 
 namespace {
 
-// state[0] = sum of squares accumulator (must be 0 on entry; re-zeroed by finalize), state[1] = step count (float), state[2] = last
-// total gradient norm (output, for logging like clip_grad_norm_'s return value)
+// state[0] = sum of squares of the gradient (written by sqnorm_reduce_kernel), state[1] = step count (float), state[2] = last total
+// gradient norm (output, for logging like clip_grad_norm_'s return value), state[3 .. 3 + CTTS_ADAM_PARTIALS) = per-block partial sums.
+// The reduction is DETERMINISTIC (fixed block -> partial assignment, fixed-order tree over the partials, no atomics): data-parallel
+// replicas that hold bit-identical gradients after the all-reduce must compute bit-identical clip coefficients, or they drift apart.
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float4* __restrict__ g, long n4, const float* __restrict__ gtail, int ntail,
                                                       float* __restrict__ state) {
   float acc = 0.f;
@@ -23,7 +25,20 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float4* __restrict__ 
   __shared__ float s[4];
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(state, s[0] + s[1] + s[2] + s[3]);
+  if (threadIdx.x == 0) state[3 + blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_reduce_kernel(float* __restrict__ state, int nparts) {
+  __shared__ float s[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += state[3 + i];       // thread t: partials t, t+256, ... in order
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) state[0] = s[0];
 }
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float coef, float wd, float b1, float b2, float eps,
@@ -66,7 +81,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 __global__ void adam_finalize_kernel(float* __restrict__ state) {
   state[2] = sqrtf(state[0]);
-  state[0] = 0.f;
   state[1] += 1.f;
 }
 
@@ -80,9 +94,11 @@ extern "C" int ctts_adam_clip_step(float* p, const float* g, float* m, float* v,
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const long n4 = n >> 2;
-  const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : ((n4 + 255) / 256 < 1 ? 1 : (n4 + 255) / 256));
+  const int blocks = (int)((n4 + 255) / 256 > CTTS_ADAM_PARTIALS ? CTTS_ADAM_PARTIALS : ((n4 + 255) / 256 < 1 ? 1 : (n4 + 255) / 256));
   hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)g, n4, g + (n4 << 2), (int)(n - (n4 << 2)), state);
   CTTS_CHECK_LAUNCH("ctts_adam_clip_step(sqnorm)");
+  hipLaunchKernelGGL(sqnorm_reduce_kernel, dim3(1), dim3(256), 0, st, state, blocks);
+  CTTS_CHECK_LAUNCH("ctts_adam_clip_step(sqnorm reduce)");
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, max_norm, state);
   CTTS_CHECK_LAUNCH("ctts_adam_clip_step(adam)");
   hipLaunchKernelGGL(adam_finalize_kernel, dim3(1), dim3(1), 0, st, state);

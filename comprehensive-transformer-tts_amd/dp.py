@@ -209,7 +209,8 @@ class FlatAdam:
         self.v = torch.zeros_like(self.flat_param)
         self.lr = lr if torch.is_tensor(lr) else torch.tensor(float(lr), dtype=torch.float32, device=dev)
         self.betas, self.eps, self.weight_decay, self.max_norm = betas, eps, weight_decay, max_norm
-        self.state = torch.zeros(3, dtype=torch.float32, device=dev)          # {sum g^2 accumulator, step count, last total norm}
+        from ._lib import ADAM_STATE_FLOATS
+        self.state = torch.zeros(ADAM_STATE_FLOATS, dtype=torch.float32, device=dev)   # {sum g^2, step count, last total norm, partials}
         self.state[1] = float(current_step)
 
     def step(self):

@@ -532,6 +532,66 @@ def rowdot_heads(a, b, n_heads):
     return out
 
 
+# ---- fused attention (csrc/attn.hip) -------------------------------------------------------------------------------------
+def mha_supported(C, H):
+    return bool(_lib.load().ctts_mha_supported(int(C), int(H)))
+
+
+def mha_fwd(qkv, lens, n_heads, scale):
+    """qkv [B,T,3C] packed projections, lens int32 [B] or None -> (out [B,T,C], lse [B,H,T])"""
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    out = torch.empty(B, T, Cc, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B, n_heads, T, dtype=torch.float32, device=qkv.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_mha_fwd(_p(_f32c(qkv, "qkv")), _p(lens), _p(out), _p(lse), B, T, n_heads, Cc, float(scale), _stream()), "ctts_mha_fwd")
+    return out, lse
+
+
+def mha_bwd(qkv, lens, out, dout, lse, n_heads, scale, q_split=1):
+    """-> dqkv [B,T,3C]"""
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    dev = qkv.device
+    dqkv = torch.empty_like(qkv)
+    Dws = torch.empty(B, n_heads, T, dtype=torch.float32, device=dev)
+    dS = torch.empty(B, n_heads, T, T, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.ctts_mha_bwd(_p(qkv), _p(lens), _p(_f32c(out, "out")), _p(_f32c(dout, "dout")), _p(lse), _p(Dws), _p(dS), _p(dqkv),
+                                B, T, n_heads, Cc, float(scale), int(q_split), _stream()), "ctts_mha_bwd")
+    return dqkv
+
+
+def relmha_fwd(qu, qv, kv, pos, n_heads, scale, p_drop=0.0, seed=None, drop_offset=0):
+    """-> (out [B,T,C], lse [B,H,T], ps [B,H,T,T] unshifted position scores, kept for the backward)"""
+    B, T, Cc = qu.shape
+    dev = qu.device
+    lib = _lib.load()
+    ps = torch.empty(lib.ctts_relmha_workspace_floats(B, T, n_heads), dtype=torch.float32, device=dev).view(B, n_heads, T, T)
+    out = torch.empty(B, T, Cc, dtype=torch.float32, device=dev)
+    lse = torch.empty(B, n_heads, T, dtype=torch.float32, device=dev)
+    _lib.check(lib.ctts_relmha_fwd(_p(_f32c(qu, "qu")), _p(_f32c(qv, "qv")), _p(_f32c(kv, "kv")), _p(_f32c(pos, "pos")), _p(ps), _p(out),
+                                   _p(lse), B, T, n_heads, Cc, float(scale), float(p_drop), _p(seed), int(drop_offset), _stream()),
+               "ctts_relmha_fwd")
+    return out, lse, ps
+
+
+def relmha_bwd(qu, qv, kv, pos, ps, out, dout, lse, n_heads, scale, p_drop=0.0, seed=None, drop_offset=0):
+    """-> (dqu, dqv [B,T,C], dkv [B,T,2C], dpos_b [B,T,C])"""
+    B, T, Cc = qu.shape
+    dev = qu.device
+    Dws = torch.empty(B, n_heads, T, dtype=torch.float32, device=dev)
+    dS = torch.empty(B, n_heads, T, T, dtype=torch.float32, device=dev)
+    dPS = torch.empty(B, n_heads, T, T, dtype=torch.float32, device=dev)
+    dqu, dqv, dkv = torch.empty_like(qu), torch.empty_like(qv), torch.empty_like(kv)
+    dpos_b = torch.empty(B, T, Cc, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.ctts_relmha_bwd(_p(qu), _p(qv), _p(kv), _p(pos), _p(ps), _p(_f32c(out, "out")), _p(_f32c(dout, "dout")), _p(lse), _p(Dws),
+                                   _p(dS), _p(dPS), _p(dqu), _p(dqv), _p(dkv), _p(dpos_b), B, T, n_heads, Cc, float(scale), float(p_drop),
+                                   _p(seed), int(drop_offset), _stream()), "ctts_relmha_bwd")
+    return dqu, dqv, dkv, dpos_b
+
+
 def weighted_colsum(x2d, w, scale=1.0, acc_into=None):
     """out[c] = scale * sum_r w[r] * x[r,c]"""
     rows, Cc = x2d.shape
@@ -562,3 +622,63 @@ def mel_l1_bwd(p1, p2, tgt, roww, sums, g):
     _lib.check(lib.ctts_mel_l1_bwd(_p(p1), _p(p2), _p(tgt), _p(roww), _p(sums), _p(_f32c(g, "g")), _p(d1), _p(d2), rows, Cc, _stream()),
                "ctts_mel_l1_bwd")
     return d1, d2
+
+
+# ---- fused variance / duration loss terms (csrc/loss.hip) ----------------------------------------------------------------
+def _var_loss_args(log_d, dur, texts, src_pad, cwt, cwt_spec, uv, mel_pad, f0m_p, f0m_t, f0s_p, f0s_t, e_pred, e_tgt):
+    B, Ts = log_d.shape
+    Tm = cwt.shape[1]
+    if dur.dtype not in (torch.int64, torch.float32):
+        raise _lib.CttsError(f"var_loss: durations must be int64 or float32, got {dur.dtype}")
+    if cwt.shape[-1] != 11 or cwt_spec.shape[-1] != 10:
+        raise _lib.CttsError("var_loss: expected cwt [B,Tm,11] (10 bins + uv logit) and cwt_spec [B,Tm,10]")
+    ptrs = [_p(_f32c(log_d, "log_d")), _p(dur), int(dur.dtype == torch.float32), _p(texts), _p(src_pad), _p(_f32c(cwt, "cwt")),
+            _p(_f32c(cwt_spec, "cwt_spec")), _p(_f32c(uv, "uv")), _p(mel_pad), _p(_f32c(f0m_p, "f0_mean")), _p(_f32c(f0m_t, "f0_mean tgt")),
+            _p(_f32c(f0s_p, "f0_std")), _p(_f32c(f0s_t, "f0_std tgt")), _p(_f32c(e_pred, "e_pred")), _p(_f32c(e_tgt, "e_tgt")), B, Ts, Tm]
+    return ptrs, B, Ts, Tm
+
+
+def var_loss_fwd(tensors, lambdas_t, cwt_l2, sil_t):
+    """tensors = (log_d, dur, texts, src_pad u8, cwt, cwt_spec, uv, mel_pad u8, f0m_p, f0m_t, f0s_p, f0s_t, e_pred, e_tgt);
+    lambdas_t float32 [5] and sil_t int64 [3] are HOST tensors (read at launch).  -> (terms [8], partials, wsum, denoms)"""
+    ptrs, B, Ts, Tm = _var_loss_args(*tensors)
+    dev = tensors[0].device
+    partials = torch.empty(B, 16, dtype=torch.float32, device=dev)
+    wsum = torch.empty(B, 2, Ts + 1, dtype=torch.float32, device=dev)
+    terms = torch.empty(8, dtype=torch.float32, device=dev)
+    denoms = torch.empty(4, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.ctts_var_loss_fwd(*ptrs, lambdas_t.data_ptr(), int(cwt_l2), sil_t.data_ptr(), _p(partials), _p(wsum), _p(terms),
+                                     _p(denoms), _stream()), "ctts_var_loss_fwd")
+    return terms, partials, wsum, denoms
+
+
+def var_loss_bwd(tensors, lambdas_t, cwt_l2, sil_t, partials, wsum, denoms, g8):
+    ptrs, B, Ts, Tm = _var_loss_args(*tensors)
+    dev = tensors[0].device
+    d_log_d = torch.empty(B, Ts, dtype=torch.float32, device=dev)
+    d_e = torch.empty(B, Ts, dtype=torch.float32, device=dev)
+    d_cwt = torch.empty(B, Tm, 11, dtype=torch.float32, device=dev)
+    d_f0m = torch.empty(B, dtype=torch.float32, device=dev)
+    d_f0s = torch.empty(B, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.ctts_var_loss_bwd(*ptrs, lambdas_t.data_ptr(), int(cwt_l2), sil_t.data_ptr(), _p(partials), _p(wsum), _p(denoms),
+                                     _p(_f32c(g8, "g8")), _p(d_log_d), _p(d_cwt), _p(d_f0m), _p(d_f0s), _p(d_e), _stream()),
+               "ctts_var_loss_bwd")
+    return d_log_d, d_cwt, d_f0m, d_f0s, d_e
+
+
+def bin_loss_fwd(soft, hard):
+    n = soft.numel()
+    partials = torch.empty(1024, dtype=torch.float32, device=soft.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=soft.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_bin_loss_fwd(_p(_f32c(soft, "soft")), _p(_f32c(hard, "hard")), n, _p(partials), _p(out2), _stream()), "ctts_bin_loss_fwd")
+    return out2
+
+
+def bin_loss_bwd(soft, hard, out2, g):
+    dsoft = torch.empty_like(soft)
+    lib = _lib.load()
+    _lib.check(lib.ctts_bin_loss_bwd(_p(soft), _p(hard), _p(out2), _p(_f32c(g, "g")), _p(dsoft), soft.numel(), _stream()), "ctts_bin_loss_bwd")
+    return dsoft

@@ -1,12 +1,12 @@
 """`CompTransTTSLoss` and `ScheduledOptim` (reference: model/loss.py:10-347, model/optimizer.py:5-53).
 
-SURVEY.md section 8(f1): the loss runs inside the timed train step, on the HIP device only: the two masked mel-L1 terms are one
-fused kernel pair (csrc/optim.hip), ForwardSumLoss is the device CTC recursion (csrc/align.hip); the [B,Ts]-sized duration / pitch /
-energy terms are stock PyTorch-ROCm ops on device tensors.  Two changes make the step
-hipGraph-capturable without changing any value: the word-duration scatter uses the static bound
-Ts+1 instead of `word_id.max()+1` (loss.py:156-157: the extra bins are zero and masked), and the
-energy L1 uses a masked mean instead of `masked_select` (loss.py:236-243) - neither needs a
-device->host sync.  learn_alignment=True adds ForwardSumLoss and BinLoss;
+SURVEY.md section 8(f1): the loss runs inside the timed train step, on the HIP device only, as a handful of fused launches: the two
+masked mel-L1 terms are one kernel pair (csrc/optim.hip); ALL duration (phone / word / sentence), pitch (cwt, uv, f0 statistics)
+and energy terms are one kernel pair (csrc/loss.hip, `ops.variance_losses`); ForwardSumLoss is the device CTC recursion
+(csrc/align.hip) and BinLoss a two-stage deterministic reduction (csrc/loss.hip).  No device->host sync anywhere (the reference's
+`word_id.max()+1` and `masked_select` are replaced by static bounds / masked sums with identical values), and no stock-torch
+multi-block reduction: its semaphore memset mis-replays inside a hipGraph on this ROCm stack, which made the replayed loss VALUE
+(not the gradients) intermittently garbage.  learn_alignment=True adds ForwardSumLoss and BinLoss;
 prosody_modeling.model_type == "liu2021" adds the prosody L1 terms (loss.py:319-324).
 """
 import numpy as np
@@ -32,45 +32,14 @@ class CompTransTTSLoss(nn.Module):
         self.model_type = model_config["prosody_modeling"]["model_type"]
         self.prosody_loss_enable_steps = train_config["prosody"]["prosody_loss_enable_steps"]
         self.sil_ph_ids = SIL_PHONEME_IDS
-
-    def _duration_loss(self, dur_pred, dur_gt, txt_tokens, nonpad):
-        losses = {}
-        B, T = txt_tokens.shape
-        dur_gt = dur_gt.float() * nonpad
-        is_sil = torch.zeros_like(txt_tokens).bool()
-        for p_id in self.sil_ph_ids:
-            is_sil = is_sil | (txt_tokens == p_id)
-        is_sil = is_sil.float()
-        pd = F.mse_loss(dur_pred, (dur_gt + 1).log(), reduction="none")
-        losses["pdur"] = (pd * nonpad).sum() / nonpad.sum() * self.loss_config["lambda_ph_dur"]
-        dur_lin = (dur_pred.exp() - 1).clamp(min=0)
-        if self.loss_config["lambda_word_dur"] > 0:
-            word_id = (is_sil.cumsum(-1) * (1 - is_sil)).long()
-            wp = dur_lin.new_zeros([B, T + 1]).scatter_add(1, word_id, dur_lin)[:, 1:]
-            wg = dur_gt.new_zeros([B, T + 1]).scatter_add(1, word_id, dur_gt)[:, 1:]
-            wl = F.mse_loss((wp + 1).log(), (wg + 1).log(), reduction="none")
-            wn = (wg > 0).float()
-            losses["wdur"] = (wl * wn).sum() / wn.sum() * self.loss_config["lambda_word_dur"]
-        if self.loss_config["lambda_sent_dur"] > 0:
-            sl = F.mse_loss((dur_lin.sum(-1) + 1).log(), (dur_gt.sum(-1) + 1).log(), reduction="mean")
-            losses["sdur"] = sl.mean() * self.loss_config["lambda_sent_dur"]
-        return losses
-
-    def _pitch_loss(self, p_pred, p_tgt, mel_nonpad):
-        lam = self.loss_config["lambda_f0"]
-        losses = {}
-        cwt_pred = p_pred["cwt"][:, :, :10]
-        if self.loss_config["cwt_loss"] == "l1":
-            losses["C"] = F.l1_loss(cwt_pred, p_tgt["cwt_spec"]) * lam
-        else:
-            losses["C"] = F.mse_loss(cwt_pred, p_tgt["cwt_spec"]) * lam
-        if self.pitch_config["use_uv"]:
-            uv_pred = p_pred["cwt"][:, :, -1]
-            losses["uv"] = ((F.binary_cross_entropy_with_logits(uv_pred, p_tgt["uv"], reduction="none") * mel_nonpad).sum()
-                            / mel_nonpad.sum() * self.loss_config["lambda_uv"])
-        losses["f0_mean"] = F.l1_loss(p_pred["f0_mean"], p_tgt["f0_mean"]) * lam
-        losses["f0_std"] = F.l1_loss(p_pred["f0_std"], p_tgt["f0_std"]) * lam
-        return losses
+        lc = self.loss_config
+        if lc.get("dur_loss", "mse") != "mse" or lc.get("cwt_loss", "l1") not in ("l1", "l2"):
+            raise NotImplementedError("CompTransTTSLoss: dur_loss 'mse' and cwt_loss 'l1' / 'l2' are built (the reference raises for the rest too)")
+        # host-side launch constants of the fused variance-loss kernel
+        self._lambdas = torch.tensor([lc["lambda_ph_dur"], lc["lambda_word_dur"], lc["lambda_sent_dur"], lc["lambda_f0"], lc["lambda_uv"]],
+                                     dtype=torch.float32)
+        self._sil = torch.tensor(list(self.sil_ph_ids), dtype=torch.int64)
+        self._cwt_l2 = int(lc.get("cwt_loss", "l1") == "l2")
 
     @staticmethod
     def forward_sum_loss(attn_logprob, in_lens, out_lens, blank_logprob=-1.0):
@@ -87,14 +56,13 @@ class CompTransTTSLoss(nn.Module):
 
     @staticmethod
     def bin_loss(hard, soft):
-        """BinLoss (loss.py:380-386) with a mask product instead of boolean indexing (no host sync)."""
-        return -(torch.log(torch.clamp(soft, min=1e-12)) * hard).sum() / hard.sum()
+        """BinLoss (loss.py:380-386) with a mask product instead of boolean indexing (no host sync) - csrc/loss.hip."""
+        from . import ops
+        return ops.bin_loss(hard, soft)
 
     def forward(self, inputs, predictions, step):
         (texts, _, _, mel_targets, _, _, pitch_targets, energy_targets, duration_targets, _, _) = inputs[3:]
         (mel_pred, post_pred, p_pred, e_pred, log_d, _, src_masks, mel_masks, src_lens, mel_lens, attn_outs, prosody_info) = predictions
-        src_nonpad = (~src_masks)
-        mel_nonpad = (~mel_masks)
         mel_targets = mel_targets[:, : mel_masks.shape[1], :]
         if not mel_pred.is_cuda:
             raise _lib.CttsError("CompTransTTSLoss runs on the HIP device only: there is no CPU path in the product")
@@ -124,13 +92,15 @@ class CompTransTTSLoss(nn.Module):
         pitch_loss = {"C": zero, "uv": zero, "f0_mean": zero, "f0_std": zero}
         energy_loss = zero
         if step > self.var_start_steps:
-            duration_loss = self._duration_loss(log_d, duration_targets, texts, src_nonpad.float())
-            if self.use_pitch_embed:
-                pitch_loss = self._pitch_loss(p_pred, pitch_targets, mel_nonpad.float())
-            if self.use_energy_embed:
-                m = src_nonpad.float()
-                energy_loss = ((e_pred - energy_targets).abs() * m).sum() / m.sum()
-            total = total + sum(duration_loss.values()) + sum(pitch_loss.values()) + energy_loss
+            # loss.py:123-243 in one fused launch: terms = (pdur, wdur, sdur, C, uv, f0_mean, f0_std, energy), lambda-weighted
+            t = ops.variance_losses(log_d, p_pred["cwt"], p_pred["f0_mean"], p_pred["f0_std"], e_pred, duration_targets, texts, src_masks,
+                                    pitch_targets["cwt_spec"], pitch_targets["uv"], mel_masks, pitch_targets["f0_mean"],
+                                    pitch_targets["f0_std"], energy_targets, self._lambdas, self._cwt_l2, self._sil)
+            duration_loss = {"pdur": t[0], "wdur": t[1] if self.loss_config["lambda_word_dur"] > 0 else zero,
+                             "sdur": t[2] if self.loss_config["lambda_sent_dur"] > 0 else zero}
+            pitch_loss = {"C": t[3], "uv": t[4], "f0_mean": t[5], "f0_std": t[6]}
+            energy_loss = t[7]
+            total = total + t.sum()
         return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, prosody_loss)
 
 

@@ -418,6 +418,45 @@ def _attn_split_k(nbatch, T, dh):
     return _ATTN_SPLIT_K if (_ATTN_SPLIT_K > 1 and tiles < 1536 and T >= 512) else 1
 
 
+# Which attention pipeline runs (CTTS_FUSED_ATTN = auto | 1 | 0, or set_fused_attention):
+#   auto  relative-position attention (conformer, d_head 32): fused - it removes 5 of the 7 [B,H,T,T] maps (46.4 -> 36.4 ms per train step);
+#         fs2 attention (2 heads x 128): fused for inference / no-grad forwards (165 vs 187 us per decoder layer, no 134 MB score tensor),
+#         UNFUSED when gradients are needed: at d_head 128 the fp32-MFMA time dominates and the recomputing backward costs 450 us per
+#         decoder layer against 305 us for the GEMM pipeline that keeps P (B*H = 32 gives one wave per SIMD and a 32-tile critical path)
+#   1 / 0 force the fused / unfused kernels everywhere (tests, A/B measurements)
+_FUSED_ATTN = {"1": True, "0": False}.get(_os.environ.get("CTTS_FUSED_ATTN", "auto"), None)
+_ATTN_Q_SPLIT = int(_os.environ.get("CTTS_ATTN_Q_SPLIT", "1"))     # >1: split a key tile's query loop (atomic dK / dV); measured slower
+
+
+def set_fused_attention(flag):
+    """True / False force a pipeline, None = auto (see above)"""
+    global _FUSED_ATTN
+    _FUSED_ATTN = flag if flag is None else bool(flag)
+
+
+class _FusedSelfAttention(torch.autograd.Function):
+    """The same operator as _SelfAttention on csrc/attn.hip: no [B,H,T,T] tensor in the forward pass (the unfused pipeline writes
+    S, rewrites it in the softmax and re-reads it in P V: 134 MB per decoder layer each time), backward by recomputation with dK / dV
+    accumulated in registers; only dS is materialised once for the dQ GEMM."""
+
+    @staticmethod
+    def forward(ctx, qkv, lens, n_heads):
+        qkv = qkv.contiguous()
+        dh = qkv.shape[-1] // 3 // n_heads
+        out, lse = K.mha_fwd(qkv, lens, n_heads, dh ** -0.5)
+        ctx.save_for_backward(qkv, lens, out, lse)
+        ctx.n_heads = n_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, lens, out, lse = ctx.saved_tensors
+        H = ctx.n_heads
+        B, T, C3 = qkv.shape
+        dh = C3 // 3 // H
+        return K.mha_bwd(qkv, lens, out, dO.contiguous(), lse, H, dh ** -0.5, max(1, _ATTN_Q_SPLIT)), None, None
+
+
 class _SelfAttention(torch.autograd.Function):
     """Multi-head self-attention core on the packed projection qkv [B,T,3C] with a key-padding
     mask given as valid lengths (F.multi_head_attention_forward semantics,
@@ -475,6 +514,9 @@ class _SelfAttention(torch.autograd.Function):
 
 
 def self_attention(qkv, lens_i32, n_heads):
+    want = _FUSED_ATTN if _FUSED_ATTN is not None else not (torch.is_grad_enabled() and qkv.requires_grad)
+    if want and K.mha_supported(qkv.shape[-1] // 3, n_heads):
+        return _FusedSelfAttention.apply(qkv, lens_i32, n_heads)
     return _SelfAttention.apply(qkv, lens_i32, n_heads)
 
 
@@ -717,9 +759,32 @@ class _RelPosAttention(torch.autograd.Function):
         return dqu, dqv, dkv, dpos, None, None, None, None, None
 
 
+class _FusedRelPosAttention(torch.autograd.Function):
+    """_RelPosAttention on csrc/attn.hip: only the unshifted position scores PS = qv pos^T (and, in the backward, dS in the two
+    layouts the remaining GEMMs read) exist as [B,H,T,T] tensors; the shifted scores, the probabilities and the dropped
+    probabilities - 5 of the 7 maps of the unfused pipeline, each 512 MB per decoder layer at B=16, T=1000 - never reach HBM.
+    Same counter-RNG element indices as the unfused path, so both draw identical dropout masks."""
+
+    @staticmethod
+    def forward(ctx, qu, qv, kv, pos, n_heads, scale, p_drop, seed, drop_offset):
+        qu, qv, kv, pos = qu.contiguous(), qv.contiguous(), kv.contiguous(), pos.contiguous()
+        out, lse, ps = K.relmha_fwd(qu, qv, kv, pos, n_heads, scale, p_drop, seed, drop_offset)
+        ctx.save_for_backward(qu, qv, kv, pos, ps, out, lse, seed)
+        ctx.cfg = (n_heads, scale, p_drop, drop_offset)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qu, qv, kv, pos, ps, out, lse, seed = ctx.saved_tensors
+        H, scale, p_drop, drop_offset = ctx.cfg
+        dqu, dqv, dkv, dpos_b = K.relmha_bwd(qu, qv, kv, pos, ps, out, dO.contiguous(), lse, H, scale, p_drop, seed, drop_offset)
+        return dqu, dqv, dkv, dpos_b.sum(0), None, None, None, None, None
+
+
 def relpos_attention(qu, qv, kv, pos, n_heads, scale, p_drop=0.0, drop=None):
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
-    return _RelPosAttention.apply(qu, qv, kv, pos, n_heads, scale, p_drop if seed is not None else 0.0, seed, off)
+    fn = _FusedRelPosAttention if (_FUSED_ATTN is not False and K.mha_supported(qu.shape[-1], n_heads)) else _RelPosAttention
+    return fn.apply(qu, qv, kv, pos, n_heads, scale, p_drop if seed is not None else 0.0, seed, off)
 
 
 # ------------------------------------------------------------------------- unsupervised alignment operators
@@ -987,3 +1052,51 @@ class _MelL1(torch.autograd.Function):
 def mel_l1_pair(mel_pred, postnet_pred, target, pad_mask):
     """-> tensor [2] = (mel_loss, postnet_mel_loss)"""
     return _MelL1.apply(mel_pred, postnet_pred, target, pad_mask)
+
+
+class _VarLoss(torch.autograd.Function):
+    """duration (phone / word / sentence), cwt, uv, f0-statistics and energy terms of CompTransTTSLoss in one kernel pair - csrc/loss.hip"""
+
+    @staticmethod
+    def forward(ctx, log_d, cwt, f0m_p, f0s_p, e_pred, dur, texts, src_pad, cwt_spec, uv, mel_pad, f0m_t, f0s_t, e_tgt, lambdas_t,
+                cwt_l2, sil_t):
+        c = lambda t: t.contiguous()                                                                    # noqa: E731
+        tensors = (c(log_d), c(dur), c(texts), c(src_pad).view(torch.uint8), c(cwt), c(cwt_spec), c(uv), c(mel_pad).view(torch.uint8),
+                   c(f0m_p), c(f0m_t), c(f0s_p), c(f0s_t), c(e_pred), c(e_tgt))
+        terms, partials, wsum, denoms = K.var_loss_fwd(tensors, lambdas_t, cwt_l2, sil_t)
+        ctx.save_for_backward(*tensors, partials, wsum, denoms)
+        ctx.cfg = (lambdas_t, cwt_l2, sil_t)
+        return terms
+
+    @staticmethod
+    def backward(ctx, g):
+        *tensors, partials, wsum, denoms = ctx.saved_tensors
+        lambdas_t, cwt_l2, sil_t = ctx.cfg
+        d_log_d, d_cwt, d_f0m, d_f0s, d_e = K.var_loss_bwd(tuple(tensors), lambdas_t, cwt_l2, sil_t, partials, wsum, denoms, g.contiguous())
+        return (d_log_d, d_cwt, d_f0m, d_f0s, d_e) + (None,) * 12
+
+
+def variance_losses(log_d, cwt, f0_mean, f0_std, e_pred, dur, texts, src_pad, cwt_spec, uv, mel_pad, f0_mean_t, f0_std_t, e_tgt,
+                    lambdas_t, cwt_l2, sil_t):
+    """-> tensor [8] = (pdur, wdur, sdur, C, uv, f0_mean, f0_std, energy), lambda-weighted (model/loss.py:123-243)"""
+    return _VarLoss.apply(log_d, cwt, f0_mean, f0_std, e_pred, dur, texts, src_pad, cwt_spec, uv, mel_pad, f0_mean_t, f0_std_t, e_tgt,
+                          lambdas_t, cwt_l2, sil_t)
+
+
+class _BinLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, soft, hard):
+        soft, hard = soft.contiguous(), hard.contiguous()
+        out2 = K.bin_loss_fwd(soft, hard)
+        ctx.save_for_backward(soft, hard, out2)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        soft, hard, out2 = ctx.saved_tensors
+        return K.bin_loss_bwd(soft, hard, out2, g.reshape(1).contiguous()), None
+
+
+def bin_loss(hard, soft):
+    """BinLoss (loss.py:380-386): -sum(log(clamp(soft, 1e-12)) * hard) / sum(hard), deterministic two-stage reduction"""
+    return _BinLoss.apply(soft, hard)

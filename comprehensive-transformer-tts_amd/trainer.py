@@ -62,6 +62,7 @@ class TrainStep:
         inputs[9:11] = out[-2:]
         losses = self.loss_fn(inputs, out[:-2], self.step_no)
         self.loss_val = losses[0].detach()
+        self.loss_terms = losses                        # the reference's 9-tuple (train.py:127-137 logs it), graph-resident under replay
         return losses[0]
 
     def _stages(self):

@@ -14,6 +14,7 @@
  */
 #ifndef CTTS_H
 #define CTTS_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -258,13 +259,72 @@ int ctts_softmax_rect_bwd(const float* P, float* dP, const int32_t* klens, const
                           void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fused multi-head attention (csrc/attn.hip): exact-fp32 MFMA, flash-style - the [T,T] score / probability tensors never reach HBM in
+ * the forward pass, the backward recomputes them.  d_head = C / H must be 32, 64 or 128 (ctts_mha_supported).
+ *
+ * ctts_mha_fwd / ctts_mha_bwd: the core of F.multi_head_attention_forward as transformer_fs2.py:385-394 calls it (q scaled by `scale` =
+ *   d_head^-0.5, key-padding mask from valid lengths, no biases, no attention dropout) on the packed projection qkv [B,T,3C] (q | k | v).
+ *   lens[b] (or NULL = T): keys >= lens[b] are masked, query rows >= lens[b] are ZERO rows of `out` [B,T,C].
+ *   lse [B,H,T]: log2-domain log-sum-exp of the scaled scores (kept for the backward).
+ *   bwd: out/dout [B,T,C]; Dws [B,H,T] and dS [B,H,T,T] are caller-provided scratch; dqkv [B,T,3C] receives all three gradients
+ *   (zero at padded rows).  q_split >= 1 splits the query loop of a key tile over several waves (atomic accumulation of dK / dV) - use
+ *   2 when B*H*T/32 waves do not fill the chip.
+ * ctts_relmha_fwd / ctts_relmha_bwd: the core of RelativeMultiHeadAttention (conformer.py:396-421) on channel-last projections:
+ *   qu = q + u_bias, qv = q + v_bias [B,T,C]; kv [B,T,2C] (k | v); pos [T,C] = pos_proj(sinusoid rows) shared by the batch;
+ *   score = (qu k^T + shift(qv pos^T)) * scale with the Transformer-XL shift of conformer.py:423-431 applied as an index map, softmax
+ *   over ALL keys (the reference passes no mask, conformer.py:243), dropout(p_drop) on the probabilities (counter RNG: seed,
+ *   drop_offset as in ctts_gemm), context = P v.  ps [B,H,T,T] (ctts_relmha_workspace_floats) receives the UNSHIFTED position scores
+ *   qv pos^T and must be kept for the backward.  bwd: Dws [B,H,T], dS and dPS [B,H,T,T] scratch; outputs dqu, dqv [B,T,C], dkv
+ *   [B,T,2C] and dpos_b [B,T,C] = per-utterance gradient of pos (the caller sums it over B). */
+int ctts_mha_supported(int C, int H);
+int ctts_mha_fwd(const float* qkv, const int32_t* lens, float* out, float* lse, int B, int T, int H, int C, float scale, void* stream);
+int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* out, const float* dout, const float* lse, float* Dws, float* dS,
+                 float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* stream);
+size_t ctts_relmha_workspace_floats(int B, int T, int H);
+int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv, const float* pos, float* ps, float* out, float* lse, int B, int T,
+                    int H, int C, float scale, float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream);
+int ctts_relmha_bwd(const float* qu, const float* qv, const float* kv, const float* pos, const float* ps, const float* out,
+                    const float* dout, const float* lse, float* Dws, float* dS, float* dPS, float* dqu, float* dqv, float* dkv,
+                    float* dpos_b, int B, int T, int H, int C, float scale, float p_drop, const uint64_t* seed, uint32_t drop_offset,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Variance / duration terms of CompTransTTSLoss (model/loss.py:123-243) as one kernel pair (csrc/loss.hip):
+ *   terms[8] = {pdur, wdur, sdur, C, uv, f0_mean, f0_std, energy}, each already multiplied by its lambda (lambdas5 = {lambda_ph_dur,
+ *   lambda_word_dur, lambda_sent_dur, lambda_f0, lambda_uv}; lambda_word / lambda_sent <= 0 switch the term off as the reference does).
+ *   log_d, e_pred, e_tgt [B,Ts] float; dur [B,Ts] int64 (dur_is_float 0) or float32 (1, the MAS durations of learn_alignment);
+ *   texts [B,Ts] int64 and sil_ids3 = the three silence token ids that delimit words (loss.py:30-33); src_pad / mel_pad uint8, 1 = pad;
+ *   cwt [B,Tm,11] (10 cwt bins + uv logit), cwt_spec [B,Tm,10], uv [B,Tm]; f0 statistics [B]; cwt_l2: 0 = l1, 1 = mse.
+ *   Scratch kept for the backward: partials [B,16], wsum [B,2,Ts+1], denoms [4].  Deterministic (no atomics, no memset nodes:
+ *   torch's multi-block reduction mis-replays its semaphore memset inside a hipGraph on this stack).
+ *   bwd: g8 = upstream gradient of every term; writes d_log_d, d_e [B,Ts], d_cwt [B,Tm,11], d_f0m, d_f0s [B].
+ * ctts_bin_loss_*: BinLoss (loss.py:380-386) = -sum(log(clamp(soft,1e-12)) * hard) / sum(hard) over n elements; partials [1024],
+ *   out2 = {loss, sum hard}. */
+int ctts_var_loss_fwd(const float* log_d, const void* dur, int dur_is_float, const int64_t* texts, const uint8_t* src_pad, const float* cwt,
+                      const float* cwt_spec, const float* uv, const uint8_t* mel_pad, const float* f0m_p, const float* f0m_t,
+                      const float* f0s_p, const float* f0s_t, const float* e_pred, const float* e_tgt, int B, int Ts, int Tm,
+                      const float* lambdas5, int cwt_l2, const int64_t* sil_ids3, float* partials, float* wsum, float* terms, float* denoms,
+                      void* stream);
+int ctts_var_loss_bwd(const float* log_d, const void* dur, int dur_is_float, const int64_t* texts, const uint8_t* src_pad, const float* cwt,
+                      const float* cwt_spec, const float* uv, const uint8_t* mel_pad, const float* f0m_p, const float* f0m_t,
+                      const float* f0s_p, const float* f0s_t, const float* e_pred, const float* e_tgt, int B, int Ts, int Tm,
+                      const float* lambdas5, int cwt_l2, const int64_t* sil_ids3, const float* partials, const float* wsum,
+                      const float* denoms, const float* g8, float* d_log_d, float* d_cwt, float* d_f0m, float* d_f0s, float* d_e,
+                      void* stream);
+int ctts_bin_loss_fwd(const float* soft, const float* hard, int64_t n, float* partials, float* out2, void* stream);
+int ctts_bin_loss_bwd(const float* soft, const float* hard, const float* out2, const float* g, float* dsoft, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Fused gradient clipping + Adam over flat fp32 arenas (train.py:118-125, model/optimizer.py:22-53):
  *   total = ||g||_2 ; g <- g * min(1, max_norm / (total + 1e-6))  (nn.utils.clip_grad_norm_; max_norm <= 0: no clipping)
  *   g <- g + weight_decay * p ; m <- b1 m + (1-b1) g ; v <- b2 v + (1-b2) g^2
  *   p <- p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)           (torch.optim.Adam, amsgrad off)
- * p, g, m, v: n floats each, 16-byte aligned.  lr: device scalar.  state: 3 device floats {sum-of-squares accumulator (0 on first
- * call, re-zeroed here), step count t-1 (incremented here), total norm of this call (output)} - all device resident so that the three
- * launches replay inside a hipGraph. */
+ * p, g, m, v: n floats each, 16-byte aligned.  lr: device scalar.  state: CTTS_ADAM_STATE_FLOATS device floats {sum of squares of this
+ * call (output), step count t-1 (incremented here), total norm of this call (output), CTTS_ADAM_PARTIALS per-block partial sums
+ * (scratch)} - all device resident so that the launches replay inside a hipGraph.  The norm is reduced in a FIXED order (no atomics):
+ * data-parallel replicas with bit-identical gradients stay bit-identical. */
+#define CTTS_ADAM_PARTIALS 2048
+#define CTTS_ADAM_STATE_FLOATS (3 + CTTS_ADAM_PARTIALS)
 int ctts_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr, float beta1, float beta2, float eps,
                         float weight_decay, float max_norm, float* state, void* stream);
 

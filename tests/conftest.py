@@ -20,5 +20,6 @@ def _reset_global_op_switches():
         from ctts_amd import ops
         ops.set_grad_accumulation_fusion(False)
         ops.set_wgrad_stream(None)
+        ops.set_fused_attention(None)
     except Exception:      # noqa: BLE001
         pass

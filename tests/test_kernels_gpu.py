@@ -137,9 +137,12 @@ def test_linear_tiny_heads():
         close(bg.grad, br.grad, 2e-5, f"head{N} db")
 
 
-@pytest.mark.parametrize("B,T,H,C", [(3, 70, 2, 256), (2, 130, 2, 256), (2, 33, 8, 256), (3, 1024, 2, 256), (2, 600, 2, 256)])
-def test_self_attention_fwd_bwd(B, T, H, C):
-    """incl. the canonical decoder shape T = 1024 with ragged lengths (long-sequence code paths: split reductions / key tiling)"""
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("B,T,H,C", [(3, 70, 2, 256), (2, 130, 2, 256), (2, 33, 8, 256), (3, 1024, 2, 256), (2, 600, 2, 256), (2, 97, 4, 256)])
+def test_self_attention_fwd_bwd(B, T, H, C, fused):
+    """fused flash-style kernels (csrc/attn.hip, d_head 128 / 32 / 64) and the unfused GEMM + softmax pipeline, incl. the canonical
+    decoder shape T = 1024 with ragged lengths (key tiling, query-loop split with atomic dK / dV, split-K dQ)"""
+    ops.set_fused_attention(fused)
     qkv = rnd(B, T, 3 * C, seed=50)
     lens = torch.tensor([T, max(1, T // 2), max(1, T - 7)][:B], dtype=torch.int32)
     dh = C // H
@@ -159,6 +162,7 @@ def test_self_attention_fwd_bwd(B, T, H, C):
     o.backward(go.double())
     out.backward(go.to(DEV))
     close(qg.grad, qr.grad, 2e-5, "attn dqkv")
+    ops.set_fused_attention(None)
 
 
 @pytest.mark.parametrize("rows,C,eps", [(100, 256, 1e-12), (37, 128, 1e-5), (64, 1024, 1e-5), (9, 80, 1e-5)])
@@ -352,8 +356,10 @@ def test_swish_linear_glu_depthwise_fwd_bwd():
         close(xg.grad, xr.grad, 2e-5, "dwconv dx"); close(wg.grad, wr.grad, 3e-5, "dwconv dw")
 
 
-@pytest.mark.parametrize("B,T,H,C", [(2, 36, 8, 256), (2, 51, 8, 256), (1, 132, 4, 128)])
-def test_relpos_attention_fwd_bwd(B, T, H, C):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("B,T,H,C", [(2, 36, 8, 256), (2, 51, 8, 256), (1, 132, 4, 128), (2, 200, 8, 256), (1, 64, 2, 256)])
+def test_relpos_attention_fwd_bwd(B, T, H, C, fused):
+    ops.set_fused_attention(fused)
     dh = C // H
     qu, qv, kv, pos = rnd(B, T, C, seed=110), rnd(B, T, C, seed=111), rnd(B, T, 2 * C, seed=112), rnd(T, C, seed=113)
     scale = 1.0 / C ** 0.5 * 4
@@ -379,6 +385,27 @@ def test_relpos_attention_fwd_bwd(B, T, H, C):
     yr.backward(go.double()); y.backward(go.to(DEV))
     for n, a, r in zip(("dqu", "dqv", "dkv", "dpos"), tg, tr):
         close(a.grad, r.grad, 3e-5, "relpos " + n)
+    ops.set_fused_attention(None)
+
+
+@pytest.mark.parametrize("B,T,p", [(2, 77, 0.3), (1, 1000, 0.1)])
+def test_fused_relpos_attention_equals_unfused_incl_dropout(B, T, p):
+    """Same counter-RNG element indices in both paths -> identical dropout masks: outputs and all four gradients of the fused kernels
+    against the unfused GEMM / softmax / shift pipeline, at a ragged T and at the conformer decoder's full length T = 1000."""
+    H, C = 8, 256
+    ts = [rnd(B, T, C, seed=130), rnd(B, T, C, seed=131), rnd(B, T, 2 * C, seed=132), rnd(T, C, seed=133)]
+    go = rnd(B, T, C, seed=134).to(DEV)
+    res = []
+    for fused in (False, True):
+        ops.set_fused_attention(fused)
+        drop = K.DropCtx(DEV, seed=77)
+        tg = [t.to(DEV).requires_grad_() for t in ts]
+        y = ops.relpos_attention(*tg, H, 1.0 / 16, p_drop=p, drop=drop)
+        y.backward(go)
+        res.append([y.detach()] + [t.grad for t in tg])
+    ops.set_fused_attention(None)
+    for n, a, b in zip(("out", "dqu", "dqv", "dkv", "dpos"), res[0], res[1]):
+        close(b, a, 2e-5, "fused vs unfused relpos " + n)
 
 
 def test_relpos_attention_dropout_consistency():
@@ -520,7 +547,7 @@ def test_fused_adam_clip_matches_torch():
         assert abs(float(fa.total_norm) - float(total)) <= 1e-5 * max(1.0, float(total))
         for p, q in zip(ref, mine):
             close(q, p, 2e-6, f"param after step {it}")
-    assert float(fa.state[1]) == 4.0 and float(fa.state[0]) == 0.0
+    assert float(fa.state[1]) == 4.0 and abs(float(fa.state[0]) ** 0.5 - float(total)) <= 1e-5 * max(1.0, float(total))
     assert mine[0].data_ptr() == fa.flat_param.data_ptr()     # parameters are views of the flat arena
 
 
