@@ -44,6 +44,8 @@ class GemmDesc(C.Structure):
 _SIGNATURES = {
     "ctts_gemm": [C.POINTER(GemmDesc), _vp],
     "ctts_rowdot_heads": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_mel_prepare": [_vp, C.c_int, C.c_int, _vp, _vp],
+    "ctts_mel_spectrogram": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp],
     "ctts_mha_fwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _vp],
     "ctts_mha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp],
     "ctts_relmha_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
@@ -78,7 +80,7 @@ _SIGNATURES = {
     "ctts_glu_fwd": [_vp, _vp, _i64, C.c_int, _vp],
     "ctts_glu_bwd": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "ctts_dwconv_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "ctts_dwconv_wgrad": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_dwconv_wgrad": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_relpos_softmax_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_relpos_softmax_bwd": [_vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_relshift_bwd": [_vp, _vp, C.c_int, C.c_int, _vp],
@@ -100,7 +102,8 @@ _SIGNATURES = {
     "ctts_softmax_rect_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_softmax_rect_bwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
 }
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version", "ctts_mha_supported", "ctts_relmha_workspace_floats"])
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version", "ctts_mha_supported", "ctts_relmha_workspace_floats",
+                                               "ctts_mel_spectrogram_workspace_bytes"])
 ADAM_STATE_FLOATS = 3 + 2048          # CTTS_ADAM_STATE_FLOATS of include/ctts.h
 
 _lib = None
@@ -131,6 +134,8 @@ def load():
     lib.ctts_version.argtypes = []
     lib.ctts_mha_supported.restype = C.c_int
     lib.ctts_mha_supported.argtypes = [C.c_int, C.c_int]
+    lib.ctts_mel_spectrogram_workspace_bytes.restype = C.c_size_t
+    lib.ctts_mel_spectrogram_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.ctts_relmha_workspace_floats.restype = C.c_size_t
     lib.ctts_relmha_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     _lib = lib

@@ -119,23 +119,29 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
 
   float kb[2][16], vb[2][16];          // ping-pong operand buffers (chunk parity)
   load16(Kb + (long)min(l31, T - 1) * d.ldk, kb[0]);
+  // position-score tile (rows i0 .. i0+31, keys j0 .. j0+31) in load order: 16 x (2 queries x 32 consecutive keys) = 128-byte rows;
+  // transposed through LDS later so that each lane gets the 16 values of ITS query column
+  // The loads are UNCONDITIONAL (invalid elements read index 0 and are zeroed through `okm` when the tile is consumed): a load
+  // under a per-element condition makes hipcc branch around it and wait vmcnt(0) at the join - 16 serialised memory round trips per tile.
+  unsigned okm = 0;
+  auto load_ps_tile = [&](int jt, float (&dst)[16]) {
+    okm = 0;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int ii = i0 + 2 * it + h, jj = jt + l31;
+      const bool ok = ii < T && jj < T && jj != ii + 1;
+      const int idx = ii * (T - 1) + (jj <= ii ? T - 1 : T - 2) + jj;
+      dst[it] = PSz[ok ? idx : 0];
+      okm |= (ok ? 1u : 0u) << it;
+    }
+  };
+  float psn[16];
+  if (BIAS) load_ps_tile(0, psn);
   for (int j0 = 0; j0 < L; j0 += 32) {
     const float* Kr = Kb + (long)min(j0 + l31, T - 1) * d.ldk;
-    float psr[16];
-    if (BIAS) {
-      // position scores of this tile, issued before the score MFMAs: 128-byte rows (fixed query, consecutive keys); they are
-      // transposed through LDS below so that each lane gets the 16 values of ITS query column
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int ii = i0 + 2 * it + h, jj = j0 + l31;
-        float v = 0.f;
-        if (ii < T && jj < T) {
-          const int idx = rel_index(ii, jj, T);
-          if (idx >= 0) v = PSz[idx];
-        }
-        psr[it] = v;
-      }
-    }
+    // position scores: the tile needed NOW was fetched one tile ago (HBM latency under load is several microseconds - far more
+    // than the 1,024 MFMA cycles of one score block)
+    // (the registers `psn` hold this tile's scores; the NEXT tile's fetch is issued as soon as they have been handed to LDS below)
     // ---- S^T[j][i] = sum_k K[j][k] Q[i][k]
     floatx16 St;
 #pragma unroll
@@ -158,11 +164,16 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
     for (int r = 0; r < 16; ++r) s[r] = St[r];
     if (BIAS) {
 #pragma unroll
-      for (int it = 0; it < 16; ++it) sb[(2 * it + h) * 33 + l31] = psr[it];
-      __syncthreads();
+      for (int it = 0; it < 16; ++it) sb[(2 * it + h) * 33 + l31] = ((okm >> it) & 1u) ? psn[it] : 0.f;
+      load_ps_tile(j0 + 32, psn);                        // next tile (unconditional: past the end every element is masked): a softmax,
+                                                         // a PV block and a score block of cover
+      // The workgroup is ONE wave and the LDS executes a wave's instructions in order, so the transposed read below sees the writes
+      // above without a barrier.  __syncthreads() here would cost far more than its s_barrier: its fence waits vmcnt(0), i.e. it
+      // drains every prefetch in flight (K, V and position-score tiles) twice per tile.  wave_barrier only pins the program order.
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] += sb[l31 * 33 + rowmap(r, h)];
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
     }
     // ---- online softmax over the keys (log2 domain); a lane owns query column i, its partner lane^32 the other 16 key rows
     float tmax = -INFINITY;
@@ -197,8 +208,8 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
       if (c + 1 < NC) {
 #pragma unroll
         for (int st = 0; st < 16; ++st) vb[(c + 1) & 1][st] = Vb[(long)min(j0 + rowmap(st, h), T - 1) * d.ldv + 32 * (c + 1)];
-      } else if (j0 + 32 < L) {         // last PV chunk: fetch the next tile's first K chunk underneath it
-        load16(Kb + (long)min(j0 + 32 + l31, T - 1) * d.ldk, kb[0]);
+      } else {                          // last PV chunk: fetch the next tile's first K chunk underneath it (unconditional, row clamped:
+        load16(Kb + (long)min(j0 + 32 + l31, T - 1) * d.ldk, kb[0]);      // a load under a runtime condition costs a vmcnt(0) at the join)
       }
       CTTS_SCHED_FENCE();
 #pragma unroll
@@ -219,8 +230,11 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
 }
 
 // --------------------------------------------------------------------------------------------------------------- backward
+#ifndef CTTS_ATTN_BWD32_WAVES
+#define CTTS_ATTN_BWD32_WAVES 2
+#endif
 template <int DH, bool BIAS>
-__global__ __launch_bounds__(64, (DH <= 32 ? 2 : 1)) void attn_bwd_kernel(const AttnArgs d) {
+__global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void attn_bwd_kernel(const AttnArgs d) {
   constexpr int NC = DH / 32;
   constexpr bool RES = DH <= 64;        // K / V fragments of the wave's 32 keys stay in registers
   const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
@@ -279,6 +293,22 @@ __global__ __launch_bounds__(64, (DH <= 32 ? 2 : 1)) void attn_bwd_kernel(const 
     load16(Qb + (long)min(q_lo * 32 + l31, T - 1) * d.ldq + 16 * h, qa[0]);
     if (!RES) load16(Kr, kb[0]);
   }
+  // position scores of a (query tile, this wave's keys) block: register r <-> query row it0 + rowmap(r, h), lane <-> key (coalesced rows)
+  // (unconditional loads + validity mask, see the forward kernel)
+  unsigned okb = 0;
+  auto load_bias_tile = [&](int it0, float (&dst)[16]) {
+    okb = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ir = it0 + rowmap(r, h);
+      const bool ok = ir < T && j < T && j != ir + 1;
+      const int bi = ir * (T - 1) + (j <= ir ? T - 1 : T - 2) + j;
+      dst[r] = PSz[ok ? bi : 0];
+      okb |= (ok ? 1u : 0u) << r;
+    }
+  };
+  float bias_n[16];
+  if (BIAS && q_lo < q_hi) load_bias_tile(q_lo * 32, bias_n);
   for (int qt = q_lo; qt < q_hi; ++qt) {
     const int i0 = qt * 32;
     const int ia = min(i0 + l31, T - 1);
@@ -308,15 +338,7 @@ __global__ __launch_bounds__(64, (DH <= 32 ? 2 : 1)) void attn_bwd_kernel(const 
     }
     // row statistics and position scores of this tile: issued before the dP MFMAs, consumed after them
     const float lse_l = lse[ia], D_l = Dz[ia];          // lanes 0..31 (and 32..63 again) hold rows i0 .. i0+31
-    float bias_r[16];
-    if (BIAS) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ir = i0 + rowmap(r, h);
-        const int bi = (ir < T && j < T) ? rel_index(ir, j, T) : -1;
-        bias_r[r] = bi >= 0 ? PSz[bi] : 0.f;
-      }
-    }
+    // (`bias_n` holds this tile's position scores, fetched one query tile ago)
     // ---- dPd[i][j] = sum_k dO[i][k] V[j][k]
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(64, (DH <= 32 ? 2 : 1)) void attn_bwd_kernel(const 
       const int rm = rowmap(r, h), ir = i0 + rm;
       const float lse_i = __shfl(lse_l, rm, 64), Di = __shfl(D_l, rm, 64);
       float s = S[r];
-      if (BIAS) s += bias_r[r];
+      if (BIAS) s += ((okb >> r) & 1u) ? bias_n[r] : 0.f;
       const bool valid = ir < L && j < L;
       const float p = valid ? fast_exp2(s * sl2 - lse_i) : 0.f;
       float ks = 1.f;
@@ -363,6 +385,7 @@ __global__ __launch_bounds__(64, (DH <= 32 ? 2 : 1)) void attn_bwd_kernel(const 
         }
       }
     }
+    if (BIAS) load_bias_tile(i0 + 32, bias_n);          // next tile's scores (unconditional, masked past the end): three MFMA blocks of cover
     // ---- dV^T[d][j] += sum_i dO[i][d] Pd[i][j],  dK^T[d][j] += sum_i Q[i][d] dS[i][j]
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(64, (DH <= 32 ? 2 : 1)) void attn_bwd_kernel(const 
           dot[(c + 1) & 1][st] = dOb[ir * d.lddo + 32 * (c + 1) + l31];
           qtt[(c + 1) & 1][st] = Qb[ir * d.ldq + 32 * (c + 1) + l31];
         }
-      } else if (qt + 1 < q_hi) {       // next query tile's first S operands
+      } else {                          // next query tile's first S operands (unconditional, row clamped)
         load16(Qb + (long)min(i0 + 32 + l31, T - 1) * d.ldq + 16 * h, qa[0]);
         if (!RES) load16(Kr, kb[0]);
       }

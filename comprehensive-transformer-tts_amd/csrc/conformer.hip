@@ -69,37 +69,57 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
     if (t0 + j < T) yb[(long)(t0 + j) * C4 + c4] = acc[j];
 }
 
-// dw[c,k] += sum over a chunk of 32 (b,t) rows; thread = channel.  The 32 dy values and the 32+K-1 x values the chunk touches are loaded
-// ONCE into registers (statically indexed after unrolling), then 32 x K FMAs: 95 loads per chunk instead of 32 x (K+1).
+// dw[c,k] = sum_{b,t} dy[b,t,c] x[b,t+k-pad,c].  Thread = channel; a workgroup walks a SLICE of (utterance, 32-row chunk) pairs and keeps
+// its 31 tap sums in registers: per chunk the 32 dy values and the 32+K-1 x values it touches are loaded ONCE (statically indexed
+// after unrolling), then 32 x K FMAs.  Slice sums go to partials[slice][c][32]; a second one-block pass adds the slices in a fixed
+// order - deterministic, and no atomics (the previous version issued 31 atomics per thread per chunk: 4 M per call, 330 us).
 constexpr int DW_MAXK = 32;
 constexpr int DW_CH = 32;
+constexpr int DW_SLICES = 128;
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            float* __restrict__ dw, int T, int C, int K, int chunk) {
-  const int c = blockIdx.z * blockDim.x + threadIdx.x;
+                                                            float* __restrict__ partials, int B, int T, int C, int K) {
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const int b = blockIdx.y;
-  const int t0 = blockIdx.x * DW_CH;
   const int pad = (K - 1) / 2;
-  const float* xb = x + (long)b * T * C + c;
-  const float* db = dy + (long)b * T * C + c;
-  float d[DW_CH], xs[DW_CH + DW_MAXK - 1], acc[DW_MAXK];
+  const int chunks_t = (T + DW_CH - 1) / DW_CH, n_chunks = B * chunks_t;
+  const int per = (n_chunks + gridDim.x - 1) / gridDim.x;
+  const int c_lo = blockIdx.x * per, c_hi = min(n_chunks, c_lo + per);
+  float acc[DW_MAXK];
 #pragma unroll
-  for (int i = 0; i < DW_CH; ++i) d[i] = (t0 + i < T) ? db[(long)(t0 + i) * C] : 0.f;
+  for (int k = 0; k < DW_MAXK; ++k) acc[k] = 0.f;
+  for (int ch = c_lo; ch < c_hi; ++ch) {
+    const int b = ch / chunks_t, t0 = (ch - b * chunks_t) * DW_CH;
+    const float* xb = x + (long)b * T * C + c;
+    const float* db = dy + (long)b * T * C + c;
+    float d[DW_CH], xs[DW_CH + DW_MAXK - 1];
 #pragma unroll
-  for (int i = 0; i < DW_CH + DW_MAXK - 1; ++i) {
-    const int u = t0 + i - pad;
-    xs[i] = (i < DW_CH + K - 1 && u >= 0 && u < T) ? xb[(long)u * C] : 0.f;
+    for (int i = 0; i < DW_CH; ++i) d[i] = (t0 + i < T) ? db[(long)(t0 + i) * C] : 0.f;
+#pragma unroll
+    for (int i = 0; i < DW_CH + DW_MAXK - 1; ++i) {
+      const int u = t0 + i - pad;
+      xs[i] = (i < DW_CH + K - 1 && u >= 0 && u < T) ? xb[(long)u * C] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < DW_MAXK; ++k) {
+      float a = acc[k];
+#pragma unroll
+      for (int i = 0; i < DW_CH; ++i) a = fmaf(d[i], xs[i + k], a);
+      acc[k] = a;
+    }
   }
+  float* p = partials + ((long)blockIdx.x * C + c) * DW_MAXK;
 #pragma unroll
-  for (int k = 0; k < DW_MAXK; ++k) {
-    float a = 0.f;
-#pragma unroll
-    for (int i = 0; i < DW_CH; ++i) a = fmaf(d[i], xs[i + k], a);
-    acc[k] = a;
-  }
-#pragma unroll
-  for (int k = 0; k < DW_MAXK; ++k)
-    if (k < K) atomicAdd(dw + (long)c * K + k, acc[k]);
+  for (int k = 0; k < DW_MAXK; ++k) p[k] = acc[k];
+}
+
+__global__ void dwconv_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int C, int K, int n_slices) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;          // e = c * 32 + k
+  if (e >= C * DW_MAXK) return;
+  const int c = e / DW_MAXK, k = e - c * DW_MAXK;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int sl = 0; sl < n_slices; ++sl) s += partials[(long)sl * C * DW_MAXK + e];
+  dw[(long)c * K + k] = s;
 }
 
 // ---- relative-position scores: shifted[i,j] = padded.flat[i*T + j + T], padded = [0 | PS] rows of T+1  (conformer.py:423-431)
@@ -211,15 +231,20 @@ extern "C" int ctts_dwconv_fwd(const float* x, const float* wT, float* y, int B,
   return 0;
 }
 
-extern "C" int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, int B, int T, int C, int K, void* stream) {
-  CTTS_REQUIRE(dy && x && dw && K <= DW_MAXK && (K & 1), "ctts_dwconv_wgrad: need odd K <= 32");
+extern "C" int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, float* partials, int B, int T, int C, int K, void* stream) {
+  CTTS_REQUIRE(dy && x && dw && partials && K <= DW_MAXK && (K & 1), "ctts_dwconv_wgrad: need odd K <= 32 and a partials workspace");
   hipStream_t st = (hipStream_t)stream;
-  if (ctts_zero_async(dw, sizeof(float) * (size_t)C * K, st) != 0) { ctts_set_error("ctts_dwconv_wgrad: memset failed"); return -2; }
-  if (B == 0 || T == 0) return 0;
-  const int chunk = 32;                       // = DW_CH
-  dim3 grid((T + chunk - 1) / chunk, B, (C + 255) / 256);
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, grid, dim3(256), 0, st, dy, x, dw, T, C, K, chunk);
+  if (B == 0 || T == 0) {
+    if (ctts_zero_async(dw, sizeof(float) * (size_t)C * K, st) != 0) { ctts_set_error("ctts_dwconv_wgrad: memset failed"); return -2; }
+    return 0;
+  }
+  const int n_chunks = B * ((T + DW_CH - 1) / DW_CH);
+  const int slices = n_chunks < DW_SLICES ? n_chunks : DW_SLICES;
+  dim3 grid(slices, (C + 255) / 256);
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, grid, dim3(256), 0, st, dy, x, partials, B, T, C, K);
   CTTS_CHECK_LAUNCH("ctts_dwconv_wgrad");
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * DW_MAXK + 255) / 256), dim3(256), 0, st, partials, dw, C, K, slices);
+  CTTS_CHECK_LAUNCH("ctts_dwconv_wgrad(reduce)");
   return 0;
 }
 

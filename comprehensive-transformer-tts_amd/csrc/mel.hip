@@ -1,0 +1,229 @@
+// Mel front end as a real FFT (reference audio/stft.py:59-88 STFT.transform, :166-185 TacotronSTFT.mel_spectrogram,
+// audio/audio_processing.py:85-91 dynamic_range_compression) - ONE kernel: waveform -> (log-mel [B,80,F], energy [B,F]).
+//
+// The reference convolves with a [1026 x 1024] windowed DFT basis: 2.1 MFLOP per frame.  Here each frame is a 1024-point real FFT
+// = one 512-point complex FFT (z[n] = x[2n] + i x[2n+1], three radix-8 Stockham passes, one wave per frame, 8 points per lane,
+// exchange through LDS) + the even/odd split, 0.03 MFLOP per frame; hann window folded into the load, reflect padding as index
+// arithmetic (no padded copy), |X| and the energy norm in registers, the mel filterbank as a banded GEMM on the fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: 16 frames x 16 filters per tile, only the K range in which the 16 triangular filters are non-zero),
+// log-clamp fused, output transposed through LDS so that both mel [B,n_mel,F] rows and the input reads are coalesced.
+// HBM traffic = the algorithmic 1 KB in + 324 B out per frame (every sample is re-read by 4 overlapping frames from L1/L2).
+#include "ctts_common.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NFFT = 1024, NC = 512, NBINS = 513;
+constexpr int TILE_F = 16;                 // frames per workgroup tile (4 waves x 4 frames)
+constexpr int MS_MAX = 517;                // magnitude-tile row stride when every bin may carry filter weight (odd: conflict-free column reads)
+constexpr int SCR = 544;                   // per-wave FFT scratch: 512 complex + padding (index + index/32)
+// workspace layout (floats): [0, 1024) W512 (cos, sin) | [1024, 1024+516) W1024 k = 0..256 (cos, sin) | melT [516][96] | int32 kranges[12]
+constexpr int WS_W512 = 0, WS_W1024 = 1024, WS_MELT = 1024 + 516, WS_KR = WS_MELT + 516 * 96, WS_FLOATS = WS_KR + 16;
+
+struct float2_ { float x, y; };
+__device__ __forceinline__ float2_ cmul(float2_ a, float2_ b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ void fft2(float2_& a, float2_& b) { const float2_ t = a; a = {t.x + b.x, t.y + b.y}; b = {t.x - b.x, t.y - b.y}; }
+__device__ __forceinline__ float2_ mul_mi(float2_ a) { return {a.y, -a.x}; }       // * (-i)
+__device__ __forceinline__ void fft4(float2_& v0, float2_& v1, float2_& v2, float2_& v3) {
+  fft2(v0, v2); fft2(v1, v3); v3 = mul_mi(v3); fft2(v0, v1); fft2(v2, v3);         // -> X0 = v0, X2 = v1, X1 = v2, X3 = v3
+}
+// forward 8-point DFT in place; afterwards X[0..7] = v0, v4, v2, v6, v1, v5, v3, v7
+__device__ __forceinline__ void fft8(float2_ (&v)[8]) {
+  constexpr float h = 0.70710678118654752440f;
+  fft2(v[0], v[4]); fft2(v[1], v[5]); fft2(v[2], v[6]); fft2(v[3], v[7]);
+  v[5] = {(v[5].x + v[5].y) * h, (v[5].y - v[5].x) * h};        // * W8^1 = (1 - i)/sqrt2
+  v[6] = mul_mi(v[6]);                                          // * W8^2 = -i
+  v[7] = {(v[7].y - v[7].x) * h, -(v[7].x + v[7].y) * h};       // * W8^3 = (-1 - i)/sqrt2
+  fft4(v[0], v[1], v[2], v[3]); fft4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ int brev3(int r) { return ((r & 1) << 2) | (r & 2) | (r >> 2); }
+__device__ __forceinline__ int pad32(int i) { return i + (i >> 5); }
+
+__device__ __forceinline__ float sample_reflect(const float* __restrict__ yb, int N, int p) {
+  // index into the reflect-padded waveform (F.pad(..., mode="reflect") by n_fft/2 on both sides, stft.py:66-71)
+  int q = p - NFFT / 2;
+  if (q < 0) q = -q;
+  if (q >= N) q = 2 * (N - 1) - q;
+  q = min(max(q, 0), N - 1);
+  return yb[q];
+}
+
+__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, const float* __restrict__ window, const float* __restrict__ ws,
+                                                   float* __restrict__ mel, float* __restrict__ energy, float* __restrict__ mag_out,
+                                                   long ld_mag, int B, int N, int F, int hop, int n_mel, float clip, int MS) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tw512 = lds;                                   // 1024
+  float* tw1024 = lds + 1024;                           // 516
+  float* magt = lds + 1540;                             // TILE_F x MS
+  float* scr = magt + TILE_F * MS;                      // 4 waves x SCR complex (re | im interleaved)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < 1540; e += 256) lds[e] = ws[e];
+  // only bins < MS-1 are kept in the tile (the filterbank is zero above fmax); columns >= 513 are K padding of the MFMA and stay zero
+  for (int e = tid; e < TILE_F * 4; e += 256) { const int c = NBINS + (e & 3); if (c < MS) magt[(e >> 2) * MS + c] = 0.f; }
+  const int* kr = reinterpret_cast<const int*>(ws + WS_KR);
+  const float* melT = ws + WS_MELT;
+  float win[16];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { win[2 * r] = window[2 * (lane + 64 * r)]; win[2 * r + 1] = window[2 * (lane + 64 * r) + 1]; }
+  float* S = scr + wave * (2 * SCR);
+  const int tiles_per_b = (F + TILE_F - 1) / TILE_F;
+  const long n_tiles = (long)B * tiles_per_b;
+  __syncthreads();
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int b = (int)(tile / tiles_per_b), f0 = (int)(tile - (long)b * tiles_per_b) * TILE_F;
+    const float* yb = y + (long)b * N;
+    // ------------------------------------------------------------------ FFT phase: wave w transforms frames f0 + 4w .. f0 + 4w + 3
+    for (int ff = 0; ff < 4; ++ff) {
+      const int fl = wave * 4 + ff, f = f0 + fl, fc = min(f, F - 1);
+      float2_ v[8];
+      const int base = fc * hop;
+      // no reflection needed and the 8-byte pair loads are aligned
+      const bool interior = base >= NFFT / 2 && base + NFFT - NFFT / 2 <= N && ((((long)b * N + base) | (reinterpret_cast<uintptr_t>(y) >> 2)) & 1) == 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int n = 2 * (lane + 64 * r);
+        float a, c;
+        if (interior) { const float2 t = *reinterpret_cast<const float2*>(yb + base - NFFT / 2 + n) ; a = t.x; c = t.y; }
+        else { a = sample_reflect(yb, N, base + n); c = sample_reflect(yb, N, base + n + 1); }
+        v[r] = {a * win[2 * r], c * win[2 * r + 1]};
+      }
+      // pass 0 (Ns = 1): no twiddles
+      fft8(v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const int o = pad32(lane * 8 + r); S[2 * o] = v[brev3(r)].x; S[2 * o + 1] = v[brev3(r)].y; }
+      __syncthreads();
+      // pass 1 (Ns = 8) and pass 2 (Ns = 64)
+#pragma unroll
+      for (int pass = 1; pass < 3; ++pass) {
+        const int Ns = pass == 1 ? 8 : 64, tmul = pass == 1 ? 8 : 1;
+        const int jm = lane & (Ns - 1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int o = pad32(lane + 64 * r); v[r] = {S[2 * o], S[2 * o + 1]}; }
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+          const int t = jm * tmul * r;                    // W512^(jm * r * 64 / Ns)
+          v[r] = cmul(v[r], float2_{tw512[2 * t], tw512[2 * t + 1]});
+        }
+        fft8(v);
+        __syncthreads();                                  // every lane of every wave has read its inputs
+        const int idx = (lane / Ns) * Ns * 8 + jm;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int o = pad32(idx + r * Ns); S[2 * o] = v[brev3(r)].x; S[2 * o + 1] = v[brev3(r)].y; }
+        __syncthreads();
+      }
+      // even / odd split: X[k] = E + W1024^k O, X[512-k] = conj(E - W1024^k O); magnitudes, energy
+      float e2 = 0.f;
+      float* mrow = magt + fl * MS;
+      float* gmag = (mag_out && f < F) ? mag_out + ((long)b * F + f) * ld_mag : nullptr;
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const int k = m < 4 ? lane + 64 * m : 256;
+        if (m == 4 && lane != 0) break;
+        const int o1 = pad32(k & 511), o2 = pad32((NC - k) & 511);
+        const float a = S[2 * o1], bb = S[2 * o1 + 1], c = S[2 * o2], dd = S[2 * o2 + 1];
+        const float er = 0.5f * (a + c), ei = 0.5f * (bb - dd), orr = 0.5f * (bb + dd), oi = -0.5f * (a - c);
+        const float wr = tw1024[2 * k], wi = tw1024[2 * k + 1];
+        const float tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+        const float m1 = sqrtf((er + tr) * (er + tr) + (ei + ti) * (ei + ti));
+        const float m2 = sqrtf((er - tr) * (er - tr) + (ei - ti) * (ei - ti));
+        if (k < MS) mrow[k] = m1;
+        e2 += m1 * m1;
+        if (gmag) gmag[k] = m1;
+        if (k != 256) { if (NC - k < MS) mrow[NC - k] = m2; e2 += m2 * m2; if (gmag) gmag[NC - k] = m2; }
+      }
+      e2 = ctts_wave_sum(e2);
+      if (lane == 0 && f < F) energy[(long)b * F + f] = sqrtf(e2);
+      __syncthreads();                                    // scratch is reused by the next frame
+    }
+    // ------------------------------------------------------------------ mel phase: [16 frames x K] x [K x 16 filters] per MFMA tile
+    const int n_tiles16 = (n_mel + 15) / 16;
+    float* T = scr;                                       // [n_mel_pad][17] staging for the transposed store
+    for (int nt = wave; nt < n_tiles16; nt += 4) {
+      const int klo = kr[2 * nt], khi = kr[2 * nt + 1];  // multiples of 4
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int fr = lane & 15, kq = lane >> 4;
+      for (int k0 = klo; k0 < khi; k0 += 4) {
+        const float av = magt[fr * MS + k0 + kq];                   // A[frame][k]
+        const float bv = melT[(long)(k0 + kq) * 96 + nt * 16 + fr]; // B[k][filter]   (fr doubles as the filter column index)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      }
+      // D: col = lane & 15 (filter), row = (lane >> 4) * 4 + reg (frame)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(nt * 16 + (lane & 15)) * 17 + (lane >> 4) * 4 + r] = logf(fmaxf(acc[r], clip));
+    }
+    __syncthreads();
+    for (int e = tid; e < n_mel * TILE_F; e += 256) {
+      const int n = e / TILE_F, fl = e - n * TILE_F;
+      if (f0 + fl < F) mel[((long)b * n_mel + n) * F + f0 + fl] = T[n * 17 + fl];
+    }
+    __syncthreads();
+  }
+}
+
+// workspace set-up (once per filterbank): twiddles in double precision, the transposed / zero-padded mel basis and, per tile of 16
+// filters, the range of DFT bins in which any of them is non-zero
+__global__ void mel_prepare_kernel(const float* __restrict__ mel_basis, int n_mel, int nbins, float* __restrict__ ws) {
+  const int tid = threadIdx.x;
+  for (int m = tid; m < 512; m += blockDim.x) {
+    double s, c; sincos(-2.0 * 3.14159265358979323846 * m / 512.0, &s, &c);
+    ws[WS_W512 + 2 * m] = (float)c; ws[WS_W512 + 2 * m + 1] = (float)s;
+  }
+  for (int m = tid; m < 258; m += blockDim.x) {
+    double s, c; sincos(-2.0 * 3.14159265358979323846 * m / 1024.0, &s, &c);
+    ws[WS_W1024 + 2 * m] = m <= 256 ? (float)c : 0.f; ws[WS_W1024 + 2 * m + 1] = m <= 256 ? (float)s : 0.f;
+  }
+  for (int e = tid; e < 516 * 96; e += blockDim.x) {
+    const int k = e / 96, n = e - k * 96;
+    ws[WS_MELT + e] = (k < nbins && n < n_mel) ? mel_basis[(long)n * nbins + k] : 0.f;
+  }
+  int* kr = reinterpret_cast<int*>(ws + WS_KR);
+  if (tid < 6) {
+    int lo = 516, hi = 0;
+    for (int n = tid * 16; n < min(tid * 16 + 16, n_mel); ++n)
+      for (int k = 0; k < nbins; ++k)
+        if (mel_basis[(long)n * nbins + k] != 0.f) { lo = min(lo, k); hi = max(hi, k + 1); }
+    if (hi <= lo) { lo = 0; hi = 0; }
+    kr[2 * tid] = lo & ~3; kr[2 * tid + 1] = min((hi + 3) & ~3, 516);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t ctts_mel_spectrogram_workspace_bytes(int n_fft, int n_mel) {
+  (void)n_fft; (void)n_mel;
+  return sizeof(float) * (size_t)WS_FLOATS;
+}
+
+extern "C" int ctts_mel_prepare(const float* mel_basis, int n_fft, int n_mel, float* workspace, void* stream) {
+  CTTS_REQUIRE(mel_basis && workspace, "ctts_mel_prepare: null pointer");
+  CTTS_REQUIRE(n_fft == NFFT && n_mel >= 1 && n_mel <= 96, "ctts_mel_prepare: built for n_fft = 1024 (reference filter_length) and n_mel <= 96; got %d / %d", n_fft, n_mel);
+  hipLaunchKernelGGL(mel_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mel_basis, n_mel, NBINS, workspace);
+  CTTS_CHECK_LAUNCH("ctts_mel_prepare");
+  return 0;
+}
+
+extern "C" int ctts_mel_spectrogram(const float* y, const float* window, const float* workspace, float* mel, float* energy, float* mag,
+                                    int64_t ld_mag, int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, void* stream) {
+  CTTS_REQUIRE(y && window && workspace && mel && energy && B > 0 && N > 0, "ctts_mel_spectrogram: bad arguments");
+  CTTS_REQUIRE(n_fft == NFFT && hop > 0 && n_mel >= 1 && n_mel <= 96, "ctts_mel_spectrogram: built for n_fft = 1024, n_mel <= 96");
+  CTTS_REQUIRE(N > NFFT / 2, "ctts_mel_spectrogram: reflect padding needs more than n_fft/2 samples (got %d)", N);
+  CTTS_REQUIRE(!mag || ld_mag >= NBINS, "ctts_mel_spectrogram: ld_mag must be >= 513");
+  const int F = 1 + N / hop;
+  const long tiles = (long)B * ((F + TILE_F - 1) / TILE_F);
+  // kmax = 1 + the highest DFT bin with a non-zero filter weight (0 = unknown: keep all 513).  The magnitude tile holds bins < kmax only
+  // (fmax 8 kHz of 11 kHz: 372 bins -> 48 KB of LDS per workgroup, 3 workgroups per CU instead of 2)
+  CTTS_REQUIRE(kmax >= 0 && kmax <= NBINS, "ctts_mel_spectrogram: kmax out of range");
+  const int MS = kmax > 0 ? (((kmax + 3) & ~3) | 1) : MS_MAX;
+  const size_t lds_bytes = sizeof(float) * (size_t)(1540 + TILE_F * MS + 4 * 2 * SCR);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_set = true;
+  }
+  const int grid = (int)(tiles < 4096 ? tiles : 4096);
+  hipLaunchKernelGGL(mel_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, y, window, workspace, mel, energy, mag, (long)ld_mag,
+                     B, N, F, hop, n_mel, clip, MS);
+  CTTS_CHECK_LAUNCH("ctts_mel_spectrogram");
+  return 0;
+}

@@ -340,8 +340,9 @@ def dwconv_fwd(x, wT, flip=False):
 def dwconv_wgrad(dy, x, Kk):
     B, T, Cc = x.shape
     dw = torch.empty(Cc, Kk, dtype=torch.float32, device=x.device)
+    partials = torch.empty(128 * Cc * 32, dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.ctts_dwconv_wgrad(_p(_f32c(dy, "dy")), _p(x), _p(dw), B, T, Cc, Kk, _stream()), "ctts_dwconv_wgrad")
+    _lib.check(lib.ctts_dwconv_wgrad(_p(_f32c(dy, "dy")), _p(x), _p(dw), _p(partials), B, T, Cc, Kk, _stream()), "ctts_dwconv_wgrad")
     return dw
 
 
@@ -682,3 +683,27 @@ def bin_loss_bwd(soft, hard, out2, g):
     lib = _lib.load()
     _lib.check(lib.ctts_bin_loss_bwd(_p(soft), _p(hard), _p(out2), _p(_f32c(g, "g")), _p(dsoft), soft.numel(), _stream()), "ctts_bin_loss_bwd")
     return dsoft
+
+
+# ---- mel front end as a real FFT (csrc/mel.hip) ------------------------------------------------------------------------------
+def mel_prepare(mel_basis, n_fft):
+    """-> workspace tensor for `mel_spectrogram_fft` (twiddles, transposed filterbank, per-tile bin ranges)"""
+    n_mel = mel_basis.shape[0]
+    lib = _lib.load()
+    ws = torch.empty(lib.ctts_mel_spectrogram_workspace_bytes(int(n_fft), int(n_mel)) // 4, dtype=torch.float32, device=mel_basis.device)
+    _lib.check(lib.ctts_mel_prepare(_p(_f32c(mel_basis, "mel_basis")), int(n_fft), int(n_mel), _p(ws), _stream()), "ctts_mel_prepare")
+    return ws
+
+
+def mel_spectrogram_fft(y, window, ws, n_fft, hop, n_mel, clip=1e-5, want_mag=False, kmax=0):
+    """y [B,N] -> (mel [B,n_mel,F], energy [B,F], mag [B*F,516] or None) in one launch"""
+    B, N = y.shape
+    F = 1 + N // hop
+    dev = y.device
+    mel = torch.empty(B, n_mel, F, dtype=torch.float32, device=dev)
+    energy = torch.empty(B, F, dtype=torch.float32, device=dev)
+    mag = torch.empty(B * F, 516, dtype=torch.float32, device=dev) if want_mag else None
+    lib = _lib.load()
+    _lib.check(lib.ctts_mel_spectrogram(_p(_f32c(y, "y")), _p(_f32c(window, "window")), _p(ws), _p(mel), _p(energy), _p(mag), 516, B, N,
+                                        int(n_fft), int(hop), int(n_mel), float(clip), int(kmax), _stream()), "ctts_mel_spectrogram")
+    return mel, energy, mag

@@ -197,7 +197,8 @@ int ctts_log_clamp_transpose(const float* mel_fm, float* out, int B, int F, int 
 int ctts_glu_fwd(const float* a, float* out, int64_t rows, int C, void* stream);
 int ctts_glu_bwd(const float* a, const float* dout, float* da, int64_t rows, int C, void* stream);
 int ctts_dwconv_fwd(const float* x, const float* wT, float* y, int B, int T, int C, int K, int flip, void* stream);
-int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, int B, int T, int C, int K, void* stream);
+int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, float* partials, int B, int T, int C, int K, void* stream);
+/* partials: scratch of 128 * C * 32 floats (slice sums, reduced in a fixed order - deterministic, no atomics) */
 int ctts_relpos_softmax_fwd(float* S, const float* PS, float* Pd, int nbatch, int T, float scale, float p_drop,
                             const uint64_t* seed, uint32_t drop_offset, void* stream);
 int ctts_relpos_softmax_bwd(const float* P, float* dPd, int nbatch, int T, float scale, float p_drop, const uint64_t* seed,
@@ -257,6 +258,23 @@ int ctts_gru_bwd(const float* dout, const float* out, const float* gates, const 
 int ctts_softmax_rect_fwd(float* S, const int32_t* klens, const int32_t* qlens, int nb, int Tq, int Tk, void* stream);
 int ctts_softmax_rect_bwd(const float* P, float* dP, const int32_t* klens, const int32_t* qlens, int nb, int Tq, int Tk,
                           void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Mel front end in ONE call (csrc/mel.hip): TacotronSTFT.mel_spectrogram (audio/stft.py:166-185) = STFT.transform (:59-88: reflect
+ * padding by n_fft/2, hann-windowed DFT, hop) -> |X| -> mel filterbank -> log(clamp(., clip)) (audio_processing.py:85-91), and
+ * energy = ||X||_2 per frame.  Computed as a 1024-point REAL FFT per frame (512-point complex radix-8 Stockham + even/odd split)
+ * instead of the reference's 1026 x 1024 basis convolution, the filterbank as a banded GEMM on the fp32 MFMA.
+ *   y [B,N] waveform in [-1,1]; window [n_fft] = analysis window zero-padded to n_fft (periodic hann); mel [B,n_mel,F],
+ *   energy [B,F], F = 1 + N / hop; mag: optional [B*F, ld_mag >= 513] magnitudes (NULL = not stored).
+ *   workspace: ctts_mel_spectrogram_workspace_bytes() bytes, filled once per filterbank by ctts_mel_prepare(mel_basis [n_mel,513]).
+ *   Built for n_fft = 1024 (the reference's filter_length) and n_mel <= 96. */
+size_t ctts_mel_spectrogram_workspace_bytes(int n_fft, int n_mel);
+int ctts_mel_prepare(const float* mel_basis, int n_fft, int n_mel, float* workspace, void* stream);
+int ctts_mel_spectrogram(const float* y, const float* window, const float* workspace, float* mel, float* energy, float* mag, int64_t ld_mag,
+                         int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, void* stream);
+/* kmax: 1 + the highest DFT bin with a non-zero filter weight (372 for fmax 8 kHz at 22.05 kHz), or 0 = unknown (all 513 bins are kept
+ * in the on-chip magnitude tile).  A smaller tile lets three workgroups share a CU instead of two; results do not depend on it as long as
+ * no filter reaches beyond bin kmax-1. */
 
 /* ---------------------------------------------------------------------------------------
  * Fused multi-head attention (csrc/attn.hip): exact-fp32 MFMA, flash-style - the [T,T] score / probability tensors never reach HBM in

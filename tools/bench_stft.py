@@ -1,5 +1,9 @@
-"""STFT / mel front-end micro-benchmark: y ~ U(-0.5,0.5)[16, 262144] -> 16 x 1025 frames."""
-import os, sys
+"""STFT / mel front-end micro-benchmark: y ~ U(-0.5,0.5)[16, 262144] -> 16 x 1025 frames, then a preprocessing-sized
+batch [64, 262144].  Prints one JSON line per path (real-FFT kernel csrc/mel.hip, and the DFT-as-GEMM path it replaced)."""
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctts_amd
@@ -7,16 +11,31 @@ import ctts_amd
 dev = "cuda"
 st = ctts_amd.TacotronSTFT(1024, 256, 1024, 80, 22050, 0, 8000).to(dev)
 g = torch.Generator().manual_seed(1)
-y = (torch.rand(16, 262144, generator=g) - 0.5).to(dev)
-for _ in range(3):
-    mel, en = st.mel_spectrogram(y)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20):
-    mel, en = st.mel_spectrogram(y)
-e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / 20 * 1e3
-frames = mel.shape[0] * mel.shape[2]
-print(f"mel_spectrogram: {frames} frames in {us:.1f} us = {frames / us:.2f} M frames/s; DFT-as-GEMM {2.18e6 * frames / us / 1e6:.1f} TFLOP/s of 157.3 "
-      f"(fp32 MFMA); algorithmic bytes {frames * 1348 / us / 1e3:.1f} GB/s")
+from ctts_amd import kernels as K
+for B in (16, 64):
+    y = (torch.rand(B, 262144, generator=g) - 0.5).to(dev)
+    for path in ("fft_kernel_only", "fft", "dft_gemm"):
+        st.use_fft = path != "dft_gemm"
+        if path == "fft_kernel_only":         # the C entry point alone (ctts_mel_spectrogram), without the reference's host-side range assert
+            ws = st._workspace()
+            run = lambda: K.mel_spectrogram_fft(y, st._window, ws, 1024, 256, 80, kmax=st._kmax)[:2]          # noqa: E731
+        else:
+            run = lambda: st.mel_spectrogram(y)                                               # noqa: E731
+        for _ in range(3):
+            mel, en = run()
+        torch.cuda.synchronize()
+        stm = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stm)
+        for _ in range(20):
+            mel, en = run()
+        e1.record(stm)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        frames = mel.shape[0] * mel.shape[2]
+        algo_bytes = y.numel() * 4 + mel.numel() * 4 + en.numel() * 4            # 1 KB in + 324 B out per frame
+        print(json.dumps({"op": "TacotronSTFT.mel_spectrogram", "path": path, "batch": B, "samples": 262144, "frames": frames,
+                          "us_per_call": us, "M_frames_per_s": frames / us, "hbm_algorithmic_GBps": algo_bytes / us / 1e3,
+                          "frac_of_8TBps": algo_bytes / us / 1e3 / 8000,
+                          "note": ("C entry point only" if path == "fft_kernel_only" else
+                                   "API call incl. the reference's host-visible [-1,1] range assert (one aminmax reduction + sync)")}))
