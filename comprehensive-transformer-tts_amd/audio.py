@@ -123,3 +123,37 @@ class TacotronSTFT(nn.Module):
                                         self.n_mel_channels, self.nbins)
         B = y.shape[0]
         return mag.view(B, -1, mag.shape[-1])[:, :, :self.nbins].transpose(1, 2)
+
+    def mel_spectrograms_ragged(self, wavs):
+        """Batched mel extraction for preprocessing (reference: preprocessor.py:387,467 -> audio/tools.py:8-15, one utterance per call,
+        B = 1): `wavs` = list of 1-D float arrays / tensors of different lengths.  ONE pinned host buffer, one H2D copy, ONE kernel
+        launch with per-utterance lengths (reflection at each utterance's own end), one D2H copy; returns the per-utterance
+        (mel [n_mel, F_b] float32 numpy, energy [F_b]) exactly as `get_mel_from_wav` would, values clipped to [-1, 1] like it does."""
+        from . import kernels as K
+        if not self.use_fft:
+            raise NotImplementedError("mel_spectrograms_ragged needs the FFT kernel (filter_length 1024)")
+        dev = self.mel_basis.device
+        if dev.type != "cuda":
+            raise RuntimeError("TacotronSTFT (ctts_amd) computes on the MI355X: move the module to the device first")
+        lens = [int(len(w)) for w in wavs]
+        if min(lens) <= self.n_fft // 2:
+            raise ValueError("reflect padding needs more than n_fft/2 samples per utterance")
+        nmax = (max(lens) + 1) // 2 * 2
+        host = torch.zeros(len(wavs), nmax, dtype=torch.float32, pin_memory=True)
+        for i, w in enumerate(wavs):
+            host[i, :lens[i]] = torch.as_tensor(np.asarray(w, dtype=np.float32)).clamp_(-1, 1)
+        y = host.to(dev, non_blocking=True)
+        lt = torch.tensor(lens, dtype=torch.int32).to(dev, non_blocking=True)
+        mel, energy, _ = K.mel_spectrogram_fft(y, self._window, self._workspace(), self.n_fft, self.hop, self.n_mel_channels,
+                                               kmax=self._kmax, lens=lt)
+        mel, energy = mel.cpu().numpy(), energy.cpu().numpy()
+        out = []
+        for i, n in enumerate(lens):
+            fb = 1 + n // self.hop
+            out.append((np.ascontiguousarray(mel[i, :, :fb]), np.ascontiguousarray(energy[i, :fb])))
+        return out
+
+
+def get_mel_from_wav(audio, _stft):
+    """audio/tools.py:8-15: one utterance (numpy) -> (mel [n_mel, F], energy [F]) float32 numpy, input clipped to [-1, 1]"""
+    return _stft.mel_spectrograms_ragged([audio])[0]

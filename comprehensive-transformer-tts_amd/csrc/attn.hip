@@ -40,6 +40,7 @@ struct AttnArgs {
   const float* dout; long lddo, sdo;
   const float* D;                   // [B,H,T] rowsum(dO * O)
   float *dk, *dv; long lddk, lddv, sdk, sdv;
+  long split_stride;                // q_split > 1: split s writes its partial dK / dV at dk/dv + s * split_stride (summed afterwards)
   float* dS;                        // [B,H,T,T]  d loss / d (q k^T + bias), scale included
   float* dPS;                       // rel: the same values scattered through the adjoint of the shift ([B,H,T,T]), or NULL
   int q_split;
@@ -243,10 +244,10 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
   const int T = d.T;
   const int L = d.lens ? min(d.lens[b], T) : T;
   const int j = j0 + l31;
-  float* dKb = d.dk + (long)b * d.sdk + head * DH;
-  float* dVb = d.dv + (long)b * d.sdv + head * DH;
-  if (j0 >= L) {                        // masked keys receive no gradient
-    if (split == 0 && d.q_split <= 1 && j < T)
+  float* dKb = d.dk + (long)b * d.sdk + head * DH + (long)split * d.split_stride;
+  float* dVb = d.dv + (long)b * d.sdv + head * DH + (long)split * d.split_stride;
+  if (j0 >= L) {                        // masked keys receive no gradient (every split zeroes its own partial)
+    if (j < T)
       for (int c = h; c < DH; c += 2) { dKb[(long)j * d.lddk + c] = 0.f; dVb[(long)j * d.lddv + c] = 0.f; }
     return;
   }
@@ -410,23 +411,28 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
     }
   }
   if (j < T) {
-    if (d.q_split > 1) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          atomicAdd(dKb + (long)j * d.lddk + 32 * c + rowmap(r, h), dKt[c][r]);
-          atomicAdd(dVb + (long)j * d.lddv + 32 * c + rowmap(r, h), dVt[c][r]);
-        }
-    } else {
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          dKb[(long)j * d.lddk + 32 * c + rowmap(r, h)] = dKt[c][r];
-          dVb[(long)j * d.lddv + 32 * c + rowmap(r, h)] = dVt[c][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        dKb[(long)j * d.lddk + 32 * c + rowmap(r, h)] = dKt[c][r];
+        dVb[(long)j * d.lddv + 32 * c + rowmap(r, h)] = dVt[c][r];
+      }
+  }
+}
+
+// dK | dV of the packed [B,T,3C] gradient = sum over the query-loop splits of the partials [S][B*T][2C] (fixed order: deterministic)
+__global__ void attn_sum_splits_kernel(const float4* __restrict__ part, int n_split, long rows, int C2_4, float4* __restrict__ dqkv, int C3_4,
+                                       int off4) {
+  const long total = rows * C2_4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / C2_4; const int c = (int)(e - r * C2_4);
+    float4 a = part[e];
+    for (int s = 1; s < n_split; ++s) {
+      const float4 v = part[(long)s * total + e];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+    dqkv[r * C3_4 + off4 + c] = a;
   }
 }
 
@@ -490,8 +496,9 @@ extern "C" int ctts_mha_fwd(const float* qkv, const int32_t* lens, float* out, f
 }
 
 extern "C" int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* out, const float* dout, const float* lse, float* Dws,
-                            float* dS, float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* stream) {
+                            float* dS, float* kv_part, float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* stream) {
   CTTS_REQUIRE(qkv && out && dout && lse && Dws && dS && dqkv && B > 0 && T > 0, "ctts_mha_bwd: bad arguments");
+  CTTS_REQUIRE(q_split <= 1 || kv_part, "ctts_mha_bwd: q_split > 1 needs the kv_part scratch [q_split, B, T, 2C]");
   CTTS_REQUIRE(ctts_mha_supported(C, H) && al16(qkv) && al16(dout) && al16(dqkv), "ctts_mha_bwd: needs d_head in {32,64,128} and 16-byte aligned tensors");
   hipStream_t st = (hipStream_t)stream;
   const int dh = C / H;
@@ -504,11 +511,21 @@ extern "C" int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* 
   a.ldq = a.ldk = a.ldv = C3; a.sq = a.sk = a.sv = (long)T * C3;
   a.lse = const_cast<float*>(lse); a.lens = lens; a.B = B; a.H = H; a.T = T; a.scale = scale;
   a.dout = dout; a.lddo = C; a.sdo = (long)T * C; a.D = Dws;
-  a.dk = dqkv + C; a.dv = dqkv + 2 * C; a.lddk = a.lddv = C3; a.sdk = a.sdv = (long)T * C3;
   a.dS = dS; a.q_split = q_split < 1 ? 1 : q_split;
-  if (a.q_split == 1) {}                 // plain stores (dqkv was zeroed anyway: padded rows)
+  if (a.q_split == 1) {
+    a.dk = dqkv + C; a.dv = dqkv + 2 * C; a.lddk = a.lddv = C3; a.sdk = a.sdv = (long)T * C3;
+  } else {                               // every split of a key tile's query loop writes its own partial; summed below, no atomics
+    a.dk = kv_part; a.dv = kv_part + C; a.lddk = a.lddv = 2L * C; a.sdk = a.sdv = (long)T * 2 * C;
+    a.split_stride = (long)B * T * 2 * C;
+  }
   rc = launch_bwd<false>(a, dh, st);
   if (rc) return rc;
+  if (a.q_split > 1) {
+    const long rows = (long)B * T, total = rows * (2 * C / 4);
+    hipLaunchKernelGGL(attn_sum_splits_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(kv_part), a.q_split, rows, 2 * C / 4, reinterpret_cast<float4*>(dqkv), (int)(C3 / 4), C / 4);
+    CTTS_CHECK_LAUNCH("ctts_mha_bwd(sum splits)");
+  }
   // dQ[i,d] = sum_j dS[i,j] K[j,d]  (valid queries / keys only); the reduction over <= T keys is split so that the launch fills the chip
   ctts_gemm_desc g = {};
   g.A = dS; g.B = qkv + C; g.C = dqkv;

@@ -49,7 +49,8 @@ __device__ __forceinline__ float sample_reflect(const float* __restrict__ yb, in
   return yb[q];
 }
 
-__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, const float* __restrict__ window, const float* __restrict__ ws,
+__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, const int32_t* __restrict__ lens, const float* __restrict__ window,
+                                                   const float* __restrict__ ws,
                                                    float* __restrict__ mel, float* __restrict__ energy, float* __restrict__ mag_out,
                                                    long ld_mag, int B, int N, int F, int hop, int n_mel, float clip, int MS) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -73,19 +74,23 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
   for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b = (int)(tile / tiles_per_b), f0 = (int)(tile - (long)b * tiles_per_b) * TILE_F;
     const float* yb = y + (long)b * N;
+    // ragged batches (preprocessing): utterance b has lens[b] samples; reflection happens at ITS end and it has Fb = 1 + lens[b]/hop
+    // frames - later frames of the padded batch row repeat its last frame (the host slices them off)
+    const int Nb = lens ? min(max(lens[b], NFFT / 2 + 1), N) : N;
+    const int Fb = min(F, 1 + Nb / hop);
     // ------------------------------------------------------------------ FFT phase: wave w transforms frames f0 + 4w .. f0 + 4w + 3
     for (int ff = 0; ff < 4; ++ff) {
-      const int fl = wave * 4 + ff, f = f0 + fl, fc = min(f, F - 1);
+      const int fl = wave * 4 + ff, f = f0 + fl, fc = min(f, Fb - 1);
       float2_ v[8];
       const int base = fc * hop;
       // no reflection needed and the 8-byte pair loads are aligned
-      const bool interior = base >= NFFT / 2 && base + NFFT - NFFT / 2 <= N && ((((long)b * N + base) | (reinterpret_cast<uintptr_t>(y) >> 2)) & 1) == 0;
+      const bool interior = base >= NFFT / 2 && base + NFFT - NFFT / 2 <= Nb && ((((long)b * N + base) | (reinterpret_cast<uintptr_t>(y) >> 2)) & 1) == 0;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int n = 2 * (lane + 64 * r);
         float a, c;
         if (interior) { const float2 t = *reinterpret_cast<const float2*>(yb + base - NFFT / 2 + n) ; a = t.x; c = t.y; }
-        else { a = sample_reflect(yb, N, base + n); c = sample_reflect(yb, N, base + n + 1); }
+        else { a = sample_reflect(yb, Nb, base + n); c = sample_reflect(yb, Nb, base + n + 1); }
         v[r] = {a * win[2 * r], c * win[2 * r + 1]};
       }
       // pass 0 (Ns = 1): no twiddles
@@ -203,8 +208,8 @@ extern "C" int ctts_mel_prepare(const float* mel_basis, int n_fft, int n_mel, fl
   return 0;
 }
 
-extern "C" int ctts_mel_spectrogram(const float* y, const float* window, const float* workspace, float* mel, float* energy, float* mag,
-                                    int64_t ld_mag, int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, void* stream) {
+extern "C" int ctts_mel_spectrogram(const float* y, const int32_t* lens, const float* window, const float* workspace, float* mel, float* energy,
+                                    float* mag, int64_t ld_mag, int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, void* stream) {
   CTTS_REQUIRE(y && window && workspace && mel && energy && B > 0 && N > 0, "ctts_mel_spectrogram: bad arguments");
   CTTS_REQUIRE(n_fft == NFFT && hop > 0 && n_mel >= 1 && n_mel <= 96, "ctts_mel_spectrogram: built for n_fft = 1024, n_mel <= 96");
   CTTS_REQUIRE(N > NFFT / 2, "ctts_mel_spectrogram: reflect padding needs more than n_fft/2 samples (got %d)", N);
@@ -222,7 +227,7 @@ extern "C" int ctts_mel_spectrogram(const float* y, const float* window, const f
     attr_set = true;
   }
   const int grid = (int)(tiles < 4096 ? tiles : 4096);
-  hipLaunchKernelGGL(mel_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, y, window, workspace, mel, energy, mag, (long)ld_mag,
+  hipLaunchKernelGGL(mel_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, y, lens, window, workspace, mel, energy, mag, (long)ld_mag,
                      B, N, F, hop, n_mel, clip, MS);
   CTTS_CHECK_LAUNCH("ctts_mel_spectrogram");
   return 0;

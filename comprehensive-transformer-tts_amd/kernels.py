@@ -557,8 +557,9 @@ def mha_bwd(qkv, lens, out, dout, lse, n_heads, scale, q_split=1):
     dqkv = torch.empty_like(qkv)
     Dws = torch.empty(B, n_heads, T, dtype=torch.float32, device=dev)
     dS = torch.empty(B, n_heads, T, T, dtype=torch.float32, device=dev)
+    part = torch.empty(q_split, B, T, 2 * Cc, dtype=torch.float32, device=dev) if q_split > 1 else None
     lib = _lib.load()
-    _lib.check(lib.ctts_mha_bwd(_p(qkv), _p(lens), _p(_f32c(out, "out")), _p(_f32c(dout, "dout")), _p(lse), _p(Dws), _p(dS), _p(dqkv),
+    _lib.check(lib.ctts_mha_bwd(_p(qkv), _p(lens), _p(_f32c(out, "out")), _p(_f32c(dout, "dout")), _p(lse), _p(Dws), _p(dS), _p(part), _p(dqkv),
                                 B, T, n_heads, Cc, float(scale), int(q_split), _stream()), "ctts_mha_bwd")
     return dqkv
 
@@ -695,7 +696,7 @@ def mel_prepare(mel_basis, n_fft):
     return ws
 
 
-def mel_spectrogram_fft(y, window, ws, n_fft, hop, n_mel, clip=1e-5, want_mag=False, kmax=0):
+def mel_spectrogram_fft(y, window, ws, n_fft, hop, n_mel, clip=1e-5, want_mag=False, kmax=0, lens=None):
     """y [B,N] -> (mel [B,n_mel,F], energy [B,F], mag [B*F,516] or None) in one launch"""
     B, N = y.shape
     F = 1 + N // hop
@@ -704,6 +705,6 @@ def mel_spectrogram_fft(y, window, ws, n_fft, hop, n_mel, clip=1e-5, want_mag=Fa
     energy = torch.empty(B, F, dtype=torch.float32, device=dev)
     mag = torch.empty(B * F, 516, dtype=torch.float32, device=dev) if want_mag else None
     lib = _lib.load()
-    _lib.check(lib.ctts_mel_spectrogram(_p(_f32c(y, "y")), _p(_f32c(window, "window")), _p(ws), _p(mel), _p(energy), _p(mag), 516, B, N,
+    _lib.check(lib.ctts_mel_spectrogram(_p(_f32c(y, "y")), _p(lens), _p(_f32c(window, "window")), _p(ws), _p(mel), _p(energy), _p(mag), 516, B, N,
                                         int(n_fft), int(hop), int(n_mel), float(clip), int(kmax), _stream()), "ctts_mel_spectrogram")
     return mel, energy, mag

@@ -425,7 +425,7 @@ def _attn_split_k(nbatch, T, dh):
 #         decoder layer against 305 us for the GEMM pipeline that keeps P (B*H = 32 gives one wave per SIMD and a 32-tile critical path)
 #   1 / 0 force the fused / unfused kernels everywhere (tests, A/B measurements)
 _FUSED_ATTN = {"1": True, "0": False}.get(_os.environ.get("CTTS_FUSED_ATTN", "auto"), None)
-_ATTN_Q_SPLIT = int(_os.environ.get("CTTS_ATTN_Q_SPLIT", "1"))     # >1: split a key tile's query loop (atomic dK / dV); measured slower
+_ATTN_Q_SPLIT = int(_os.environ.get("CTTS_ATTN_Q_SPLIT", "0"))     # 0 = auto; n: split a key tile's query loop over n waves
 
 
 def set_fused_attention(flag):
@@ -454,7 +454,10 @@ class _FusedSelfAttention(torch.autograd.Function):
         H = ctx.n_heads
         B, T, C3 = qkv.shape
         dh = C3 // 3 // H
-        return K.mha_bwd(qkv, lens, out, dO.contiguous(), lse, H, dh ** -0.5, max(1, _ATTN_Q_SPLIT)), None, None
+        # one wave per 32 keys walks ALL query tiles: with B*H*T/32 <= 2 waves per SIMD (fs2: 1,024 waves for 1,024 SIMDs) the launch
+        # lasts as long as its longest wave, so the query loop is split over 2 waves (partial dK / dV, summed in a fixed order)
+        qs = _ATTN_Q_SPLIT if _ATTN_Q_SPLIT > 0 else (2 if (B * H * ((T + 31) // 32) <= 2048 and T >= 256) else 1)
+        return K.mha_bwd(qkv, lens, out, dO.contiguous(), lse, H, dh ** -0.5, qs), None, None
 
 
 class _SelfAttention(torch.autograd.Function):

@@ -270,8 +270,11 @@ int ctts_softmax_rect_bwd(const float* P, float* dP, const int32_t* klens, const
  *   Built for n_fft = 1024 (the reference's filter_length) and n_mel <= 96. */
 size_t ctts_mel_spectrogram_workspace_bytes(int n_fft, int n_mel);
 int ctts_mel_prepare(const float* mel_basis, int n_fft, int n_mel, float* workspace, void* stream);
-int ctts_mel_spectrogram(const float* y, const float* window, const float* workspace, float* mel, float* energy, float* mag, int64_t ld_mag,
-                         int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, void* stream);
+int ctts_mel_spectrogram(const float* y, const int32_t* lens, const float* window, const float* workspace, float* mel, float* energy, float* mag,
+                         int64_t ld_mag, int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, void* stream);
+/* lens (optional, [B] int32): ragged batch for preprocessing (preprocessor.py:387,467 extracts one utterance at a time) - row b holds
+ * lens[b] <= N samples (rest padding); reflection happens at the utterance's own end and its 1 + lens[b]/hop leading frames equal the
+ * single-utterance result; the remaining frames of the row are don't-care. */
 /* kmax: 1 + the highest DFT bin with a non-zero filter weight (372 for fmax 8 kHz at 22.05 kHz), or 0 = unknown (all 513 bins are kept
  * in the on-chip magnitude tile).  A smaller tile lets three workgroups share a CU instead of two; results do not depend on it as long as
  * no filter reaches beyond bin kmax-1. */
@@ -285,8 +288,9 @@ int ctts_mel_spectrogram(const float* y, const float* window, const float* works
  *   lens[b] (or NULL = T): keys >= lens[b] are masked, query rows >= lens[b] are ZERO rows of `out` [B,T,C].
  *   lse [B,H,T]: log2-domain log-sum-exp of the scaled scores (kept for the backward).
  *   bwd: out/dout [B,T,C]; Dws [B,H,T] and dS [B,H,T,T] are caller-provided scratch; dqkv [B,T,3C] receives all three gradients
- *   (zero at padded rows).  q_split >= 1 splits the query loop of a key tile over several waves (atomic accumulation of dK / dV) - use
- *   2 when B*H*T/32 waves do not fill the chip.
+ *   (zero at padded rows).  q_split >= 1 splits the query loop of a key tile over several waves - use 2 when B*H*T/32 waves do not fill
+ *   the chip; each split writes its partial dK | dV into kv_part [q_split, B, T, 2C] (scratch, may be NULL for q_split 1) and a
+ *   fixed-order sum produces the result: deterministic, no atomics.
  * ctts_relmha_fwd / ctts_relmha_bwd: the core of RelativeMultiHeadAttention (conformer.py:396-421) on channel-last projections:
  *   qu = q + u_bias, qv = q + v_bias [B,T,C]; kv [B,T,2C] (k | v); pos [T,C] = pos_proj(sinusoid rows) shared by the batch;
  *   score = (qu k^T + shift(qv pos^T)) * scale with the Transformer-XL shift of conformer.py:423-431 applied as an index map, softmax
@@ -297,7 +301,7 @@ int ctts_mel_spectrogram(const float* y, const float* window, const float* works
 int ctts_mha_supported(int C, int H);
 int ctts_mha_fwd(const float* qkv, const int32_t* lens, float* out, float* lse, int B, int T, int H, int C, float scale, void* stream);
 int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* out, const float* dout, const float* lse, float* Dws, float* dS,
-                 float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* stream);
+                 float* kv_part, float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* stream);
 size_t ctts_relmha_workspace_floats(int B, int T, int H);
 int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv, const float* pos, float* ps, float* out, float* lse, int B, int T,
                     int H, int C, float scale, float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream);

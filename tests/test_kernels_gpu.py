@@ -342,6 +342,23 @@ def test_mel_fft_kernel_vs_float64_ragged_lengths(B, N):
     close(energy, energy2, 2e-5, "fft vs dft-gemm energy")
 
 
+def test_batched_ragged_mel_extraction_equals_per_utterance_calls():
+    """preprocessing path: one launch over a ragged batch == the reference's one-utterance-at-a-time get_mel_from_wav"""
+    from ctts_amd.audio import get_mel_from_wav
+    st = ctts_amd.TacotronSTFT(1024, 256, 1024, 80, 22050, 0, 8000).to(DEV)
+    rng = np.random.RandomState(3)
+    wavs = [rng.uniform(-1.2, 1.2, size=n).astype(np.float32) for n in (22050, 700, 9001, 4096, 30001)]     # incl. values to clip
+    batched = st.mel_spectrograms_ragged(wavs)
+    for w, (mel, en) in zip(wavs, batched):
+        y = torch.from_numpy(np.clip(w, -1, 1))[None].to(DEV)
+        m1, e1 = st.mel_spectrogram(y)
+        assert mel.shape == (80, 1 + len(w) // 256) and en.shape == (1 + len(w) // 256,) and mel.dtype == np.float32
+        close(torch.from_numpy(mel).exp(), m1[0].exp(), 1e-6, "ragged batch vs single utterance (linear mel)")
+        close(torch.from_numpy(en), e1[0], 1e-6, "ragged batch vs single utterance (energy)")
+        m2, e2 = get_mel_from_wav(w, st)
+        assert np.array_equal(m2, mel) and np.array_equal(e2, en)
+
+
 def test_pad_row_skipping_is_equivalent_on_valid_rows():
     """Padded-row tile / K-block skipping (ctts_gemm_desc.row_lens) changes nothing that the model consumes:
     valid rows of the forward, and every gradient when the upstream gradient is zero on padded rows."""
