@@ -724,6 +724,9 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
         for (int i = 0; i < MT; ++i) fetch_frag<A_KC, A_LD>(sA, wm0 + i * 32, l31, h, ksub, fa[i]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) fetch_frag<B_KC, B_LD>(sB, wn0 + j * 32, l31, h, ksub, fb[j]);
+#ifdef CTTS_GEMM_SETPRIO
+        __builtin_amdgcn_s_setprio(CTTS_GEMM_SETPRIO);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
@@ -731,6 +734,9 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
 #pragma unroll
             for (int j = 0; j < NT; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+#ifdef CTTS_GEMM_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
     }
     if (KSKIP && !act_cur && !act_next) continue;
