@@ -43,7 +43,8 @@ def slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
     """Restatement of librosa==0.7.2 `filters.mel(sr, n_fft, n_mels, fmin, fmax)`
     (htk=False, norm=1 i.e. Slaney area normalisation) - the call at
     audio/stft.py:152-154.  librosa is not installed, so this is the published
-    algorithm restated; see oracle/stft_oracle.py for the copy that travels."""
+    algorithm restated; the copy that travels to the GPU box is `ctts_amd.audio.slaney_mel_basis` (checked against this
+    one through golden G8, which stores the basis the reference run used)."""
     import numpy as np
 
     def hz_to_mel(f):
