@@ -297,14 +297,21 @@ def main():
         step.step_no = 100001                                 # every loss term on: bin-loss weight 1, prosody loss enabled
     mode = "eager"
     if not a.no_graph:
+        ok = 1
         try:
             step.capture()
+        except Exception as e:                                # noqa: BLE001
+            ok = 0
+            print(f"[bench] rank {rank}: graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
+        if world > 1:                                         # ranks must not diverge in launch mode: all replay graphs or all run eager
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag)
+        if ok:
             mode = (f"hipgraph({step.n_stages} backward stages, bucketed all-reduce between replays | clip+adam)" if step.staged
                     else "hipgraph(fwd+bwd | clip+adam)")
-        except Exception as e:                                # noqa: BLE001
-            if world > 1:
-                raise                                         # ranks must not diverge in launch mode
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+        else:
+            print("[bench] running eager", file=sys.stderr)
             step.graphs = step.g_opt = None
 
     def timed(fn, n):

@@ -97,11 +97,12 @@ class TrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        # every stage is captured on the SAME stream (autograd runs a node's backward on the stream of its forward) and into one pool
+        # every stage is captured on the SAME stream (autograd runs a node's backward on the stream of its forward) and into one pool;
+        # thread_local capture mode: the RCCL watchdog / a prefetch thread may touch the runtime while this thread captures
         graphs, gen, pool = [], self._stages(), None
         for s in range(self.n_stages):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=side):
+            with torch.cuda.graph(g, pool=pool, stream=side, capture_error_mode="thread_local"):
                 got = next(gen)
             assert got == s
             pool = g.pool()
@@ -111,7 +112,7 @@ class TrainStep:
         self.graphs = graphs
         if self.fadam is not None:                        # torch's foreach clip + Adam are not capture-safe on strided parameters: eager
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=pool, stream=side):
+            with torch.cuda.graph(self.g_opt, pool=pool, stream=side, capture_error_mode="thread_local"):
                 self._optimizer_step()
 
     # ---- inputs as views of one packed device buffer (data.PackedBatch layout)
