@@ -3,8 +3,11 @@
 //
 //   fs2   (transformer_fs2.py:385-394, F.multi_head_attention_forward): softmax(q k^T / sqrt(d_h), keys >= len masked) v, 2 heads x 128
 //   rel   (conformer.py:347-431, RelativeMultiHeadAttention): softmax(((q+u) k^T + shift((q+v) p^T)) / sqrt(d_model)) with NO mask,
-//         dropout on the probabilities, 8 heads x 32; the position scores PS = (q+v) p^T come from ctts_gemm and are read through the
-//         Transformer-XL shift as an index map (rel_index) - the shifted map, the probabilities and the dropped probabilities never exist
+//         dropout on the probabilities, 8 heads x 32.  The position scores PS = (q+v) p^T come from ctts_gemm, written straight into the
+//         reference's `padded` layout (conformer.py:423-431: rows of T+1 = [0 | PS row]); the Transformer-XL shift is then what it is in
+//         the reference - a reinterpretation of the same memory: shifted[i][j] = padded.flat[(i+1)*T + j].  The backward kernel writes
+//         dS in that very layout, so the gradient of the unshifted scores is again only a view (rows of T+1, first column skipped):
+//         no shifted map, no second gradient tensor, no probabilities or dropped probabilities in HBM.
 //
 // Work decomposition: ONE WAVE PER WORKGROUP, 32 queries (forward) or 32 keys (backward) per wave, flash-style loop over the other
 // axis in tiles of 32.  fp32 MFMA issues one 32x32x2 step per 64 cycles, so a wave needs only ~1 operand dword per 64 cycles: every
@@ -16,8 +19,8 @@
 // accumulator registers (+ one exchange with lane^32), and P^T is already laid out as the B operand of O^T += V^T P^T.
 // Backward (one wave = 32 keys, loop over query tiles) computes S = Q K^T and dP = dO V^T with the keys on the lanes, so that
 // Pd and dS are the B operands of dV^T += dO^T Pd and dK^T += Q^T dS; dV / dK stay in registers for the whole loop (no atomics
-// unless the query range is split, fs2 only), dS is written once (and, rel, a second time in the layout of the shift's adjoint)
-// for the remaining gradients dQ = dS K, dQV = dPS pos, dpos = dPS^T QV, which are plain GEMMs.
+// unless the query range is split, fs2 only), dS is written once for the remaining gradients dQ = dS K, dQV = dPS pos,
+// dpos = dPS^T QV, which are plain GEMMs (rel: dPS is the padded view of the dS memory).
 #include "ctts_common.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -31,7 +34,7 @@ struct AttnArgs {
   long ldq, ldk, ldv, sq, sk, sv;
   float* out; long ldo, so;         // [B,T,H*dh]
   float* lse;                       // [B,H,T]  log2-domain log-sum-exp of the scaled scores
-  const float* bias;                // rel: PS [B,H,T,T] UNSHIFTED position scores, else NULL
+  const float* bias;                // rel: position scores in the padded layout, [B,H] slabs of T*(T+1) floats (see above), else NULL
   const int32_t* lens;              // fs2: valid length per utterance (keys >= len masked, query rows >= len are zero rows), else NULL
   int B, H, T;
   float scale, p_drop;
@@ -41,20 +44,12 @@ struct AttnArgs {
   const float* D;                   // [B,H,T] rowsum(dO * O)
   float *dk, *dv; long lddk, lddv, sdk, sdv;
   long split_stride;                // q_split > 1: split s writes its partial dK / dV at dk/dv + s * split_stride (summed afterwards)
-  float* dS;                        // [B,H,T,T]  d loss / d (q k^T + bias), scale included
-  float* dPS;                       // rel: the same values scattered through the adjoint of the shift ([B,H,T,T]), or NULL
+  float* dS;                        // d loss / d (q k^T + bias), scale included: [B,H,T,T], or (rel) [B,H] slabs of T*(T+1) floats
+                                    // whose first T floats are padding: dS[i][j] = slab[(i+1)*T + j], the layout of `bias`
   int q_split;
 };
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // C/D row of accumulator register r
-
-// conformer.py:423-431 `_relative_shift`: shifted[i,j] = padded.flat[i*T + j + T] with padded = [0 | PS] (rows of T+1).
-// -> flat index into PS[T,T] of the element that lands at (i,j); -1 for the inserted zero (j == i+1).
-// (32-bit: the C ABI checks T*T < 2^31)
-__device__ __forceinline__ int rel_index(int i, int j, int T) {
-  if (j == i + 1) return -1;
-  return i * (T - 1) + (j <= i ? T - 1 : T - 2) + j;
-}
 
 __device__ __forceinline__ void load16(const float* __restrict__ p, float (&f)[16]) {
   const float4* q = reinterpret_cast<const float4*>(p);
@@ -71,6 +66,41 @@ __device__ __forceinline__ void load16(const float* __restrict__ p, float (&f)[1
 #define CTTS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32; arguments here are <= 0 or -inf
+
+// ctts_drop_scale(key, idx) with the index hash split into a lane-constant and a wave-uniform part: pre = idx * G + key arrives
+// ready-made (one v_add per element instead of a quarter-rate multiply), and the uniform compare u >= p is done on the integer:
+// (h >> 8) * 2^-24 >= p  <=>  h >= ceil(p * 2^24) << 8  (both sides exact) - the same keep decisions as every other kernel's.
+constexpr uint32_t DROP_G = 0x9E3779B1U;
+__device__ __forceinline__ uint32_t drop_threshold(float p) { return ((uint32_t)ceilf(p * 16777216.0f)) << 8; }
+__device__ __forceinline__ float drop_scale_pre(uint32_t pre, uint32_t thr, float inv_keep) {
+  return ctts_mix32(pre) >= thr ? inv_keep : 0.0f;
+}
+
+// Addressing inside the tile loops goes through buffer descriptors: 32-bit byte offsets = (lane constant) + (wave-uniform term computed
+// on the SALU); rows / keys outside a tensor are handled by the hardware range check (loads return 0, stores vanish) instead of
+// clamps, selects and exec-mask branches around every access.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int ctts_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+constexpr float BIG = 1.0e30f;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float bld(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void bst(rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void bld16(rsrc_t r, unsigned off, float (&f)[16]) {
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    ctts_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16u * x, 0, 0);
+    const float4 v = *reinterpret_cast<float4*>(&u);
+    f[4 * x + 0] = v.x; f[4 * x + 1] = v.y; f[4 * x + 2] = v.z; f[4 * x + 3] = v.w;
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------- forward
 // occupancy targets (waves per SIMD): d_head 32 (conformer: thousands of waves) 3 forward / 2 backward (no spills), 64 -> 2, 128 -> 1
@@ -94,9 +124,12 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
     return;
   }
   const float* Qr = d.q + (long)b * d.sq + head * DH + (long)min(i, T - 1) * d.ldq;
-  const float* Kb = d.k + (long)b * d.sk + head * DH + 16 * h;
-  const float* Vb = d.v + (long)b * d.sv + head * DH + l31;
-  const float* PSz = BIAS ? d.bias + (long)z * T * T : nullptr;
+  const unsigned ldk4 = 4u * (unsigned)d.ldk, ldv4 = 4u * (unsigned)d.ldv, T4 = 4u * (unsigned)T;
+  const rsrc_t rK = make_rsrc(d.k + (long)b * d.sk + head * DH, (unsigned)(T - 1) * ldk4 + 4u * DH);     // rows >= T read as 0
+  const rsrc_t rV = make_rsrc(d.v + (long)b * d.sv + head * DH, (unsigned)(T - 1) * ldv4 + 4u * DH);
+  const rsrc_t rPS = make_rsrc(BIAS ? d.bias + (long)z * T * (T + 1) : nullptr, BIAS ? T4 * (unsigned)(T + 1) : 0u);
+  const unsigned ka_l = (unsigned)l31 * ldk4 + 64u * h;          // A operand of S^T: key row l31, k-half h
+  const unsigned vt_l = 4u * h * ldv4 + 4u * l31;                // A operand of O^T: key row rowmap(st,h), column l31
 
   float Qf[DH / 2];                    // B operand of S^T = K Q^T: Q[i][32c + 16h + q]
 #pragma unroll
@@ -116,30 +149,27 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
   const bool do_drop = d.p_drop > 0.f;
   uint32_t dkey = 0; float inv_keep = 1.f;
   if (do_drop) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
-  const uint32_t drow = ((uint32_t)z * (uint32_t)T + (uint32_t)i) * (uint32_t)T;     // dropout element index = ((z*T + i)*T + j)
+  const uint32_t dthr = drop_threshold(d.p_drop);
+  // dropout element index ((z*T + i)*T + j), j = j0 + rowmap(r,0) + 4h: lane part of the hash input idx * G + key
+  const uint32_t xk_l = ((((uint32_t)z * (uint32_t)T + (uint32_t)i) * (uint32_t)T) + 4u * h) * DROP_G + dkey;
+  const float b_one = h == 0 ? 1.f : 0.f;
 
   float kb[2][16], vb[2][16];          // ping-pong operand buffers (chunk parity)
-  load16(Kb + (long)min(l31, T - 1) * d.ldk, kb[0]);
+  bld16(rK, ka_l, kb[0]);
   // position-score tile (rows i0 .. i0+31, keys j0 .. j0+31) in load order: 16 x (2 queries x 32 consecutive keys) = 128-byte rows;
-  // transposed through LDS later so that each lane gets the 16 values of ITS query column
-  // The loads are UNCONDITIONAL (invalid elements read index 0 and are zeroed through `okm` when the tile is consumed): a load
-  // under a per-element condition makes hipcc branch around it and wait vmcnt(0) at the join - 16 serialised memory round trips per tile.
-  unsigned okm = 0;
+  // transposed through LDS later so that each lane gets the 16 values of ITS query column.  Element (ii, jj) = (i0 + 2it + h, jt + l31)
+  // of the shifted scores sits at slab[(ii+1)*T + jj]; keys >= T and rows past the slab read as 0 through the range check
+  // (unconditional loads: a load under a per-element condition makes hipcc branch around it and wait vmcnt(0) at the join).
+  const unsigned ps_l = (unsigned)(h + 1) * T4 + 4u * l31;
   auto load_ps_tile = [&](int jt, float (&dst)[16]) {
-    okm = 0;
+    const unsigned base = (jt + l31 < T) ? ps_l + 4u * (unsigned)jt + (unsigned)i0 * T4 : OOB;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int ii = i0 + 2 * it + h, jj = jt + l31;
-      const bool ok = ii < T && jj < T && jj != ii + 1;
-      const int idx = ii * (T - 1) + (jj <= ii ? T - 1 : T - 2) + jj;
-      dst[it] = PSz[ok ? idx : 0];
-      okm |= (ok ? 1u : 0u) << it;
-    }
+    for (int it = 0; it < 16; ++it) dst[it] = bld(rPS, base + (unsigned)(2 * it) * T4);
   };
   float psn[16];
   if (BIAS) load_ps_tile(0, psn);
   for (int j0 = 0; j0 < L; j0 += 32) {
-    const float* Kr = Kb + (long)min(j0 + l31, T - 1) * d.ldk;
+    const unsigned s_k = (unsigned)j0 * ldk4, s_v = (unsigned)j0 * ldv4;
     // position scores: the tile needed NOW was fetched one tile ago (HBM latency under load is several microseconds - far more
     // than the 1,024 MFMA cycles of one score block)
     // (the registers `psn` hold this tile's scores; the NEXT tile's fetch is issued as soon as they have been handed to LDS below)
@@ -150,23 +180,25 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       if (c + 1 < NC) {
-        load16(Kr + 32 * (c + 1), kb[(c + 1) & 1]);
+        bld16(rK, ka_l + s_k + 128u * (c + 1), kb[(c + 1) & 1]);
       } else {                          // last score chunk: fetch the first V chunk of this tile underneath it
 #pragma unroll
-        for (int st = 0; st < 16; ++st) vb[0][st] = Vb[(long)min(j0 + rowmap(st, h), T - 1) * d.ldv];
+        for (int st = 0; st < 16; ++st) vb[0][st] = bld(rV, vt_l + s_v + (unsigned)rowmap(st, 0) * ldv4);
       }
       CTTS_SCHED_FENCE();
 #pragma unroll
       for (int q = 0; q < 16; ++q) St = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[c & 1][q], Qf[16 * c + q], St, 0, 0, 0);
       CTTS_SCHED_FENCE();
     }
+    if (j0 + 32 > L)                    // ragged last tile: S^T[j][i] -= BIG for the keys j >= L (one MFMA step instead of 16 selects)
+      St = __builtin_amdgcn_mfma_f32_32x32x2f32((h == 0 && j0 + l31 >= L) ? -BIG : 0.f, b_one, St, 0, 0, 0);
     float s[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = St[r];
     if (BIAS) {
 #pragma unroll
-      for (int it = 0; it < 16; ++it) sb[(2 * it + h) * 33 + l31] = ((okm >> it) & 1u) ? psn[it] : 0.f;
-      load_ps_tile(j0 + 32, psn);                        // next tile (unconditional: past the end every element is masked): a softmax,
+      for (int it = 0; it < 16; ++it) sb[(2 * it + h) * 33 + l31] = psn[it];
+      load_ps_tile(j0 + 32, psn);                        // next tile (past the end every element is out of range): a softmax,
                                                          // a PV block and a score block of cover
       // The workgroup is ONE wave and the LDS executes a wave's instructions in order, so the transposed read below sees the writes
       // above without a barrier.  __syncthreads() here would cost far more than its s_barrier: its fence waits vmcnt(0), i.e. it
@@ -180,13 +212,11 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
     float tmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = j0 + rowmap(r, h);
-      const float v = j < L ? s[r] * sl2 : -INFINITY;
-      s[r] = v;
-      tmax = fmaxf(tmax, v);
+      s[r] *= sl2;
+      tmax = fmaxf(tmax, s[r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float mnew = fmaxf(m, tmax);               // finite: the tile holds at least one key < L
+    const float mnew = fmaxf(m, tmax);               // > -BIG*sl2: the tile holds at least one key < L
     const float alpha = fast_exp2(m - mnew);
     float psum = 0.f;
     floatx16 Pt;
@@ -194,7 +224,7 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
     for (int r = 0; r < 16; ++r) {
       float p = fast_exp2(s[r] - mnew);
       psum += p;
-      if (do_drop) p *= ctts_drop_scale(dkey, drow + (uint32_t)(j0 + rowmap(r, h)), d.p_drop, inv_keep);
+      if (do_drop) p *= drop_scale_pre(xk_l + (uint32_t)(j0 + rowmap(r, 0)) * DROP_G, dthr, inv_keep);
       Pt[r] = p;
     }
     lsum = lsum * alpha + psum;
@@ -208,9 +238,9 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
     for (int c = 0; c < NC; ++c) {
       if (c + 1 < NC) {
 #pragma unroll
-        for (int st = 0; st < 16; ++st) vb[(c + 1) & 1][st] = Vb[(long)min(j0 + rowmap(st, h), T - 1) * d.ldv + 32 * (c + 1)];
-      } else {                          // last PV chunk: fetch the next tile's first K chunk underneath it (unconditional, row clamped:
-        load16(Kb + (long)min(j0 + 32 + l31, T - 1) * d.ldk, kb[0]);      // a load under a runtime condition costs a vmcnt(0) at the join)
+        for (int st = 0; st < 16; ++st) vb[(c + 1) & 1][st] = bld(rV, vt_l + s_v + (unsigned)rowmap(st, 0) * ldv4 + 128u * (c + 1));
+      } else {                          // last PV chunk: fetch the next tile's first K chunk underneath it (rows past the end read as 0)
+        bld16(rK, ka_l + s_k + 32u * ldk4, kb[0]);
       }
       CTTS_SCHED_FENCE();
 #pragma unroll
@@ -231,6 +261,8 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
 }
 
 // --------------------------------------------------------------------------------------------------------------- backward
+// Row statistics reach the accumulator layout through the matrix core itself: one extra 32x32x2 step adds -lse_i/sl2 (k = 0) and
+// -BIG * [key masked] (k = 1) to S, a second one broadcasts D_i - no cross-lane lookups, selects or branches in the element loop.
 #ifndef CTTS_ATTN_BWD32_WAVES
 #define CTTS_ATTN_BWD32_WAVES 2
 #endif
@@ -255,11 +287,19 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
   const float* dOb = d.dout + (long)b * d.sdo + head * DH;
   const float* Kr = d.k + (long)b * d.sk + head * DH + (long)min(j, T - 1) * d.ldk + 16 * h;
   const float* Vr = d.v + (long)b * d.sv + head * DH + (long)min(j, T - 1) * d.ldv + 16 * h;
-  const float* PSz = BIAS ? d.bias + (long)z * T * T : nullptr;
   const float* lse = d.lse + (long)z * T;
   const float* Dz = d.D + (long)z * T;
-  float* dSz = d.dS + (long)z * T * T;
-  float* dPSz = (BIAS && d.dPS) ? d.dPS + (long)z * T * T : nullptr;
+  const unsigned ldq4 = 4u * (unsigned)d.ldq, lddo4 = 4u * (unsigned)d.lddo, T4 = 4u * (unsigned)T;
+  const unsigned slab = T4 * (unsigned)(BIAS ? T + 1 : T);                 // bytes of one [T,T] (rel: padded) slab (the C ABI checks < 2^31)
+  const rsrc_t rQ = make_rsrc(Qb, (unsigned)(T - 1) * ldq4 + 4u * DH);      // rows >= T are out of range
+  const rsrc_t rdO = make_rsrc(dOb, (unsigned)(T - 1) * lddo4 + 4u * DH);
+  const rsrc_t rdS = make_rsrc(d.dS + (long)z * (slab / 4u), slab);
+  const rsrc_t rPS = make_rsrc(BIAS ? d.bias + (long)z * (slab / 4u) : nullptr, BIAS ? slab : 0u);
+  // lane-constant byte offsets; the wave-uniform (query tile, register) terms are added per access
+  const unsigned qa_l = (unsigned)l31 * ldq4 + 64u * h, da_l = (unsigned)l31 * lddo4 + 64u * h;     // A operands: row l31, k-half h
+  const unsigned qt_l = 4u * h * ldq4 + 4u * l31, dt_l = 4u * h * lddo4 + 4u * l31;                  // transposed: row rowmap(st,h), column l31
+  const unsigned x_l = 4u * h * (unsigned)T + (unsigned)j;                  // element (row 4h, key j) of a [T,T] map
+  const unsigned e_l = j < T ? 4u * x_l + (BIAS ? T4 : 0u) : OOB;           // its byte offset in the dS (and rel: score) slab; keys >= T: none
 
   float Kf[RES ? DH / 2 : 1], Vf[RES ? DH / 2 : 1];
   if (RES) {
@@ -279,10 +319,16 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
   for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dKt[c][r] = 0.f; dVt[c][r] = 0.f; }
-  const float sl2 = d.scale * LOG2E;
+  const float sl2 = d.scale * LOG2E, inv_sl2 = 1.f / sl2;
   const bool do_drop = d.p_drop > 0.f;
   uint32_t dkey = 0; float inv_keep = 1.f;
   if (do_drop) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
+  const uint32_t zTT = (uint32_t)z * (uint32_t)T * (uint32_t)T;
+  const uint32_t dthr = drop_threshold(d.p_drop);
+  const uint32_t xk_l = x_l * DROP_G + dkey;                                // lane part of hash input (z*T*T + ir*T + j) * G + key
+  // B operands of the two statistic steps (lane <-> key j, k-half h)
+  const float b_aug = h == 0 ? 1.f : (j < L ? 0.f : 1.f);
+  const float b_one = h == 0 ? 1.f : 0.f;
 
   const int nq = (L + 31) / 32;
   const int per = (nq + d.q_split - 1) / max(d.q_split, 1);
@@ -291,30 +337,24 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
   // are streamed, dO^T / Q^T rows as A operands of dV^T and dK^T
   float qa[2][16], da[2][16], kb[2][16], vb[2][16], dot[2][16], qtt[2][16];
   if (q_lo < q_hi) {
-    load16(Qb + (long)min(q_lo * 32 + l31, T - 1) * d.ldq + 16 * h, qa[0]);
+    bld16(rQ, qa_l + (unsigned)(q_lo * 32) * ldq4, qa[0]);
     if (!RES) load16(Kr, kb[0]);
   }
-  // position scores of a (query tile, this wave's keys) block: register r <-> query row it0 + rowmap(r, h), lane <-> key (coalesced rows)
-  // (unconditional loads + validity mask, see the forward kernel)
-  unsigned okb = 0;
+  // position scores of a (query tile, this wave's keys) block: register r <-> query row it0 + rowmap(r, h), lane <-> key (coalesced rows);
+  // same slab offsets as the dS stores below; keys >= T and rows past the slab come back as 0 from the range check
   auto load_bias_tile = [&](int it0, float (&dst)[16]) {
-    okb = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ir = it0 + rowmap(r, h);
-      const bool ok = ir < T && j < T && j != ir + 1;
-      const int bi = ir * (T - 1) + (j <= ir ? T - 1 : T - 2) + j;
-      dst[r] = PSz[ok ? bi : 0];
-      okb |= (ok ? 1u : 0u) << r;
-    }
+    for (int r = 0; r < 16; ++r) dst[r] = bld(rPS, e_l + (unsigned)(it0 + rowmap(r, 0)) * T4);
   };
   float bias_n[16];
   if (BIAS && q_lo < q_hi) load_bias_tile(q_lo * 32, bias_n);
   for (int qt = q_lo; qt < q_hi; ++qt) {
     const int i0 = qt * 32;
+    const unsigned s_q = (unsigned)i0 * ldq4, s_do = (unsigned)i0 * lddo4;
+    // row statistics of this tile (lanes 0..31 and 32..63 again hold rows i0 .. i0+31): consumed after the S MFMAs
     const int ia = min(i0 + l31, T - 1);
-    const float* Qr = Qb + (long)ia * d.ldq + 16 * h;
-    const float* dOr = dOb + (long)ia * d.lddo + 16 * h;
+    const bool rowok = i0 + l31 < L;
+    const float lse_l = lse[ia], D_l = Dz[ia];
     // ---- S[i][j] = sum_k Q[i][k] K[j][k]
     floatx16 S, dP;
 #pragma unroll
@@ -322,10 +362,10 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       if (c + 1 < NC) {
-        load16(Qr + 32 * (c + 1), qa[(c + 1) & 1]);
+        bld16(rQ, qa_l + s_q + 128u * (c + 1), qa[(c + 1) & 1]);
         if (!RES) load16(Kr + 32 * (c + 1), kb[(c + 1) & 1]);
       } else {
-        load16(dOr, da[0]);
+        bld16(rdO, da_l + s_do, da[0]);
         if (!RES) load16(Vr, vb[0]);
       }
       CTTS_SCHED_FENCE();
@@ -337,21 +377,30 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
       }
       CTTS_SCHED_FENCE();
     }
-    // row statistics and position scores of this tile: issued before the dP MFMAs, consumed after them
-    const float lse_l = lse[ia], D_l = Dz[ia];          // lanes 0..31 (and 32..63 again) hold rows i0 .. i0+31
+    // S[i][j] += -lse_i / sl2  - BIG * [row i or key j masked]   ->   P = exp2(sl2 * (S + bias)) needs no selects;  Dbc[i][j] = D_i
+    floatx16 Dbc;
+    {
+      const float a_aug = (h == 0 && rowok) ? -lse_l * inv_sl2 : -BIG;
+      const float a_d = (h == 0 && rowok) ? D_l : 0.f;
+      floatx16 zero;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, S, 0, 0, 0);
+      Dbc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_d, b_one, zero, 0, 0, 0);
+    }
     // (`bias_n` holds this tile's position scores, fetched one query tile ago)
     // ---- dPd[i][j] = sum_k dO[i][k] V[j][k]
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       if (c + 1 < NC) {
-        load16(dOr + 32 * (c + 1), da[(c + 1) & 1]);
+        bld16(rdO, da_l + s_do + 128u * (c + 1), da[(c + 1) & 1]);
         if (!RES) load16(Vr + 32 * (c + 1), vb[(c + 1) & 1]);
       } else {                          // operands of the first dV^T / dK^T chunk
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
-          const long ir = min(i0 + rowmap(st, h), T - 1);
-          dot[0][st] = dOb[ir * d.lddo + l31];
-          qtt[0][st] = Qb[ir * d.ldq + l31];
+          const unsigned sr = (unsigned)(i0 + rowmap(st, 0));
+          dot[0][st] = bld(rdO, dt_l + sr * lddo4);
+          qtt[0][st] = bld(rQ, qt_l + sr * ldq4);
         }
       }
       CTTS_SCHED_FENCE();
@@ -363,42 +412,34 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
       }
       CTTS_SCHED_FENCE();
     }
-    // ---- P = exp2(scale*log2e*(S + bias) - lse),  Pd = P*keep/(1-p),  dS = scale * P * (dPd*keep/(1-p) - D)
+    // ---- P = exp2(sl2 * (S + bias)),  Pd = P*keep/(1-p),  dS = scale * P * (dPd*keep/(1-p) - D)
     floatx16 Pd, dSv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int rm = rowmap(r, h), ir = i0 + rm;
-      const float lse_i = __shfl(lse_l, rm, 64), Di = __shfl(D_l, rm, 64);
+      const int sc = i0 + rowmap(r, 0);                 // uniform: the h = 0 half's query row of register r
       float s = S[r];
-      if (BIAS) s += ((okb >> r) & 1u) ? bias_n[r] : 0.f;
-      const bool valid = ir < L && j < L;
-      const float p = valid ? fast_exp2(s * sl2 - lse_i) : 0.f;
+      if (BIAS) s += bias_n[r];
+      const float p = fast_exp2(s * sl2);
       float ks = 1.f;
-      if (do_drop) ks = ctts_drop_scale(dkey, ((uint32_t)z * (uint32_t)T + (uint32_t)ir) * (uint32_t)T + (uint32_t)j, d.p_drop, inv_keep);
-      const float ds = p * (dP[r] * ks - Di) * d.scale;
+      if (do_drop) ks = drop_scale_pre(xk_l + (zTT + (uint32_t)sc * (uint32_t)T) * DROP_G, dthr, inv_keep);
+      const float ds = p * (dP[r] * ks - Dbc[r]) * d.scale;
       Pd[r] = p * ks;
       dSv[r] = ds;
-      if (valid) {
-        dSz[(long)ir * T + j] = ds;
-        if (BIAS) {                      // the same element through the adjoint of the shift (index recomputed: cheaper than 16 live registers)
-          const int bi = rel_index(ir, j, T);
-          if (dPSz && bi >= 0) dPSz[bi] = ds;
-        }
-      }
+      bst(rdS, e_l + (unsigned)sc * T4, ds);             // masked rows / keys inside the slab receive their exact value 0
     }
-    if (BIAS) load_bias_tile(i0 + 32, bias_n);          // next tile's scores (unconditional, masked past the end): three MFMA blocks of cover
+    if (BIAS) load_bias_tile(i0 + 32, bias_n);          // next tile's scores: three MFMA blocks of cover
     // ---- dV^T[d][j] += sum_i dO[i][d] Pd[i][j],  dK^T[d][j] += sum_i Q[i][d] dS[i][j]
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       if (c + 1 < NC) {
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
-          const long ir = min(i0 + rowmap(st, h), T - 1);
-          dot[(c + 1) & 1][st] = dOb[ir * d.lddo + 32 * (c + 1) + l31];
-          qtt[(c + 1) & 1][st] = Qb[ir * d.ldq + 32 * (c + 1) + l31];
+          const unsigned sr = (unsigned)(i0 + rowmap(st, 0));
+          dot[(c + 1) & 1][st] = bld(rdO, dt_l + sr * lddo4 + 128u * (c + 1));
+          qtt[(c + 1) & 1][st] = bld(rQ, qt_l + sr * ldq4 + 128u * (c + 1));
         }
-      } else {                          // next query tile's first S operands (unconditional, row clamped)
-        load16(Qb + (long)min(i0 + 32 + l31, T - 1) * d.ldq + 16 * h, qa[0]);
+      } else {                          // next query tile's first S operands (rows past the end read as 0)
+        bld16(rQ, qa_l + s_q + 32u * ldq4, qa[0]);
         if (!RES) load16(Kr, kb[0]);
       }
       CTTS_SCHED_FENCE();
@@ -436,12 +477,11 @@ __global__ void attn_sum_splits_kernel(const float4* __restrict__ part, int n_sp
   }
 }
 
-// row 0 of the shift's adjoint layout is only partly covered by the scatter (columns 0..T-2 of row 0 are never read by the shift)
-__global__ void dps_row0_zero_kernel(float* dPS, int nz, int T) {
-  const long n = (long)nz * (T - 1);
+// padded score slabs ([T, T+1] = [T+1, T] floats): the zero column the shift inserts (forward), the T floats in front of dS (backward)
+__global__ void pad_zero_kernel(float* p, long n, long outer_stride, int inner, int inner_stride) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const long zz = e / (T - 1);
-    dPS[zz * T * T + (e - zz * (T - 1))] = 0.f;
+    const long o = e / inner;
+    p[o * outer_stride + (e - o * inner) * inner_stride] = 0.f;
   }
 }
 
@@ -499,6 +539,7 @@ extern "C" int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* 
                             float* dS, float* kv_part, float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* stream) {
   CTTS_REQUIRE(qkv && out && dout && lse && Dws && dS && dqkv && B > 0 && T > 0, "ctts_mha_bwd: bad arguments");
   CTTS_REQUIRE(q_split <= 1 || kv_part, "ctts_mha_bwd: q_split > 1 needs the kv_part scratch [q_split, B, T, 2C]");
+  CTTS_REQUIRE((long)T * T * 4 < 0x7FFFFFFFL && (long)T * C * 12 < 0x7FFFFFFFL, "ctts_mha_bwd: one utterance exceeds the 32-bit byte offsets of the kernel");
   CTTS_REQUIRE(ctts_mha_supported(C, H) && al16(qkv) && al16(dout) && al16(dqkv), "ctts_mha_bwd: needs d_head in {32,64,128} and 16-byte aligned tensors");
   hipStream_t st = (hipStream_t)stream;
   const int dh = C / H;
@@ -538,7 +579,22 @@ extern "C" int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* 
   return ctts_gemm(&g, stream);
 }
 
-extern "C" size_t ctts_relmha_workspace_floats(int B, int T, int H) { return (size_t)B * H * T * T; }
+extern "C" size_t ctts_relmha_workspace_floats(int B, int T, int H) { return (size_t)B * H * T * (T + 1); }
+
+namespace {
+int relmha_check_sizes(int B, int T, int H, int C, const char* who) {
+  CTTS_REQUIRE((long)T * (T + 1) * 4 < 0x7FFFFFFFL && (long)T * C * 8 < 0x7FFFFFFFL && (long)B * H * T * T < 0xFFFFFFFFL,
+               "%s: one utterance exceeds the 32-bit offsets of the kernel", who);
+  return 0;
+}
+int pad_zero(float* p, long outer, long outer_stride, int inner, int inner_stride, hipStream_t st) {
+  const long n = outer * inner;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pad_zero_kernel, dim3((unsigned)min((n + 255) / 256, 4096L)), dim3(256), 0, st, p, n, outer_stride, inner, inner_stride);
+  CTTS_CHECK_LAUNCH("ctts_relmha(pad)");
+  return 0;
+}
+}  // namespace
 
 extern "C" int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv, const float* pos, float* ps, float* out, float* lse,
                                int B, int T, int H, int C, float scale, float p_drop, const uint64_t* seed, uint32_t drop_offset,
@@ -546,15 +602,18 @@ extern "C" int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv
   CTTS_REQUIRE(qu && qv && kv && pos && ps && out && lse && B > 0 && T > 0, "ctts_relmha_fwd: bad arguments");
   CTTS_REQUIRE(ctts_mha_supported(C, H) && al16(qu) && al16(kv) && al16(out), "ctts_relmha_fwd: needs d_head in {32,64,128} and 16-byte aligned tensors");
   CTTS_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "ctts_relmha_fwd: p_drop out of range");
-  CTTS_REQUIRE((long)B * H * T * T < 0xFFFFFFFFL && (long)T * T < 0x7FFFFFFFL, "ctts_relmha_fwd: [B,H,T,T] exceeds the 32-bit element index");
+  if (relmha_check_sizes(B, T, H, C, "ctts_relmha_fwd")) return -1;
   const int dh = C / H;
-  // PS[b,h] = (q + v_bias)[b,:,h] pos[:,h]^T   (conformer.py:405-407; unshifted, the shift is an index map inside the fused kernel)
+  const long slab = (long)T * (T + 1);
+  // padded[b,h] = [0 | (q + v_bias)[b,:,h] pos[:,h]^T]   (conformer.py:405-407, 423-427): the GEMM writes rows of T+1 behind the zero column
+  int rc = pad_zero(ps, (long)B * H * T, T + 1, 1, 1, (hipStream_t)stream);
+  if (rc) return rc;
   ctts_gemm_desc g = {};
-  g.A = qv; g.B = pos; g.C = ps;
-  g.M = T; g.N = T; g.K = dh; g.lda = C; g.ldb = C; g.ldc = T; g.a_kc = 1; g.b_kc = 1;
-  g.nb0 = B; g.nb1 = H; g.sA0 = (long)T * C; g.sA1 = dh; g.sB0 = 0; g.sB1 = dh; g.sC0 = (long)H * T * T; g.sC1 = (long)T * T;
+  g.A = qv; g.B = pos; g.C = ps + 1;
+  g.M = T; g.N = T; g.K = dh; g.lda = C; g.ldb = C; g.ldc = T + 1; g.a_kc = 1; g.b_kc = 1;
+  g.nb0 = B; g.nb1 = H; g.sA0 = (long)T * C; g.sA1 = dh; g.sB0 = 0; g.sB1 = dh; g.sC0 = (long)H * slab; g.sC1 = slab;
   g.alpha = 1.f; g.split_k = 1;
-  int rc = ctts_gemm(&g, stream);
+  rc = ctts_gemm(&g, stream);
   if (rc) return rc;
   AttnArgs a = {};
   a.q = qu; a.ldq = C; a.sq = (long)T * C;
@@ -565,21 +624,20 @@ extern "C" int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv
 }
 
 extern "C" int ctts_relmha_bwd(const float* qu, const float* qv, const float* kv, const float* pos, const float* ps, const float* out,
-                               const float* dout, const float* lse, float* Dws, float* dS, float* dPS, float* dqu, float* dqv, float* dkv,
+                               const float* dout, const float* lse, float* Dws, float* dS, float* dqu, float* dqv, float* dkv,
                                float* dpos_b, int B, int T, int H, int C, float scale, float p_drop, const uint64_t* seed,
                                uint32_t drop_offset, void* stream) {
-  CTTS_REQUIRE(qu && qv && kv && pos && ps && out && dout && lse && Dws && dS && dPS && dqu && dqv && dkv && dpos_b && B > 0 && T > 0,
+  CTTS_REQUIRE(qu && qv && kv && pos && ps && out && dout && lse && Dws && dS && dqu && dqv && dkv && dpos_b && B > 0 && T > 0,
                "ctts_relmha_bwd: bad arguments");
   CTTS_REQUIRE(ctts_mha_supported(C, H) && al16(qu) && al16(kv) && al16(dout) && al16(dkv), "ctts_relmha_bwd: needs d_head in {32,64,128} and 16-byte aligned tensors");
+  if (relmha_check_sizes(B, T, H, C, "ctts_relmha_bwd")) return -1;
   hipStream_t st = (hipStream_t)stream;
   const int dh = C / H;
+  const long slab = (long)T * (T + 1);
   int rc = ctts_rowdot_heads(dout, out, Dws, B, T, H, dh, stream);
   if (rc) return rc;
-  if (T > 1) {
-    const long n = (long)B * H * (T - 1);
-    hipLaunchKernelGGL(dps_row0_zero_kernel, dim3((unsigned)min((n + 255) / 256, 4096L)), dim3(256), 0, st, dPS, B * H, T);
-    CTTS_CHECK_LAUNCH("ctts_relmha_bwd(dps row 0)");
-  }
+  rc = pad_zero(dS, (long)B * H, slab, T, 1, st);          // the T floats in front of every dS map: row 0 of the padded view reads them
+  if (rc) return rc;
   AttnArgs a = {};
   a.q = qu; a.ldq = C; a.sq = (long)T * C;
   a.k = kv; a.v = kv + C; a.ldk = a.ldv = 2L * C; a.sk = a.sv = (long)T * 2 * C;
@@ -587,23 +645,22 @@ extern "C" int ctts_relmha_bwd(const float* qu, const float* qv, const float* kv
   a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.drop_offset = drop_offset;
   a.dout = dout; a.lddo = C; a.sdo = (long)T * C; a.D = Dws;
   a.dk = dkv; a.dv = dkv + C; a.lddk = a.lddv = 2L * C; a.sdk = a.sdv = (long)T * 2 * C;
-  a.dS = dS; a.dPS = dPS; a.q_split = 1;
+  a.dS = dS; a.q_split = 1;
   rc = launch_bwd<true>(a, dh, st);
   if (rc) return rc;
-  const long sS0 = (long)H * T * T, sS1 = (long)T * T;
   ctts_gemm_desc g = {};
-  // dQU[i,d] = sum_j dS[i,j] K[j,d]
-  g.A = dS; g.B = kv; g.C = dqu; g.M = T; g.N = dh; g.K = T; g.lda = T; g.ldb = 2L * C; g.ldc = C; g.a_kc = 1; g.b_kc = 0;
-  g.nb0 = B; g.nb1 = H; g.sA0 = sS0; g.sA1 = sS1; g.sB0 = (long)T * 2 * C; g.sB1 = dh; g.sC0 = (long)T * C; g.sC1 = dh;
+  // dQU[i,d] = sum_j dS[i,j] K[j,d]                      (dS map = slab + T, rows of T)
+  g.A = dS + T; g.B = kv; g.C = dqu; g.M = T; g.N = dh; g.K = T; g.lda = T; g.ldb = 2L * C; g.ldc = C; g.a_kc = 1; g.b_kc = 0;
+  g.nb0 = B; g.nb1 = H; g.sA0 = (long)H * slab; g.sA1 = slab; g.sB0 = (long)T * 2 * C; g.sB1 = dh; g.sC0 = (long)T * C; g.sC1 = dh;
   g.alpha = 1.f; g.split_k = 1;
   rc = ctts_gemm(&g, stream);
   if (rc) return rc;
-  // dQV[i,d] = sum_m dPS[i,m] pos[m,d]
-  g.A = dPS; g.B = pos; g.C = dqv; g.ldb = C; g.sB0 = 0; g.sB1 = dh;
+  // dQV[i,d] = sum_m dPS[i,m] pos[m,d]                   (dPS = the padded view of the same memory: slab + 1, rows of T+1)
+  g.A = dS + 1; g.lda = T + 1; g.B = pos; g.C = dqv; g.ldb = C; g.sB0 = 0; g.sB1 = dh;
   rc = ctts_gemm(&g, stream);
   if (rc) return rc;
   // dpos_b[b][m,d] = sum_i dPS[b][i,m] QV[b][i,d]   (caller sums over b: pos is shared by the batch)
-  g.A = dPS; g.B = qv; g.C = dpos_b; g.a_kc = 0; g.b_kc = 0; g.lda = T; g.ldb = C; g.ldc = C;
+  g.B = qv; g.C = dpos_b; g.a_kc = 0; g.b_kc = 0; g.ldb = C; g.ldc = C;
   g.sB0 = (long)T * C; g.sB1 = dh; g.sC0 = (long)T * C; g.sC1 = dh;
   return ctts_gemm(&g, stream);
 }

@@ -799,12 +799,15 @@ int dispatch_layout(const ctts_gemm_desc& d, hipStream_t st) {
 }
 
 // eligibility of the branch-free 16-byte loaders (see VLoaderKC)
+bool chunks_ok(const ctts_gemm_desc& d) {          // every 4-float chunk along the contiguous dimension lies inside the operand or outside it
+  const bool a_ext = d.a_kc ? (d.K % 4 == 0) : (d.M % 4 == 0);
+  const bool b_ext = d.b_kc ? (d.K % 4 == 0) : (d.N % 4 == 0);
+  return a_ext && b_ext;
+}
 bool vec_ok(const ctts_gemm_desc& d) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool strides = !((d.lda | d.ldb | d.sA0 | d.sA1 | d.sB0 | d.sB1) & 3);
-  const bool a_ext = d.a_kc ? (d.K % 4 == 0) : (d.M % 4 == 0);
-  const bool b_ext = d.b_kc ? (d.K % 4 == 0) : (d.N % 4 == 0);
-  return strides && a_ext && b_ext && al16(d.A) && al16(d.B);
+  return strides && chunks_ok(d) && al16(d.A) && al16(d.B);
 }
 
 }  // namespace
@@ -881,7 +884,16 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   // micro-benchmark (96.6 -> 86 us FFN linear, 711 -> 683 us FFN conv) - in-step effect measured separately, off by default.
   static const bool tn_natural = getenv("CTTS_TN_NATURAL") != nullptr;
   if ((natural || (tn_natural && !d.a_kc && !d.b_kc)) && !d.tile_map) d.tile_map = reinterpret_cast<const int32_t*>(1);
-  if (!vec_ok(d)) return dispatch_layout<64, 64, false>(d, st);
+  // 16-byte BUFFER loads only need dword-aligned addresses (the LDS side of the tile is aligned by construction), so the buffer kernels
+  // also take operands whose base / leading dimension is not a multiple of 4 floats - the padded views (rows of T+1) of the relative
+  // attention score slabs - as long as the chunking fits.  Pointer-based 16-byte loads (the non-buffer VEC path) need full alignment.
+  const bool aligned = vec_ok(d);
+#ifdef CTTS_NO_BUF
+  const bool buf_unaligned = false;
+#else
+  const bool buf_unaligned = !aligned && chunks_ok(d) && d.conv_T <= 0 && !(d.lens && (d.lim_m || d.lim_n || d.lim_k));
+#endif
+  if (!aligned && !(buf_unaligned && buf_ok(d))) return dispatch_layout<64, 64, false>(d, st);
 #ifndef CTTS_NO_BUF
   if (buf_ok(d)) {
     // 64x64 tiles (64 VGPRs: 8 waves/SIMD) match the 128x128 kernel on every measured shape (109 / 119 / 108 / 107 TFLOP/s on FFN conv fwd,

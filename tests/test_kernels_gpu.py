@@ -51,6 +51,33 @@ def test_gemm_tn_splitk(M, N, Kd, split):
     close(C, 0.5 * (A.double().t() @ B.double()), 3e-6 * max(1, Kd / 16), "tn")
 
 
+@pytest.mark.parametrize("T,dh,nb", [(64, 32, 3), (200, 32, 2), (1000, 32, 1)])
+def test_gemm_padded_view_operands(T, dh, nb):
+    """Operands whose base / leading dimension is not a multiple of 4 floats (the relative-attention score slabs viewed as rows of
+    T+1, conformer.py:423-431): both contractions of the buffer kernels, batched, against fp64."""
+    slab = T * (T + 1)
+    g = torch.Generator().manual_seed(12)
+    mem = torch.randn(nb, slab, generator=g)
+    view = torch.stack([mem[z, 1:1 + (T - 1) * (T + 1) + T].unfold(0, T, T + 1) for z in range(nb)])          # [nb, T, T] rows of T+1 behind 1 float
+    assert view.shape == (nb, T, T)
+    Bm = torch.randn(T, dh, generator=g)
+    Cm = torch.randn(nb, T, dh, generator=g)
+    dmem = mem.to(DEV)
+    out = torch.empty(nb, T, dh, device=DEV)
+    K.gemm(dmem, Bm.to(DEV), out, T, dh, T, T + 1, dh, dh, True, False, a_off=1, nb0=nb, nb1=1, sA=(slab, 0), sC=(T * dh, 0))
+    close(out, view.double() @ Bm.double(), 2e-6 * max(1, T / 16), "padded view, K contiguous")
+    out2 = torch.empty(nb, T, dh, device=DEV)
+    K.gemm(dmem, Cm.to(DEV), out2, T, dh, T, T + 1, dh, dh, False, False, a_off=1, nb0=nb, nb1=1, sA=(slab, 0), sB=(T * dh, 0), sC=(T * dh, 0))
+    close(out2, view.double().transpose(1, 2) @ Cm.double(), 2e-6 * max(1, T / 16), "padded view, M contiguous")
+    # and as an output: rows of T+1 behind one float
+    A2, B2 = torch.randn(nb, T, dh, generator=g), torch.randn(T, dh, generator=g)
+    omem = torch.zeros(nb, slab, device=DEV)
+    K.gemm(A2.to(DEV), B2.to(DEV), omem, T, T, dh, dh, dh, T + 1, True, True, c_off=1, nb0=nb, nb1=1, sA=(T * dh, 0), sC=(slab, 0))
+    got = omem.view(nb, T, T + 1)
+    close(got[:, :, 1:], A2.double() @ B2.double().t(), 2e-6 * max(1, dh / 16), "padded output")
+    assert float(got[:, :, 0].abs().max()) == 0.0
+
+
 def test_gemm_epilogue_all():
     M, N, Kd = 150, 200, 64
     A, B, bias, R, rs = rnd(M, Kd, seed=7), rnd(N, Kd, seed=8), rnd(N, seed=9), rnd(M, N, seed=10), (rnd(M, seed=11) > 0).float()
