@@ -3,11 +3,13 @@
 //
 //   fs2   (transformer_fs2.py:385-394, F.multi_head_attention_forward): softmax(q k^T / sqrt(d_h), keys >= len masked) v, 2 heads x 128
 //   rel   (conformer.py:347-431, RelativeMultiHeadAttention): softmax(((q+u) k^T + shift((q+v) p^T)) / sqrt(d_model)) with NO mask,
-//         dropout on the probabilities, 8 heads x 32.  The position scores PS = (q+v) p^T come from ctts_gemm, written straight into the
-//         reference's `padded` layout (conformer.py:423-431: rows of T+1 = [0 | PS row]); the Transformer-XL shift is then what it is in
-//         the reference - a reinterpretation of the same memory: shifted[i][j] = padded.flat[(i+1)*T + j].  The backward kernel writes
-//         dS in that very layout, so the gradient of the unshifted scores is again only a view (rows of T+1, first column skipped):
-//         no shifted map, no second gradient tensor, no probabilities or dropped probabilities in HBM.
+//         dropout on the probabilities, 8 heads x 32.  The reference pads PS = (q+v) p^T with a zero column and reinterprets the memory
+//         (conformer.py:423-431); element (i, j) of the result is QVsel . Pt[j - i + T - 1] with the extended table
+//         Pt = [pos rows | 0 | pos rows] and QVsel = (q+v)[i] below x = T, (q+v)[i+1] above - Toeplitz in (i, j).  Both kernels compute the
+//         band a tile needs on the matrix cores and read it along the anti-diagonals: no score tensor, no shifted map, no probabilities
+//         or dropped probabilities in HBM.  The backward kernel writes dS in the reference's `padded` layout ([B,H] slabs of T*(T+1)
+//         floats, dS[i][j] = slab[(i+1)*T + j]), so the gradient of the unshifted scores is a VIEW of the same memory (rows of T+1, first
+//         column skipped) for the two position GEMMs.
 //
 // Work decomposition: ONE WAVE PER WORKGROUP, 32 queries (forward) or 32 keys (backward) per wave, flash-style loop over the other
 // axis in tiles of 32.  fp32 MFMA issues one 32x32x2 step per 64 cycles, so a wave needs only ~1 operand dword per 64 cycles: every
@@ -34,7 +36,8 @@ struct AttnArgs {
   long ldq, ldk, ldv, sq, sk, sv;
   float* out; long ldo, so;         // [B,T,H*dh]
   float* lse;                       // [B,H,T]  log2-domain log-sum-exp of the scaled scores
-  const float* bias;                // rel: position scores in the padded layout, [B,H] slabs of T*(T+1) floats (see above), else NULL
+  const float* qv; long ldqv, sqv;  // rel: q + v_bias, same indexing as q; NULL selects the plain (fs2) kernels' behaviour
+  const float* pos; long ldpos;     // rel: projected sinusoid rows [T, H*dh] shared by the batch
   const int32_t* lens;              // fs2: valid length per utterance (keys >= len masked, query rows >= len are zero rows), else NULL
   int B, H, T;
   float scale, p_drop;
@@ -105,9 +108,14 @@ __device__ __forceinline__ void bld16(rsrc_t r, unsigned off, float (&f)[16]) {
 // ---------------------------------------------------------------------------------------------------------------- forward
 // occupancy targets (waves per SIMD): d_head 32 (conformer: thousands of waves) 3 forward / 2 backward (no spills), 64 -> 2, 128 -> 1
 template <int DH, bool BIAS>
-__global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS ? 1 : 2) : 1))) void attn_fwd_kernel(const AttnArgs d) {
+#ifndef CTTS_ATTN_FWD32B_MAXW
+#define CTTS_ATTN_FWD32B_MAXW 3
+#endif
+__global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS ? 1 : 2) : 1)))
+__attribute__((amdgpu_waves_per_eu(1, (DH <= 32 && BIAS) ? CTTS_ATTN_FWD32B_MAXW : 8))) void attn_fwd_kernel(const AttnArgs d) {
   constexpr int NC = DH / 32;
-  __shared__ float sb[BIAS ? 32 * 33 : 1];
+  constexpr int GLD = 34;              // row stride of the band ring in LDS: conflict-free for the row writes and the skewed reads
+  __shared__ float sg[BIAS ? 64 * GLD : 1];
   const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
   const int i0 = blockIdx.x * 32, head = blockIdx.y, b = blockIdx.z;
   const int T = d.T, z = b * d.H + head;
@@ -127,7 +135,6 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
   const unsigned ldk4 = 4u * (unsigned)d.ldk, ldv4 = 4u * (unsigned)d.ldv, T4 = 4u * (unsigned)T;
   const rsrc_t rK = make_rsrc(d.k + (long)b * d.sk + head * DH, (unsigned)(T - 1) * ldk4 + 4u * DH);     // rows >= T read as 0
   const rsrc_t rV = make_rsrc(d.v + (long)b * d.sv + head * DH, (unsigned)(T - 1) * ldv4 + 4u * DH);
-  const rsrc_t rPS = make_rsrc(BIAS ? d.bias + (long)z * T * (T + 1) : nullptr, BIAS ? T4 * (unsigned)(T + 1) : 0u);
   const unsigned ka_l = (unsigned)l31 * ldk4 + 64u * h;          // A operand of S^T: key row l31, k-half h
   const unsigned vt_l = 4u * h * ldv4 + 4u * l31;                // A operand of O^T: key row rowmap(st,h), column l31
 
@@ -156,23 +163,60 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
 
   float kb[2][16], vb[2][16];          // ping-pong operand buffers (chunk parity)
   bld16(rK, ka_l, kb[0]);
-  // position-score tile (rows i0 .. i0+31, keys j0 .. j0+31) in load order: 16 x (2 queries x 32 consecutive keys) = 128-byte rows;
-  // transposed through LDS later so that each lane gets the 16 values of ITS query column.  Element (ii, jj) = (i0 + 2it + h, jt + l31)
-  // of the shifted scores sits at slab[(ii+1)*T + jj]; keys >= T and rows past the slab read as 0 through the range check
-  // (unconditional loads: a load under a per-element condition makes hipcc branch around it and wait vmcnt(0) at the join).
-  const unsigned ps_l = (unsigned)(h + 1) * T4 + 4u * l31;
-  auto load_ps_tile = [&](int jt, float (&dst)[16]) {
-    const unsigned base = (jt + l31 < T) ? ps_l + 4u * (unsigned)jt + (unsigned)i0 * T4 : OOB;
+  // ---- relative position scores, computed in the kernel (no [T,T] score tensor).  conformer.py:423-431 pads PS = QV pos^T with a zero
+  // column and reinterprets the memory; element (i, j) of the result is
+  //     x = j - i + T - 1:   x <= T-1: QV[i] . pos[x]      x == T: 0      x >= T+1: QV[i+1] . pos[x - T - 1]
+  // i.e. QVsel . Pt[x] with the extended table Pt = [pos rows 0..T-1 | 0 | pos rows 0..T-2] - Toeplitz in (i, j).  A key tile needs
+  // the band x0 .. x0+62, x0 = j0 - i0 + T - 32; bands move by 32 per key tile, so every tile adds ONE 32-row block
+  // G^T[mm][i] = Pt[xb + mm] . QVsel[i] (16 MFMA steps per chunk; a block lies wholly on one side of x = T, so QVsel is uniform), kept in
+  // a two-block LDS ring; lane i then reads its 16 scores of the tile along the anti-diagonal: mm = 31 - (i - i0) + (j - j0).
+  float QVf[BIAS ? DH / 2 : 1], QVn[BIAS ? DH / 2 : 1], pa[BIAS ? DH / 2 : 1];
+  const unsigned ldp4 = BIAS ? 4u * (unsigned)d.ldpos : 0u;
+  const rsrc_t rP = make_rsrc(BIAS ? d.pos + head * DH : nullptr, BIAS ? (unsigned)(T - 1) * ldp4 + 4u * DH : 0u);
+  const int xb0 = T - 32 - i0;         // first band row of block 0 (tile 0 reads blocks 0 and 1)
+  auto load_band = [&](int bidx) {     // A operand: band row xb + l31, k-half h
+    const int x = xb0 + 32 * bidx + l31;
+    const int prow = x <= T - 1 ? x : x - T - 1;
+    const unsigned off = (x < 0 || x == T) ? OOB : (unsigned)prow * ldp4 + 64u * h;      // rows past the table: out of range -> 0
 #pragma unroll
-    for (int it = 0; it < 16; ++it) dst[it] = bld(rPS, base + (unsigned)(2 * it) * T4);
+    for (int c = 0; c < NC; ++c) {
+      float t[16];
+      bld16(rP, off + 128u * c, t);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pa[BIAS ? 16 * c + q : 0] = t[q];
+    }
   };
-  float psn[16];
-  if (BIAS) load_ps_tile(0, psn);
+  auto band_block = [&](int bidx) {    // G^T block from `pa` into ring slot bidx & 1
+    const bool lower = xb0 + 32 * bidx + 31 <= T - 1;
+    floatx16 G;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < DH / 2; ++q)
+      G = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[BIAS ? q : 0], lower ? QVf[BIAS ? q : 0] : QVn[BIAS ? q : 0], G, 0, 0, 0);
+    float* slot = sg + (bidx & 1) * 32 * GLD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slot[rowmap(r, h) * GLD + l31] = G[r];
+  };
+  if (BIAS) {
+    const float* QVr = d.qv + (long)b * d.sqv + head * DH;
+    const rsrc_t rQV = make_rsrc(QVr, (unsigned)(T - 1) * 4u * (unsigned)d.ldqv + 4u * DH);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float t[16];
+      bld16(rQV, (unsigned)i * 4u * (unsigned)d.ldqv + 64u * h + 128u * c, t);             // rows >= T read as 0
+#pragma unroll
+      for (int q = 0; q < 16; ++q) QVf[BIAS ? 16 * c + q : 0] = t[q];
+      bld16(rQV, (unsigned)(i + 1) * 4u * (unsigned)d.ldqv + 64u * h + 128u * c, t);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) QVn[BIAS ? 16 * c + q : 0] = t[q];
+    }
+    load_band(0);
+    band_block(0);
+    load_band(1);
+  }
   for (int j0 = 0; j0 < L; j0 += 32) {
     const unsigned s_k = (unsigned)j0 * ldk4, s_v = (unsigned)j0 * ldv4;
-    // position scores: the tile needed NOW was fetched one tile ago (HBM latency under load is several microseconds - far more
-    // than the 1,024 MFMA cycles of one score block)
-    // (the registers `psn` hold this tile's scores; the NEXT tile's fetch is issued as soon as they have been handed to LDS below)
     // ---- S^T[j][i] = sum_k K[j][k] Q[i][k]
     floatx16 St;
 #pragma unroll
@@ -196,16 +240,16 @@ __global__ __launch_bounds__(64, (DH <= 32 ? (BIAS ? 2 : 3) : (DH <= 64 ? (BIAS 
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = St[r];
     if (BIAS) {
-#pragma unroll
-      for (int it = 0; it < 16; ++it) sb[(2 * it + h) * 33 + l31] = psn[it];
-      load_ps_tile(j0 + 32, psn);                        // next tile (past the end every element is out of range): a softmax,
-                                                         // a PV block and a score block of cover
-      // The workgroup is ONE wave and the LDS executes a wave's instructions in order, so the transposed read below sees the writes
+      const int tb = j0 >> 5;
+      band_block(tb + 1);              // this tile's second block (the first one is the previous tile's second)
+      load_band(tb + 2);               // next tile's: a whole tile of cover
+      // The workgroup is ONE wave and the LDS executes a wave's instructions in order, so the skewed read below sees the writes
       // above without a barrier.  __syncthreads() here would cost far more than its s_barrier: its fence waits vmcnt(0), i.e. it
-      // drains every prefetch in flight (K, V and position-score tiles) twice per tile.  wave_barrier only pins the program order.
+      // drains every prefetch in flight.  wave_barrier only pins the program order.
       __builtin_amdgcn_wave_barrier();
+      const int mm0 = 31 - l31 + 32 * (tb & 1);          // ring row of band element mm: (mm + 32 * (tb & 1)) & 63
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] += sb[l31 * 33 + rowmap(r, h)];
+      for (int r = 0; r < 16; ++r) s[r] += sg[((mm0 + rowmap(r, h)) & 63) * GLD + l31];
       __builtin_amdgcn_wave_barrier();
     }
     // ---- online softmax over the keys (log2 domain); a lane owns query column i, its partner lane^32 the other 16 key rows
@@ -294,12 +338,16 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
   const rsrc_t rQ = make_rsrc(Qb, (unsigned)(T - 1) * ldq4 + 4u * DH);      // rows >= T are out of range
   const rsrc_t rdO = make_rsrc(dOb, (unsigned)(T - 1) * lddo4 + 4u * DH);
   const rsrc_t rdS = make_rsrc(d.dS + (long)z * (slab / 4u), slab);
-  const rsrc_t rPS = make_rsrc(BIAS ? d.bias + (long)z * (slab / 4u) : nullptr, BIAS ? slab : 0u);
+  // rel: position scores recomputed per tile (see the forward kernel): G[i][mm] = QVsel[i] . Pt[x0 + mm], x0 = j0 - i0 + T - 32
+  const unsigned ldqv4 = BIAS ? 4u * (unsigned)d.ldqv : 0u, ldp4 = BIAS ? 4u * (unsigned)d.ldpos : 0u;
+  const rsrc_t rQV = make_rsrc(BIAS ? d.qv + (long)b * d.sqv + head * DH : nullptr, BIAS ? (unsigned)(T - 1) * ldqv4 + 4u * DH : 0u);
+  const rsrc_t rP = make_rsrc(BIAS ? d.pos + head * DH : nullptr, BIAS ? (unsigned)(T - 1) * ldp4 + 4u * DH : 0u);
+  const unsigned qva_l = (unsigned)l31 * ldqv4 + 64u * h;
   // lane-constant byte offsets; the wave-uniform (query tile, register) terms are added per access
   const unsigned qa_l = (unsigned)l31 * ldq4 + 64u * h, da_l = (unsigned)l31 * lddo4 + 64u * h;     // A operands: row l31, k-half h
   const unsigned qt_l = 4u * h * ldq4 + 4u * l31, dt_l = 4u * h * lddo4 + 4u * l31;                  // transposed: row rowmap(st,h), column l31
   const unsigned x_l = 4u * h * (unsigned)T + (unsigned)j;                  // element (row 4h, key j) of a [T,T] map
-  const unsigned e_l = j < T ? 4u * x_l + (BIAS ? T4 : 0u) : OOB;           // its byte offset in the dS (and rel: score) slab; keys >= T: none
+  const unsigned e_l = j < T ? 4u * x_l + (BIAS ? T4 : 0u) : OOB;           // its byte offset in the dS slab; keys >= T: none
 
   float Kf[RES ? DH / 2 : 1], Vf[RES ? DH / 2 : 1];
   if (RES) {
@@ -340,14 +388,40 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
     bld16(rQ, qa_l + (unsigned)(q_lo * 32) * ldq4, qa[0]);
     if (!RES) load16(Kr, kb[0]);
   }
-  // position scores of a (query tile, this wave's keys) block: register r <-> query row it0 + rowmap(r, h), lane <-> key (coalesced rows);
-  // same slab offsets as the dS stores below; keys >= T and rows past the slab come back as 0 from the range check
-  auto load_bias_tile = [&](int it0, float (&dst)[16]) {
+  // rel: the two band blocks of a tile (B operands: lane <-> band row, k-half h) and the QVsel rows (A operands) are fetched while the
+  // previous tile's dV / dK MFMAs run and are dead after the G MFMAs (held longer they would push the kernel out of 2 waves per SIMD)
+  float pb[2][BIAS ? DH / 2 : 1], qva[BIAS ? DH / 2 : 1];
+  auto load_band = [&](int xb, float (&dst)[BIAS ? DH / 2 : 1]) {
+    const int x = xb + l31;
+    const int prow = x <= T - 1 ? x : x - T - 1;
+    const unsigned off = (x < 0 || x == T) ? OOB : (unsigned)prow * ldp4 + 64u * h;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[r] = bld(rPS, e_l + (unsigned)(it0 + rowmap(r, 0)) * T4);
+    for (int c = 0; c < NC; ++c) {
+      float t[16];
+      bld16(rP, off + 128u * c, t);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dst[BIAS ? 16 * c + q : 0] = t[q];
+    }
   };
+  auto load_qv = [&](int row0) {        // A operand rows row0 + l31 (past the end: 0)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float t[16];
+      bld16(rQV, qva_l + (unsigned)row0 * ldqv4 + 128u * c, t);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) qva[BIAS ? 16 * c + q : 0] = t[q];
+    }
+  };
+  auto band_upper = [&](int xb) -> int { return xb + 31 <= T - 1 ? 0 : 1; };     // a block lies wholly on one side of x = T
+  auto load_rel_operands = [&](int it0) {
+    const int x0 = j0 - it0 + T - 32;
+    load_band(x0, pb[0]);
+    load_band(x0 + 32, pb[1]);
+    load_qv(it0 + band_upper(x0));
+  };
+  if (BIAS && q_lo < q_hi) load_rel_operands(q_lo * 32);
   float bias_n[16];
-  if (BIAS && q_lo < q_hi) load_bias_tile(q_lo * 32, bias_n);
+  const int skew_l = 31 - 4 * h + l31;                  // source lane of register r: (skew_l - rowmap(r,0)) & 31, same half
   for (int qt = q_lo; qt < q_hi; ++qt) {
     const int i0 = qt * 32;
     const unsigned s_q = (unsigned)i0 * ldq4, s_do = (unsigned)i0 * lddo4;
@@ -355,6 +429,31 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
     const int ia = min(i0 + l31, T - 1);
     const bool rowok = i0 + l31 < L;
     const float lse_l = lse[ia], D_l = Dz[ia];
+    // keep hipcc from hoisting the 16 per-register variants of each lane constant out of the loop (48 VGPRs -> spills): they are one
+    // v_add with a scalar away
+    unsigned e_i = e_l; uint32_t xk_i = xk_l; int skew_i = skew_l;
+    asm volatile("" : "+v"(e_i), "+v"(xk_i), "+v"(skew_i));
+    if (BIAS) {
+      // ---- position scores of this tile: G_t[i][mm] = QVsel_t[i] . Pt[x0 + 32t + mm]; element (i, j) is G[i][31 - (i-i0) + (j-j0)]:
+      // the source lane picks the block it has to supply, one rotation per register brings it to the key's lane
+      const int x0 = j0 - i0 + T - 32;
+      const int up0 = band_upper(x0), up1 = band_upper(x0 + 32);
+      floatx16 G0, G1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { G0[r] = 0.f; G1[r] = 0.f; }
+#pragma unroll
+      for (int q = 0; q < DH / 2; ++q) G0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qva[BIAS ? q : 0], pb[0][BIAS ? q : 0], G0, 0, 0, 0);
+      if (up1 != up0) load_qv(i0 + up1);                // the one tile per wave that straddles x = T (uniform branch)
+#pragma unroll
+      for (int q = 0; q < DH / 2; ++q) G1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qva[BIAS ? q : 0], pb[1][BIAS ? q : 0], G1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rm0 = rowmap(r, 0);
+        const float v = (l31 + 4 * h >= 31 - rm0) ? G0[r] : G1[r];
+        const int src = ((skew_i - rm0) & 31) | (h << 5);
+        bias_n[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v)));
+      }
+    }
     // ---- S[i][j] = sum_k Q[i][k] K[j][k]
     floatx16 S, dP;
 #pragma unroll
@@ -377,18 +476,12 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
       }
       CTTS_SCHED_FENCE();
     }
-    // S[i][j] += -lse_i / sl2  - BIG * [row i or key j masked]   ->   P = exp2(sl2 * (S + bias)) needs no selects;  Dbc[i][j] = D_i
-    floatx16 Dbc;
-    {
-      const float a_aug = (h == 0 && rowok) ? -lse_l * inv_sl2 : -BIG;
-      const float a_d = (h == 0 && rowok) ? D_l : 0.f;
-      floatx16 zero;
+    // S[i][j] += -lse_i / sl2  - BIG * [row i or key j masked]   ->   P = exp2(sl2 * (S + bias)) needs no selects
+    S = __builtin_amdgcn_mfma_f32_32x32x2f32((h == 0 && rowok) ? -lse_l * inv_sl2 : -BIG, b_aug, S, 0, 0, 0);
+    if (BIAS) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-      S = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, S, 0, 0, 0);
-      Dbc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_d, b_one, zero, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) S[r] += bias_n[r];
     }
-    // (`bias_n` holds this tile's position scores, fetched one query tile ago)
     // ---- dPd[i][j] = sum_k dO[i][k] V[j][k]
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -412,22 +505,25 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
       }
       CTTS_SCHED_FENCE();
     }
-    // ---- P = exp2(sl2 * (S + bias)),  Pd = P*keep/(1-p),  dS = scale * P * (dPd*keep/(1-p) - D)
-    floatx16 Pd, dSv;
+    // ---- P = exp2(sl2 * (S + bias)),  Pd = P*keep/(1-p),  dS = scale * P * (dPd*keep/(1-p) - D);  Dbc[i][j] = D_i via one MFMA step
+    floatx16 Pd, dSv, Dbc;
+    {
+      floatx16 zero;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+      Dbc = __builtin_amdgcn_mfma_f32_32x32x2f32((h == 0 && rowok) ? D_l : 0.f, b_one, zero, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int sc = i0 + rowmap(r, 0);                 // uniform: the h = 0 half's query row of register r
-      float s = S[r];
-      if (BIAS) s += bias_n[r];
-      const float p = fast_exp2(s * sl2);
+      const float p = fast_exp2(S[r] * sl2);
       float ks = 1.f;
-      if (do_drop) ks = drop_scale_pre(xk_l + (zTT + (uint32_t)sc * (uint32_t)T) * DROP_G, dthr, inv_keep);
+      if (do_drop) ks = drop_scale_pre(xk_i + (zTT + (uint32_t)sc * (uint32_t)T) * DROP_G, dthr, inv_keep);
       const float ds = p * (dP[r] * ks - Dbc[r]) * d.scale;
       Pd[r] = p * ks;
       dSv[r] = ds;
-      bst(rdS, e_l + (unsigned)sc * T4, ds);             // masked rows / keys inside the slab receive their exact value 0
+      bst(rdS, e_i + (unsigned)sc * T4, ds);             // masked rows / keys inside the slab receive their exact value 0
     }
-    if (BIAS) load_bias_tile(i0 + 32, bias_n);          // next tile's scores: three MFMA blocks of cover
     // ---- dV^T[d][j] += sum_i dO[i][d] Pd[i][j],  dK^T[d][j] += sum_i Q[i][d] dS[i][j]
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -441,6 +537,7 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
       } else {                          // next query tile's first S operands (rows past the end read as 0)
         bld16(rQ, qa_l + s_q + 32u * ldq4, qa[0]);
         if (!RES) load16(Kr, kb[0]);
+        if (BIAS) load_rel_operands(i0 + 32);
       }
       CTTS_SCHED_FENCE();
 #pragma unroll
@@ -596,40 +693,30 @@ int pad_zero(float* p, long outer, long outer_stride, int inner, int inner_strid
 }
 }  // namespace
 
-extern "C" int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv, const float* pos, float* ps, float* out, float* lse,
+extern "C" int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv, const float* pos, float* out, float* lse,
                                int B, int T, int H, int C, float scale, float p_drop, const uint64_t* seed, uint32_t drop_offset,
                                void* stream) {
-  CTTS_REQUIRE(qu && qv && kv && pos && ps && out && lse && B > 0 && T > 0, "ctts_relmha_fwd: bad arguments");
-  CTTS_REQUIRE(ctts_mha_supported(C, H) && al16(qu) && al16(kv) && al16(out), "ctts_relmha_fwd: needs d_head in {32,64,128} and 16-byte aligned tensors");
+  CTTS_REQUIRE(qu && qv && kv && pos && out && lse && B > 0 && T > 0, "ctts_relmha_fwd: bad arguments");
+  CTTS_REQUIRE(ctts_mha_supported(C, H) && al16(qu) && al16(qv) && al16(kv) && al16(pos) && al16(out),
+               "ctts_relmha_fwd: needs d_head in {32,64,128} and 16-byte aligned tensors");
   CTTS_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "ctts_relmha_fwd: p_drop out of range");
   if (relmha_check_sizes(B, T, H, C, "ctts_relmha_fwd")) return -1;
-  const int dh = C / H;
-  const long slab = (long)T * (T + 1);
-  // padded[b,h] = [0 | (q + v_bias)[b,:,h] pos[:,h]^T]   (conformer.py:405-407, 423-427): the GEMM writes rows of T+1 behind the zero column
-  int rc = pad_zero(ps, (long)B * H * T, T + 1, 1, 1, (hipStream_t)stream);
-  if (rc) return rc;
-  ctts_gemm_desc g = {};
-  g.A = qv; g.B = pos; g.C = ps + 1;
-  g.M = T; g.N = T; g.K = dh; g.lda = C; g.ldb = C; g.ldc = T + 1; g.a_kc = 1; g.b_kc = 1;
-  g.nb0 = B; g.nb1 = H; g.sA0 = (long)T * C; g.sA1 = dh; g.sB0 = 0; g.sB1 = dh; g.sC0 = (long)H * slab; g.sC1 = slab;
-  g.alpha = 1.f; g.split_k = 1;
-  rc = ctts_gemm(&g, stream);
-  if (rc) return rc;
   AttnArgs a = {};
   a.q = qu; a.ldq = C; a.sq = (long)T * C;
   a.k = kv; a.v = kv + C; a.ldk = a.ldv = 2L * C; a.sk = a.sv = (long)T * 2 * C;
-  a.out = out; a.ldo = C; a.so = (long)T * C; a.lse = lse; a.bias = ps;
+  a.out = out; a.ldo = C; a.so = (long)T * C; a.lse = lse;
+  a.qv = qv; a.ldqv = C; a.sqv = (long)T * C; a.pos = pos; a.ldpos = C;
   a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.drop_offset = drop_offset;
-  return launch_fwd<true>(a, dh, (hipStream_t)stream);
+  return launch_fwd<true>(a, C / H, (hipStream_t)stream);
 }
 
-extern "C" int ctts_relmha_bwd(const float* qu, const float* qv, const float* kv, const float* pos, const float* ps, const float* out,
+extern "C" int ctts_relmha_bwd(const float* qu, const float* qv, const float* kv, const float* pos, const float* out,
                                const float* dout, const float* lse, float* Dws, float* dS, float* dqu, float* dqv, float* dkv,
                                float* dpos_b, int B, int T, int H, int C, float scale, float p_drop, const uint64_t* seed,
                                uint32_t drop_offset, void* stream) {
-  CTTS_REQUIRE(qu && qv && kv && pos && ps && out && dout && lse && Dws && dS && dqu && dqv && dkv && dpos_b && B > 0 && T > 0,
+  CTTS_REQUIRE(qu && qv && kv && pos && out && dout && lse && Dws && dS && dqu && dqv && dkv && dpos_b && B > 0 && T > 0,
                "ctts_relmha_bwd: bad arguments");
-  CTTS_REQUIRE(ctts_mha_supported(C, H) && al16(qu) && al16(kv) && al16(dout) && al16(dkv), "ctts_relmha_bwd: needs d_head in {32,64,128} and 16-byte aligned tensors");
+  CTTS_REQUIRE(ctts_mha_supported(C, H) && al16(qu) && al16(qv) && al16(kv) && al16(pos) && al16(dout) && al16(dkv), "ctts_relmha_bwd: needs d_head in {32,64,128} and 16-byte aligned tensors");
   if (relmha_check_sizes(B, T, H, C, "ctts_relmha_bwd")) return -1;
   hipStream_t st = (hipStream_t)stream;
   const int dh = C / H;
@@ -641,7 +728,8 @@ extern "C" int ctts_relmha_bwd(const float* qu, const float* qv, const float* kv
   AttnArgs a = {};
   a.q = qu; a.ldq = C; a.sq = (long)T * C;
   a.k = kv; a.v = kv + C; a.ldk = a.ldv = 2L * C; a.sk = a.sv = (long)T * 2 * C;
-  a.lse = const_cast<float*>(lse); a.bias = ps;
+  a.lse = const_cast<float*>(lse);
+  a.qv = qv; a.ldqv = C; a.sqv = (long)T * C; a.pos = pos; a.ldpos = C;
   a.B = B; a.H = H; a.T = T; a.scale = scale; a.p_drop = p_drop; a.seed = seed; a.drop_offset = drop_offset;
   a.dout = dout; a.lddo = C; a.sdo = (long)T * C; a.D = Dws;
   a.dk = dkv; a.dv = dkv + C; a.lddk = a.lddv = 2L * C; a.sdk = a.sdv = (long)T * 2 * C;

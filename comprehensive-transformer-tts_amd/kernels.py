@@ -565,29 +565,28 @@ def mha_bwd(qkv, lens, out, dout, lse, n_heads, scale, q_split=1):
 
 
 def relmha_fwd(qu, qv, kv, pos, n_heads, scale, p_drop=0.0, seed=None, drop_offset=0):
-    """-> (out [B,T,C], lse [B,H,T], ps [B,H,T,T+1] position scores in the reference's `padded` layout, kept for the backward)"""
+    """-> (out [B,T,C], lse [B,H,T])"""
     B, T, Cc = qu.shape
     dev = qu.device
     lib = _lib.load()
-    ps = torch.empty(lib.ctts_relmha_workspace_floats(B, T, n_heads), dtype=torch.float32, device=dev).view(B, n_heads, T, T + 1)
     out = torch.empty(B, T, Cc, dtype=torch.float32, device=dev)
     lse = torch.empty(B, n_heads, T, dtype=torch.float32, device=dev)
-    _lib.check(lib.ctts_relmha_fwd(_p(_f32c(qu, "qu")), _p(_f32c(qv, "qv")), _p(_f32c(kv, "kv")), _p(_f32c(pos, "pos")), _p(ps), _p(out),
+    _lib.check(lib.ctts_relmha_fwd(_p(_f32c(qu, "qu")), _p(_f32c(qv, "qv")), _p(_f32c(kv, "kv")), _p(_f32c(pos, "pos")), _p(out),
                                    _p(lse), B, T, n_heads, Cc, float(scale), float(p_drop), _p(seed), int(drop_offset), _stream()),
                "ctts_relmha_fwd")
-    return out, lse, ps
+    return out, lse
 
 
-def relmha_bwd(qu, qv, kv, pos, ps, out, dout, lse, n_heads, scale, p_drop=0.0, seed=None, drop_offset=0):
+def relmha_bwd(qu, qv, kv, pos, out, dout, lse, n_heads, scale, p_drop=0.0, seed=None, drop_offset=0):
     """-> (dqu, dqv [B,T,C], dkv [B,T,2C], dpos_b [B,T,C])"""
     B, T, Cc = qu.shape
     dev = qu.device
+    lib = _lib.load()
     Dws = torch.empty(B, n_heads, T, dtype=torch.float32, device=dev)
-    dS = torch.empty(_lib.load().ctts_relmha_workspace_floats(B, T, n_heads), dtype=torch.float32, device=dev)
+    dS = torch.empty(lib.ctts_relmha_workspace_floats(B, T, n_heads), dtype=torch.float32, device=dev)
     dqu, dqv, dkv = torch.empty_like(qu), torch.empty_like(qv), torch.empty_like(kv)
     dpos_b = torch.empty(B, T, Cc, dtype=torch.float32, device=dev)
-    lib = _lib.load()
-    _lib.check(lib.ctts_relmha_bwd(_p(qu), _p(qv), _p(kv), _p(pos), _p(ps), _p(_f32c(out, "out")), _p(_f32c(dout, "dout")), _p(lse), _p(Dws),
+    _lib.check(lib.ctts_relmha_bwd(_p(qu), _p(qv), _p(kv), _p(pos), _p(_f32c(out, "out")), _p(_f32c(dout, "dout")), _p(lse), _p(Dws),
                                    _p(dS), _p(dqu), _p(dqv), _p(dkv), _p(dpos_b), B, T, n_heads, Cc, float(scale), float(p_drop),
                                    _p(seed), int(drop_offset), _stream()), "ctts_relmha_bwd")
     return dqu, dqv, dkv, dpos_b

@@ -763,24 +763,24 @@ class _RelPosAttention(torch.autograd.Function):
 
 
 class _FusedRelPosAttention(torch.autograd.Function):
-    """_RelPosAttention on csrc/attn.hip: only the unshifted position scores PS = qv pos^T (and, in the backward, dS in the two
-    layouts the remaining GEMMs read) exist as [B,H,T,T] tensors; the shifted scores, the probabilities and the dropped
-    probabilities - 5 of the 7 maps of the unfused pipeline, each 512 MB per decoder layer at B=16, T=1000 - never reach HBM.
+    """_RelPosAttention on csrc/attn.hip: the position scores are computed inside the kernels (the reference's pad-and-reshape shift,
+    conformer.py:423-431, in closed form); the only [B,H,T,T]-sized tensor left is dS in the backward, written once in the layout
+    the three remaining GEMMs read it in.  The unfused pipeline moves 7 such maps, each 512 MB per decoder layer at B=16, T=1000.
     Same counter-RNG element indices as the unfused path, so both draw identical dropout masks."""
 
     @staticmethod
     def forward(ctx, qu, qv, kv, pos, n_heads, scale, p_drop, seed, drop_offset):
         qu, qv, kv, pos = qu.contiguous(), qv.contiguous(), kv.contiguous(), pos.contiguous()
-        out, lse, ps = K.relmha_fwd(qu, qv, kv, pos, n_heads, scale, p_drop, seed, drop_offset)
-        ctx.save_for_backward(qu, qv, kv, pos, ps, out, lse, seed)
+        out, lse = K.relmha_fwd(qu, qv, kv, pos, n_heads, scale, p_drop, seed, drop_offset)
+        ctx.save_for_backward(qu, qv, kv, pos, out, lse, seed)
         ctx.cfg = (n_heads, scale, p_drop, drop_offset)
         return out
 
     @staticmethod
     def backward(ctx, dO):
-        qu, qv, kv, pos, ps, out, lse, seed = ctx.saved_tensors
+        qu, qv, kv, pos, out, lse, seed = ctx.saved_tensors
         H, scale, p_drop, drop_offset = ctx.cfg
-        dqu, dqv, dkv, dpos_b = K.relmha_bwd(qu, qv, kv, pos, ps, out, dO.contiguous(), lse, H, scale, p_drop, seed, drop_offset)
+        dqu, dqv, dkv, dpos_b = K.relmha_bwd(qu, qv, kv, pos, out, dO.contiguous(), lse, H, scale, p_drop, seed, drop_offset)
         return dqu, dqv, dkv, dpos_b.sum(0), None, None, None, None, None
 
 

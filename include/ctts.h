@@ -294,21 +294,20 @@ int ctts_mel_spectrogram(const float* y, const int32_t* lens, const float* windo
  * ctts_relmha_fwd / ctts_relmha_bwd: the core of RelativeMultiHeadAttention (conformer.py:396-421) on channel-last projections:
  *   qu = q + u_bias, qv = q + v_bias [B,T,C]; kv [B,T,2C] (k | v); pos [T,C] = pos_proj(sinusoid rows) shared by the batch;
  *   score = (qu k^T + shift(qv pos^T)) * scale, softmax over ALL keys (the reference passes no mask, conformer.py:243),
- *   dropout(p_drop) on the probabilities (counter RNG: seed, drop_offset as in ctts_gemm), context = P v.
- *   ps (ctts_relmha_workspace_floats(B,T,H) = B*H*T*(T+1) floats) receives the position scores in the layout of the reference's
- *   `padded` tensor (conformer.py:423-431): per (b,h) T rows of T+1 = [0 | qv pos^T row]; the Transformer-XL shift is the reference's
- *   own reinterpretation of that memory, shifted[i][j] = slab[(i+1)*T + j].  Keep ps for the backward.
- *   bwd: Dws [B,H,T] and dS (again ctts_relmha_workspace_floats floats: d loss / d score in the same slab layout, whose padded view
- *   is the gradient of the unshifted scores) are scratch; outputs dqu, dqv [B,T,C], dkv [B,T,2C] and dpos_b [B,T,C] = per-utterance
- *   gradient of pos (the caller sums it over B). */
+ *   dropout(p_drop) on the probabilities (counter RNG: seed, drop_offset as in ctts_gemm), context = P v.  shift() is the
+ *   Transformer-XL memory reinterpretation of conformer.py:423-431; the kernels evaluate it in closed form (no [B,H,T,T] score
+ *   tensor exists, nothing but out and lse [B,H,T] has to be kept for the backward).
+ *   bwd: Dws [B,H,T] and dS (ctts_relmha_workspace_floats(B,T,H) = B*H*T*(T+1) floats: d loss / d score in the layout of the
+ *   reference's `padded` tensor, so that the gradient of the unshifted scores is a view of the same memory) are scratch; outputs
+ *   dqu, dqv [B,T,C], dkv [B,T,2C] and dpos_b [B,T,C] = per-utterance gradient of pos (the caller sums it over B). */
 int ctts_mha_supported(int C, int H);
 int ctts_mha_fwd(const float* qkv, const int32_t* lens, float* out, float* lse, int B, int T, int H, int C, float scale, void* stream);
 int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* out, const float* dout, const float* lse, float* Dws, float* dS,
                  float* kv_part, float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* stream);
 size_t ctts_relmha_workspace_floats(int B, int T, int H);
-int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv, const float* pos, float* ps, float* out, float* lse, int B, int T,
+int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv, const float* pos, float* out, float* lse, int B, int T,
                     int H, int C, float scale, float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream);
-int ctts_relmha_bwd(const float* qu, const float* qv, const float* kv, const float* pos, const float* ps, const float* out,
+int ctts_relmha_bwd(const float* qu, const float* qv, const float* kv, const float* pos, const float* out,
                     const float* dout, const float* lse, float* Dws, float* dS, float* dqu, float* dqv, float* dkv,
                     float* dpos_b, int B, int T, int H, int C, float scale, float p_drop, const uint64_t* seed, uint32_t drop_offset,
                     void* stream);
