@@ -449,7 +449,8 @@ def test_swish_linear_glu_depthwise_fwd_bwd():
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("B,T,H,C", [(2, 36, 8, 256), (2, 51, 8, 256), (1, 132, 4, 128), (2, 200, 8, 256), (1, 64, 2, 256)])
+@pytest.mark.parametrize("B,T,H,C", [(2, 36, 8, 256), (2, 51, 8, 256), (1, 132, 4, 128), (2, 200, 8, 256), (1, 64, 2, 256), (2, 9, 8, 256),
+                                     (2, 1, 8, 256), (1, 33, 4, 256)])
 def test_relpos_attention_fwd_bwd(B, T, H, C, fused):
     ops.set_fused_attention(fused)
     dh = C // H

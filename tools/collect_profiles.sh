@@ -38,4 +38,17 @@ for w in ffn1_step dgrad wgrad; do
     grep TFLOP /tmp/pmc.log >> $OUT/${R}_pmc_traffic_gemm_shapes.md
   done
 done
-ls -la $OUT | grep ${R}_ | head -40
+# SQ counters (two passes each: they do not fit one) of the fused attention kernels and of the dominant GEMM as the step launches it
+P1="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"
+P2="SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS"
+for job in "attention:bench_attn.py conformer --fused-only:attn_" "gemm:bench_one.py ffn1_step 10:gemm_buf"; do
+  n=${job%%:*}; rest=${job#*:}; cmd=${rest%%:*}; pat=${rest#*:}
+  : > $OUT/${R}_pmc_sq_$n.md
+  for P in "$P1" "$P2"; do
+    rm -rf /tmp/pmc; timeout 200 rocprofv3 --kernel-trace --pmc $P -d /tmp/pmc -- python $ROOT/tools/$cmd > /tmp/pmc.log 2>&1
+    python $ROOT/tools/rocpd_pmc_summary.py $(find /tmp/pmc -name "*results.db" | head -1) 2>&1 < /dev/null | grep -E "^\| kernel|$pat" | cut -c1-400 >> $OUT/${R}_pmc_sq_$n.md
+  done
+done
+# does a wave's VALU work overlap with its own (or a co-resident wave's) fp32 MFMAs?  (it does not: tools/ubench/mfma_valu.hip)
+timeout 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_valu $ROOT/tools/ubench/mfma_valu.hip > /dev/null 2>&1 && timeout 60 /tmp/mfma_valu > $OUT/${R}_ubench_mfma_valu.txt 2>&1
+ls -la $OUT | grep ${R}_ | head -60
