@@ -257,55 +257,36 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsign
   return *reinterpret_cast<float4*>(&v);
 }
 
-// fp32 MFMA runs on the SIMD's VALU datapath on gfx950 (tools/ubench/mfma_valu.hip: 16 MFMAs + 512 v_fma take the SUM of their times,
-// from one wave or from two): every VALU instruction in the K loop is taken out of the matrix rate.  The loaders therefore keep the
-// per-block address work at ONE v_add per 16-byte chunk whenever the tile is "interior" (no im2col row of the tile touches an
-// utterance boundary, no K tail, no per-batch limits) and fall back to a window compare (no integer division in the loop) otherwise.
 template <int ROWS, bool CONV, bool PARTIAL>
 struct BLoaderKC {
   static constexpr int NV = ROWS * BK / 4 / 256;
   unsigned boff[NV];      // byte offset of (row, kq) relative to the descriptor base, or CTTS_OOB
-  int kbase[NV];          // window start of the chunk's row minus kq:  gk - klo = k0 - kbase
-  unsigned kspan[NV];     // window length khi - klo (0: row out of range); conv: the taps that stay inside the row's utterance
-  int kq, tid;
-  bool fast;              // uniform: every chunk of every K block is valid or statically out of range
+  int trow[NV];
+  int kq, tid, T, cin, pad;
   int nk_cur;             // PARTIAL: valid elements of this thread's chunk in the staged K-block (same for all rows)
-  __device__ void init(long ld, int row0, int row_lim, ConvView cv, int tid_, int k_begin, int k_end) {
-    tid = tid_;
+  __device__ void init(long ld, int row0, int row_lim, ConvView cv, int tid_) {
+    tid = tid_; T = cv.T; cin = cv.cin; pad = cv.pad;
     kq = (tid % KCH) << 2;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int gr = row0 + ((tid + i * 256) / KCH);
       const long e = (long)(CONV ? gr - cv.pad : gr) * ld + kq;      // conv: im2col row starts pad rows earlier
-      const bool valid = gr < row_lim;
-      boff[i] = valid ? (unsigned)(e * 4) : CTTS_OOB;
-      int klo = 0, khi = k_end;
-      if (CONV) {
-        const int t = gr % cv.T;
-        klo = max(0, cv.pad - t) * cv.cin;
-        khi = min(k_end, (cv.T + cv.pad - t) * cv.cin);
-      }
-      kbase[i] = klo - kq;
-      kspan[i] = (valid && khi > klo) ? (unsigned)(khi - klo) : 0u;
+      boff[i] = gr < row_lim ? (unsigned)(e * 4) : CTTS_OOB;
+      trow[i] = CONV ? gr % cv.T : 0;
     }
     nk_cur = 4;
-    fast = !PARTIAL && ((k_end - k_begin) % BK) == 0;
-    if (CONV) {
-      const int t0 = row0 % cv.T;
-      fast = fast && t0 >= cv.pad && t0 + ROWS - 1 + cv.pad < cv.T;
-    }
   }
-  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int k0, int k_end, float4 (&r)[NV], bool /*interior: see BLoaderRC*/) {
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int k0, int k_end, float4 (&r)[NV]) {
+    const int gk = k0 + kq;
+    const bool kok = gk < k_end;                       // K tail: chunk fully masked, or (PARTIAL) cut at k_end
+    if (PARTIAL) nk_cur = min(4, k_end - gk);
     const unsigned koff = (unsigned)k0 * 4u;
-    if (fast) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) r[i] = buf_load16(rsrc, boff[i] + koff);    // CTTS_OOB + koff stays out of range
-      return;
-    }
-    if (PARTIAL) nk_cur = min(4, k_end - (k0 + kq));      // K tail: chunk cut at k_end
+    int tap = 0;
+    if (CONV) tap = gk / cin - pad;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const bool ok = (unsigned)(k0 - kbase[i]) < kspan[i];
+      bool ok = kok && (boff[i] != CTTS_OOB);
+      if (CONV) ok = ok && ((unsigned)(trow[i] + tap) < (unsigned)T);
       const unsigned off = ok ? boff[i] + koff : CTTS_OOB;   // select LAST: a wrapped (negative) boff plus an offset must never look valid
       r[i] = buf_load16(rsrc, off);
     }
@@ -328,7 +309,7 @@ struct BLoaderRC {
   unsigned ldb4;          // row stride in bytes
   int tid, T;
   int ncol[NV];           // PARTIAL: valid elements of the chunk along the contiguous dim (loop invariant)
-  __device__ void init(long ld, int col0, int col_lim, ConvView cv, int tid_, int, int) {
+  __device__ void init(long ld, int col0, int col_lim, ConvView cv, int tid_) {
     tid = tid_; T = cv.T; ldb4 = (unsigned)(ld * 4);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -341,14 +322,8 @@ struct BLoaderRC {
       ncol[i] = PARTIAL ? min(4, col_lim - gc) : 4;
     }
   }
-  // `interior` (uniform): all BK rows of this block lie below k_end and (conv) far enough inside one utterance for every tap
-  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int k0, int k_end, float4 (&r)[NV], bool interior) const {
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int k0, int k_end, float4 (&r)[NV]) const {
     const unsigned k0off = (unsigned)k0 * ldb4;
-    if (interior) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) r[i] = buf_load16(rsrc, boff[i] + k0off);
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int gk = k0 + (tid + i * 256) / (COLS / 4);
@@ -704,8 +679,8 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   using LA = typename BLoaderSel<A_KC, BM, CONV_A, PARTIAL>::type;
   using LB = typename BLoaderSel<B_KC, BN, CONV_B, PARTIAL>::type;
   LA la; LB lb;
-  la.init(d.lda, row0, Mv, CONV_A ? cv : nocv, threadIdx.x, k_begin, k_end);
-  lb.init(d.ldb, col0, Nv, CONV_B ? cv : nocv, threadIdx.x, k_begin, k_end);
+  la.init(d.lda, row0, Mv, CONV_A ? cv : nocv, threadIdx.x);
+  lb.init(d.ldb, col0, Nv, CONV_B ? cv : nocv, threadIdx.x);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -725,20 +700,11 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
     const int b0 = k0 / d.row_T;
     return !(b0 == lastk / d.row_T && (k0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo);
   };
-  // row-contiguous operands: a K block is "interior" (one v_add per chunk, no masks) when all its BK rows lie below k_end and, for the
-  // im2col view of the weight gradient, far enough inside one utterance for every tap; k mod T is tracked on the SALU
-  int kt = CONV_B ? k_begin % cv.T : 0;
-  auto rc_interior = [&](int k) -> bool {
-    bool in = k + BK <= k_end;
-    if (CONV_B) in = in && kt >= cv.pad && kt + BK - 1 + cv.pad < cv.T;
-    return in;
-  };
   float4 ra[LA::NV], rb[LB::NV];
   bool act_cur = kblock_active(k_begin);
   if (act_cur) {
-    const bool in = rc_interior(k_begin);
-    la.load(ra_src, k_begin, k_end, ra, in);
-    lb.load(rb_src, k_begin, k_end, rb, in);
+    la.load(ra_src, k_begin, k_end, ra);
+    lb.load(rb_src, k_begin, k_end, rb);
     la.store(sA, ra);
     lb.store(sB, rb);
   }
@@ -746,14 +712,9 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     const bool has_next = (k0 + BK) < k_end;
     const bool act_next = has_next && kblock_active(k0 + BK);
-    if (CONV_B) {
-      kt += BK;
-      while (kt >= cv.T) kt -= cv.T;
-    }
     if (act_next) {
-      const bool in = rc_interior(k0 + BK);
-      la.load(ra_src, k0 + BK, k_end, ra, in);
-      lb.load(rb_src, k0 + BK, k_end, rb, in);
+      la.load(ra_src, k0 + BK, k_end, ra);
+      lb.load(rb_src, k0 + BK, k_end, rb);
     }
     if (act_cur) {
 #pragma unroll
