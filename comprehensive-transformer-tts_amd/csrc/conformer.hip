@@ -28,16 +28,22 @@ __global__ void glu_bwd_kernel(const float4* __restrict__ a, const float4* __res
   }
 }
 
-// depthwise conv: block = (C/4 lanes) x 4 time groups; each thread: 4 channels x DW_TT consecutive time steps,
-// weights [K][C] in LDS, inputs streamed once through a register window.
+// depthwise conv: block = (C/4 lanes) x 4 time groups; each thread: 4 channels x DW_TT consecutive time steps, weights [K][C] in LDS.
+// The DW_TT + K - 1 input rows a thread needs are fetched up front into registers (unconditional loads from clamped rows, masked
+// afterwards: nothing in the tap loop waits on memory), then one LDS weight read per tap feeds DW_TT FMAs on statically indexed rows.
 constexpr int DW_TT = 8;
+constexpr int DW_MAXTAPS = 32;
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wT,
                                                           float* __restrict__ y, int T, int C, int K, int flip) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];   // [K][C]
   const int C4 = C >> 2;
-  for (int e = threadIdx.x; e < K * C; e += blockDim.x) {
-    const int k = e / C, c = e - k * C;
-    s_w[e] = wT[(flip ? (K - 1 - k) : k) * C + c];
+  {
+    const float4* w4 = reinterpret_cast<const float4*>(wT);
+    float4* s4 = reinterpret_cast<float4*>(s_w);
+    for (int e = threadIdx.x; e < K * C4; e += blockDim.x) {
+      const int k = e / C4, c = e - k * C4;
+      s4[e] = w4[(flip ? (K - 1 - k) : k) * C4 + c];
+    }
   }
   __syncthreads();
   const int pad = (K - 1) / 2;
@@ -47,26 +53,32 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
   const int tg = threadIdx.x / C4, c4 = threadIdx.x - tg * C4;
   const int t0 = (blockIdx.x * groups_per_block + tg) * DW_TT;
   if (tg >= groups_per_block || t0 >= T) return;
-  const float4* xb = reinterpret_cast<const float4*>(x + (long)b * T * C);
+  const float4* xb = reinterpret_cast<const float4*>(x + (long)b * T * C) + c4;
+  float4 xr[DW_TT + DW_MAXTAPS - 1];            // input rows t0 - pad .. t0 + DW_TT - 1 + (K - 1 - pad)
+#pragma unroll
+  for (int i = 0; i < DW_TT + DW_MAXTAPS - 1; ++i) {
+    const int u = t0 - pad + i;
+    const bool ok = i < DW_TT + K - 1 && u >= 0 && u < T;
+    const float4 v = xb[(long)min(max(u, 0), T - 1) * C4];
+    xr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float4 acc[DW_TT];
 #pragma unroll
   for (int j = 0; j < DW_TT; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int u = t0 - pad; u < t0 + DW_TT + pad; ++u) {
-    if (u < 0 || u >= T) continue;
-    const float4 xv = xb[(long)u * C4 + c4];
 #pragma unroll
-    for (int j = 0; j < DW_TT; ++j) {
-      const int k = u - (t0 + j) + pad;
-      if (k >= 0 && k < K) {
-        const float4 w = *reinterpret_cast<const float4*>(s_w + k * C + c4 * 4);
-        acc[j].x += w.x * xv.x; acc[j].y += w.y * xv.y; acc[j].z += w.z * xv.z; acc[j].w += w.w * xv.w;
+  for (int k = 0; k < DW_MAXTAPS; ++k) {
+    if (k < K) {                                  // uniform
+      const float4 w = *reinterpret_cast<const float4*>(s_w + k * C + c4 * 4);
+#pragma unroll
+      for (int j = 0; j < DW_TT; ++j) {           // y[t0+j] += w[k] * x[t0+j + k - pad]
+        acc[j].x += w.x * xr[j + k].x; acc[j].y += w.y * xr[j + k].y; acc[j].z += w.z * xr[j + k].z; acc[j].w += w.w * xr[j + k].w;
       }
     }
   }
-  float4* yb = reinterpret_cast<float4*>(y + (long)b * T * C);
+  float4* yb = reinterpret_cast<float4*>(y + (long)b * T * C) + c4;
 #pragma unroll
   for (int j = 0; j < DW_TT; ++j)
-    if (t0 + j < T) yb[(long)(t0 + j) * C4 + c4] = acc[j];
+    if (t0 + j < T) yb[(long)(t0 + j) * C4] = acc[j];
 }
 
 // dw[c,k] = sum_{b,t} dy[b,t,c] x[b,t+k-pad,c].  Thread = channel; a workgroup walks a SLICE of (utterance, 32-row chunk) pairs and keeps
@@ -218,7 +230,8 @@ extern "C" int ctts_glu_bwd(const float* a, const float* dout, float* da, int64_
 }
 
 extern "C" int ctts_dwconv_fwd(const float* x, const float* wT, float* y, int B, int T, int C, int K, int flip, void* stream) {
-  CTTS_REQUIRE(x && wT && y && (C % 4) == 0 && C >= 4 && C <= 1024 && (K & 1) && K >= 1, "ctts_dwconv_fwd: need C %% 4 == 0, C <= 1024, odd K");
+  CTTS_REQUIRE(x && wT && y && (C % 4) == 0 && C >= 4 && C <= 1024 && (K & 1) && K >= 1 && K <= DW_MAXTAPS,
+               "ctts_dwconv_fwd: need C %% 4 == 0, C <= 1024, odd K <= 32");
   CTTS_REQUIRE((size_t)K * C * 4 <= 64 * 1024, "ctts_dwconv_fwd: K*C weights do not fit the LDS staging buffer");
   if (B == 0 || T == 0) return 0;
   const int C4 = C / 4;
