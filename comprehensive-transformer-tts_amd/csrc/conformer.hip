@@ -129,9 +129,19 @@ __global__ void dwconv_wgrad_reduce_kernel(const float* __restrict__ partials, f
   if (e >= C * DW_MAXK) return;
   const int c = e / DW_MAXK, k = e - c * DW_MAXK;
   if (k >= K) return;
-  float s = 0.f;
-  for (int sl = 0; sl < n_slices; ++sl) s += partials[(long)sl * C * DW_MAXK + e];
-  dw[(long)c * K + k] = s;
+  // fixed association (4 interleaved chains, then a fixed tree): deterministic, and 8 loads in flight instead of one
+  const long st = (long)C * DW_MAXK;
+  const float* p = partials + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int sl = 0;
+  for (; sl + 8 <= n_slices; sl += 8) {
+    const float a0 = p[(sl + 0) * st], a1 = p[(sl + 1) * st], a2 = p[(sl + 2) * st], a3 = p[(sl + 3) * st];
+    const float a4 = p[(sl + 4) * st], a5 = p[(sl + 5) * st], a6 = p[(sl + 6) * st], a7 = p[(sl + 7) * st];
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+  }
+  for (; sl < n_slices; ++sl) s0 += p[sl * st];
+  dw[(long)c * K + k] = (s0 + s1) + (s2 + s3);
 }
 
 // ---- relative-position scores: shifted[i,j] = padded.flat[i*T + j + T], padded = [0 | PS] rows of T+1  (conformer.py:423-431)
@@ -256,7 +266,7 @@ extern "C" int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, flo
   dim3 grid(slices, (C + 255) / 256);
   hipLaunchKernelGGL(dwconv_wgrad_kernel, grid, dim3(256), 0, st, dy, x, partials, B, T, C, K);
   CTTS_CHECK_LAUNCH("ctts_dwconv_wgrad");
-  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * DW_MAXK + 255) / 256), dim3(256), 0, st, partials, dw, C, K, slices);
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * DW_MAXK + 63) / 64), dim3(64), 0, st, partials, dw, C, K, slices);
   CTTS_CHECK_LAUNCH("ctts_dwconv_wgrad(reduce)");
   return 0;
 }

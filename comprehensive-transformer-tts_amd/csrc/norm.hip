@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// V float4 per lane per row (C <= 256 V), R rows per wave and loop iteration: with one row in flight a wave is bound by the latency of
+// its two row loads (16 iterations x ~1.3 us at [16384, 256]); R rows issue their loads back to back and reduce independently.
+template <int V, int R>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -69,71 +72,92 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                              float* __restrict__ dbeta, int rows, int C, float p_drop,
                                                              const uint64_t* seed, uint32_t drop_offset,
                                                              const float* __restrict__ rowscale, const float* __restrict__ dres) {
-  __shared__ float s_red[2][4][LN_MAXV * 64 * 4];
+  __shared__ float s_red[2][4][V * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
   const bool do_drop = p_drop > 0.f;
   uint32_t dkey = 0; float inv_keep = 1.f;
   if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
   const float invC = 1.f / (float)C;
-  float ag[LN_MAXV][4], ab[LN_MAXV][4];
+  float ag[V][4], ab[V][4];
+  float4 gv[V];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i)
+  for (int i = 0; i < V; ++i) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
-    const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * C);
-    const float mu = mean[row], rs = rstd[row];
-    const float sc = rowscale ? rowscale[row] : 1.f;
-    float xh[LN_MAXV][4], g[LN_MAXV][4];
-    float s1 = 0.f, s2 = 0.f;
+    const int c = lane + 64 * i;
+    gv[i] = c < nvec ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row0 = (blockIdx.x * 4 + wave) * R; row0 < rows; row0 += gridDim.x * 4 * R) {
+    float4 xv[R][V], dv[R][V];
+    float mu[R], rs[R], sc[R];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
-        const float4 xv = xr[c], dv = dr[c], gv = reinterpret_cast<const float4*>(gamma)[c];
-        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, da[4] = {dv.x, dv.y, dv.z, dv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+    for (int r = 0; r < R; ++r) {          // every load of the R rows first (rows past the end: row clamped, contribution masked)
+      const int row = min(row0 + r, rows - 1);
+      const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
+      const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * C);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const int c = min(lane + 64 * i, nvec - 1);
+        xv[r][i] = xr[c]; dv[r][i] = dr[c];
+      }
+      mu[r] = mean[row]; rs[r] = rstd[row];
+      sc[r] = (row0 + r < rows) ? (rowscale ? rowscale[row] : 1.f) : 0.f;
+    }
+    float xh[R][V][4], g[R][V][4], s1[R], s2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s1[r] = 0.f; s2[r] = 0.f;
+      const int row = row0 + r;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const int c = lane + 64 * i;
+        const bool live = c < nvec;
+        const float xa[4] = {xv[r][i].x, xv[r][i].y, xv[r][i].z, xv[r][i].w}, da[4] = {dv[r][i].x, dv[r][i].y, dv[r][i].z, dv[r][i].w};
+        const float ga[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float d = da[e] * sc;
+          float d = live ? da[e] * sc[r] : 0.f;
           if (do_drop) d *= ctts_drop_scale(dkey, (uint32_t)row * (uint32_t)C + (uint32_t)(c * 4 + e), p_drop, inv_keep);
-          xh[i][e] = (xa[e] - mu) * rs;
-          ag[i][e] += d * xh[i][e];
+          xh[r][i][e] = live ? (xa[e] - mu[r]) * rs[r] : 0.f;
+          ag[i][e] += d * xh[r][i][e];
           ab[i][e] += d;
-          g[i][e] = d * ga[e];
-          s1 += g[i][e];
-          s2 += g[i][e] * xh[i][e];
+          g[r][i][e] = d * ga[e];
+          s1[r] += g[r][i][e];
+          s2[r] += g[r][i][e] * xh[r][i][e];
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { xh[i][e] = 0.f; g[i][e] = 0.f; }
       }
     }
-    const float c1 = ctts_wave_sum(s1) * invC, c2 = ctts_wave_sum(s2) * invC;
-    float4* dxr = reinterpret_cast<float4*>(dx + (long)row * C);
-    const float4* rr = dres ? reinterpret_cast<const float4*>(dres + (long)row * C) : nullptr;   // gradient of the residual branch
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
-        float4 o = make_float4(rs * (g[i][0] - c1 - xh[i][0] * c2), rs * (g[i][1] - c1 - xh[i][1] * c2),
-                               rs * (g[i][2] - c1 - xh[i][2] * c2), rs * (g[i][3] - c1 - xh[i][3] * c2));
-        if (rr) { const float4 a = rr[c]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
-        dxr[c] = o;
+    for (int r = 0; r < R; ++r) {
+      const int row = row0 + r;
+      const float c1 = ctts_wave_sum(s1[r]) * invC, c2 = ctts_wave_sum(s2[r]) * invC;
+      if (row < rows) {
+        float4* dxr = reinterpret_cast<float4*>(dx + (long)row * C);
+        const float4* rr = dres ? reinterpret_cast<const float4*>(dres + (long)row * C) : nullptr;   // gradient of the residual branch
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const int c = lane + 64 * i;
+          if (c < nvec) {
+            float4 o = make_float4(rs[r] * (g[r][i][0] - c1 - xh[r][i][0] * c2), rs[r] * (g[r][i][1] - c1 - xh[r][i][1] * c2),
+                                   rs[r] * (g[r][i][2] - c1 - xh[r][i][2] * c2), rs[r] * (g[r][i][3] - c1 - xh[r][i][3] * c2));
+            if (rr) { const float4 a = rr[c]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+            dxr[c] = o;
+          }
+        }
       }
     }
   }
   // block reduce of the per-wave dgamma/dbeta partials, then one atomic per channel per block
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i)
+  for (int i = 0; i < V; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       s_red[0][wave][(i * 64 + lane) * 4 + e] = ag[i][e];
       s_red[1][wave][(i * 64 + lane) * 4 + e] = ab[i][e];
     }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < LN_MAXV * 64 * 4; idx += 256) {
+  for (int idx = threadIdx.x; idx < V * 64 * 4; idx += 256) {
     const int v = idx >> 2, e = idx & 3;  // v = i*64 + lane -> channel vector index = lane + 64*i
     const int cvec = (v & 63) + 64 * (v >> 6);
     if (cvec < nvec) {
@@ -306,8 +330,15 @@ extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* 
   if (rows == 0) return 0;
   static const int ln_blocks = getenv("CTTS_LN_BWD_BLOCKS") ? atoi(getenv("CTTS_LN_BWD_BLOCKS")) : 256;     // tuning knob
   const int blocks = min((rows + 3) / 4, ln_blocks);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
-                     C, p_drop, seed, drop_offset, rowscale, dres);
+  if (C <= 256)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<1, 4>), dim3(min((rows + 15) / 16, ln_blocks)), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx,
+                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres);
+  else if (C <= 512)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<2, 2>), dim3(min((rows + 7) / 8, ln_blocks)), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx,
+                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_kernel<4, 1>), dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
+                       C, p_drop, seed, drop_offset, rowscale, dres);
   CTTS_CHECK_LAUNCH("ctts_layernorm_bwd");
   return 0;
 }
