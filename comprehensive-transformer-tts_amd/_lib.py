@@ -77,6 +77,8 @@ _SIGNATURES = {
     "ctts_reflect_pad": [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_stft_magnitude": [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _vp],
     "ctts_log_clamp_transpose": [_vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],
+    "ctts_relattn_split_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp],
+    "ctts_relattn_split_bwd": [_vp, _vp, _vp, _vp, _i64, C.c_int, _vp],
     "ctts_glu_fwd": [_vp, _vp, _i64, C.c_int, _vp],
     "ctts_glu_bwd": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "ctts_dwconv_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],

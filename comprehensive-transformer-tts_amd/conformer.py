@@ -125,10 +125,9 @@ class ConformerBlock(nn.Module):
         h, xr = ops.layer_norm_res(x, m.layer_norm.weight, m.layer_norm.bias, 1e-5)
         w_qkv = torch.cat([at.query_proj.linear.weight, at.key_proj.linear.weight, at.value_proj.linear.weight], 0)
         qkv = ops.linear(h, w_qkv)                                       # one [768,256] GEMM for q | k | v
-        q, kv = qkv[..., :C], qkv[..., C:]
+        qu, qv, kv = ops.relattn_split(qkv, at.u_bias, at.v_bias)        # q + u_bias, q + v_bias, k | v in one pass
         pos = ops.linear(pos_table, at.pos_proj.linear.weight)           # [T,C], batch independent
-        ctxv = ops.relpos_attention(q + at.u_bias.reshape(1, 1, C), q + at.v_bias.reshape(1, 1, C), kv, pos, self.n_heads,
-                                    1.0 / math.sqrt(C), p_drop=p, drop=drop)
+        ctxv = ops.relpos_attention(qu, qv, kv, pos, self.n_heads, 1.0 / math.sqrt(C), p_drop=p, drop=drop)
         x = ops.linear(ctxv, at.out_proj.linear.weight, None, residual=xr, p_drop=p, drop=drop)
         # ---- convolution module
         s = getattr(seq, "2").module.sequential

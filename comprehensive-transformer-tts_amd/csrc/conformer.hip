@@ -271,6 +271,63 @@ extern "C" int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, flo
   return 0;
 }
 
+namespace {
+// RelativeMultiHeadAttention.forward's operand preparation (conformer.py:396-407) from the packed q | k | v projection [rows, 3C]:
+// qu = q + u_bias, qv = q + v_bias, kv = k | v - one pass over the projection instead of two broadcast adds and a slice copy
+__global__ void relattn_split_fwd_kernel(const float4* __restrict__ qkv, const float4* __restrict__ u, const float4* __restrict__ v,
+                                         float4* __restrict__ qu, float4* __restrict__ qv, float4* __restrict__ kv, long rows, int C4) {
+  const long total = rows * 3 * C4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / (3 * C4); const int c = (int)(e - r * 3 * C4);
+    const float4 x = qkv[e];
+    if (c < C4) {
+      const float4 a = u[c], b = v[c];
+      qu[r * C4 + c] = make_float4(x.x + a.x, x.y + a.y, x.z + a.z, x.w + a.w);
+      qv[r * C4 + c] = make_float4(x.x + b.x, x.y + b.y, x.z + b.z, x.w + b.w);
+    } else {
+      kv[r * 2 * C4 + (c - C4)] = x;
+    }
+  }
+}
+// its adjoint: dqkv = (dqu + dqv) | dkv   (the bias gradients are column sums of dqu / dqv: ctts_colsum)
+__global__ void relattn_split_bwd_kernel(const float4* __restrict__ dqu, const float4* __restrict__ dqv, const float4* __restrict__ dkv,
+                                         float4* __restrict__ dqkv, long rows, int C4) {
+  const long total = rows * 3 * C4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / (3 * C4); const int c = (int)(e - r * 3 * C4);
+    if (c < C4) {
+      const float4 a = dqu[r * C4 + c], b = dqv[r * C4 + c];
+      dqkv[e] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    } else {
+      dqkv[e] = dkv[r * 2 * C4 + (c - C4)];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ctts_relattn_split_fwd(const float* qkv, const float* u_bias, const float* v_bias, float* qu, float* qv, float* kv,
+                                      int64_t rows, int C, void* stream) {
+  CTTS_REQUIRE(qkv && u_bias && v_bias && qu && qv && kv && C > 0 && (C % 4) == 0 && rows >= 0, "ctts_relattn_split_fwd: bad arguments");
+  if (rows == 0) return 0;
+  const long total = rows * 3 * (C / 4);
+  hipLaunchKernelGGL(relattn_split_fwd_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(qkv), reinterpret_cast<const float4*>(u_bias), reinterpret_cast<const float4*>(v_bias),
+                     reinterpret_cast<float4*>(qu), reinterpret_cast<float4*>(qv), reinterpret_cast<float4*>(kv), (long)rows, C / 4);
+  CTTS_CHECK_LAUNCH("ctts_relattn_split_fwd");
+  return 0;
+}
+
+extern "C" int ctts_relattn_split_bwd(const float* dqu, const float* dqv, const float* dkv, float* dqkv, int64_t rows, int C, void* stream) {
+  CTTS_REQUIRE(dqu && dqv && dkv && dqkv && C > 0 && (C % 4) == 0 && rows >= 0, "ctts_relattn_split_bwd: bad arguments");
+  if (rows == 0) return 0;
+  const long total = rows * 3 * (C / 4);
+  hipLaunchKernelGGL(relattn_split_bwd_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(dqu), reinterpret_cast<const float4*>(dqv), reinterpret_cast<const float4*>(dkv),
+                     reinterpret_cast<float4*>(dqkv), (long)rows, C / 4);
+  CTTS_CHECK_LAUNCH("ctts_relattn_split_bwd");
+  return 0;
+}
+
 extern "C" int ctts_relpos_softmax_fwd(float* S, const float* PS, float* Pd, int nbatch, int T, float scale, float p_drop,
                                        const uint64_t* seed, uint32_t drop_offset, void* stream) {
   CTTS_REQUIRE(S && PS && nbatch > 0 && T > 0, "ctts_relpos_softmax_fwd: bad arguments");

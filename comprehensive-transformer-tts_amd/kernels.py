@@ -564,6 +564,28 @@ def mha_bwd(qkv, lens, out, dout, lse, n_heads, scale, q_split=1):
     return dqkv
 
 
+def relattn_split_fwd(qkv, u_bias, v_bias):
+    """packed q | k | v projection [..., 3C] -> (qu = q + u_bias, qv = q + v_bias [..., C], kv [..., 2C])"""
+    Cc = qkv.shape[-1] // 3
+    rows = qkv.numel() // (3 * Cc)
+    qu = torch.empty(*qkv.shape[:-1], Cc, dtype=torch.float32, device=qkv.device)
+    qv = torch.empty_like(qu)
+    kv = torch.empty(*qkv.shape[:-1], 2 * Cc, dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().ctts_relattn_split_fwd(_p(_f32c(qkv, "qkv")), _p(_f32c(u_bias, "u_bias")), _p(_f32c(v_bias, "v_bias")), _p(qu), _p(qv),
+                                                  _p(kv), rows, Cc, _stream()), "ctts_relattn_split_fwd")
+    return qu, qv, kv
+
+
+def relattn_split_bwd(dqu, dqv, dkv):
+    """-> dqkv [..., 3C] = (dqu + dqv) | dkv"""
+    Cc = dqu.shape[-1]
+    rows = dqu.numel() // Cc
+    dqkv = torch.empty(*dqu.shape[:-1], 3 * Cc, dtype=torch.float32, device=dqu.device)
+    _lib.check(_lib.load().ctts_relattn_split_bwd(_p(_f32c(dqu, "dqu")), _p(_f32c(dqv, "dqv")), _p(_f32c(dkv, "dkv")), _p(dqkv), rows, Cc,
+                                                  _stream()), "ctts_relattn_split_bwd")
+    return dqkv
+
+
 def relmha_fwd(qu, qv, kv, pos, n_heads, scale, p_drop=0.0, seed=None, drop_offset=0):
     """-> (out [B,T,C], lse [B,H,T])"""
     B, T, Cc = qu.shape

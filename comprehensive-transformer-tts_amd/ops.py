@@ -784,6 +784,39 @@ class _FusedRelPosAttention(torch.autograd.Function):
         return dqu, dqv, dkv, dpos_b.sum(0), None, None, None, None, None
 
 
+class _RelAttnSplit(torch.autograd.Function):
+    """(qkv [B,T,3C], u_bias [C], v_bias [C]) -> (q + u_bias, q + v_bias, k | v): the operand preparation of
+    RelativeMultiHeadAttention.forward (conformer.py:396-407) in one pass; backward one pass + two column sums."""
+
+    @staticmethod
+    def forward(ctx, qkv, u_bias, v_bias):
+        ctx.fuse = (_fusable(u_bias), _fusable(v_bias))
+        ctx.biases = (u_bias, v_bias)
+        return K.relattn_split_fwd(qkv.contiguous(), u_bias.contiguous(), v_bias.contiguous())
+
+    @staticmethod
+    def backward(ctx, dqu, dqv, dkv):
+        dqu, dqv, dkv = dqu.contiguous(), dqv.contiguous(), dkv.contiguous()
+        Cc = dqu.shape[-1]
+        u_bias, v_bias = ctx.biases
+        du = dv = None
+        if ctx.needs_input_grad[1]:
+            if ctx.fuse[0]:
+                K.colsum(dqu.view(-1, Cc), acc_into=u_bias.grad.view(-1))
+            else:
+                du = K.colsum(dqu.view(-1, Cc)).view_as(u_bias)
+        if ctx.needs_input_grad[2]:
+            if ctx.fuse[1]:
+                K.colsum(dqv.view(-1, Cc), acc_into=v_bias.grad.view(-1))
+            else:
+                dv = K.colsum(dqv.view(-1, Cc)).view_as(v_bias)
+        return K.relattn_split_bwd(dqu, dqv, dkv), du, dv
+
+
+def relattn_split(qkv, u_bias, v_bias):
+    return _RelAttnSplit.apply(qkv, u_bias, v_bias)
+
+
 def relpos_attention(qu, qv, kv, pos, n_heads, scale, p_drop=0.0, drop=None):
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
     fn = _FusedRelPosAttention if (_FUSED_ATTN is not False and K.mha_supported(qu.shape[-1], n_heads)) else _RelPosAttention

@@ -194,6 +194,12 @@ int ctts_log_clamp_transpose(const float* mel_fm, float* out, int B, int F, int 
  *     shift = Transformer-XL _relative_shift (conformer.py:423-431); P overwrites S, Pd = inverted-dropout(P) (optional).
  *   relpos_softmax_bwd: dS = P * (dP - sum_j dP*P) * scale with dP = dropmask/(1-p) * dPd, in place on dPd;
  *   relshift_bwd: dPS = inverse of the shift applied to dS.                                               */
+/* Operand preparation of RelativeMultiHeadAttention.forward (conformer.py:396-407) from the packed q | k | v projection [rows, 3C] in
+ * one pass: qu = q + u_bias, qv = q + v_bias [rows, C], kv = k | v [rows, 2C]; and its adjoint dqkv = (dqu + dqv) | dkv (the bias
+ * gradients are column sums of dqu / dqv: ctts_colsum). */
+int ctts_relattn_split_fwd(const float* qkv, const float* u_bias, const float* v_bias, float* qu, float* qv, float* kv, int64_t rows,
+                           int C, void* stream);
+int ctts_relattn_split_bwd(const float* dqu, const float* dqv, const float* dkv, float* dqkv, int64_t rows, int C, void* stream);
 int ctts_glu_fwd(const float* a, float* out, int64_t rows, int C, void* stream);
 int ctts_glu_bwd(const float* a, const float* dout, float* da, int64_t rows, int C, void* stream);
 int ctts_dwconv_fwd(const float* x, const float* wT, float* y, int B, int T, int C, int K, int flip, void* stream);
