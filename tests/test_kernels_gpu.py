@@ -481,6 +481,23 @@ def test_relpos_attention_fwd_bwd(B, T, H, C, fused):
     ops.set_fused_attention(None)
 
 
+def test_relattn_split_fwd_bwd():
+    """q + u_bias, q + v_bias, k | v from the packed projection (conformer.py:396-407) and the adjoint, against autograd."""
+    B, T, H, C = 2, 37, 8, 256
+    qkv, u, v = rnd(B, T, 3 * C, seed=140), rnd(H, C // H, seed=141), rnd(H, C // H, seed=142)
+    gs = [rnd(B, T, C, seed=143), rnd(B, T, C, seed=144), rnd(B, T, 2 * C, seed=145)]
+    tr = [t.double().requires_grad_() for t in (qkv, u, v)]
+    outs_r = (tr[0][..., :C] + tr[1].reshape(1, 1, C), tr[0][..., :C] + tr[2].reshape(1, 1, C), tr[0][..., C:])
+    torch.autograd.backward(outs_r, [g.double() for g in gs])
+    tg = [t.to(DEV).requires_grad_() for t in (qkv, u, v)]
+    outs = ops.relattn_split(*tg)
+    for n, a, r in zip(("qu", "qv", "kv"), outs, outs_r):
+        close(a, r, 1e-6, "relattn_split " + n)
+    torch.autograd.backward(outs, [g.to(DEV) for g in gs])
+    for n, a, r in zip(("dqkv", "du", "dv"), tg, tr):
+        close(a.grad, r.grad, 2e-5, "relattn_split " + n)
+
+
 @pytest.mark.parametrize("B,T,p", [(2, 77, 0.3), (1, 1000, 0.1)])
 def test_fused_relpos_attention_equals_unfused_incl_dropout(B, T, p):
     """Same counter-RNG element indices in both paths -> identical dropout masks: outputs and all four gradients of the fused kernels
