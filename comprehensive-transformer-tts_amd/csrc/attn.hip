@@ -313,7 +313,12 @@ __attribute__((amdgpu_waves_per_eu(1, (DH <= 32 && BIAS) ? CTTS_ATTN_FWD32B_MAXW
 template <int DH, bool BIAS>
 __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void attn_bwd_kernel(const AttnArgs d) {
   constexpr int NC = DH / 32;
-  constexpr bool RES = DH <= 64;        // K / V fragments of the wave's 32 keys stay in registers
+  constexpr bool RES = DH <= 128;       // K / V fragments of the wave's 32 keys stay in registers
+  // d_head > 32 (one wave per SIMD): a tile is L2-bound when Q and dO are fetched in both operand layouts (rows for S / dP, columns for
+  // dV^T / dK^T).  The row fragments are written to LDS as they are consumed and the transposed operands are read back from there.
+  constexpr bool STAGE = DH > 32;
+  constexpr int SLD = DH + 4;           // row stride: conflict-free 16-byte row writes and column reads
+  __shared__ __attribute__((aligned(16))) float t_q[STAGE ? 32 * SLD : 1], t_do[STAGE ? 32 * SLD : 1];
   const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
   const int j0 = blockIdx.x * 32, split = blockIdx.y, z = blockIdx.z;
   const int b = z / d.H, head = z - b * d.H;
@@ -474,6 +479,12 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
         if constexpr (RES) bq = Kf[16 * c + q]; else bq = kb[c & 1][q];
         S = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[c & 1][q], bq, S, 0, 0, 0);
       }
+      if constexpr (STAGE) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          *reinterpret_cast<float4*>(t_q + l31 * SLD + 32 * c + 16 * h + 4 * x) =
+              make_float4(qa[c & 1][4 * x], qa[c & 1][4 * x + 1], qa[c & 1][4 * x + 2], qa[c & 1][4 * x + 3]);
+      }
       CTTS_SCHED_FENCE();
     }
     // S[i][j] += -lse_i / sl2  - BIG * [row i or key j masked]   ->   P = exp2(sl2 * (S + bias)) needs no selects
@@ -492,8 +503,13 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
           const unsigned sr = (unsigned)(i0 + rowmap(st, 0));
-          dot[0][st] = bld(rdO, dt_l + sr * lddo4);
-          qtt[0][st] = bld(rQ, qt_l + sr * ldq4);
+          if constexpr (STAGE) {          // chunk 0 columns were staged by the first dP / S chunk of this tile
+            dot[0][st] = t_do[rowmap(st, h) * SLD + l31];
+            qtt[0][st] = t_q[rowmap(st, h) * SLD + l31];
+          } else {
+            dot[0][st] = bld(rdO, dt_l + sr * lddo4);
+            qtt[0][st] = bld(rQ, qt_l + sr * ldq4);
+          }
         }
       }
       CTTS_SCHED_FENCE();
@@ -502,6 +518,12 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
         float bq;
         if constexpr (RES) bq = Vf[16 * c + q]; else bq = vb[c & 1][q];
         dP = __builtin_amdgcn_mfma_f32_32x32x2f32(da[c & 1][q], bq, dP, 0, 0, 0);
+      }
+      if constexpr (STAGE) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          *reinterpret_cast<float4*>(t_do + l31 * SLD + 32 * c + 16 * h + 4 * x) =
+              make_float4(da[c & 1][4 * x], da[c & 1][4 * x + 1], da[c & 1][4 * x + 2], da[c & 1][4 * x + 3]);
       }
       CTTS_SCHED_FENCE();
     }
@@ -531,8 +553,13 @@ __global__ __launch_bounds__(64, (DH <= 32 ? CTTS_ATTN_BWD32_WAVES : 1)) void at
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
           const unsigned sr = (unsigned)(i0 + rowmap(st, 0));
-          dot[(c + 1) & 1][st] = bld(rdO, dt_l + sr * lddo4 + 128u * (c + 1));
-          qtt[(c + 1) & 1][st] = bld(rQ, qt_l + sr * ldq4 + 128u * (c + 1));
+          if constexpr (STAGE) {
+            dot[(c + 1) & 1][st] = t_do[rowmap(st, h) * SLD + 32 * (c + 1) + l31];
+            qtt[(c + 1) & 1][st] = t_q[rowmap(st, h) * SLD + 32 * (c + 1) + l31];
+          } else {
+            dot[(c + 1) & 1][st] = bld(rdO, dt_l + sr * lddo4 + 128u * (c + 1));
+            qtt[(c + 1) & 1][st] = bld(rQ, qt_l + sr * ldq4 + 128u * (c + 1));
+          }
         }
       } else {                          // next query tile's first S operands (rows past the end read as 0)
         bld16(rQ, qa_l + s_q + 32u * ldq4, qa[0]);
