@@ -14,8 +14,9 @@
 // Work decomposition: ONE WAVE PER WORKGROUP, 32 queries (forward) or 32 keys (backward) per wave, flash-style loop over the other
 // axis in tiles of 32.  fp32 MFMA issues one 32x32x2 step per 64 cycles, so a wave needs only ~1 operand dword per 64 cycles: every
 // operand is fetched straight from global / L2 in MFMA fragment order (A/B operand of lane (l31, h) = element [row l31][k-half h]),
-// 64-byte runs per lane for the K-contiguous side and fully coalesced 128-byte rows for the transposed side.  No LDS tiles, no
-// barriers (the only LDS use is a 32x33 transpose buffer for the position-score tile in the forward kernel).
+// 64-byte runs per lane for the K-contiguous side and fully coalesced 128-byte rows for the transposed side.  No operand tiles in
+// LDS and no workgroup barriers; LDS holds the two-block ring of position-score bands (rel forward) and, at d_head > 32, the staged
+// Q / dO rows whose transposed reads feed dV^T / dK^T (backward).
 //
 // Forward computes S^T = K Q^T so that a lane owns one QUERY column: the online-softmax max / sum run over the lane's own 16
 // accumulator registers (+ one exchange with lane^32), and P^T is already laid out as the B operand of O^T += V^T P^T.
@@ -36,7 +37,7 @@ struct AttnArgs {
   long ldq, ldk, ldv, sq, sk, sv;
   float* out; long ldo, so;         // [B,T,H*dh]
   float* lse;                       // [B,H,T]  log2-domain log-sum-exp of the scaled scores
-  const float* qv; long ldqv, sqv;  // rel: q + v_bias, same indexing as q; NULL selects the plain (fs2) kernels' behaviour
+  const float* qv; long ldqv, sqv;  // rel: q + v_bias, same indexing as q (q itself is q + u_bias there)
   const float* pos; long ldpos;     // rel: projected sinusoid rows [T, H*dh] shared by the batch
   const int32_t* lens;              // fs2: valid length per utterance (keys >= len masked, query rows >= len are zero rows), else NULL
   int B, H, T;
@@ -48,7 +49,7 @@ struct AttnArgs {
   float *dk, *dv; long lddk, lddv, sdk, sdv;
   long split_stride;                // q_split > 1: split s writes its partial dK / dV at dk/dv + s * split_stride (summed afterwards)
   float* dS;                        // d loss / d (q k^T + bias), scale included: [B,H,T,T], or (rel) [B,H] slabs of T*(T+1) floats
-                                    // whose first T floats are padding: dS[i][j] = slab[(i+1)*T + j], the layout of `bias`
+                                    // whose first T floats are padding: dS[i][j] = slab[(i+1)*T + j] (the reference's `padded` layout)
   int q_split;
 };
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ void load16(const float* __restrict__ p, float (&f)[1
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32; arguments here are <= 0 or -inf
 
 // ctts_drop_scale(key, idx) with the index hash split into a lane-constant and a wave-uniform part: pre = idx * G + key arrives
-// ready-made (one v_add per element instead of a quarter-rate multiply), and the uniform compare u >= p is done on the integer:
+// ready-made (one v_add per element instead of a multiply and an add), and the uniform compare u >= p is done on the integer:
 // (h >> 8) * 2^-24 >= p  <=>  h >= ceil(p * 2^24) << 8  (both sides exact) - the same keep decisions as every other kernel's.
 constexpr uint32_t DROP_G = 0x9E3779B1U;
 __device__ __forceinline__ uint32_t drop_threshold(float p) { return ((uint32_t)ceilf(p * 16777216.0f)) << 8; }
