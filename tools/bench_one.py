@@ -26,6 +26,16 @@ elif which == "dgrad":
 elif which == "wgrad":
     x = torch.randn(B, T, 256, device=dev); dz = torch.randn(M, 1024, device=dev); C = torch.zeros(1024, 2304, device=dev)
     fn = lambda: K.gemm(dz, x, C, 1024, 2304, M, 1024, 256, 2304, False, False, conv=(T, 4, 256), conv_on_b=True, split_k=4); fl = 2 * M * 1024 * 2304
+elif which in ("proj", "proj_sk2", "proj_nn", "proj_nn_sk2"):      # conformer-sized projections: M = B*T, N = K = 256 (latency-bound)
+    sk = 2 if which.endswith("sk2") else 1
+    x = torch.randn(M, 256, device=dev); C = torch.zeros(M, 256, device=dev)
+    if "nn" in which:
+        w = torch.randn(256, 256, device=dev)
+        fn = lambda: K.gemm(x, w, C, M, 256, 256, 256, 256, 256, True, False, split_k=sk)
+    else:
+        w = torch.randn(256, 256, device=dev)
+        fn = lambda: K.gemm(x, w, C, M, 256, 256, 256, 256, 256, True, True, split_k=sk)
+    fl = 2 * M * 256 * 256
 elif which == "sq":
     n = 4096
     x = torch.randn(n, n, device=dev); w = torch.randn(n, n, device=dev); C = torch.empty(n, n, device=dev)
