@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("tile_map", _vp),
         ("tile_group_n", _i32),
         ("E", _vp), ("rowsub", _vp),
+        ("sk_ws", _vp), ("sk_ws_bytes", _i64),
     ]
 
 
@@ -105,7 +106,7 @@ _SIGNATURES = {
     "ctts_softmax_rect_bwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version", "ctts_mha_supported", "ctts_relmha_workspace_floats",
-                                               "ctts_mel_spectrogram_workspace_bytes"])
+                                               "ctts_mel_spectrogram_workspace_bytes", "ctts_gemm_workspace_bytes"])
 ADAM_STATE_FLOATS = 3 + 2048          # CTTS_ADAM_STATE_FLOATS of include/ctts.h
 
 _lib = None
@@ -138,6 +139,8 @@ def load():
     lib.ctts_mha_supported.argtypes = [C.c_int, C.c_int]
     lib.ctts_mel_spectrogram_workspace_bytes.restype = C.c_size_t
     lib.ctts_mel_spectrogram_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.ctts_gemm_workspace_bytes.restype = C.c_size_t
+    lib.ctts_gemm_workspace_bytes.argtypes = []
     lib.ctts_relmha_workspace_floats.restype = C.c_size_t
     lib.ctts_relmha_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     _lib = lib

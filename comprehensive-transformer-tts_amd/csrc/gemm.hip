@@ -10,9 +10,8 @@
 // batch/length limits for free.  blockIdx.x is remapped so that each XCD owns a contiguous
 // run of tiles (tiles that share an A panel hit the same L2).
 #include "ctts_common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -371,67 +370,6 @@ __device__ __forceinline__ void fetch_frag(const float* s, int ext0, int l31, in
 #pragma unroll
     for (int j = 0; j < 16; ++j) f[j] = p[j * LD];
   }
-}
-
-// ---- epilogue shared by the kernels.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int MT, int NT>
-__device__ __forceinline__ void gemm_epilogue(const ctts_gemm_desc& d, floatx16 (&acc)[MT][NT], float* Cb, int z, int row0, int col0,
-                                              int wm0, int wn0, int l31, int h, int Mv, int Nv) {
-  const float alpha = d.alpha;
-  if (d.split_k > 1) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int n = col0 + wn0 + j * 32 + l31;
-          if (m < Mv && n < Nv) atomicAdd(Cb + (long)m * d.ldc + n, alpha * acc[i][j][r]);
-        }
-    return;
-  }
-  const bool do_drop = d.p_drop > 0.f;
-  uint32_t dkey = 0;
-  float inv_keep = 1.f;
-  if (do_drop) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
-  const uint32_t zoff = (uint32_t)z * (uint32_t)d.M * (uint32_t)d.N;
-  if (d.E) {           // fused softmax backward: dS = P * (dP - D)
-    const float* Eb = d.E + (Cb - d.C);
-    const float* rs = d.rowsub + (long)z * d.M;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = col0 + wn0 + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < Mv && n < Nv) Cb[(long)m * d.ldc + n] = Eb[(long)m * d.ldc + n] * (alpha * acc[i][j][r] - rs[m]);
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = col0 + wn0 + j * 32 + l31;
-      const float bv = (d.bias && n < Nv) ? d.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < Mv && n < Nv) {
-          float v = alpha * (acc[i][j][r] + bv);
-          if (d.Z) d.Z[(long)m * d.ldz + n] = v;
-          v = ctts_act(v, d.act);
-          if (do_drop) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
-          if (d.R) v += d.R[(long)m * d.ldr + n];
-          if (d.rowscale) v *= d.rowscale[m];
-          Cb[(long)m * d.ldc + n] = v;
-        }
-      }
-    }
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool VEC>
@@ -865,6 +803,10 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   CTTS_REQUIRE(!d.E || (d.rowsub && d.split_k <= 1 && !d.bias && !d.act && d.p_drop == 0.f && !d.R && !d.rowscale && !d.Z),
                "ctts_gemm: the E/rowsub epilogue excludes bias, activation, dropout, residual, rowscale and split-K");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    const int sk = ctts_gemm_sk_try(d, st);      // persistent stream-K kernel (gemm_sk.hip) when the descriptor is eligible
+    if (sk != 0) return sk > 0 ? 0 : sk;
+  }
   const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : 1) * d.nb0 * d.nb1;
   static const int force_tile = getenv("CTTS_FORCE_TILE") ? atoi(getenv("CTTS_FORCE_TILE")) : 0;   // tuning knob
   static const bool natural = getenv("CTTS_NATURAL_ORDER") != nullptr;

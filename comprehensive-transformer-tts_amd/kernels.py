@@ -67,10 +67,27 @@ class DropCtx:
         self.seed.add_(0x632BE5AB)
 
 
+import os as _os
+
+SK_ENABLED = _os.environ.get("CTTS_SK", "1") != "0"      # persistent stream-K GEMM (csrc/gemm_sk.hip) for large unbatched launches
+_SK_WS = {}          # (device index, stream handle) -> zero-filled workspace of the persistent stream-K GEMM
+
+
+def gemm_workspace(device):
+    """Workspace of the persistent stream-K GEMM (include/ctts.h ctts_gemm_desc.sk_ws): one per (device, stream), because launches
+    that share it must be stream-ordered.  Zero-filled once; the kernel leaves every flag at zero when it finishes."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ws = _SK_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(_lib.load().ctts_gemm_workspace_bytes(), dtype=torch.uint8, device=device)
+        _SK_WS[key] = ws
+    return ws
+
+
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_off=0, c_off=0, nb0=1, nb1=1,
          sA=(0, 0), sB=(0, 0), sC=(0, 0), lens=None, lim=(0, 0, 0), conv=None, conv_on_b=False, split_k=1, alpha=1.0,
          bias=None, Z=None, ldz=0, act=ACT_NONE, p_drop=0.0, seed=None, drop_offset=0, R=None, ldr=0, rowscale=None,
-         row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None):
+         row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None, use_sk=None):
     """C = epi(alpha * (opA @ opB + bias)); see include/ctts.h ctts_gemm_desc."""
     d = GemmDesc()
     d.A, d.B, d.C = _p(A, a_off), _p(B, b_off), _p(Cout, c_off)
@@ -101,6 +118,10 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_of
         d.tile_map = _p(tile_map)
     d.E, d.rowsub = _p(E), _p(rowsub)
     lib = _lib.load()
+    if (SK_ENABLED if use_sk is None else use_sk) and nb0 * nb1 == 1 and M * N * K >= (1 << 24):
+        # large unbatched GEMMs may run on the persistent stream-K kernel (the library decides: ctts_gemm_sk_try)
+        ws = gemm_workspace(A.device)
+        d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
     _lib.check(lib.ctts_gemm(C.byref(d), _stream()), "ctts_gemm")
     return Cout
 

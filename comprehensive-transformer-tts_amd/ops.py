@@ -231,6 +231,8 @@ class _LinearConv(torch.autograd.Function):
         act, alpha, p_drop, drop_offset, ksize, has_bias, has_res, row_T = ctx.cfg
         rl = dict(row_lens=row_lens, row_T=row_T) if row_lens is not None else {}
         pr = ctx.pr
+        # weight gradients reduce over the (b,t) rows: the same device-built map, read as a schedule of the active 64-row K-blocks
+        kmap = pr.tile_map(0, x.numel() // x.shape[-1]) if (pr is not None and row_lens is not None) else None
         dY = dY.contiguous()
         Cin = x.shape[-1]
         M = x.numel() // Cin
@@ -265,7 +267,10 @@ class _LinearConv(torch.autograd.Function):
                 # few output tiles but a long reduction (FFN conv dgrad: 1024 tiles, K = 9216): split K so that the launch fills
                 # all 256 CUs x 8 resident workgroups (atomic accumulation into a zero-filled dX)
                 tiles = -(-M // 64) * -(-Cin // 64)
+                # (the persistent stream-K kernel balances the reduction itself: no split, no zero fill, no atomics)
                 sk = min(4, max(2, -(-2304 // tiles))) if (_DGRAD_SPLIT_K and tiles < 1536 and ksize * N >= 4096) else 1
+                if K.SK_ENABLED and N % 32 == 0 and M * Cin * ksize * N >= (1 << 24):
+                    sk = 1
                 dX = torch.zeros_like(x) if sk > 1 else torch.empty_like(x)
                 K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, conv=(T, pad, N), alpha=alpha, row_halo=pad,
                        split_k=sk, tile_map=pr.tile_map(pad, M) if pr is not None else None, **rl)
@@ -276,12 +281,12 @@ class _LinearConv(torch.autograd.Function):
                 if gmaj is not None:             # GEMM-major parameter: the split-K partials are added straight into param.grad
                     with _wgrad_scope(True, dZ, x):
                         K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
+                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, **rl)
                 else:
                     dwf = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
                     with _wgrad_scope(fused, dZ, x, dwf):
                         K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
+                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, **rl)
                         if fused:
                             K.conv_weight_repack(dwf, w.grad, N, Cin, ksize, 3)
                         elif _gemm_major(w) is not None:
@@ -304,7 +309,7 @@ class _LinearConv(torch.autograd.Function):
                 dW = w.grad if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
                 with _wgrad_scope(fused, dZ, x):
                     K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha,
-                           **rl)
+                           tile_map=kmap, **rl)
                 if fused:
                     dW = None
         return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None

@@ -76,9 +76,15 @@ typedef struct ctts_gemm_desc {
    * batch strides) and rowsub indexed [batch * M + row]:  dS = P * (dP - D), D = rowsum(dO * O), straight out of the dP = dO V^T GEMM -
    * no separate pass over the [T,T] maps.  NULL = off; not combinable with bias / act / dropout / R / rowscale / split_k. */
   const float* E; const float* rowsub;
+  /* Optional workspace of the persistent stream-K kernel (csrc/gemm_sk.hip): ctts_gemm_workspace_bytes() bytes, zero-filled ONCE by the
+   * caller, private to the stream the launch goes to (launches that share it must be stream-ordered).  With it, large unbatched GEMMs
+   * run on a persistent grid that cuts the (tile, K-block) space evenly over the CUs and sums cut tiles in a fixed order; split_k > 1
+   * then only means "C += alpha * A B" (no atomics).  NULL = tile-per-workgroup kernels only. */
+  void* sk_ws; int64_t sk_ws_bytes;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
+size_t ctts_gemm_workspace_bytes(void);
 
 /* out[b,h,t] = sum_d a[b,t,h*dh+d] * b[b,t,h*dh+d]   (a, b [B,T,H*dh] channel-last; the D vector of the fused softmax backward). */
 int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, int H, int dh, void* stream);
