@@ -267,13 +267,12 @@ class _LinearConv(torch.autograd.Function):
                 # few output tiles but a long reduction (FFN conv dgrad: 1024 tiles, K = 9216): split K so that the launch fills
                 # all 256 CUs x 8 resident workgroups (atomic accumulation into a zero-filled dX)
                 tiles = -(-M // 64) * -(-Cin // 64)
-                # (the persistent stream-K kernel balances the reduction itself: no split, no zero fill, no atomics)
                 sk = min(4, max(2, -(-2304 // tiles))) if (_DGRAD_SPLIT_K and tiles < 1536 and ksize * N >= 4096) else 1
-                if K.SK_ENABLED and N % 32 == 0 and M * Cin * ksize * N >= (1 << 24):
-                    sk = 1
+                dg = dict(conv=(T, pad, N), alpha=alpha, row_halo=pad, tile_map=pr.tile_map(pad, M) if pr is not None else None, **rl)
+                if sk > 1 and K.gemm_takes_persistent(dZ, wd, x, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=1, **dg):
+                    sk = 1          # the persistent stream-K kernel balances the reduction itself: no split, no zero fill, no atomics
                 dX = torch.zeros_like(x) if sk > 1 else torch.empty_like(x)
-                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, conv=(T, pad, N), alpha=alpha, row_halo=pad,
-                       split_k=sk, tile_map=pr.tile_map(pad, M) if pr is not None else None, **rl)
+                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=sk, **dg)
             if ctx.needs_input_grad[1]:
                 Kd = ksize * Cin
                 fused = _fusable(w)

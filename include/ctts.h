@@ -85,6 +85,10 @@ typedef struct ctts_gemm_desc {
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
 size_t ctts_gemm_workspace_bytes(void);
+/* 1 when ctts_gemm would run this descriptor on the persistent stream-K kernel (sk_ws given, shape / alignment eligible, enough tiles
+ * for the grid), else 0.  Callers that otherwise split the reduction (split_k > 1 + zero fill) ask first: the persistent kernel balances
+ * the reduction itself and wants split_k = 1. */
+int ctts_gemm_takes_persistent(const ctts_gemm_desc* d);
 
 /* out[b,h,t] = sum_d a[b,t,h*dh+d] * b[b,t,h*dh+d]   (a, b [B,T,H*dh] channel-last; the D vector of the fused softmax backward). */
 int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, int H, int dh, void* stream);

@@ -30,6 +30,15 @@ def err_word():
     return int(ws.view(torch.int32)[2048].item())
 
 
+def sk_clock():
+    """GHz of the shader clock during the last stream-K launch (CTTS_SK_DEBUG & 16), else None"""
+    if not (int(os.environ.get("CTTS_SK_DEBUG", "0")) & 16):
+        return ""
+    ws = K.gemm_workspace(torch.device(dev))
+    c = ws.view(torch.int64)[(2048 + 2) // 2:(2048 + 2) // 2 + 2].tolist()
+    return f" clk {c[0] / max(c[1], 1) * 0.1:.3f} GHz" if c[1] else ""
+
+
 def run(name, make, flops, outs):
     """make(use_sk) -> callable; outs() -> list of output tensors to compare"""
     if only and only not in name:
@@ -46,7 +55,7 @@ def run(name, make, flops, outs):
     scale = max(float(a.abs().max()) for a in ref)
     t0, t1 = timeit(f0), timeit(f1)
     print(f"{name:34s} old {t0*1e6:8.1f} us {flops/t0/1e12:7.2f} TF | sk {t1*1e6:8.1f} us {flops/t1/1e12:7.2f} TF | x{t0/t1:5.2f} | "
-          f"maxdiff {diff:.2e} (scale {scale:.2e}) err {err_word()}", flush=True)
+          f"maxdiff {diff:.2e} (scale {scale:.2e}) err {err_word()}{sk_clock()}", flush=True)
 
 
 B, T = 16, 1024
@@ -103,6 +112,30 @@ run("ffn1 wgrad dense", lambda sk: wgrad(sk, False), 2 * M * 1024 * 2304, lambda
 dz.mul_(rowmask)
 run("ffn1 wgrad step (ragged)", lambda sk: wgrad(sk, True), 2 * nvalid * 1024 * 2304, lambda: [dW])
 dz = torch.randn(M, 1024, device=dev)
+
+# ---- PostNet Conv1d(512 -> 512, k = 5): dense rows (BatchNorm needs the padded rows), forward / data gradient and weight gradient
+xp = torch.randn(B, T, 512, device=dev); wp = torch.randn(512, 2560, device=dev) * 0.02; Cp = torch.empty(B, T, 512, device=dev)
+run("postnet conv fwd", lambda sk: (lambda: K.gemm(xp, wp, Cp, M, 512, 2560, 512, 2560, 512, True, True, conv=(T, 2, 512), use_sk=sk)),
+    2 * M * 512 * 2560, lambda: [Cp])
+dzp = torch.randn(M, 512, device=dev); dWp = torch.zeros(512, 2560, device=dev)
+
+
+def wgrad_post(sk):
+    def f():
+        dWp.zero_()
+        K.gemm(dzp, xp, dWp, 512, 2560, M, 512, 512, 2560, False, False, conv=(T, 2, 512), conv_on_b=True, split_k=7, use_sk=sk)
+    return f
+
+
+run("postnet conv wgrad", wgrad_post, 2 * M * 512 * 2560, lambda: [dWp])
+# ---- encoder FFN conv (16 x 128 phoneme rows, ragged)
+Te = 128; Me = B * Te
+lens_e = torch.tensor(list(CANONICAL_SRC_LENS), dtype=torch.int32, device=dev)
+tmap_e = K.row_tile_map(lens_e, Te, 0, Me)
+xe = torch.randn(B, Te, 256, device=dev); Ce = torch.empty(B, Te, 1024, device=dev)
+run("encoder ffn1 fwd (2048 rows)", lambda sk: (lambda: K.gemm(xe, wf, Ce, Me, 1024, 2304, 256, 2304, 1024, True, True, conv=(Te, 4, 256),
+                                                                 row_lens=lens_e, row_T=Te, row_halo=0, tile_map=tmap_e, use_sk=sk)),
+    2 * int(lens_e.sum()) * 1024 * 2304, lambda: [Ce])
 
 # ---- linears
 for name, m, n, k in [("qkv NT 256->768", M, 768, 256), ("ffn2 NT 1024->256", M, 256, 1024), ("conf FF1 NT 256->1024", 16000, 1024, 256),
