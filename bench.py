@@ -11,7 +11,8 @@ Step (train.py:102-125 of the reference): forward -> CompTransTTSLoss (step > va
 clip_grad_norm_(1.0) -> Adam (Noam LR) -> zero_grad, fp32, dropout ON, synthetic LJSpeech-shaped canonical batch (SURVEY.md 8(d):
 B=16, src<=128, mel<=1024, 11,992 valid frames) resident in HBM.
   --scaling weak   (default): every rank runs its own canonical batch of 16 (what the reference de facto does)
-  --scaling strong : ONE global canonical batch of 16, rank r takes utterances r, r+N, ... (DistributedSampler, train.py:44)
+  --scaling strong : ONE global canonical batch of 16 dealt out over the ranks: --shard snake (default, length-balanced) or
+                     --shard strided (r, r+N, ...: DistributedSampler, train.py:44 - 28 % more frames on rank 0 than on rank 7 at N = 8)
 value = valid mel frames of all ranks per step / max-over-ranks wall time per step.
 
 Adds `roofline` (dominant kernel: the implicit-GEMM Conv1d k=9 of the decoder FFN, fp32 MFMA peak 157.3 TFLOP/s), `cpu_baseline`
@@ -45,12 +46,16 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: 16 utterances per GPU; strong: 16 utterances in total, sharded r::N")
+    ap.add_argument("--shard", default="snake", choices=["snake", "strided"],
+                    help="strong scaling: how the global batch is dealt out - snake = length-balanced (default), strided = r::N like "
+                         "DistributedSampler (train.py:44); the bench line reports max/mean valid frames per rank for both")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-overlap", action="store_true", help="DP: one blocking all-reduce of the whole arena after backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "primary"],
                     help="primary: only C2 at physical cores; full: C1 and C2 at physical cores and at 8 threads")
     ap.add_argument("--no-pcie", action="store_true", help="skip the second timed loop with the host data path inside")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE configs[2..4] lines measured after the headline")
     ap.add_argument("--batch", default="canonical", choices=["canonical", "c1"])
     ap.add_argument("--block", default="transformer_fs2", choices=["transformer_fs2", "conformer"],
                     help="block_type plugin; the headline metric (BASELINE configs[1]) is transformer_fs2, conformer = configs[2]")
@@ -139,13 +144,18 @@ def measure_dominant_kernel(dev, batch, iters=20):
     valid = int(batch["mel_lens"].sum())
     algo_flops = 2.0 * cout * ks * cin * valid          # 4,718,592 FLOP per valid frame per layer
     padded_flops = 2.0 * cout * ks * cin * M
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "pmc_traffic_dominant_kernel.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, see profiles/
+    # traffic is NOT measured by this run: it is the committed result of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+    # same launch (tools/collect_profiles.sh); traffic_source says which passes (file, date, commit)
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic_dominant_kernel.json")
     if os.path.exists(tj):
         with open(tj) as f:
-            traffic = json.load(f).get("traffic_bytes_per_launch")
+            tjs = json.load(f)
+        traffic = tjs.get("traffic_bytes_per_launch")
+        traffic_src = {"file": "profiles/pmc_traffic_dominant_kernel.json", "collected": tjs.get("collected"), "commit": tjs.get("commit"),
+                       "kernel": tjs.get("kernel")}
     return {"bound": "mfma", "achieved": algo_flops / dt / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": algo_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "frac": algo_flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "ctts_gemm conv fwd (decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments incl. padded-row skipping)",
             "launch_us": dt * 1e6, "padded_tflops": padded_flops / dt / 1e12}
 
@@ -210,8 +220,10 @@ def cpu_baseline(mode="full"):
     from ctts_amd.synthetic import C1_SRC_LENS
     phys = _physical_cores()
     runs = []
-    plan = [("C2", None, phys, 1, 1)] if mode == "primary" else \
-           [("C1", C1_SRC_LENS, phys, 2, 1), ("C1", C1_SRC_LENS, 8, 1, 1), ("C2", None, phys, 1, 1), ("C2", None, 8, 1, 0)]
+    # (config, lengths, threads, timed steps, warm-up steps); the run that becomes the headline (C2 at 8 threads, the faster thread count on
+    # every host measured) gets a warm-up step and the median of 2 timed steps - the first step pays allocator / thread-pool start-up
+    plan = [("C2", None, 8, 2, 1)] if mode == "primary" else \
+           [("C1", C1_SRC_LENS, 8, 2, 1), ("C2", None, phys, 1, 0), ("C2", None, 8, 2, 1)]
     for name, lens, nt, n_timed, warm in plan:
         sec, valid = _cpu_train_steps(lens, nt, n_timed, warm)
         runs.append({"config": name, "threads": nt, "valid_frames": valid, "s_per_step": sec, "frames_per_s": valid / sec,
@@ -228,6 +240,115 @@ def cpu_baseline(mode="full"):
                       f"{best['timed_steps']} timed step(s) after {best['warmup_steps']} warm-up, {best['s_per_step']:.2f} s/step, torch CPU fp32 "
                       f"{best['threads']} threads ({phys} physical / {os.cpu_count()} logical cores on this host)",
             "runs": runs, "reference_over_port_time_ratio": ratio}
+
+
+def build_step(dev, rank, world, dataset, block, prosody, learn_alignment, batch, scaling, use_graph=True, overlap=True, shard_order="snake"):
+    """model + loss + optimizer + synthetic batch + (captured) TrainStep of one BASELINE configuration"""
+    import ctts_amd
+    from ctts_amd.configs import get_configs
+    from ctts_amd.data import PackedBatch
+    from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
+    from ctts_amd.synthetic import (make_batch, make_unsup_batch, as_collated_tuple, shard, shard_valid_frames, C1_SRC_LENS,
+                                    CANONICAL_SRC_LENS)
+    from ctts_amd.trainer import TrainStep
+
+    pre, mc, tc = get_configs(dataset)
+    mc["block_type"] = block
+    mc["prosody_modeling"]["model_type"] = prosody
+    mc["duration_modeling"]["learn_alignment"] = learn_alignment
+    torch.manual_seed(1234)                                   # identical init on every rank (DDP broadcast equivalent)
+    model = ctts_amd.CompTransTTS(pre, mc, tc).to(dev)
+    model.train()
+    loss_fn = CompTransTTSLoss(pre, mc, tc).to(dev)
+    optim = ScheduledOptim(model, tc, mc, 50000, capturable=True)
+    src_lens = None if batch == "canonical" else C1_SRC_LENS
+    extra = {}
+    if dataset == "VCTK":            # C4: 8 utterances per GPU (every second canonical length), speaker embeddings ~ N(0,1)[B,512]
+        src_lens = CANONICAL_SRC_LENS[rank % 2::2] if batch == "canonical" else src_lens
+        extra = dict(multi_speaker=True)
+    # conformer decoders crop to max_seq_len = 1000 in training (conformer.py:148-154): cap mel length (SURVEY C3)
+    mk = make_unsup_batch if learn_alignment else make_batch
+    cap = 1000 if block == "conformer" else None
+    balance = None
+    if scaling == "strong":          # ONE global batch (identical on every rank before sharding), dealt out by `shard_order`
+        gb = mk(src_lens, seed=1234, max_mel_cap=cap, **extra)
+        batch_cpu = shard(gb, rank, world, shard_order)
+        per = {o: shard_valid_frames(gb, world, o) for o in ("strided", "snake")}
+        balance = {"order": shard_order, "valid_frames_per_rank": per[shard_order],
+                   "max_over_mean": {o: max(v) / (sum(v) / len(v)) for o, v in per.items()}}
+    else:                            # weak: a full batch per rank, different data on every rank
+        batch_cpu = mk(src_lens, seed=1234 + rank, max_mel_cap=cap, **extra)
+    valid_frames = int(batch_cpu["mel_lens"].sum())
+    padded_frames = batch_cpu["mels"].shape[0] * batch_cpu["mels"].shape[1]
+    # host data path (SURVEY f4): collate layout -> ONE pinned buffer -> ONE H2D copy; the model inputs are views of the device buffer
+    collated = as_collated_tuple(batch_cpu)
+    packed = PackedBatch.pack(collated)
+    views, ev = packed.to_device(dev)
+    torch.cuda.current_stream().wait_event(ev)
+    model_args = views[2:]
+
+    step = TrainStep(model, loss_fn, optim, model_args, world=world, use_graph=use_graph, overlap=overlap,
+                     adam_step=optim.current_step)   # steady state: both the Noam schedule and Adam's bias correction at step 50,000
+    step.bind_static_buffer(packed.device_buffer)
+    if prosody != "none" or learn_alignment:
+        step.step_no = 100001                                 # every loss term on: bin-loss weight 1, prosody loss enabled
+    mode = "eager"
+    if use_graph:
+        ok = 1
+        try:
+            step.capture()
+        except Exception as e:                                # noqa: BLE001
+            ok = 0
+            print(f"[bench] rank {rank}: graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
+        if world > 1:                                         # ranks must not diverge in launch mode: all replay graphs or all run eager
+            import torch.distributed as dist
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag)
+        if ok:
+            mode = (f"hipgraph({step.n_stages} backward stages, bucketed all-reduce between replays | clip+adam)" if step.staged
+                    else "hipgraph(fwd+bwd | clip+adam)")
+        else:
+            print("[bench] running eager", file=sys.stderr)
+            step.graphs = step.g_opt = None
+    return {"step": step, "mode": mode, "batch_cpu": batch_cpu, "collated": collated, "packed": packed,
+            "valid_frames": valid_frames, "padded_frames": padded_frames, "shard_balance": balance}
+
+
+SECONDARY = [   # BASELINE configs[2..4] measured in the same invocation (N = 1 only), so that every claimed configuration is driver-run
+    ("configs[2] LJSpeech conformer batch=16", dict(dataset="LJSpeech", block="conformer", prosody="none", learn_alignment=False), 113.9e6),
+    ("configs[3] VCTK multi-speaker transformer_fs2, per-GPU slice (8 of 64 utterances)",
+     dict(dataset="VCTK", block="transformer_fs2", prosody="none", learn_alignment=False), 157.4e6),
+    ("configs[4] LJSpeech transformer_fs2 + liu2021 prosody + learn_alignment batch=16",
+     dict(dataset="LJSpeech", block="transformer_fs2", prosody="liu2021", learn_alignment=True), 157.4e6),
+]
+
+
+def measure_secondary(dev, steps=10, warmup=3):
+    """same step definition and timing as the headline (inputs resident, hipGraph replay), fewer steps; FLOP per valid frame from SURVEY 8(d)"""
+    out = []
+    for name, cfg, flop_per_frame in SECONDARY:
+        try:
+            b = build_step(dev, 0, 1, cfg["dataset"], cfg["block"], cfg["prosody"], cfg["learn_alignment"], "canonical", "weak")
+            st = b["step"]
+            for _ in range(warmup):
+                st()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                st()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            v = b["valid_frames"] * steps / el
+            out.append({"config": name, "value": v, "unit": "mel-frames/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
+                        "valid_frames": b["valid_frames"], "padded_frames": b["padded_frames"],
+                        "step_frac_of_fp32_mfma_peak": v * flop_per_frame / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                        "final_loss": float(st.loss_val), "launch_mode": b["mode"], "dtype": "f32"})
+            del b, st
+        except Exception as e:                                # noqa: BLE001
+            out.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -253,66 +374,20 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    import ctts_amd
-    from ctts_amd.configs import get_configs
-    from ctts_amd.data import PackedBatch, Prefetcher
-    from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
-    from ctts_amd.synthetic import make_batch, make_unsup_batch, as_collated_tuple, shard, C1_SRC_LENS, CANONICAL_SRC_LENS
-    from ctts_amd.trainer import TrainStep
+    from ctts_amd.data import Prefetcher
+    from ctts_amd.synthetic import make_batch
 
-    pre, mc, tc = get_configs(a.dataset)
-    mc["block_type"] = a.block
-    mc["prosody_modeling"]["model_type"] = a.prosody
-    mc["duration_modeling"]["learn_alignment"] = a.learn_alignment
-    torch.manual_seed(1234)                                   # identical init on every rank (DDP broadcast equivalent)
-    model = ctts_amd.CompTransTTS(pre, mc, tc).to(dev)
-    model.train()
-    loss_fn = CompTransTTSLoss(pre, mc, tc).to(dev)
-    optim = ScheduledOptim(model, tc, mc, 50000, capturable=True)
-    src_lens = None if a.batch == "canonical" else C1_SRC_LENS
-    extra = {}
-    if a.dataset == "VCTK":          # C4: 8 utterances per GPU (every second canonical length), speaker embeddings ~ N(0,1)[B,512]
-        src_lens = CANONICAL_SRC_LENS[rank % 2::2] if a.batch == "canonical" else src_lens
-        extra = dict(multi_speaker=True)
-    # conformer decoders crop to max_seq_len = 1000 in training (conformer.py:148-154): cap mel length
-    mk = make_unsup_batch if a.learn_alignment else make_batch
-    cap = 1000 if a.block == "conformer" else None
-    if a.scaling == "strong":        # ONE global batch, utterances rank::world (identical on every rank before sharding)
-        batch_cpu = shard(mk(src_lens, seed=1234, max_mel_cap=cap, **extra), rank, world)
-    else:                            # weak: a full batch per rank, different data on every rank
-        batch_cpu = mk(src_lens, seed=1234 + rank, max_mel_cap=cap, **extra)
-    valid_frames = int(batch_cpu["mel_lens"].sum())
-    padded_frames = batch_cpu["mels"].shape[0] * batch_cpu["mels"].shape[1]
-    # host data path: collate layout -> ONE pinned buffer -> ONE H2D copy; the model inputs are views of the device buffer
-    collated = as_collated_tuple(batch_cpu)
-    packed = PackedBatch.pack(collated)
-    views, ev = packed.to_device(dev)
-    torch.cuda.current_stream().wait_event(ev)
-    model_args = views[2:]
-
-    step = TrainStep(model, loss_fn, optim, model_args, world=world, use_graph=not a.no_graph, overlap=not a.no_overlap,
-                     adam_step=optim.current_step)   # steady state: both the Noam schedule and Adam's bias correction at step 50,000
-    step.bind_static_buffer(packed.device_buffer)
-    if a.prosody != "none" or a.learn_alignment:
-        step.step_no = 100001                                 # every loss term on: bin-loss weight 1, prosody loss enabled
-    mode = "eager"
-    if not a.no_graph:
-        ok = 1
+    built = build_step(dev, rank, world, a.dataset, a.block, a.prosody, a.learn_alignment, a.batch, a.scaling,
+                       use_graph=not a.no_graph, overlap=not a.no_overlap, shard_order=a.shard)
+    step, mode, batch_cpu, collated, packed = built["step"], built["mode"], built["batch_cpu"], built["collated"], built["packed"]
+    valid_frames, padded_frames = built["valid_frames"], built["padded_frames"]
+    if world > 1 and rank == 0:       # evidence for a SCALE run that N ranks and RCCL were really in play
         try:
-            step.capture()
-        except Exception as e:                                # noqa: BLE001
-            ok = 0
-            print(f"[bench] rank {rank}: graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
-        if world > 1:                                         # ranks must not diverge in launch mode: all replay graphs or all run eager
-            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag)
-        if ok:
-            mode = (f"hipgraph({step.n_stages} backward stages, bucketed all-reduce between replays | clip+adam)" if step.staged
-                    else "hipgraph(fwd+bwd | clip+adam)")
-        else:
-            print("[bench] running eager", file=sys.stderr)
-            step.graphs = step.g_opt = None
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:             # noqa: BLE001
+            ver = "?"
+        print(f"[bench] world_size={dist.get_world_size()} backend={dist.get_backend()} rccl={ver} "
+              f"devices_visible={torch.cuda.device_count()} scaling={a.scaling}", file=sys.stderr)
 
     def timed(fn, n):
         if world > 1:
@@ -380,6 +455,7 @@ def main():
         roof = measure_dominant_kernel(dev, make_batch(None, seed=1234)) if headline else None
         # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
         step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
+        secondary = measure_secondary(dev) if (headline and world == 1 and not a.no_secondary) else None
         cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.cpu_baseline)      # reported baseline: rank 0 at N = 1 only
         nb = len(batch_cpu["src_lens"])
         what = ("supervised durations, multi-speaker (per-GPU slice of BASELINE configs[3] = 64 utterances over 8 GPUs)"
@@ -393,15 +469,17 @@ def main():
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{a.dataset} {a.block} batch={nb}/GPU"
                                     + (f" (global batch {nb * world}, weak scaling)" if a.scaling == "weak" else
-                                       " (global batch 16 sharded r::N, strong scaling)")
+                                       f" (global batch 16, {a.shard} shard, strong scaling)")
                                     + f", seq<=128 -> mel<={batch_cpu['mels'].shape[1]}x80, " + what
                                     + "; full train step fwd+loss+bwd+clip+Adam, dropout on"),
                        "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
                        "parallelism": f"dp{world}", "final_loss": loss_final,
-                       "grad_buckets_bytes": step.reducer.bucket_bytes() if world > 1 else None},
+                       "grad_buckets_bytes": step.reducer.bucket_bytes() if world > 1 else None,
+                       "strong_scaling_shard": built["shard_balance"]},
             "roofline": roof, "step_model_tflops_per_gpu": step_tflops,
             "step_frac_of_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
             "pcie_inclusive": pcie,
+            "secondary": secondary,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -4,10 +4,16 @@ mel_spectrogram(y[B,N] in [-1,1]) -> (mel[B,80,F], energy[B,F]),  F = 1 + N // h
 For the reference's filter_length = 1024 the whole front end is ONE launch (csrc/mel.hip): a 1024-point real FFT per frame, hann
 window and reflect padding folded into the load, |X| + energy in registers, the mel filterbank as a banded fp32-MFMA GEMM,
 log-clamp fused.  Other FFT sizes take the DFT-as-GEMM path (the [2*(n_fft/2+1), n_fft] windowed basis the reference feeds
-to F.conv1d, stft.py:32-56: rows = real parts then imaginary parts, periodic hann window).  The mel
-filterbank restates librosa==0.7.2 `filters.mel` (Slaney scale, area normalisation, htk=False),
-which the reference pulls from a third-party dependency (requirements.txt:9) - parity of that
-basis is pinned by the golden `tests/golden/g8_stft.npz` captured from the reference run.
+to F.conv1d, stft.py:32-56: rows = real parts then imaginary parts, periodic hann window).
+
+PARITY UNPINNED for one ingredient: the mel filterbank restates the published algorithm of librosa==0.7.2 `filters.mel` (Slaney scale,
+area normalisation, htk=False), which the reference pulls from a third-party dependency (requirements.txt:9) that is absent from
+/root/reference and from this image.  The golden `tests/golden/g8_stft.npz` was captured from the reference's own `TacotronSTFT`
+running on THIS restated basis (oracle/ref_import.py stubs librosa with it), so G8 pins the STFT / magnitude / log arithmetic against
+the reference, but not the basis.  What pins the basis is tests/test_mel_basis_cpu.py: the Slaney mel scale against the worked examples
+of librosa's own documentation (hz_to_mel / mel_to_hz / mel_frequencies(n_mels=40), all 40 values), and the triangle construction with
+the 2 / (f[i+2] - f[i]) area normalisation against its published definition.  Swap in librosa's array (`stft.mel_basis.copy_(...)`)
+where it is available.
 """
 import math
 

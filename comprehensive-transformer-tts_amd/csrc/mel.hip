@@ -221,11 +221,10 @@ extern "C" int ctts_mel_spectrogram(const float* y, const int32_t* lens, const f
   CTTS_REQUIRE(kmax >= 0 && kmax <= NBINS, "ctts_mel_spectrogram: kmax out of range");
   const int MS = kmax > 0 ? (((kmax + 3) & ~3) | 1) : MS_MAX;
   const size_t lds_bytes = sizeof(float) * (size_t)(1540 + TILE_F * MS + 4 * 2 * SCR);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_set = true;
-  }
+  // raise the kernel's dynamic-LDS limit to the LARGEST footprint (kmax = 0) on every call: the attribute is per device and per
+  // process-wide function handle, a one-shot static flag would pin the first call's (possibly smaller) size and the first device
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * (size_t)(1540 + TILE_F * MS_MAX + 4 * 2 * SCR)));
   const int grid = (int)(tiles < 4096 ? tiles : 4096);
   hipLaunchKernelGGL(mel_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, y, lens, window, workspace, mel, energy, mag, (long)ld_mag,
                      B, N, F, hop, n_mel, clip, MS);

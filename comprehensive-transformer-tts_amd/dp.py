@@ -44,12 +44,15 @@ class FlatGradArena:
 
     def __init__(self, params):
         items = list(params)
-        if items and isinstance(items[0], tuple):
-            named = [(n, p) for n, p in items if p.requires_grad]
-        else:
-            named = [(str(i), p) for i, p in enumerate(items) if p.requires_grad]
+        if items and not isinstance(items[0], tuple):
+            items = [(str(i), p) for i, p in enumerate(items)]
+        named = [(n, p) for n, p in items if p.requires_grad]
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
+        # index of every trainable tensor in the FULL list that was handed in (frozen ones included): torch.optim.Adam - the reference's
+        # and ScheduledOptim's - numbers its state over that full list (model/optimizer.py:8-14, utils/model.py:22-26)
+        self.positions = [i for i, (_, p) in enumerate(items) if p.requires_grad]
+        self.n_all = len(items)
         self.offsets, n = arena_offsets(self.params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)     # alignment gaps stay zero forever
         self.bind()
@@ -154,11 +157,17 @@ class BucketedReducer:
         return [sum(b - a for a, b in r) * 4 for r in self.ranges]
 
     def _reduce(self, s):
+        # one collective per contiguous range (the stage plans of both block types give exactly ONE range per bucket); on RCCL the
+        # division by the world size rides inside the collective (ReduceOp.AVG), gloo has no AVG: sum, then scale
+        avg = self.is_cuda and dist.get_backend(self.group) == "nccl"
         inv = 1.0 / self.world
         for a, b in self.ranges[s]:
             seg = self.arena.flat[a:b]
-            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
-            seg.mul_(inv)
+            if avg:
+                dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+                seg.mul_(inv)
 
     def launch(self, s):
         self.launched += 1
@@ -187,10 +196,11 @@ class FlatAdam:
     `lr` is a device scalar tensor (share ScheduledOptim's capturable lr - `ScheduledOptim.lr_tensor` - so the Noam schedule keeps
     driving it); the step counter lives on the device, so `step()` replays inside a hipGraph.
 
-    `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format (state: {index: {step, exp_avg, exp_avg_sq}}, indices in
-    arena order = `model.parameters()` order restricted to trainable tensors), so the optimizer half of a reference checkpoint
-    (`train.py:190-200`: {"model": ..., "optimizer": adam.state_dict()}) round-trips; frozen parameters the reference also hands to
-    Adam (energy_bins) never get state there either."""
+    `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format over the FULL parameter list the arena was built from
+    (state: {index: {step, exp_avg, exp_avg_sq}}, param_groups[0]["params"] = 0 .. n_all-1, indices = positions in
+    `model.parameters()`, frozen tensors included but without a state entry - exactly what torch writes for a parameter that never
+    received a gradient), so the optimizer half of a reference checkpoint (`train.py:190-200`: {"model": ...,
+    "optimizer": adam.state_dict()}) loads here and a checkpoint written here loads into `torch.optim.Adam(model.parameters())`."""
 
     def __init__(self, grad_arena, lr, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0, max_norm=1.0, current_step=0):
         from . import kernels
@@ -225,19 +235,30 @@ class FlatAdam:
     def state_dict(self):
         step = float(self.state[1])
         st = {}
-        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+        for pos, p, o in zip(self.arena.positions, self.arena.params, self.arena.offsets):
             sl = slice(o, o + p.numel())
-            st[i] = {"step": torch.tensor(step), "exp_avg": _strided_like(self.m[sl], p).detach().clone(),
-                     "exp_avg_sq": _strided_like(self.v[sl], p).detach().clone()}
+            st[pos] = {"step": torch.tensor(step), "exp_avg": _strided_like(self.m[sl], p).detach().clone(),
+                       "exp_avg_sq": _strided_like(self.v[sl], p).detach().clone()}
         group = {"lr": float(self.lr), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
-                 "amsgrad": False, "maximize": False, "params": list(range(len(self.arena.params)))}
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(self.arena.n_all))}
         return {"state": st, "param_groups": [group]}
 
     def load_state_dict(self, sd, param_index=None):
-        """`param_index`: optional list mapping arena position -> index in the checkpoint's param list (use it when the checkpoint's
-        Adam was built over ALL `model.parameters()` including frozen ones, as the reference does)."""
+        """Accepts a state dict of an Adam built over ALL `model.parameters()` (the reference's, ScheduledOptim's, this class's own):
+        arena tensor i reads state[arena.positions[i]].  A dict whose param group lists only the trainable tensors (the round-2 format
+        of this class) is recognised by its length.  `param_index` overrides the mapping (arena position -> checkpoint index)."""
         n = len(self.arena.params)
-        idx = list(range(n)) if param_index is None else list(param_index)
+        n_ckpt = len(sd["param_groups"][0]["params"])
+        if param_index is not None:
+            idx = list(param_index)
+        elif n_ckpt == self.arena.n_all:
+            idx = list(self.arena.positions)
+        elif n_ckpt == n:
+            idx = list(range(n))
+        else:
+            raise ValueError(f"FlatAdam.load_state_dict: the checkpoint's optimizer covers {n_ckpt} parameters, this model has "
+                             f"{self.arena.n_all} ({n} trainable)")
         if len(idx) != n:
             raise ValueError(f"FlatAdam.load_state_dict: need {n} parameter indices, got {len(idx)}")
         steps = set()

@@ -515,6 +515,11 @@ def forward_sum_bwd(attn_logprob, in32, out32, blank, lse, alpha, nll, gscale):
 
 def adam_clip_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, max_norm, state):
     """fused clip_grad_norm_ + Adam on flat fp32 arenas (csrc/optim.hip); lr / state are device tensors (graph-replayable)"""
+    if state.numel() < _lib.ADAM_STATE_FLOATS or state.dtype != torch.float32:
+        raise _lib.CttsError(f"adam_clip_step: state must hold CTTS_ADAM_STATE_FLOATS = {_lib.ADAM_STATE_FLOATS} float32 "
+                             f"(got {state.numel()} {state.dtype}): the kernel writes its per-block norm partials behind the 3 scalars")
+    if not (p.numel() == g.numel() == m.numel() == v.numel()):
+        raise _lib.CttsError("adam_clip_step: p, g, m, v must have the same number of elements")
     lib = _lib.load()
     _lib.check(lib.ctts_adam_clip_step(_p(_f32c(p, "p")), _p(_f32c(g, "g")), _p(_f32c(m, "m")), _p(_f32c(v, "v")), p.numel(), _p(lr),
                                        float(beta1), float(beta2), float(eps), float(weight_decay), float(max_norm), _p(state),
@@ -684,6 +689,8 @@ def mel_l1_bwd(p1, p2, tgt, roww, sums, g):
 def _var_loss_args(log_d, dur, texts, src_pad, cwt, cwt_spec, uv, mel_pad, f0m_p, f0m_t, f0s_p, f0s_t, e_pred, e_tgt):
     B, Ts = log_d.shape
     Tm = cwt.shape[1]
+    if texts.dtype != torch.int64:
+        raise _lib.CttsError(f"var_loss: texts must be int64 token ids, got {texts.dtype}")
     if dur.dtype not in (torch.int64, torch.float32):
         raise _lib.CttsError(f"var_loss: durations must be int64 or float32, got {dur.dtype}")
     if cwt.shape[-1] != 11 or cwt_spec.shape[-1] != 10:
@@ -694,9 +701,21 @@ def _var_loss_args(log_d, dur, texts, src_pad, cwt, cwt_spec, uv, mel_pad, f0m_p
     return ptrs, B, Ts, Tm
 
 
+def _check_var_loss_host_args(lambdas_t, sil_t):
+    """the C ABI reads lambdas5[0..4] and sil_ids3[0..2] through HOST pointers at launch"""
+    if lambdas_t.is_cuda or sil_t.is_cuda:
+        raise _lib.CttsError("var_loss: lambdas / silence ids must be HOST tensors (the library reads them at launch); a .to(device) on "
+                             "the loss module must not move them")
+    if lambdas_t.dtype != torch.float32 or lambdas_t.numel() != 5 or not lambdas_t.is_contiguous():
+        raise _lib.CttsError(f"var_loss: lambdas must be 5 contiguous float32, got {lambdas_t.numel()} {lambdas_t.dtype}")
+    if sil_t.dtype != torch.int64 or sil_t.numel() != 3 or not sil_t.is_contiguous():
+        raise _lib.CttsError(f"var_loss: silence ids must be 3 contiguous int64 (loss.py:149), got {sil_t.numel()} {sil_t.dtype}")
+
+
 def var_loss_fwd(tensors, lambdas_t, cwt_l2, sil_t):
     """tensors = (log_d, dur, texts, src_pad u8, cwt, cwt_spec, uv, mel_pad u8, f0m_p, f0m_t, f0s_p, f0s_t, e_pred, e_tgt);
     lambdas_t float32 [5] and sil_t int64 [3] are HOST tensors (read at launch).  -> (terms [8], partials, wsum, denoms)"""
+    _check_var_loss_host_args(lambdas_t, sil_t)
     ptrs, B, Ts, Tm = _var_loss_args(*tensors)
     dev = tensors[0].device
     partials = torch.empty(B, 16, dtype=torch.float32, device=dev)
@@ -710,6 +729,7 @@ def var_loss_fwd(tensors, lambdas_t, cwt_l2, sil_t):
 
 
 def var_loss_bwd(tensors, lambdas_t, cwt_l2, sil_t, partials, wsum, denoms, g8):
+    _check_var_loss_host_args(lambdas_t, sil_t)
     ptrs, B, Ts, Tm = _var_loss_args(*tensors)
     dev = tensors[0].device
     d_log_d = torch.empty(B, Ts, dtype=torch.float32, device=dev)

@@ -162,3 +162,8 @@ class ScheduledOptim:
 
     def load_state_dict(self, sd):
         self._optimizer.load_state_dict(sd)
+
+    def state_dict(self):
+        """torch.optim.Adam's state.  When trainer.TrainStep runs the fused FlatAdam this optimizer never steps: take the optimizer
+        half of a checkpoint from `TrainStep.optimizer_state_dict()` instead (same format, same indices)."""
+        return self._optimizer.state_dict()

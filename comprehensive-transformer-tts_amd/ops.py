@@ -27,6 +27,10 @@ def set_grad_accumulation_fusion(flag):
     _FUSE_GRAD_ACCUM = bool(flag)
 
 
+def grad_accumulation_fusion():
+    return _FUSE_GRAD_ACCUM
+
+
 def _fusable(p):
     return (_FUSE_GRAD_ACCUM and p is not None and p.is_leaf and p.requires_grad and p.grad is not None
             and p.grad.dtype == torch.float32 and (p.grad.is_contiguous() or p.grad.stride() == p.stride()))

@@ -110,10 +110,35 @@ def as_collated_tuple(batch):
             n(p.get("mel2ph")) if batch.get("d_targets") is not None else None, n(batch.get("attn_priors")), n(batch.get("spker_embeds")))
 
 
-def shard(batch, rank, world):
-    """DistributedSampler-like shard of a CPU batch (train.py:44): utterances rank, rank+world, ...; padded widths shrink to the
-    shard's own maxima exactly as a per-rank `collate_fn` would produce them."""
-    idx = list(range(rank, batch["texts"].shape[0], world))
+def shard_indices(mel_lens, rank, world, order="strided"):
+    """Which utterances of a global batch rank `rank` takes.
+    "strided": r, r+world, ... - DistributedSampler order (train.py:44).  On a length-sorted batch (collate_fn sorts, dataset.py:230-236)
+               rank 0 always gets the longest utterance of every group of `world`: at 16 utterances over 8 ranks that is 128+82 against
+               96+55 phonemes - ~28 % more frames on rank 0 than on rank 7, and the step waits for rank 0.
+    "snake":   utterances sorted by mel length, dealt 0..world-1, world-1..0, 0..: long and short ones pair up, same count per rank."""
+    n = len(mel_lens)
+    if order == "strided":
+        return list(range(rank, n, world))
+    if order != "snake":
+        raise ValueError(f"shard order {order!r}: expected 'strided' or 'snake'")
+    by_len = sorted(range(n), key=lambda i: (-int(mel_lens[i]), i))
+    out = []
+    for pos, i in enumerate(by_len):
+        lap, k = divmod(pos, world)
+        if (k if lap % 2 == 0 else world - 1 - k) == rank:
+            out.append(i)
+    return out
+
+
+def shard_valid_frames(batch, world, order="strided"):
+    """valid mel frames per rank of the sharded global batch -> list of `world` ints (the step time follows the maximum)"""
+    return [int(sum(int(batch["mel_lens"][i]) for i in shard_indices(batch["mel_lens"], r, world, order))) for r in range(world)]
+
+
+def shard(batch, rank, world, order="strided"):
+    """Shard of a CPU batch (see shard_indices for the two orders); padded widths shrink to the shard's own maxima exactly as a
+    per-rank `collate_fn` would produce them."""
+    idx = shard_indices(batch["mel_lens"], rank, world, order)
     src, mel = batch["src_lens"][idx], batch["mel_lens"][idx]
     Ts, Tm = int(src.max()), int(mel.max())
 

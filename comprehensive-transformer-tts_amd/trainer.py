@@ -87,8 +87,22 @@ class TrainStep:
         self.reducer.finish()
         self._optimizer_step()
 
+    # ---- checkpointing (train.py:190-200 saves {"model": ..., "optimizer": optimizer._optimizer.state_dict()})
+    def optimizer_state_dict(self):
+        """the optimizer half of a checkpoint in torch.optim.Adam's format over ALL model.parameters() - from the fused FlatAdam when
+        it does the updates (then `optim._optimizer` never steps and its own state stays empty), else from torch's Adam"""
+        return self.fadam.state_dict() if self.fadam is not None else self.optim._optimizer.state_dict()
+
+    def load_optimizer_state_dict(self, sd):
+        if self.fadam is not None:
+            self.fadam.load_state_dict(sd)
+        else:
+            self.optim._optimizer.load_state_dict(sd)
+
     # ---- graph capture
     def capture(self, warmup=2):
+        """Side effects: the `warmup` eager steps are REAL optimizer steps (parameters, moments and the Noam step counter advance by
+        `warmup`, exactly as if the loop had run them) - capture right before the training loop, not in the middle of an evaluation."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

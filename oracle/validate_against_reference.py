@@ -6,7 +6,11 @@ restatement (oracle/restate.py) side by side at the BASELINE shapes and records
   * eval forward, canonical fs2 batch (B=16, Ts<=128, Tm<=1024): max-abs of mel / postnet mel / log-duration / cwt / energy;
   * train-mode forward + backward of the reference's loss, dropout patched to identity on both sides: max-abs of the outputs and
     the worst per-tensor relative error over all parameter gradients;
-  * conformer, B=4 canonical lengths capped at T = 1000 (rel-shift index arithmetic at full length): eval forward max-abs;
+  * conformer, B=4 canonical lengths capped at T = 1000 (rel-shift index arithmetic at full length): eval forward max-abs, and the
+    train-mode forward + backward (dropout off) with the worst per-tensor gradient error (licenses the oracle for the GPU test
+    test_conformer_b4_t1000_train_mode_gradients_vs_oracle_full_length);
+  * C5 = liu2021 prosody + learn_alignment at the canonical batch, train mode, dropout off: forward outputs, soft alignment, hard
+    durations (licenses test_c5_canonical_batch_forward_vs_oracle_full_size);
   * wall time of one full train step (dropout on, same thread count) of both -> r = t_reference / t_restatement, the factor that
     converts bench.py's `cpu_baseline` (restatement timed on the GPU host) into "reference CPU PyTorch path" time.
 
@@ -39,12 +43,12 @@ def maxabs(a, b):
     return float((a.detach().double() - b.detach().double()).abs().max())
 
 
-def build(block):
+def build(block, learn_alignment=False, prosody="none"):
     from model import CompTransTTS, CompTransTTSLoss
     pre, mc, tc = ref_import.load_configs("LJSpeech")
     mc["block_type"] = block
-    mc["duration_modeling"]["learn_alignment"] = False          # BASELINE configs[1] / [2]: supervised durations
-    mc["prosody_modeling"]["model_type"] = "none"
+    mc["duration_modeling"]["learn_alignment"] = learn_alignment   # False: BASELINE configs[1] / [2], supervised durations
+    mc["prosody_modeling"]["model_type"] = prosody
     model = CompTransTTS(pre, mc, tc)
     sd = closed_form_state_dict(model.state_dict())
     model.load_state_dict(sd)
@@ -70,9 +74,75 @@ def oracle_step(sd, cfgs, batch, fwd, train_dropout, step=50001):
     return out[:-2], RefLoss(pre, mc, tc)(inputs, out[:-2], step)
 
 
+def grad_pin(model, loss_fn, cfgs, sd, batch, fwd, step=50001):
+    """train mode, dropout off on both sides: outputs + worst per-tensor relative gradient error (reference vs restatement)"""
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+    try:
+        model.train()
+        model.zero_grad()
+        out_r, loss_r = ref_step(model, loss_fn, batch, step)
+        loss_r[0].backward()
+        g_ref = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+        sdg = {k: (v.clone().requires_grad_(True) if k in trainable else v.clone()) for k, v in sd.items()}
+        out_o, loss_o = oracle_step(sdg, cfgs, batch, fwd, False, step)
+        loss_o[0].backward()
+    finally:
+        F.dropout = _real_dropout
+    worst, worst_k = 0.0, None
+    gmax = max(float(g.abs().max()) for g in g_ref.values())
+    for k, g in g_ref.items():
+        go = sdg[k].grad if sdg[k].grad is not None else torch.zeros_like(g)
+        e = float((go - g).abs().max() / max(float(g.abs().max()), 1e-4 * gmax))
+        if e > worst:
+            worst, worst_k = e, k
+    return {"mel": maxabs(out_r[0], out_o[0]), "postnet_mel": maxabs(out_r[1], out_o[1]), "total_loss_ref": float(loss_r[0]),
+            "total_loss_oracle": float(loss_o[0]), "n_grad_tensors": len(g_ref), "largest_grad_entry": gmax,
+            "worst_grad_rel_max_err": worst, "worst_grad_tensor": worst_k}, out_r, out_o
+
+
+def extra_pins(rec):
+    """round 3: conformer train-mode gradients at T = 1000 and the C5 forward at the canonical batch"""
+    model, loss_fn, cfgs, sd = build("conformer")
+    b4 = make_batch(CANONICAL_SRC_LENS[:4], max_mel_cap=1000)
+    rec["conformer_train_nodropout_B4_T1000"], _, _ = grad_pin(model, loss_fn, cfgs, sd, b4, R.comp_trans_tts_forward_conformer)
+    print("conformer train", rec["conformer_train_nodropout_B4_T1000"], flush=True)
+    del model
+    from ctts_amd.synthetic import make_unsup_batch
+    model, loss_fn, cfgs, sd = build("transformer_fs2", learn_alignment=True, prosody="liu2021")
+    bu = make_unsup_batch()
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+    try:
+        model.train()
+        import copy
+        with torch.no_grad():
+            # deep copies: on a CPU tensor the reference's get_phoneme_level_energy (modules.py:882-888, tools.py:56-66) averages IN PLACE
+            # on `energy_frame.cpu().numpy()`, i.e. it overwrites the caller's frame-level energy targets
+            a = list(as_model_args(copy.deepcopy(bu))); a[7] = dict(a[7])
+            ref = model(*a, step=100001)
+            a = list(as_model_args(copy.deepcopy(bu))); a[7] = dict(a[7])
+            ora = R.comp_trans_tts_forward(sd, cfgs[1], cfgs[0], *a, step=100001, training=True, train_dropout=False, new_stats={})
+    finally:
+        F.dropout = _real_dropout
+    rec["c5_train_forward_nodropout_B16"] = {
+        "mel": maxabs(ref[0], ora[0]), "postnet_mel": maxabs(ref[1], ora[1]), "log_d": maxabs(ref[4], ora[4]),
+        "attn_soft": maxabs(ref[10][0], ora[10][0]), "attn_logprob": maxabs(ref[10][3], ora[10][3]),
+        "hard_durations_identical": bool(torch.equal(ref[5].to(ora[5].dtype), ora[5])), "Tm": int(ref[0].shape[1])}
+    print("C5 forward", rec["c5_train_forward_nodropout_B16"], flush=True)
+
+
 def main():
     nthreads = int(os.environ.get("CTTS_VALIDATE_THREADS", str(os.cpu_count() or 1)))
     torch.set_num_threads(nthreads)
+    if "--extra-only" in sys.argv:            # add the round-3 pins to the committed record without re-running the timings
+        with open(OUT) as f:
+            rec = json.load(f)
+        extra_pins(rec)
+        os.chdir(ROOT)
+        with open(OUT, "w") as f:
+            json.dump(rec, f, indent=1)
+        print("wrote", OUT)
+        return
     rec = {"threads": nthreads, "torch": torch.__version__, "host": "build container (CPU only)"}
 
     # ---------------- fs2, canonical batch
@@ -164,6 +234,8 @@ def main():
     rec["conformer_eval_B4_T1000"] = {"mel": maxabs(ref[0], ora[0]), "postnet_mel": maxabs(ref[1], ora[1]), "log_d": maxabs(ref[4], ora[4]),
                                       "T": int(ref[0].shape[1])}
     print("conformer eval", rec["conformer_eval_B4_T1000"], flush=True)
+    del model
+    extra_pins(rec)
     os.chdir(ROOT)
     with open(OUT, "w") as f:
         json.dump(rec, f, indent=1)

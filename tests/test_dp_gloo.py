@@ -77,6 +77,32 @@ def test_two_rank_gradient_equals_single_process_average():
     assert shard_batch_indices(7, 1, 2) == [1, 3, 5]
 
 
+@__import__("pytest").mark.parametrize("world", [2, 4, 8])
+@__import__("pytest").mark.parametrize("order", ["strided", "snake"])
+def test_strong_scaling_shard_covers_the_global_batch_once(world, order):
+    """bench.py --scaling strong: the canonical 16 utterances dealt over 2 / 4 / 8 ranks (2 per rank at 8: BatchNorm still sees two
+    utterances); every utterance lands on exactly one rank, widths shrink to the shard's own maxima, and the snake order is the
+    better balanced one"""
+    from ctts_amd.synthetic import make_batch, shard, shard_indices, shard_valid_frames
+    gb = make_batch()
+    B = gb["texts"].shape[0]
+    seen = []
+    for r in range(world):
+        idx = shard_indices(gb["mel_lens"], r, world, order)
+        assert len(idx) == B // world
+        sh = shard(gb, r, world, order)
+        assert sh["texts"].shape == (B // world, int(gb["src_lens"][idx].max()))
+        assert sh["mels"].shape[:2] == (B // world, int(gb["mel_lens"][idx].max())) and sh["max_mel_len"] == sh["mels"].shape[1]
+        assert torch.equal(sh["mel_lens"], gb["mel_lens"][idx]) and torch.equal(sh["d_targets"], gb["d_targets"][idx][:, :sh["max_src_len"]])
+        seen += idx
+    assert sorted(seen) == list(range(B))
+    v_str, v_snk = shard_valid_frames(gb, world, "strided"), shard_valid_frames(gb, world, "snake")
+    assert sum(v_str) == sum(v_snk) == int(gb["mel_lens"].sum())
+    assert max(v_snk) <= max(v_str)
+    if world == 8:
+        assert max(v_str) / (sum(v_str) / 8) > 1.10 and max(v_snk) / (sum(v_snk) / 8) < 1.05
+
+
 def test_arena_views_alias_param_grads():
     m = _model()
     arena = FlatGradArena(m.parameters())
@@ -128,8 +154,9 @@ def _real_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_real_model_bucketed_allreduce_two_ranks():
-    world = 2
+@__import__("pytest").mark.parametrize("world", [2, 4, 8])
+def test_real_model_bucketed_allreduce(world):
+    """world 2, 4 and 8 (the node size BASELINE names): stage plan + one collective per bucket over the real parameter set"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -147,8 +174,7 @@ def test_real_model_bucketed_allreduce_two_ranks():
     m = _real_model()
     arena = FlatGradArena(m.named_parameters())
     n = arena.flat.numel()
-    g0, g1 = _standin_grad(n, 0), _standin_grad(n, 1)
-    arena.flat.copy_(g1)
+    arena.flat.copy_(_standin_grad(n, 1))
     m.variance_adaptor.energy_predictor.linear.weight.grad.zero_()
     g1 = arena.flat.clone()
     mask = torch.zeros(n, dtype=torch.bool)                    # reduced positions = parameter storage + its alignment tail
@@ -156,14 +182,18 @@ def test_real_model_bucketed_allreduce_two_ranks():
     for o, e in zip(arena.offsets, ends):
         mask[o:e] = True
     assert bool(mask.all())                                    # the buckets tile the whole arena
-    expect = (g0 + g1) / 2
+    expect = g1.clone()
+    for r in range(world):
+        if r != 1:
+            expect += _standin_grad(n, r)
+    expect /= world
     assert abs(res[0][0] - float(expect.double().sum())) < 1e-3 * max(1.0, abs(float(expect.double().sum())))
-    assert res[0][0] == res[1][0]
+    assert all(res[r][0] == res[0][0] for r in range(world))
     arena.flat.copy_(expect)
     for name, v in res[0][1].items():
         p = dict(zip(arena.names, arena.params))[name]
-        assert torch.allclose(v, p.grad.flatten()[:5], atol=1e-6), name
-        assert torch.equal(v, res[1][1][name]), name
+        assert torch.allclose(v, p.grad.flatten()[:5], atol=1e-5), name
+        assert all(torch.equal(v, res[r][1][name]) for r in range(1, world)), name
     bb = res[0][2]
     assert len(bb) == 4 and sum(bb) == 4 * n and min(bb) > 20e6 and max(bb) < 60e6     # ~25-55 MB buckets, nothing dropped
 
@@ -210,6 +240,44 @@ def test_flat_adam_state_dict_roundtrips_in_torch_adam_format():
     # parameters were re-homed into the flat arena without changing their values or the module's state_dict
     for (k, a), (_, b) in zip(m.state_dict().items(), _model().state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_flat_adam_state_dict_is_keyed_like_adam_over_all_parameters_of_the_real_model():
+    """The reference builds Adam over ALL model.parameters() (model/optimizer.py:8-14): the frozen variance_adaptor.energy_bins sits at
+    position 43 of 171, so every later index differs from an enumeration of the trainable tensors.  FlatAdam's state dict must load
+    into torch.optim.Adam(list(model.parameters())) and back."""
+    from ctts_amd.dp import FlatAdam
+    m = _real_model()
+    allp = list(m.named_parameters())
+    frozen = [i for i, (_, p) in enumerate(allp) if not p.requires_grad]
+    assert frozen and frozen[0] < len(allp) - 1                      # a frozen tensor in the MIDDLE of the list
+    arena = FlatGradArena(m.named_parameters())
+    assert arena.n_all == len(allp) and len(arena.positions) == len(allp) - len(frozen)
+    fa = FlatAdam(arena, 1e-3, current_step=11)
+    fa.m.copy_(torch.arange(fa.m.numel(), dtype=torch.float32) % 997 * 1e-3)
+    fa.v.copy_(torch.arange(fa.v.numel(), dtype=torch.float32) % 991 * 1e-4)
+    sd = fa.state_dict()
+    assert sd["param_groups"][0]["params"] == list(range(len(allp))) and all(i not in sd["state"] for i in frozen)
+    ref = torch.optim.Adam([p for _, p in allp], lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    ref.load_state_dict(sd)                                          # torch accepts it as its own
+    from ctts_amd.dp import _strided_like
+    name_of = {id(p): n for n, p in allp}
+    checked = 0
+    for p, st in ref.state.items():
+        i = arena.names.index(name_of[id(p)])
+        o = arena.offsets[i]
+        assert torch.equal(st["exp_avg"], _strided_like(fa.m[o:o + p.numel()], p)), arena.names[i]
+        assert torch.equal(st["exp_avg_sq"], _strided_like(fa.v[o:o + p.numel()], p)), arena.names[i]
+        checked += 1
+    assert checked == len(arena.params)
+    # and back: a checkpoint written by torch's Adam over all parameters loads without a hand-built index map
+    m2 = _real_model()
+    fb = FlatAdam(FlatGradArena(m2.named_parameters()), 1e-3)
+    fb.load_state_dict(ref.state_dict())
+    for p, o in zip(arena.params, arena.offsets):
+        sl = slice(o, o + p.numel())
+        assert torch.equal(fb.m[sl], fa.m[sl]) and torch.equal(fb.v[sl], fa.v[sl])
+    assert float(fb.state[1]) == 11.0
 
 
 def test_zero_grad_set_to_none_is_detected():

@@ -347,6 +347,10 @@ def test_mel_spectrogram_vs_reference_golden(path):
           f"linear mel rel err {lin:.2e}; loud fraction {loud.float().mean():.2f}")
     assert all_ours <= max(1.5 * all_ref, 1e-4), (all_ours, all_ref)
     assert mag_ours <= max(1.5 * mag_ref, 2e-5), (mag_ours, mag_ref)
+    # the all-bin number, asserted: 4e-3 in the log domain over ALL 80 x F bins against the reference's own output (measured 2.4e-3 FFT /
+    # 3.0e-3 DFT-GEMM; the reference itself is 1.75e-3 from the float64 truth on this waveform - near-silent bins, where exp(mel) ~ 1e-5,
+    # carry all of it; INTEGRATION.md section 5 states this bound next to the 1e-3 loud-bin bound)
+    assert all_vs_ref <= 4e-3, all_vs_ref
 
 
 @pytest.mark.parametrize("B,N", [(1, 700), (3, 4096 + 37), (2, 22050), (1, 256 * 40)])
@@ -450,8 +454,10 @@ def test_swish_linear_glu_depthwise_fwd_bwd():
 
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("B,T,H,C", [(2, 36, 8, 256), (2, 51, 8, 256), (1, 132, 4, 128), (2, 200, 8, 256), (1, 64, 2, 256), (2, 9, 8, 256),
-                                     (2, 1, 8, 256), (1, 33, 4, 256)])
+                                     (2, 1, 8, 256), (1, 33, 4, 256), (1, 1000, 8, 256)])
 def test_relpos_attention_fwd_bwd(B, T, H, C, fused):
+    """(1, 1000, 8, 256) is the conformer decoder's full length: the fused backward's 63-wide Toeplitz band, the lane rotation and the
+    padded dS slab against an independent float64 reference (not only against the unfused pipeline)."""
     ops.set_fused_attention(fused)
     dh = C // H
     qu, qv, kv, pos = rnd(B, T, C, seed=110), rnd(B, T, C, seed=111), rnd(B, T, 2 * C, seed=112), rnd(T, C, seed=113)

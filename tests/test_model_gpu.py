@@ -216,6 +216,148 @@ def test_canonical_batch_train_mode_gradients_vs_oracle_full_size():
     assert n >= 170 and worst[1] <= 2e-3, worst
 
 
+def _grads_vs_oracle(m, sdg, min_tensors, bar):
+    """worst per-tensor relative gradient error of the product's parameters against the oracle's autograd"""
+    worst, n = ("", 0.0), 0
+    gmax = max(float(v.grad.abs().max()) for v in sdg.values() if v.requires_grad and v.grad is not None)
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        g_ref = sdg[k].grad
+        if g_ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        e = maxerr(p.grad, g_ref.numpy()) / max(float(g_ref.abs().max()), 1e-4 * gmax)
+        n += 1
+        if e > worst[1]:
+            worst = (k, e)
+    assert n >= min_tensors and worst[1] <= bar, (n, worst)
+    return worst, n
+
+
+def test_canonical_batch_fused_accumulation_through_trainstep_vs_oracle_full_size():
+    """The mode bench.py runs: trainer.TrainStep switches gradient-accumulation fusion ON (kernels add straight into the flat arena,
+    weight-gradient partials land in param.grad, the persistent stream-K GEMM takes the large reductions).  One eager forward + loss +
+    backward through TrainStep's own code path at the canonical size, dropout off, and the arena against the oracle's autograd."""
+    from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
+    from ctts_amd.trainer import TrainStep
+    from oracle.loss_restate import RefLoss
+    torch.manual_seed(1)
+    m, (pre, mc, tc) = build()
+    m.train()
+    no_dropout(m)
+    sd = {k: v.detach().cpu().contiguous().clone() for k, v in m.state_dict().items()}
+    batch = make_batch()
+    args = list(as_model_args(to_device(batch, DEV)))
+    loss_fn = CompTransTTSLoss(pre, mc, tc).to(DEV)
+    optim = ScheduledOptim(m, tc, mc, 50000, capturable=True)
+    step = TrainStep(m, loss_fn, optim, args, use_graph=False, adam_step=optim.current_step)
+    assert __import__("ctts_amd").ops.grad_accumulation_fusion()
+    for _ in step._stages():            # forward + loss + backward into the arena, exactly as _eager() does before the optimizer
+        pass
+    torch.cuda.synchronize()
+    trainable = {k for k, p in m.named_parameters() if p.requires_grad}
+    sdg = {k: (v.requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    a = list(as_model_args(batch))
+    a[7] = dict(a[7])
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    ref = R.comp_trans_tts_forward(sdg, mc, pre, *a, step=50001, training=True, train_dropout=False, new_stats={})
+    rin = [None, None] + a
+    rin[9:11] = ref[-2:]
+    rl = RefLoss(pre, mc, tc)(rin, ref[:-2], 50001)
+    rl[0].backward()
+    assert abs(float(step.loss_val) - float(rl[0])) <= 1e-4 * abs(float(rl[0]))
+    for p in step.params:                # every trainable parameter's gradient IS a view of the arena
+        assert p.grad is not None and p.grad.data_ptr() >= step.flat_grad.data_ptr()
+    worst, n = _grads_vs_oracle(m, sdg, 170, 2e-3)
+    print(f"TrainStep (fusion on), canonical batch: loss {float(step.loss_val):.6f} vs {float(rl[0]):.6f}; worst gradient {worst[1]:.2e} "
+          f"({worst[0]}) over {n} tensors")
+
+
+def test_conformer_b4_t1000_train_mode_gradients_vs_oracle_full_length():
+    """BASELINE configs[2] geometry, train mode (BatchNorm batch statistics), dropout off, decoder at the full T = 1000: outputs and every
+    parameter gradient against the oracle's autograd - the fused relative-position attention BACKWARD (63-wide Toeplitz band, lane
+    rotation, padded dS slab) and the depthwise-conv weight gradient at the length the bench runs."""
+    from ctts_amd.loss import CompTransTTSLoss
+    from ctts_amd.synthetic import CANONICAL_SRC_LENS
+    from oracle.loss_restate import RefLoss
+    ops_mod = __import__("ctts_amd").ops
+    ops_mod.set_grad_accumulation_fusion(False)
+    torch.manual_seed(2)
+    m, (pre, mc, tc) = build(block="conformer")
+    m.train()
+    no_dropout(m)
+    sd = {k: v.detach().cpu().contiguous().clone() for k, v in m.state_dict().items()}
+    batch = make_batch(CANONICAL_SRC_LENS[:4], max_mel_cap=1000)
+    args = list(as_model_args(to_device(batch, DEV)))
+    args[7] = dict(args[7])
+    out = m(*args, step=50001)
+    inputs = [None, None] + args
+    inputs[9:11] = out[-2:]
+    losses = CompTransTTSLoss(pre, mc, tc).to(DEV)(inputs, out[:-2], 50001)
+    losses[0].backward()
+    torch.cuda.synchronize()
+    trainable = {k for k, p in m.named_parameters() if p.requires_grad}
+    sdg = {k: (v.requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    a = list(as_model_args(batch))
+    a[7] = dict(a[7])
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    ref = R.comp_trans_tts_forward_conformer(sdg, mc, pre, *a, step=50001, training=True, train_dropout=False, new_stats={})
+    rin = [None, None] + a
+    rin[9:11] = ref[-2:]
+    rl = RefLoss(pre, mc, tc)(rin, ref[:-2], 50001)
+    rl[0].backward()
+    e_mel, e_post = maxerr(out[0], ref[0].detach().numpy()), maxerr(out[1], ref[1].detach().numpy())
+    assert out[0].shape[1] == 1000 and e_mel <= MEL_TOL and e_post <= MEL_TOL, (e_mel, e_post)
+    assert abs(float(losses[0]) - float(rl[0])) <= 1e-4 * abs(float(rl[0]))
+    worst, n = _grads_vs_oracle(m, sdg, 300, 2e-3)
+    print(f"conformer B=4 T=1000, train mode: mel {e_mel:.2e} postnet {e_post:.2e} loss {float(losses[0]):.6f} vs {float(rl[0]):.6f}; "
+          f"worst gradient {worst[1]:.2e} ({worst[0]}) over {n} tensors")
+
+
+def test_c5_canonical_batch_forward_vs_oracle_full_size():
+    """BASELINE configs[4] (liu2021 prosody + learn_alignment) at the canonical batch, train mode (prosody encoders read the mel,
+    BatchNorm batch statistics), dropout off: the GRU over ~1,000 mel steps, the Conv2d stack on [16, Tm, 80], the aligner's
+    671 MB-class distance map and the device MAS against the CPU oracle."""
+    from ctts_amd.synthetic import make_unsup_batch
+    torch.manual_seed(3)
+    pre, mc, tc = get_configs()
+    mc["prosody_modeling"]["model_type"] = "liu2021"
+    mc["duration_modeling"]["learn_alignment"] = True
+    m = ctts_amd.CompTransTTS(pre, mc, tc).to(DEV)
+    m.train()
+    no_dropout(m)
+    sd = {k: v.detach().cpu().contiguous().clone() for k, v in m.state_dict().items()}
+    batch = make_unsup_batch()
+    args = list(as_model_args(to_device(batch, DEV)))
+    args[7] = dict(args[7])
+    with torch.no_grad():
+        out = m(*args, step=100001)
+    a = list(as_model_args(batch))
+    a[7] = dict(a[7])
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = R.comp_trans_tts_forward(sd, mc, pre, *a, step=100001, training=True, train_dropout=False, new_stats={})
+        # the device MAS against the host MAS on IDENTICAL input (the product's own soft alignment): bit-exact
+        hard_on_product_soft = R.binarize_attention(out[10][0].cpu(), batch["src_lens"], batch["mel_lens"])
+    assert torch.equal(out[10][1].cpu(), hard_on_product_soft)
+    e_soft = maxerr(out[10][0], ref[10][0].numpy())
+    e_logp = maxerr(out[10][3], ref[10][3].numpy())
+    assert e_soft <= 1e-4 and e_logp <= 2e-3, (e_soft, e_logp)
+    same_path = torch.equal(out[5].cpu().to(ref[5].dtype), ref[5])
+    e_mel, e_post, e_logd = maxerr(out[0], ref[0].numpy()), maxerr(out[1], ref[1].numpy()), maxerr(out[4], ref[4].numpy())
+    print(f"C5 canonical batch: attn_soft {e_soft:.2e} logprob {e_logp:.2e} durations identical {same_path}; "
+          f"mel {e_mel:.2e} postnet {e_post:.2e} log_d {e_logd:.2e}")
+    assert e_logd <= MEL_TOL                              # duration predictor does not depend on the alignment path
+    # monotonic search on a [Tm, Ts] map of near-ties can legitimately pick another path after a 1e-6 change of the scores: the mel
+    # comparison is only meaningful when both sides expanded with the same durations (they do on every box measured so far)
+    assert same_path, "hard alignments differ: re-check MAS tie handling"
+    assert e_mel <= MEL_TOL and e_post <= MEL_TOL
+    for n, v, r in zip(("up_vec?", "pp?"), out[11] or (), ref[11] or ()):
+        if v is not None and r is not None:
+            assert maxerr(v, r.numpy()) <= 1e-3, n
+
+
 def test_conformer_b4_t1000_forward_vs_oracle_full_length():
     """BASELINE configs[2] geometry at full length: 4 utterances, decoder T = 1000 (the max_seq_len crop), 512 MB-class attention
     maps in the reference - relative-shift index arithmetic and the unmasked softmax at large T against the CPU oracle."""
