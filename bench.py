@@ -111,7 +111,7 @@ def spawn_ranks(n):
 
 
 # ----------------------------------------------------------------------------------------------------------- measurement
-def measure_dominant_kernel(dev, batch, iters=20):
+def measure_dominant_kernel(dev, batch, iters=50, warm=30):
     """HIP-event timing (on the launch stream) of the dominant kernel at its train-step arguments:
     decoder FFN Conv1d(256->1024, k=9) as implicit GEMM, M=B*Tm rows, N=1024, K=2304."""
     from ctts_amd import kernels as K
@@ -131,7 +131,9 @@ def measure_dominant_kernel(dev, batch, iters=20):
     def launch():
         K.gemm(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, conv=(T, ks // 2, cin), alpha=ks ** -0.5, bias=bias,
                Z=Z, ldz=cout, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1, row_lens=lens, row_T=T, row_halo=0, tile_map=tmap)
-    for _ in range(3):
+    # `warm` launches first: after the host-side pause between the timed loops and this measurement the first ~30 launches run 15 %
+    # slower (594 vs 511 us, tools/dbg_dom.py) while the clocks come back up; inside the train step the GPU never idles
+    for _ in range(warm):
         launch()
     st = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
