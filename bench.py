@@ -56,6 +56,8 @@ def parse():
                     help="primary: only C2 at physical cores; full: C1 and C2 at physical cores and at 8 threads")
     ap.add_argument("--no-pcie", action="store_true", help="skip the second timed loop with the host data path inside")
     ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE configs[2..4] lines measured after the headline")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the stand-alone timing of the dominant kernel (kernel-trace runs: keeps "
+                                                               "the 80 extra launches out of the per-step statistics)")
     ap.add_argument("--batch", default="canonical", choices=["canonical", "c1"])
     ap.add_argument("--block", default="transformer_fs2", choices=["transformer_fs2", "conformer"],
                     help="block_type plugin; the headline metric (BASELINE configs[1]) is transformer_fs2, conformer = configs[2]")
@@ -454,7 +456,7 @@ def main():
     if rank == 0:
         headline = (a.batch == "canonical" and a.block == "transformer_fs2" and a.prosody == "none" and not a.learn_alignment
                     and a.dataset == "LJSpeech")
-        roof = measure_dominant_kernel(dev, make_batch(None, seed=1234)) if headline else None
+        roof = measure_dominant_kernel(dev, make_batch(None, seed=1234)) if (headline and not a.no_roofline) else None
         # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
         step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
         secondary = measure_secondary(dev) if (headline and world == 1 and not a.no_secondary) else None

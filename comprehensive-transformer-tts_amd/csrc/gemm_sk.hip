@@ -185,6 +185,11 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : ((MT * NT >= 2 || STAGES >
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  if (p.debug & 96) {      // tools: de-phase the co-resident workgroups of a CU by half a K-block (bits 5 / 6 pick which ones wait)
+    const int wjp = (int)(blockIdx.x >> 3), Wp = (int)(gridDim.x >> 3);
+    const bool late = (p.debug & 32) ? (wjp & 1) : (wjp >= Wp / 2);
+    if (late) for (int i = 0; i < ((p.debug >> 8) & 255); ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 cycles per iteration
+  }
   const unsigned long long dbg_c0 = (p.debug & 16) ? clock64() : 0ull, dbg_w0 = (p.debug & 16) ? wall_clock64() : 0ull;
 
   // ---- schedule inputs that live in device memory

@@ -43,7 +43,7 @@ elif which == "sq":
 else:
     x = torch.randn(M, 256, device=dev); w = torch.randn(768, 256, device=dev); C = torch.empty(M, 768, device=dev)
     fn = lambda: K.gemm(x, w, C, M, 768, 256, 256, 256, 768, True, True); fl = 2 * M * 768 * 256
-for _ in range(3):
+for _ in range(30):          # steady state: the first ~30 launches after an idle period run 15 % slower (clock ramp)
     fn()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
