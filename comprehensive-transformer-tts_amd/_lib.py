@@ -84,7 +84,7 @@ _SIGNATURES = {
     "ctts_glu_fwd": [_vp, _vp, _i64, C.c_int, _vp],
     "ctts_glu_bwd": [_vp, _vp, _vp, _i64, C.c_int, _vp],
     "ctts_dwconv_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
-    "ctts_dwconv_wgrad": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_dwconv_wgrad": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_relpos_softmax_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_relpos_softmax_bwd": [_vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_relshift_bwd": [_vp, _vp, C.c_int, C.c_int, _vp],

@@ -123,8 +123,9 @@ class ConformerBlock(nn.Module):
         m = getattr(seq, "1").module
         at = m.attention
         h, xr = ops.layer_norm_res(x, m.layer_norm.weight, m.layer_norm.bias, 1e-5)
-        w_qkv = torch.cat([at.query_proj.linear.weight, at.key_proj.linear.weight, at.value_proj.linear.weight], 0)
-        qkv = ops.linear(h, w_qkv)                                       # one [768,256] GEMM for q | k | v
+        # one [768,256] GEMM for q | k | v; the three weights are neighbours in model.parameters() order, so in the flat parameter /
+        # gradient arenas the stacked matrix and its gradient are views (no cat, no split-and-add in the backward)
+        qkv = ops.linear_packed(h, (at.query_proj.linear.weight, at.key_proj.linear.weight, at.value_proj.linear.weight))
         qu, qv, kv = ops.relattn_split(qkv, at.u_bias, at.v_bias)        # q + u_bias, q + v_bias, k | v in one pass
         pos = ops.linear(pos_table, at.pos_proj.linear.weight)           # [T,C], batch independent
         ctxv = ops.relpos_attention(qu, qv, kv, pos, self.n_heads, 1.0 / math.sqrt(C), p_drop=p, drop=drop)

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
   for (int k = 0; k < DW_MAXK; ++k) p[k] = acc[k];
 }
 
-__global__ void dwconv_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int C, int K, int n_slices) {
+__global__ void dwconv_wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int C, int K, int n_slices, int accumulate) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;          // e = c * 32 + k
   if (e >= C * DW_MAXK) return;
   const int c = e / DW_MAXK, k = e - c * DW_MAXK;
@@ -141,7 +141,8 @@ __global__ void dwconv_wgrad_reduce_kernel(const float* __restrict__ partials, f
     s0 += a4; s1 += a5; s2 += a6; s3 += a7;
   }
   for (; sl < n_slices; ++sl) s0 += p[sl * st];
-  dw[(long)c * K + k] = (s0 + s1) + (s2 + s3);
+  const float r = (s0 + s1) + (s2 + s3);
+  if (accumulate) dw[(long)c * K + k] += r; else dw[(long)c * K + k] = r;
 }
 
 // ---- relative-position scores: shifted[i,j] = padded.flat[i*T + j + T], padded = [0 | PS] rows of T+1  (conformer.py:423-431)
@@ -254,7 +255,7 @@ extern "C" int ctts_dwconv_fwd(const float* x, const float* wT, float* y, int B,
   return 0;
 }
 
-extern "C" int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, float* partials, int B, int T, int C, int K, void* stream) {
+extern "C" int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, float* partials, int B, int T, int C, int K, int accumulate, void* stream) {
   CTTS_REQUIRE(dy && x && dw && partials && K <= DW_MAXK && (K & 1), "ctts_dwconv_wgrad: need odd K <= 32 and a partials workspace");
   hipStream_t st = (hipStream_t)stream;
   if (B == 0 || T == 0) {
@@ -266,7 +267,7 @@ extern "C" int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, flo
   dim3 grid(slices, (C + 255) / 256);
   hipLaunchKernelGGL(dwconv_wgrad_kernel, grid, dim3(256), 0, st, dy, x, partials, B, T, C, K);
   CTTS_CHECK_LAUNCH("ctts_dwconv_wgrad");
-  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * DW_MAXK + 63) / 64), dim3(64), 0, st, partials, dw, C, K, slices);
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3((C * DW_MAXK + 63) / 64), dim3(64), 0, st, partials, dw, C, K, slices, accumulate);
   CTTS_CHECK_LAUNCH("ctts_dwconv_wgrad(reduce)");
   return 0;
 }

@@ -238,8 +238,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
   uint32_t dkey = 0; float inv_keep = 1.f;
   if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
   const float invR = 1.f / (float)rows;
+  const bool accumulate = (batch_stats & 2) != 0;      // bit 1: add to dgamma / dbeta (gradient-accumulation fusion into param.grad)
+  batch_stats &= 1;
   if (blockIdx.x == 0)
-    for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      if (accumulate) { dbeta[c] += (float)sums[c]; dgamma[c] += (float)sums[C + c]; }
+      else { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
+    }
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int c = (int)(e % C);
     float d = dy[e];

@@ -258,19 +258,24 @@ def bn_apply(x2d, mean, rstd, gamma, beta, act, p_drop=0.0, seed=None, drop_offs
     return y
 
 
-def bn_bwd(dy, x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats):
+def bn_bwd(dy, x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats, acc_into=None):
+    """acc_into = (dgamma, dbeta): existing float32 [C] buffers the parameter gradients are ADDED to (param.grad); returns (dx, None, None)"""
     rows, Cc = x2d.shape
     sums = torch.empty(2 * Cc, dtype=torch.float64, device=x2d.device)
     dx = torch.empty_like(x2d)
-    dgamma = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
-    dbeta = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    if acc_into is not None:
+        dgamma, dbeta = _f32c(acc_into[0], "dgamma"), _f32c(acc_into[1], "dbeta")
+        batch_stats = int(batch_stats) | 2
+    else:
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
     lib = _lib.load()
     _lib.check(lib.ctts_bn_bwd_reduce(_p(_f32c(dy, "dy")), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), rows,
                                       Cc, act, p_drop, _p(seed), drop_offset, _stream()), "ctts_bn_bwd_reduce")
     _lib.check(lib.ctts_bn_bwd_apply(_p(dy), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), _p(dx), _p(dgamma),
                                      _p(dbeta), rows, Cc, act, p_drop, _p(seed), drop_offset, int(batch_stats), _stream()),
                "ctts_bn_bwd_apply")
-    return dx, dgamma, dbeta
+    return (dx, None, None) if acc_into is not None else (dx, dgamma, dbeta)
 
 
 def softmax_fwd(S, lens, nb0, nb1, T):
@@ -371,13 +376,15 @@ def dwconv_fwd(x, wT, flip=False):
     return y
 
 
-def dwconv_wgrad(dy, x, Kk):
+def dwconv_wgrad(dy, x, Kk, acc_into=None):
+    """acc_into: existing contiguous float32 buffer of C * K elements ([C,1,K] = nn.Conv1d groups=C layout) the gradient is ADDED to"""
     B, T, Cc = x.shape
-    dw = torch.empty(Cc, Kk, dtype=torch.float32, device=x.device)
+    dw = _f32c(acc_into, "dw") if acc_into is not None else torch.empty(Cc, Kk, dtype=torch.float32, device=x.device)
     partials = torch.empty(128 * Cc * 32, dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.ctts_dwconv_wgrad(_p(_f32c(dy, "dy")), _p(x), _p(dw), _p(partials), B, T, Cc, Kk, _stream()), "ctts_dwconv_wgrad")
-    return dw
+    _lib.check(lib.ctts_dwconv_wgrad(_p(_f32c(dy, "dy")), _p(x), _p(dw), _p(partials), B, T, Cc, Kk, int(acc_into is not None), _stream()),
+               "ctts_dwconv_wgrad")
+    return None if acc_into is not None else dw
 
 
 def relpos_softmax_fwd(S, PS, T, scale, p_drop=0.0, seed=None, drop_offset=0, want_dropped=True):

@@ -31,9 +31,26 @@ def grad_accumulation_fusion():
     return _FUSE_GRAD_ACCUM
 
 
+def _grad_of(p):
+    """The buffer a kernel may ACCUMULATE the gradient of `p` into when gradient-accumulation fusion is on, or None: `p.grad` of a leaf,
+    or - for a dense reshaping view of a leaf, e.g. `conv.weight.view(Cout, Cin)` of a pointwise convolution - the same view of the
+    leaf's gradient (autograd then gets None for the view, so nothing is added twice)."""
+    if not _FUSE_GRAD_ACCUM or p is None or not p.requires_grad:
+        return None
+    if p.is_leaf:
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not (g.is_contiguous() or g.stride() == p.stride()):
+            return None
+        return g
+    base = p._base
+    if (base is None or not base.is_leaf or base.grad is None or base.grad.dtype != torch.float32 or p.numel() != base.numel()
+            or not p.is_contiguous() or not base.is_contiguous() or not base.grad.is_contiguous()):
+        return None
+    return base.grad.view(p.shape)
+
+
 def _fusable(p):
-    return (_FUSE_GRAD_ACCUM and p is not None and p.is_leaf and p.requires_grad and p.grad is not None
-            and p.grad.dtype == torch.float32 and (p.grad.is_contiguous() or p.grad.stride() == p.stride()))
+    return _grad_of(p) is not None
 
 
 # ---- staged backward (dp.py): named cut points in the forward ---------------------------------------------------------------
@@ -248,13 +265,13 @@ class _LinearConv(torch.autograd.Function):
             dZ, d_res = dY, (dY if has_res else None)          # plain linear: nothing to undo
             if want_bias:
                 if fuse_bias:
-                    K.colsum(dZ.view(M, N), scale=alpha, acc_into=b.grad)
+                    K.colsum(dZ.view(M, N), scale=alpha, acc_into=_grad_of(b))
                 else:
                     dB = K.colsum(dZ.view(M, N), scale=alpha)
         else:
             # one pass: gm = dY * rowscale (gradient of the residual), dZ = gm * drop * act'(Z), bias gradient = alpha * colsum(dZ)
             dZ, gm, dBn = K.epilogue_bwd(dY, rowscale, Z, act, p_drop, seed, drop_offset, want_gm=has_res and rowscale is not None,
-                                         want_bias=want_bias, bias_scale=alpha, bias_acc_into=b.grad if fuse_bias else None)
+                                         want_bias=want_bias, bias_scale=alpha, bias_acc_into=_grad_of(b) if fuse_bias else None)
             d_res = (gm if rowscale is not None else dY) if has_res else None
             if want_bias and not fuse_bias:
                 dB = dBn
@@ -280,7 +297,7 @@ class _LinearConv(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 Kd = ksize * Cin
                 fused = _fusable(w)
-                gmaj = _gemm_major(w.grad) if fused else None
+                gmaj = _gemm_major(_grad_of(w)) if fused else None
                 if gmaj is not None:             # GEMM-major parameter: the split-K partials are added straight into param.grad
                     with _wgrad_scope(True, dZ, x):
                         K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
@@ -291,7 +308,7 @@ class _LinearConv(torch.autograd.Function):
                         K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
                                split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, **rl)
                         if fused:
-                            K.conv_weight_repack(dwf, w.grad, N, Cin, ksize, 3)
+                            K.conv_weight_repack(dwf, _grad_of(w), N, Cin, ksize, 3)
                         elif _gemm_major(w) is not None:
                             dW = dwf.view(N, ksize, Cin).permute(0, 2, 1)      # a view with the parameter's own strides: no repack
                         else:
@@ -305,11 +322,11 @@ class _LinearConv(torch.autograd.Function):
             if ctx.needs_input_grad[1] and N == 1 and row_lens is None:
                 # one-output head: dW[0,:] = alpha * sum_r dZ[r] x[r,:] - a weighted column sum, not a 1 x C GEMM
                 fused = _fusable(w)
-                got = K.weighted_colsum(x.view(M, Cin), dZ.reshape(M), scale=alpha, acc_into=w.grad.view(-1) if fused else None)
+                got = K.weighted_colsum(x.view(M, Cin), dZ.reshape(M), scale=alpha, acc_into=_grad_of(w).view(-1) if fused else None)
                 dW = None if fused else got.view(1, Cin)
             elif ctx.needs_input_grad[1]:
                 fused = _fusable(w)
-                dW = w.grad if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
+                dW = _grad_of(w) if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
                 with _wgrad_scope(fused, dZ, x):
                     K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha,
                            tile_map=kmap, **rl)
@@ -357,6 +374,69 @@ def conv1d(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, 
     rl, rT, pr = _pad_rows(pad_rows)
     return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off,
                              w.shape[2], rl, rT, pr)
+
+
+def _adjacent(ts):
+    """the tensors are dense, share one storage and follow each other without gaps (consecutive parameters of a flat arena)"""
+    if any((not t.is_contiguous()) or t.dtype != torch.float32 for t in ts):
+        return False
+    try:
+        st = ts[0].untyped_storage().data_ptr()
+        if any(t.untyped_storage().data_ptr() != st for t in ts):
+            return False
+    except Exception:          # noqa: BLE001
+        return False
+    return all(b.data_ptr() == a.data_ptr() + a.numel() * 4 for a, b in zip(ts, ts[1:]))
+
+
+class _PackedLinear(torch.autograd.Function):
+    """y = x [w_0; w_1; ...]^T for weights that share the input (conformer q / k / v projections, conformer.py:264-295) as ONE GEMM.
+    When the weights are consecutive tensors of one storage (trainer.TrainStep re-homes parameters into dp.FlatAdam's flat arena, in
+    model.parameters() order) the stacked matrix is a VIEW: no concatenation in the forward, and in the backward the weight gradient
+    is accumulated straight into the equally consecutive gradients of the flat gradient arena.  Otherwise: cat + split."""
+
+    @staticmethod
+    def forward(ctx, x, *ws):
+        x = x.contiguous()
+        Kd = x.shape[-1]
+        M = x.numel() // Kd
+        sizes = [w.shape[0] for w in ws]
+        N = sum(sizes)
+        wd = [w.detach() for w in ws]
+        W = torch.as_strided(wd[0], (N, Kd), (Kd, 1)) if _adjacent(wd) else torch.cat(wd, 0)
+        out = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)
+        K.gemm(x, W, out, M, N, Kd, Kd, Kd, N, True, True)
+        ctx.save_for_backward(x, *ws)
+        ctx.sizes = sizes
+        return out
+
+    @staticmethod
+    def backward(ctx, dY):
+        x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dY = dY.contiguous()
+        Kd = x.shape[-1]
+        M = x.numel() // Kd
+        N = sum(ctx.sizes)
+        wd = [w.detach() for w in ws]
+        W = torch.as_strided(wd[0], (N, Kd), (Kd, 1)) if _adjacent(wd) else torch.cat(wd, 0)
+        dX = None
+        if ctx.needs_input_grad[0]:
+            dX = torch.empty_like(x)
+            K.gemm(dY, W, dX, M, Kd, N, N, Kd, Kd, True, False)
+        gs = [_grad_of(w) for w in ws]
+        sk = max(2, _split_k_for(N, Kd, M))
+        if all(g is not None for g in gs) and _adjacent(gs):
+            G = torch.as_strided(gs[0], (N, Kd), (Kd, 1))
+            K.gemm(dY, x, G, N, Kd, M, N, Kd, Kd, False, False, split_k=sk)
+            return (dX,) + (None,) * len(ws)
+        dW = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
+        K.gemm(dY, x, dW, N, Kd, M, N, Kd, Kd, False, False, split_k=sk)
+        return (dX,) + tuple(dW.split(ctx.sizes, 0))
+
+
+def linear_packed(x, weights):
+    """x @ cat(weights, 0)^T without the concatenation when the weights are neighbours in memory (see _PackedLinear)"""
+    return _PackedLinear.apply(x, *weights)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -576,7 +656,9 @@ class _BatchNormAct(torch.autograd.Function):
     def backward(ctx, dy):
         x2d, gamma, beta, mean, rstd, seed = ctx.saved_tensors
         act, p_drop, drop_offset, batch_stats = ctx.cfg
-        dx, dg, db = K.bn_bwd(dy.contiguous(), x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats)
+        gg, gb = _grad_of(gamma), _grad_of(beta)
+        acc = (gg, gb) if (gg is not None and gb is not None and gg.is_contiguous() and gb.is_contiguous()) else None
+        dx, dg, db = K.bn_bwd(dy.contiguous(), x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats, acc_into=acc)
         return dx, dg, db, None, None, None, None, None, None, None
 
 
@@ -694,16 +776,22 @@ class _DepthwiseConv(torch.autograd.Function):
         x = x.contiguous()
         C, _, Kk = w.shape
         wT = w.view(C, Kk).t().contiguous()          # [K, C] tap-major copy (31 x 256 floats)
-        ctx.save_for_backward(x, wT)
+        ctx.save_for_backward(x, wT, w)
         ctx.wshape = w.shape
         return K.dwconv_fwd(x, wT, False)
 
     @staticmethod
     def backward(ctx, dy):
-        x, wT = ctx.saved_tensors
+        x, wT, w = ctx.saved_tensors
         dy = dy.contiguous()
         dx = K.dwconv_fwd(dy, wT, True) if ctx.needs_input_grad[0] else None
-        dw = K.dwconv_wgrad(dy, x, wT.shape[0]).view(ctx.wshape) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            g = _grad_of(w)
+            if g is not None and g.is_contiguous():
+                K.dwconv_wgrad(dy, x, wT.shape[0], acc_into=g)          # straight into param.grad ([C,1,K] is [C,K] in memory)
+            else:
+                dw = K.dwconv_wgrad(dy, x, wT.shape[0]).view(ctx.wshape)
         return dx, dw
 
 

@@ -152,7 +152,8 @@ int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
  * stats: sums[0..C) = sum x, sums[C..2C) = sum x^2 (double, pre-zeroed by the call).
  * apply: y = drop(act((x-mean)*rstd*gamma+beta)).
  * bwd_reduce: sums[0..C) = sum dt, sums[C..2C) = sum dt*xhat with dt = dy*dropmask*act'(u).
- * bwd_apply: dx = gamma*rstd*(dt - sum_dt/rows - xhat*sum_dtxhat/rows); dgamma/dbeta from sums. */
+ * bwd_apply: dx = gamma*rstd*(dt - sum_dt/rows - xhat*sum_dtxhat/rows); dgamma/dbeta from sums.
+ *   batch_stats bit 0: train-mode statistics (the two correction terms above), bit 1: ADD to dgamma / dbeta instead of storing. */
 int ctts_colstats(const float* x, double* sums, int rows, int C, void* stream);
 /* mean / rstd of the batch from ctts_colstats sums, plus the nn.BatchNorm train-mode bookkeeping (running_mean / running_var with
  * momentum and the unbiased variance, num_batches_tracked += 1; NULL pointers skip) - one launch instead of a dozen [C]-sized ops. */
@@ -213,7 +214,8 @@ int ctts_relattn_split_bwd(const float* dqu, const float* dqv, const float* dkv,
 int ctts_glu_fwd(const float* a, float* out, int64_t rows, int C, void* stream);
 int ctts_glu_bwd(const float* a, const float* dout, float* da, int64_t rows, int C, void* stream);
 int ctts_dwconv_fwd(const float* x, const float* wT, float* y, int B, int T, int C, int K, int flip, void* stream);
-int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, float* partials, int B, int T, int C, int K, void* stream);
+int ctts_dwconv_wgrad(const float* dy, const float* x, float* dw, float* partials, int B, int T, int C, int K, int accumulate,
+                      void* stream);      /* accumulate != 0: dw += (gradient-accumulation fusion straight into param.grad) */
 /* partials: scratch of 128 * C * 32 floats (slice sums, reduced in a fixed order - deterministic, no atomics) */
 int ctts_relpos_softmax_fwd(float* S, const float* PS, float* Pd, int nbatch, int T, float scale, float p_drop,
                             const uint64_t* seed, uint32_t drop_offset, void* stream);

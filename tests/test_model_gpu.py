@@ -494,6 +494,44 @@ def test_grad_accumulation_fusion_matches_plain_autograd():
         assert err <= 1e-5 * max(1.0, g0.abs().max().item()), err
 
 
+def test_conformer_fused_accumulation_in_flat_arenas_matches_plain_autograd():
+    """conformer with parameters re-homed into dp.FlatAdam's flat arena (what trainer.TrainStep does): q / k / v weights are then
+    neighbours in memory and ops.linear_packed runs the stacked [768,256] projection on VIEWS (no cat), accumulating its weight
+    gradient straight into the flat gradient arena; pointwise-conv weights (views of [Cout,Cin,1] leaves), BatchNorm parameters and
+    the depthwise-conv weight accumulate in place as well.  Same gradients as plain autograd."""
+    from ctts_amd import ops
+    from ctts_amd.dp import FlatGradArena, FlatAdam
+    torch.manual_seed(6)
+    m, _ = build(block="conformer")
+    m.train()
+    no_dropout(m)
+    arena = FlatGradArena(m.named_parameters())
+    FlatAdam(arena, 1e-3)                                   # re-homes every parameter into one flat buffer
+    at = getattr(getattr(m.decoder.layer_stack, "0").sequential, "1").module.attention
+    qkv = [at.query_proj.linear.weight, at.key_proj.linear.weight, at.value_proj.linear.weight]
+    assert ops._adjacent([w.detach() for w in qkv]) and ops._adjacent([w.grad for w in qkv])
+    batch = make_batch([40, 33, 21, 12], 8, seed=9)
+
+    def run(fuse):
+        arena.zero_()
+        ops.set_grad_accumulation_fusion(fuse)
+        try:
+            for bn in [x for x in m.modules() if hasattr(x, "running_mean")]:
+                bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+            out = m(*as_model_args(to_device(batch, DEV)))
+            loss = (out[0].abs().mean() + out[1].abs().mean() + out[4].pow(2).mean() + out[3].pow(2).mean()
+                    + out[2]["cwt"].abs().mean() + out[2]["f0_mean"].abs().mean() + out[2]["f0_std"].abs().mean())
+            loss.backward()
+        finally:
+            ops.set_grad_accumulation_fusion(False)
+        arena.check_bound()
+        return arena.flat.clone()
+    g0, g1 = run(False), run(True)
+    assert g0.abs().sum() > 0
+    err = (g0 - g1).abs().max().item()
+    assert err <= 2e-5 * max(1.0, g0.abs().max().item()), err
+
+
 @pytest.mark.parametrize("gname,step", [("g6_unsup_soft_step100", 100), ("g6_unsup_hard_step60000", 60000)])
 def test_g6_unsupervised_alignment_matches_reference(gname, step):
     """learn_alignment=True (the reference's default yaml): AlignmentEncoder + MAS on the device + soft/hard upsampling."""
