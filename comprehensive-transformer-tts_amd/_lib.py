@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ("tile_group_n", _i32),
         ("E", _vp), ("rowsub", _vp),
         ("sk_ws", _vp), ("sk_ws_bytes", _i64),
+        ("epi_bwd", _i32),
     ]
 
 

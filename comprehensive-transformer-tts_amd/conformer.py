@@ -109,8 +109,9 @@ class ConformerBlock(nn.Module):
         s = res.module.sequential
         ln, l1, l2 = getattr(s, "0"), getattr(s, "1").linear, getattr(s, "4").linear
         h, xr = ops.layer_norm_res(x, ln.weight, ln.bias, 1e-5)
-        h = ops.linear(h, l1.weight, l1.bias, act=ops.ACT_SWISH, p_drop=p, drop=drop)
-        return ops.linear(h, l2.weight, l2.bias, alpha=self.ff_factor, residual=xr, p_drop=p, drop=drop)
+        link = ops.EpiLink()       # Swish' and the dropout mask of the first linear ride in the second one's data-gradient GEMM
+        h = ops.linear(h, l1.weight, l1.bias, act=ops.ACT_SWISH, p_drop=p, drop=drop, link=link, link_role=1)
+        return ops.linear(h, l2.weight, l2.bias, alpha=self.ff_factor, residual=xr, p_drop=p, drop=drop, link=link, link_role=2)
 
     def forward(self, x, nonpad, pos_table):
         """x [B,T,C]; nonpad float [B*T]; pos_table [T,C] (rows of the sinusoid table)"""

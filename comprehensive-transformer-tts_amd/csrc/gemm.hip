@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
       for (int e = threadIdx.x; e < nrows * ncols; e += 256) {
         const int r = e / ncols, c = e - r * ncols;
         Cz[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
-        if (d.Z) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
+        if (d.Z && !d.epi_bwd) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
       }
       return;
     }
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
       for (int e = threadIdx.x; e < nrows * ncols; e += 256) {
         const int r = e / ncols, c = e - r * ncols;
         Cb[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
-        if (d.Z) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
+        if (d.Z && !d.epi_bwd) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
       }
       return;
     }
@@ -800,6 +800,8 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
     CTTS_REQUIRE(d.conv_on_b ? (!d.a_kc && !d.b_kc) : (d.a_kc != 0), "ctts_gemm: conv view on an unsupported operand layout");
   }
   CTTS_REQUIRE(d.p_drop >= 0.f && d.p_drop < 1.f, "ctts_gemm: p_drop out of range");
+  CTTS_REQUIRE(!d.epi_bwd || (d.split_k <= 1 && !d.bias && !d.R && !d.rowscale && !d.E && (!d.act || d.Z)),
+               "ctts_gemm: epi_bwd excludes bias, residual, rowscale, E and split-K, and needs Z when an activation is given");
   CTTS_REQUIRE(!d.E || (d.rowsub && d.split_k <= 1 && !d.bias && !d.act && d.p_drop == 0.f && !d.R && !d.rowscale && !d.Z),
                "ctts_gemm: the E/rowsub epilogue excludes bias, activation, dropout, residual, rowscale and split-K");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

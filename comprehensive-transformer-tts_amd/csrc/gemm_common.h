@@ -45,6 +45,25 @@ __device__ __forceinline__ void gemm_epilogue(const ctts_gemm_desc& d, floatx16 
       }
     return;
   }
+  if (d.epi_bwd) {       // backward of the previous layer's epilogue: C = alpha * acc * drop_mask * act'(Z_prev)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = col0 + wn0 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < Mv && n < Nv) {
+            float v = alpha * acc[i][j][r];
+            if (do_drop) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
+            if (d.act) v *= ctts_act_grad(d.Z[(long)m * d.ldz + n], d.act);
+            Cb[(long)m * d.ldc + n] = v;
+          }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll

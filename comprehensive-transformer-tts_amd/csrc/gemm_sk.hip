@@ -90,7 +90,7 @@ struct SkLoadKC {
       const int r = (wave * NI + j) * 8 + (lane >> 3);
       const int c = (lane & 7) ^ (((j & 1) * 4) | (lane >> 4));     // = (lane & 7) ^ ((r >> 1) & 7)
       const int row = ext0 + r;
-      voff[j] = row < ext_lim ? (unsigned)(((long)row * ld + c * 4) * 4) : SK_OOB;
+      voff[j] = row < ext_lim ? ((unsigned)row * (unsigned)ld + (unsigned)(c * 4)) * 4u : SK_OOB;     // < 2^31 (host check)
       if (CONV) {
         int t = t0 + r;                                               // T >= ROWS (host check)
         trow[j] = t >= T ? t - T : t;
@@ -123,7 +123,7 @@ struct SkLoadRC {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       klocal[j] = (wave * NI + j) * RPI + lane / (COLS / 4);
-      voff[j] = col < ext_lim ? (unsigned)(((long)klocal[j] * ld + col) * 4) : SK_OOB;
+      voff[j] = col < ext_lim ? ((unsigned)klocal[j] * (unsigned)ld + (unsigned)col) * 4u : SK_OOB;
     }
     ctap = CONV ? col / cin - pad : 0;
   }
@@ -164,7 +164,7 @@ __device__ __forceinline__ void sk_zero_tile(const ctts_gemm_desc& d, int row0, 
     const int r = e / BN, c = e - r * BN;
     if (c < ncols) {
       d.C[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
-      if (d.Z) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
+      if (d.Z && !d.epi_bwd) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
     }
   }
 }

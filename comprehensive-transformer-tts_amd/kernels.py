@@ -87,7 +87,7 @@ def gemm_workspace(device):
 def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_off=0, c_off=0, nb0=1, nb1=1,
                sA=(0, 0), sB=(0, 0), sC=(0, 0), lens=None, lim=(0, 0, 0), conv=None, conv_on_b=False, split_k=1, alpha=1.0,
                bias=None, Z=None, ldz=0, act=ACT_NONE, p_drop=0.0, seed=None, drop_offset=0, R=None, ldr=0, rowscale=None,
-               row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None, use_sk=None):
+               row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None, use_sk=None, epi_bwd=False):
     d = GemmDesc()
     d.A, d.B, d.C = _p(A, a_off), _p(B, b_off), _p(Cout, c_off)
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -116,6 +116,7 @@ def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0
         d.row_lens, d.row_T, d.row_halo = _p(row_lens), int(row_T), int(row_halo)
         d.tile_map = _p(tile_map)
     d.E, d.rowsub = _p(E), _p(rowsub)
+    d.epi_bwd = int(bool(epi_bwd))
     if (SK_ENABLED if use_sk is None else use_sk) and nb0 * nb1 == 1 and M * N * K >= (1 << 24):
         # large unbatched GEMMs may run on the persistent stream-K kernel (the library decides: ctts_gemm_sk_try)
         ws = gemm_workspace(A.device)

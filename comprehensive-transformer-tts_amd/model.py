@@ -168,10 +168,12 @@ class FFTBlocks(nn.Module):
             a = ops.self_attention(qkv, lens, self.num_heads)
             x = ops.linear(a, op.self_attn.out_proj.weight, None, residual=xr, rowscale=nonpad, p_drop=p, drop=drop, pad_rows=pr)
             h, xr = ops.layer_norm_res(x, op.layer_norm2.weight, op.layer_norm2.bias, 1e-12)
+            # g feeds ffn_2 only: its epilogue backward (GELU', dropout mask) rides in the epilogue of ffn_2's data-gradient GEMM
+            link = ops.EpiLink()
             g = ops.conv1d(h, op.ffn.ffn_1.weight, op.ffn.ffn_1.bias, act=ops.ACT_GELU, alpha=alpha, p_drop=p, drop=drop,
-                           pad_rows=pr)
+                           pad_rows=pr, link=link, link_role=1)
             x = ops.linear(g, op.ffn.ffn_2.weight, op.ffn.ffn_2.bias, residual=xr, rowscale=nonpad, p_drop=p, drop=drop,
-                           pad_rows=pr)
+                           pad_rows=pr, link=link, link_role=2)
         return ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, 1e-5, rowscale=nonpad)
 
     def forward(self, x, padding_mask=None):

@@ -198,7 +198,8 @@ def _wgrad_scope(fused, *operands):
 
 
 import os as _os
-_DGRAD_SPLIT_K = int(_os.environ.get("CTTS_DGRAD_SPLIT_K", "1"))     # tuning knob; 0 = never split the data-gradient reduction
+_DGRAD_SPLIT_K = int(_os.environ.get("CTTS_DGRAD_SPLIT_K", "1"))
+_FUSE_EPILOGUE_BWD = _os.environ.get("CTTS_FUSE_EPI_BWD", "1") != "0"      # EpiLink: producer's epilogue backward inside the consumer's dgrad GEMM     # tuning knob; 0 = never split the data-gradient reduction
 _WGRAD_SPLIT_MULT = float(_os.environ.get("CTTS_WGRAD_SPLIT_MULT", "1"))
 
 
@@ -212,6 +213,24 @@ def _split_k_for(Mo, No, Kred):
     return int(max(1, min(want, max(1, Kred // 512))))
 
 
+class EpiLink:
+    """Couples a layer whose forward epilogue is `drop(act(alpha (x (*) w + b)))` (the PRODUCER: FFN conv / first FF linear) with the ONE
+    layer that consumes its output (the CONSUMER: ffn_2).  In the backward pass the consumer's data-gradient GEMM applies the producer's
+    epilogue backward in its own epilogue (`ctts_gemm_desc.epi_bwd`): what it returns for its input is already the producer's dZ, and the
+    producer skips its separate pass over the [M, N] gradient (epilogue_bwd: 2.9 % of the fs2 step).  Only valid when the producer's
+    output has no other consumer - the model code that creates the link guarantees that."""
+
+    def __init__(self):
+        self.Z = self.seed = None
+        self.act, self.p_drop, self.drop_offset = ACT_NONE, 0.0, 0
+        self.armed = False          # producer forward has run with this link
+        self.done = False           # consumer backward has delivered dZ instead of dY
+
+    def arm(self, Z, act, p_drop, seed, drop_offset):
+        self.Z, self.act, self.p_drop, self.seed, self.drop_offset = Z, act, p_drop, seed, drop_offset
+        self.armed, self.done = True, False
+
+
 class _LinearConv(torch.autograd.Function):
     """y = rowscale * (residual + drop(act(alpha * (x (*) w + b))))      (*) = matmul or Conv1d('same')
 
@@ -219,7 +238,8 @@ class _LinearConv(torch.autograd.Function):
     modules.py:140-148,1299-1356 and CompTransTTS.py:133 (fwd, dgrad, wgrad all on MFMA)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, rowscale, act, alpha, p_drop, seed, drop_offset, ksize, row_lens, row_T, pr=None):
+    def forward(ctx, x, w, b, residual, rowscale, act, alpha, p_drop, seed, drop_offset, ksize, row_lens, row_T, pr=None, link=None,
+                link_role=0):
         x = x.contiguous()
         Cin = x.shape[-1]
         M = x.numel() // Cin
@@ -244,6 +264,13 @@ class _LinearConv(torch.autograd.Function):
         ctx.save_for_backward(x, w, Z, rowscale, seed, row_lens, b)
         ctx.cfg = (act, alpha, p_drop, drop_offset, ksize, b is not None, residual is not None, row_T)
         ctx.pr = pr
+        ctx.link, ctx.link_role = None, 0
+        if link is not None and _FUSE_EPILOGUE_BWD:
+            if link_role == 1 and rowscale is None and residual is None and (act != ACT_NONE or p_drop > 0):
+                link.arm(Z, act, p_drop, seed, drop_offset)
+                ctx.link, ctx.link_role = link, 1
+            elif link_role == 2 and link.armed and not ksize:
+                ctx.link, ctx.link_role = link, 2
         return out
 
     @staticmethod
@@ -261,7 +288,16 @@ class _LinearConv(torch.autograd.Function):
         dX = dW = dB = None
         want_bias = has_bias and ctx.needs_input_grad[2]
         fuse_bias = want_bias and _fusable(b)
-        if rowscale is None and act == ACT_NONE and p_drop == 0:
+        if ctx.link_role == 1 and ctx.link.done:
+            # the consumer's data-gradient GEMM already applied this layer's epilogue backward: dY IS dZ (EpiLink)
+            ctx.link.done = False
+            dZ, d_res = dY, None
+            if want_bias:
+                if fuse_bias:
+                    K.colsum(dZ.view(M, N), scale=alpha, acc_into=_grad_of(b))
+                else:
+                    dB = K.colsum(dZ.view(M, N), scale=alpha)
+        elif rowscale is None and act == ACT_NONE and p_drop == 0:
             dZ, d_res = dY, (dY if has_res else None)          # plain linear: nothing to undo
             if want_bias:
                 if fuse_bias:
@@ -317,8 +353,15 @@ class _LinearConv(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[0]:
                 dX = torch.empty_like(x)
-                K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha,
-                       tile_map=pr.tile_map(0, M) if pr is not None else None, **rl)
+                lk = ctx.link if ctx.link_role == 2 else None
+                if lk is not None:       # hand the producer its dZ: mask / (1-p) * act'(Z_producer) applied in this GEMM's epilogue
+                    K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha, epi_bwd=True, Z=lk.Z, ldz=Cin, act=lk.act,
+                           p_drop=lk.p_drop, seed=lk.seed, drop_offset=lk.drop_offset,
+                           tile_map=pr.tile_map(0, M) if pr is not None else None, **rl)
+                    lk.done = True
+                else:
+                    K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha,
+                           tile_map=pr.tile_map(0, M) if pr is not None else None, **rl)
             if ctx.needs_input_grad[1] and N == 1 and row_lens is None:
                 # one-output head: dW[0,:] = alpha * sum_r dZ[r] x[r,:] - a weighted column sum, not a 1 x C GEMM
                 fused = _fusable(w)
@@ -332,7 +375,7 @@ class _LinearConv(torch.autograd.Function):
                            tile_map=kmap, **rl)
                 if fused:
                     dW = None
-        return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None
+        return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class PadRows:
@@ -360,20 +403,23 @@ def _pad_rows(pad_rows):
     return pad_rows[0], int(pad_rows[1]), PadRows(pad_rows[0], pad_rows[1])
 
 
-def linear(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None, pad_rows=None):
+def linear(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None, pad_rows=None, link=None,
+           link_role=0):
     """pad_rows=(lens int32 [B], T) or an ops.PadRows: rows (b,t) with t >= lens[b] are padding - their outputs are don't-care
     (written as zero) and the incoming gradient there is zero, so whole padded tiles / K-blocks are skipped."""
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
     rl, rT, pr = _pad_rows(pad_rows)
-    return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off, 0, rl, rT, pr)
+    return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off, 0, rl, rT, pr,
+                             link, link_role)
 
 
-def conv1d(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None, pad_rows=None):
+def conv1d(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None, pad_rows=None, link=None,
+           link_role=0):
     """x [B,T,Cin], w [Cout,Cin,k] (nn.Conv1d layout), 'same' zero padding, stride 1."""
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
     rl, rT, pr = _pad_rows(pad_rows)
     return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off,
-                             w.shape[2], rl, rT, pr)
+                             w.shape[2], rl, rT, pr, link, link_role)
 
 
 def _adjacent(ts):

@@ -81,6 +81,10 @@ typedef struct ctts_gemm_desc {
    * run on a persistent grid that cuts the (tile, K-block) space evenly over the CUs and sums cut tiles in a fixed order; split_k > 1
    * then only means "C += alpha * A B" (no atomics).  NULL = tile-per-workgroup kernels only. */
   void* sk_ws; int64_t sk_ws_bytes;
+  /* epi_bwd != 0: the epilogue is the BACKWARD of a previous layer's forward epilogue - Z is then an INPUT (that layer's stored
+   * pre-activation, laid out like C with ldz) and  C = drop_mask(seed, drop_offset, m*N+n)/(1-p) * act'(Z) * alpha * acc : the data-gradient
+   * GEMM of layer k+1 hands layer k its dZ directly, no separate pass over the [M,N] gradient.  Excludes bias / R / rowscale / E / split_k. */
+  int32_t epi_bwd;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);

@@ -170,7 +170,14 @@ def test_bench_gpus_2_spawns_two_ranks_itself(scaling):
     assert d["config"]["parallelism"] == "dp2" and np.isfinite(d["config"]["final_loss"])
     assert "4 backward stages" in d["config"]["launch_mode"] and len(d["config"]["grad_buckets_bytes"]) == 4
     per = d["config"]["valid_frames_per_gpu"]
-    assert per == (3032 if scaling == "weak" else (128 + 78) * 8)            # strong: rank 0 takes utterances 0 and 2 of C1
+    if scaling == "weak":
+        assert per == 3032
+    else:            # strong: ONE global C1 batch dealt in snake order (default) - rank 0 gets the longest and the shortest utterance
+        from ctts_amd.synthetic import make_batch, shard_valid_frames, C1_SRC_LENS
+        want = shard_valid_frames(make_batch(C1_SRC_LENS, seed=1234), 2, "snake")
+        bal = d["config"]["strong_scaling_shard"]
+        assert per == want[0] and bal["order"] == "snake" and bal["valid_frames_per_rank"] == want
+        assert bal["max_over_mean"]["snake"] <= bal["max_over_mean"]["strided"]
     assert d["pcie_inclusive"]["value"] > 0
 
 
