@@ -487,6 +487,93 @@ def test_relpos_attention_fwd_bwd(B, T, H, C, fused):
     ops.set_fused_attention(None)
 
 
+def _sk_error_word():
+    ws = K.gemm_workspace(torch.device(DEV))
+    return int(ws.view(torch.int32)[2048].item())
+
+
+@pytest.mark.parametrize("case", ["conv_fwd_ragged_epilogue", "conv_dgrad_halo", "conv_fwd_dense_128", "wgrad_tn_accumulate", "nn_dense"])
+def test_persistent_stream_k_gemm_equals_tile_kernels(case):
+    """csrc/gemm_sk.hip (persistent grid, direct-to-LDS operands, tiles cut between workgroups and summed in a fixed order) against the
+    tile-per-workgroup kernels of csrc/gemm.hip on the same descriptor: conv views with time-boundary taps, padded-row schedules with
+    halo, fused epilogue (bias + GELU + dropout + pre-activation store), 128x128 and 64x128 tiles, K-block schedule of the weight
+    gradient with accumulation into an existing buffer.  The descriptor must really take the persistent path (asserted)."""
+    torch.manual_seed(11)
+    B, T = 16, 512
+    M = B * T
+    lens = torch.tensor([512, 490, 77, 300, 512, 64, 1, 257, 400, 333, 128, 129, 500, 20, 256, 384], dtype=torch.int32, device=DEV)
+    if case == "conv_fwd_ragged_epilogue":
+        x = torch.randn(B, T, 256, device=DEV); w = torch.randn(512, 2304, device=DEV) * 0.03
+        bias = torch.randn(512, device=DEV); seed = torch.zeros(1, dtype=torch.int64, device=DEV)
+        outs = [torch.empty(B, T, 512, device=DEV), torch.empty(B, T, 512, device=DEV)]
+        args = (x, w, outs[0], M, 512, 2304, 256, 2304, 512, True, True)
+        kw = dict(conv=(T, 4, 256), alpha=1 / 3, bias=bias, Z=outs[1], ldz=512, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=3,
+                  row_lens=lens, row_T=T, row_halo=0, tile_map=K.row_tile_map(lens, T, 0, M))
+    elif case == "conv_dgrad_halo":
+        dz = torch.randn(M, 512, device=DEV); wd = torch.randn(512, 4608, device=DEV) * 0.03
+        outs = [torch.empty(B, T, 512, device=DEV)]
+        args = (dz, wd, outs[0], M, 512, 4608, 512, 4608, 512, True, True)
+        kw = dict(conv=(T, 4, 512), alpha=0.5, row_lens=lens, row_T=T, row_halo=4, tile_map=K.row_tile_map(lens, T, 4, M))
+    elif case == "conv_fwd_dense_128":
+        x = torch.randn(B, T, 512, device=DEV); w = torch.randn(512, 2560, device=DEV) * 0.03
+        outs = [torch.empty(B, T, 512, device=DEV)]
+        args = (x, w, outs[0], M, 512, 2560, 512, 2560, 512, True, True)
+        kw = dict(conv=(T, 2, 512))
+    elif case == "wgrad_tn_accumulate":
+        rowmask = (torch.arange(T, device=DEV)[None, :] < lens[:, None]).reshape(M, 1).float()
+        dz = torch.randn(M, 2048, device=DEV) * rowmask; x = torch.randn(B, T, 256, device=DEV)
+        outs = [torch.zeros(2048, 2304, device=DEV)]
+        args = (dz, x, outs[0], 2048, 2304, M, 2048, 256, 2304, False, False)
+        kw = dict(conv=(T, 4, 256), conv_on_b=True, split_k=4, alpha=0.25, row_lens=lens, row_T=T, tile_map=K.row_tile_map(lens, T, 0, M))
+    else:
+        a = torch.randn(M, 2048, device=DEV); w = torch.randn(2048, 1024, device=DEV) * 0.03
+        outs = [torch.empty(M, 1024, device=DEV)]
+        args = (a, w, outs[0], M, 1024, 2048, 2048, 1024, 1024, True, False)
+        kw = {}
+    assert K.gemm_takes_persistent(*args, **kw), "the descriptor is expected to take the persistent path"
+    res = []
+    for use_sk in (False, True):
+        for o in outs:
+            o.fill_(0.5 if case == "wgrad_tn_accumulate" else float("nan"))      # accumulate: onto an existing value; else: every element written
+        K.gemm(*args, use_sk=use_sk, **kw)
+        torch.cuda.synchronize()
+        res.append([o.clone() for o in outs])
+    assert _sk_error_word() == 0
+    for u, v in zip(res[0], res[1]):
+        assert torch.isfinite(v).all()
+        close(v, u, 3e-6 if case != "wgrad_tn_accumulate" else 2e-5, "stream-K vs tiles " + case)
+
+
+@pytest.mark.parametrize("ksize,act", [(9, "gelu"), (0, "swish")])
+def test_epilogue_backward_in_the_consumer_gemm_equals_the_separate_pass(ksize, act):
+    """ops.EpiLink: producer (Conv1d k=9 + GELU + dropout, or Linear + Swish + dropout) -> consumer Linear.  With the link the consumer's
+    data-gradient GEMM applies mask / (1-p) * act'(Z) in its epilogue (ctts_gemm_desc.epi_bwd) and the producer skips epilogue_bwd;
+    same dropout masks (same seed and call-site offsets) -> all gradients equal the unlinked run's, ragged rows included."""
+    B, T, C, Hd, p = 3, 70, 64, 256, 0.2
+    a = K.ACT_GELU if act == "gelu" else K.ACT_SWISH
+    x0 = rnd(B, T, C, seed=150)
+    w1 = rnd(Hd, C, ksize, seed=151, scale=0.2) if ksize else rnd(Hd, C, seed=151, scale=0.2)
+    b1, w2, b2 = rnd(Hd, seed=152), rnd(C, Hd, seed=153, scale=0.2), rnd(C, seed=154)
+    lens = torch.tensor([70, 33, 51], dtype=torch.int32, device=DEV)
+    nonpad = (torch.arange(T, device=DEV)[None, :] < lens[:, None]).float().reshape(-1).contiguous()
+    go = rnd(B, T, C, seed=155).to(DEV) * nonpad.view(B, T, 1)
+    res = []
+    for linked in (False, True):
+        drop = K.DropCtx(DEV, seed=5)
+        ts = [t.to(DEV).requires_grad_() for t in (x0, w1, b1, w2, b2)]
+        pr = ops.PadRows(lens, T)
+        link = ops.EpiLink() if linked else None
+        f1 = ops.conv1d if ksize else ops.linear
+        h = f1(ts[0], ts[1], ts[2], act=a, alpha=0.5, p_drop=p, drop=drop, pad_rows=pr, link=link, link_role=1)
+        y = ops.linear(h, ts[3], ts[4], residual=ts[0], rowscale=nonpad, p_drop=p, drop=drop, pad_rows=pr, link=link, link_role=2)
+        y.backward(go)
+        if linked:
+            assert link.armed and not link.done              # armed in the forward, consumed by the producer's backward
+        res.append([y.detach()] + [t.grad for t in ts])
+    for n, u, v in zip(("y", "dx", "dw1", "db1", "dw2", "db2"), res[0], res[1]):
+        close(v, u, 2e-5, "EpiLink " + n)
+
+
 def test_relattn_split_fwd_bwd():
     """q + u_bias, q + v_bias, k | v from the packed projection (conformer.py:396-407) and the adjoint, against autograd."""
     B, T, H, C = 2, 37, 8, 256
