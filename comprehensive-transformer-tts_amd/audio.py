@@ -93,6 +93,34 @@ class TacotronSTFT(nn.Module):
         self.use_fft = filter_length == 1024 and n_mel_channels <= 96
         nz = np.nonzero(np.abs(mel).sum(0))[0]
         self._kmax = int(nz.max()) + 1 if len(nz) else 0       # bins above fmax carry no filter weight: not kept on chip
+        self._range = None           # deferred range check of the FFT path: (flag in pinned host memory, event of the last launch)
+
+    # ---- the reference asserts min(y) >= -1 and max(y) <= 1 on the host before computing (stft.py:177-178): two reductions and a
+    # device -> host synchronisation per call, which halves the throughput of a 50 us kernel.  Here the kernel raises a flag while it
+    # loads the samples - one word of pinned host memory, written only by an offending input - and the flag is looked at, without
+    # waiting, at the NEXT call, or on demand with check_range().  Same AssertionError, raised one call later at the latest.
+    def _range_state(self, dev):
+        if self._range is None:
+            self._range = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        return self._range
+
+    def _raise_if_out_of_range(self, wait):
+        if self._range is None:
+            return
+        host, ev = self._range
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        bits = int(host[0]) & 0xFFFFFFFF
+        if bits:
+            host.zero_()
+            val = np.array([bits], dtype=np.uint32).view(np.float32)[0]
+            raise AssertionError(f"TacotronSTFT.mel_spectrogram: waveform outside [-1, 1] (largest |sample| {val})  [audio/stft.py:177-178]")
+
+    def check_range(self):
+        """block until the range flag of every mel_spectrogram call issued so far has arrived and raise if a waveform left [-1, 1]"""
+        self._raise_if_out_of_range(wait=True)
 
     def _workspace(self):
         from . import kernels as K
@@ -104,15 +132,18 @@ class TacotronSTFT(nn.Module):
         """y [B,N] float32 on the HIP device, values in [-1, 1] (asserted like stft.py:177-178)."""
         if not y.is_cuda:
             raise RuntimeError("TacotronSTFT (ctts_amd) computes on the MI355X: pass a device tensor")
-        lo, hi = torch.aminmax(y.detach())              # one reduction + one sync for the reference's two range asserts
-        assert lo >= -1 and hi <= 1
         if self._dft_basis.device != y.device:
             self.to(y.device)
         if self.use_fft:
             from . import kernels as K
+            self._raise_if_out_of_range(wait=False)          # earlier calls: never blocks
+            host, ev = self._range_state(y.device)
             mel, energy, _ = K.mel_spectrogram_fft(y.float().contiguous(), self._window, self._workspace(), self.n_fft, self.hop,
-                                                   self.n_mel_channels, kmax=self._kmax)
+                                                   self.n_mel_channels, kmax=self._kmax, range_flag=host)
+            ev.record()
             return mel, energy
+        lo, hi = torch.aminmax(y.detach())              # DFT-as-GEMM path (other FFT sizes): one reduction + one sync for the two asserts
+        assert lo >= -1 and hi <= 1
         mel, energy, _ = ops.mel_spectrogram(y.float(), self._dft_basis, self._mel_basis_padded, self.n_fft, self.hop,
                                              self.n_mel_channels, self.nbins)
         return mel, energy

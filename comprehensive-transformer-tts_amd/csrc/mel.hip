@@ -52,8 +52,11 @@ __device__ __forceinline__ float sample_reflect(const float* __restrict__ yb, in
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, const int32_t* __restrict__ lens, const float* __restrict__ window,
                                                    const float* __restrict__ ws,
                                                    float* __restrict__ mel, float* __restrict__ energy, float* __restrict__ mag_out,
-                                                   long ld_mag, int B, int N, int F, int hop, int n_mel, float clip, int MS) {
+                                                   long ld_mag, int B, int N, int F, int hop, int n_mel, float clip, int MS,
+                                                   unsigned* __restrict__ range_flag) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned amax = 0u;      // largest |sample| this thread loaded, as float bits with the sign cleared (orders like the magnitudes, and every
+                           // NaN pattern sorts above 1.0): raises *range_flag when the waveform leaves [-1, 1] (the reference's asserts)
   float* tw512 = lds;                                   // 1024
   float* tw1024 = lds + 1024;                           // 516
   float* magt = lds + 1540;                             // TILE_F x MS
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
         float a, c;
         if (interior) { const float2 t = *reinterpret_cast<const float2*>(yb + base - NFFT / 2 + n) ; a = t.x; c = t.y; }
         else { a = sample_reflect(yb, Nb, base + n); c = sample_reflect(yb, Nb, base + n + 1); }
+        amax = max(amax, max(__float_as_uint(a) & 0x7FFFFFFFu, __float_as_uint(c) & 0x7FFFFFFFu));
         v[r] = {a * win[2 * r], c * win[2 * r + 1]};
       }
       // pass 0 (Ns = 1): no twiddles
@@ -164,6 +168,9 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
     }
     __syncthreads();
   }
+  // out-of-range or NaN input.  No traffic at all for valid input; the flag may live in pinned host memory (plain store: any offending
+  // value will do, the host only tests for non-zero)
+  if (range_flag && amax > 0x3F800000u) *reinterpret_cast<volatile unsigned*>(range_flag) = amax;
 }
 
 // workspace set-up (once per filterbank): twiddles in double precision, the transposed / zero-padded mel basis and, per tile of 16
@@ -209,7 +216,8 @@ extern "C" int ctts_mel_prepare(const float* mel_basis, int n_fft, int n_mel, fl
 }
 
 extern "C" int ctts_mel_spectrogram(const float* y, const int32_t* lens, const float* window, const float* workspace, float* mel, float* energy,
-                                    float* mag, int64_t ld_mag, int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, void* stream) {
+                                    float* mag, int64_t ld_mag, int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, uint32_t* range_flag,
+                                    void* stream) {
   CTTS_REQUIRE(y && window && workspace && mel && energy && B > 0 && N > 0, "ctts_mel_spectrogram: bad arguments");
   CTTS_REQUIRE(n_fft == NFFT && hop > 0 && n_mel >= 1 && n_mel <= 96, "ctts_mel_spectrogram: built for n_fft = 1024, n_mel <= 96");
   CTTS_REQUIRE(N > NFFT / 2, "ctts_mel_spectrogram: reflect padding needs more than n_fft/2 samples (got %d)", N);
@@ -227,7 +235,7 @@ extern "C" int ctts_mel_spectrogram(const float* y, const int32_t* lens, const f
                             (int)(sizeof(float) * (size_t)(1540 + TILE_F * MS_MAX + 4 * 2 * SCR)));
   const int grid = (int)(tiles < 4096 ? tiles : 4096);
   hipLaunchKernelGGL(mel_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, y, lens, window, workspace, mel, energy, mag, (long)ld_mag,
-                     B, N, F, hop, n_mel, clip, MS);
+                     B, N, F, hop, n_mel, clip, MS, range_flag);
   CTTS_CHECK_LAUNCH("ctts_mel_spectrogram");
   return 0;
 }

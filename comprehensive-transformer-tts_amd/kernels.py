@@ -778,8 +778,9 @@ def mel_prepare(mel_basis, n_fft):
     return ws
 
 
-def mel_spectrogram_fft(y, window, ws, n_fft, hop, n_mel, clip=1e-5, want_mag=False, kmax=0, lens=None):
-    """y [B,N] -> (mel [B,n_mel,F], energy [B,F], mag [B*F,516] or None) in one launch"""
+def mel_spectrogram_fft(y, window, ws, n_fft, hop, n_mel, clip=1e-5, want_mag=False, kmax=0, lens=None, range_flag=None):
+    """y [B,N] -> (mel [B,n_mel,F], energy [B,F], mag [B*F,516] or None) in one launch; range_flag: optional device int32 [1] the kernel
+    raises when a sample leaves [-1, 1] (float bits of the largest |sample|)"""
     B, N = y.shape
     F = 1 + N // hop
     dev = y.device
@@ -788,5 +789,7 @@ def mel_spectrogram_fft(y, window, ws, n_fft, hop, n_mel, clip=1e-5, want_mag=Fa
     mag = torch.empty(B * F, 516, dtype=torch.float32, device=dev) if want_mag else None
     lib = _lib.load()
     _lib.check(lib.ctts_mel_spectrogram(_p(_f32c(y, "y")), _p(lens), _p(_f32c(window, "window")), _p(ws), _p(mel), _p(energy), _p(mag), 516, B, N,
-                                        int(n_fft), int(hop), int(n_mel), float(clip), int(kmax), _stream()), "ctts_mel_spectrogram")
+                                        int(n_fft), int(hop), int(n_mel), float(clip), int(kmax),
+                                        None if range_flag is None else range_flag.data_ptr(),      # device or pinned host memory
+                                        _stream()), "ctts_mel_spectrogram")
     return mel, energy, mag

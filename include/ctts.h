@@ -293,7 +293,11 @@ int ctts_softmax_rect_bwd(const float* P, float* dP, const int32_t* klens, const
 size_t ctts_mel_spectrogram_workspace_bytes(int n_fft, int n_mel);
 int ctts_mel_prepare(const float* mel_basis, int n_fft, int n_mel, float* workspace, void* stream);
 int ctts_mel_spectrogram(const float* y, const int32_t* lens, const float* window, const float* workspace, float* mel, float* energy, float* mag,
-                         int64_t ld_mag, int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, void* stream);
+                         int64_t ld_mag, int B, int N, int n_fft, int hop, int n_mel, float clip, int kmax, uint32_t* range_flag,
+                         void* stream);
+/* range_flag (optional, one uint32 in device OR pinned host memory, zero-initialised by the caller): the kernel stores the float bits of an
+ * offending |sample| (> 1.0, or a NaN pattern) there when the waveform leaves [-1, 1] - the reference's two range asserts
+ * (audio/stft.py:177-178) without a reduction pass and without a host synchronisation; valid input writes nothing. */
 /* lens (optional, [B] int32): ragged batch for preprocessing (preprocessor.py:387,467 extracts one utterance at a time) - row b holds
  * lens[b] <= N samples (rest padding); reflection happens at the utterance's own end and its 1 + lens[b]/hop leading frames equal the
  * single-utterance result; the remaining frames of the row are don't-care. */

@@ -353,6 +353,26 @@ def test_mel_spectrogram_vs_reference_golden(path):
     assert all_vs_ref <= 4e-3, all_vs_ref
 
 
+def test_mel_spectrogram_range_assert_is_deferred_not_dropped():
+    """audio/stft.py:177-178 asserts min(y) >= -1 and max(y) <= 1 before computing.  The FFT kernel raises a device flag instead of a
+    reduction + host sync per call: a waveform outside [-1, 1] still raises AssertionError - at check_range(), or at the next call once
+    the flag has arrived - and a valid waveform raises nothing; NaN input is caught as well."""
+    st = ctts_amd.TacotronSTFT(1024, 256, 1024, 80, 22050, 0, 8000).to(DEV)
+    y = (torch.rand(2, 8192, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    st.mel_spectrogram(y)
+    st.check_range()                                   # valid input: silent
+    bad = y.clone(); bad[1, 4000] = 1.5
+    st.mel_spectrogram(bad)                            # launch succeeds (no sync) ...
+    with pytest.raises(AssertionError, match="outside"):
+        st.check_range()                               # ... the assertion arrives here
+    st.mel_spectrogram(y); st.check_range()            # flag was cleared
+    nan = y.clone(); nan[0, 100] = float("nan")
+    st.mel_spectrogram(nan)
+    torch.cuda.synchronize()
+    with pytest.raises(AssertionError):
+        st.mel_spectrogram(y)                          # the NEXT call notices the earlier one without waiting for anything new
+
+
 @pytest.mark.parametrize("B,N", [(1, 700), (3, 4096 + 37), (2, 22050), (1, 256 * 40)])
 def test_mel_fft_kernel_vs_float64_ragged_lengths(B, N):
     """frame counts that are not multiples of the 16-frame tile, odd sample counts (unaligned pair loads), clips shorter than two FFT

@@ -37,6 +37,7 @@ done
 timeout 200 python $ROOT/tools/bench_sk.py 50 > $OUT/${R}_microbench_gemm_streamk_vs_tiles.txt 2>&1
 timeout 200 python $ROOT/tools/profile_gemm_shapes.py > $OUT/${R}_gemm_shapes_in_step_fs2.txt 2>&1
 timeout 200 python $ROOT/tools/profile_gemm_shapes.py --block conformer > $OUT/${R}_gemm_shapes_in_step_conformer.txt 2>&1
+timeout 100 python $ROOT/tools/bench_stft.py > $OUT/${R}_bench_stft.jsonl 2>/dev/null
 timeout 200 python $ROOT/tools/bench_staged_host_cost.py > $OUT/${R}_staged_step_host_cost.txt 2>&1
 for u in mfma_sustained mfma_patterns mfma_mix; do
   timeout 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/$u $ROOT/tools/ubench/$u.hip > /dev/null 2>&1
