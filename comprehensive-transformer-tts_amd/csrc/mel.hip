@@ -49,6 +49,11 @@ __device__ __forceinline__ float sample_reflect(const float* __restrict__ yb, in
   return yb[q];
 }
 
+// The FFT scratch S is private to a wave: its 64 lanes exchange data through LDS in program order (LDS operations of one wave complete in
+// order), so the passes need no workgroup barrier - only a fence that keeps hipcc from moving LDS accesses across the exchange points.
+// (Round 2 had __syncthreads() there: five workgroup barriers per frame that made the four independent FFTs of a workgroup march in step.)
+#define CTTS_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier()
+
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, const int32_t* __restrict__ lens, const float* __restrict__ window,
                                                    const float* __restrict__ ws,
                                                    float* __restrict__ mel, float* __restrict__ energy, float* __restrict__ mag_out,
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
       fft8(v);
 #pragma unroll
       for (int r = 0; r < 8; ++r) { const int o = pad32(lane * 8 + r); S[2 * o] = v[brev3(r)].x; S[2 * o + 1] = v[brev3(r)].y; }
-      __syncthreads();
+      CTTS_WAVE_SYNC();
       // pass 1 (Ns = 8) and pass 2 (Ns = 64)
 #pragma unroll
       for (int pass = 1; pass < 3; ++pass) {
@@ -115,11 +120,11 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
           v[r] = cmul(v[r], float2_{tw512[2 * t], tw512[2 * t + 1]});
         }
         fft8(v);
-        __syncthreads();                                  // every lane of every wave has read its inputs
+        CTTS_WAVE_SYNC();                                 // every lane of THIS wave has read its inputs
         const int idx = (lane / Ns) * Ns * 8 + jm;
 #pragma unroll
         for (int r = 0; r < 8; ++r) { const int o = pad32(idx + r * Ns); S[2 * o] = v[brev3(r)].x; S[2 * o + 1] = v[brev3(r)].y; }
-        __syncthreads();
+        CTTS_WAVE_SYNC();
       }
       // even / odd split: X[k] = E + W1024^k O, X[512-k] = conj(E - W1024^k O); magnitudes, energy
       float e2 = 0.f;
@@ -143,8 +148,9 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
       }
       e2 = ctts_wave_sum(e2);
       if (lane == 0 && f < F) energy[(long)b * F + f] = sqrtf(e2);
-      __syncthreads();                                    // scratch is reused by the next frame
+      CTTS_WAVE_SYNC();                                   // this wave's scratch is reused by its next frame
     }
+    __syncthreads();                                      // the magnitude tile is complete (the mel phase reads every wave's rows)
     // ------------------------------------------------------------------ mel phase: [16 frames x K] x [K x 16 filters] per MFMA tile
     const int n_tiles16 = (n_mel + 15) / 16;
     float* T = scr;                                       // [n_mel_pad][17] staging for the transposed store
