@@ -27,6 +27,59 @@ def _no_dropout(m):
             sub.dropout = 0.0
 
 
+def _literal_loop(use_amp, n_steps=2):
+    """train.py:102-125 with `--use_amp` on or off (train.py:13,59,104-123: amp.autocast(args.use_amp), GradScaler(enabled=args.use_amp))"""
+    from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
+    ops.set_grad_accumulation_fusion(False)
+    pre, mc, tc = get_configs()
+    torch.manual_seed(11)
+    model = ctts_amd.CompTransTTS(pre, mc, tc)
+    _no_dropout(model)
+    model = model.to(DEV)
+    model.train()
+    grad_acc_step, grad_clip_thresh = tc["optimizer"]["grad_acc_step"], tc["optimizer"]["grad_clip_thresh"]
+    Loss = CompTransTTSLoss(pre, mc, tc).to(DEV)
+    optimizer = ScheduledOptim(model, tc, mc, 50000)
+    scaler = torch.amp.GradScaler("cuda", enabled=use_amp)
+    packed = PackedBatch.pack(as_collated_tuple(make_batch([31, 24, 17, 9], 6, seed=21)))
+    step, out_losses, dtypes = 50001, [], set()
+    for _ in range(n_steps):
+        batch, ev = packed.to_device(DEV)
+        torch.cuda.current_stream().wait_event(ev)
+        with torch.amp.autocast("cuda", enabled=use_amp):
+            output = model(*(batch[2:]), step=step)
+            batch[9:11], output = output[-2:], output[:-2]
+            losses = Loss(batch, output, step=step)
+            total_loss = losses[0]
+            total_loss = total_loss / grad_acc_step
+        dtypes |= {output[0].dtype, output[1].dtype, total_loss.dtype}
+        scaler.scale(total_loss).backward()
+        if step % grad_acc_step == 0:
+            scaler.unscale_(optimizer._optimizer)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip_thresh)
+        optimizer.step_and_update_lr(scaler)
+        scaler.update()
+        optimizer.zero_grad()
+        out_losses.append(float(losses[0].detach()))
+        step += 1
+    return out_losses, dtypes, {k: v.detach().clone() for k, v in model.state_dict().items()}, scaler
+
+
+def test_reference_train_loop_under_use_amp_stays_fp32_correct():
+    """`train.py --use_amp` on the product: the loop under amp.autocast(True) + GradScaler(enabled=True) runs, everything on the hot path
+    stays fp32 (the HIP kernels take and return fp32; autocast only casts inputs of stock torch ops, of which none is a matmul here), the
+    65536x loss scaling is undone before the clip, and losses and weights track the run without --use_amp.  (A BF16-MFMA mode is not
+    built: the metric is the fp32 path.)"""
+    l0, d0, sd0, _ = _literal_loop(False)
+    l1, d1, sd1, scaler = _literal_loop(True)
+    assert d0 == {torch.float32} and d1 == {torch.float32}, (d0, d1)
+    assert scaler.get_scale() >= 1.0 and all(np.isfinite(l1))           # no inf / nan step was skipped into oblivion
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (l0, l1)
+    worst = max(float((sd0[k].float() - sd1[k].float()).abs().max()) for k in sd0 if sd0[k].is_floating_point())
+    assert worst <= 2e-4, worst
+
+
 def test_reference_train_loop_runs_literally_on_the_product_and_tracks_the_oracle():
     """train.py:102-125, statement by statement, with the product's CompTransTTS / CompTransTTSLoss / ScheduledOptim standing where the
     reference's classes stand (plain torch.optim.Adam over the strided parameters, GradScaler(enabled=False), clip_grad_norm_,
