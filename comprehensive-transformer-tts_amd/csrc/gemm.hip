@@ -806,6 +806,10 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
                "ctts_gemm: the E/rowsub epilogue excludes bias, activation, dropout, residual, rowscale and split-K");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
+    const int ws = ctts_gemm_ws_try(d, st);      // weight-stationary kernel (gemm_ws.hip) for K = 256 linears with many rows
+    if (ws != 0) return ws > 0 ? 0 : ws;
+  }
+  {
     const int sk = ctts_gemm_sk_try(d, st);      // persistent stream-K kernel (gemm_sk.hip) when the descriptor is eligible
     if (sk != 0) return sk > 0 ? 0 : sk;
   }

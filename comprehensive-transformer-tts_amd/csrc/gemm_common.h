@@ -91,3 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(const ctts_gemm_desc& d, floatx16 
 // gemm_sk.hip: persistent stream-K kernel with direct-to-LDS operand loads.  Returns 1 when it took the launch, 0 when the descriptor is
 // not eligible (the caller then uses the tile-per-workgroup kernels), < 0 on error.
 int ctts_gemm_sk_try(const ctts_gemm_desc& d, hipStream_t st);
+
+// gemm_ws.hip: weight-stationary kernel for K = 256 (the weight slice of a workgroup lives in registers, A tiles stream through LDS).
+// Same return convention.
+int ctts_gemm_ws_try(const ctts_gemm_desc& d, hipStream_t st);

@@ -140,6 +140,17 @@ def gemm_takes_persistent(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=Tr
     return bool(_lib.load().ctts_gemm_takes_persistent(C.byref(d)))
 
 
+def gemm_takes_weight_stationary(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):
+    """True when ctts_gemm would run these arguments on the weight-stationary K = 256 kernel (no launch)."""
+    d = _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc, b_kc, **kw)
+    return bool(_lib.load().ctts_gemm_takes_weight_stationary(C.byref(d)))
+
+
+def gemm_ws_enable(on):
+    """Switch of the weight-stationary K = 256 kernel (csrc/gemm_ws.hip); returns the previous setting.  Tests / A-B timing only."""
+    return bool(_lib.load().ctts_gemm_ws_enable(1 if on else 0))
+
+
 def row_tile_map(row_lens, row_T, row_halo, M):
     """m-tile schedule (active 64-row tiles first) for GEMMs over padded (b,t) rows; int32 [1 + ceil(M/64)]"""
     tm = torch.empty(1 + (M + 63) // 64, dtype=torch.int32, device=row_lens.device)

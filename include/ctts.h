@@ -93,6 +93,11 @@ size_t ctts_gemm_workspace_bytes(void);
  * for the grid), else 0.  Callers that otherwise split the reduction (split_k > 1 + zero fill) ask first: the persistent kernel balances
  * the reduction itself and wants split_k = 1. */
 int ctts_gemm_takes_persistent(const ctts_gemm_desc* d);
+/* Switch for the weight-stationary K = 256 kernel (csrc/gemm_ws.hip; default on, env CTTS_WS=0 turns it off): returns the previous
+ * setting.  Process-wide, not thread-safe - for parity tests and A/B timing (same descriptor on both kernel families). */
+int ctts_gemm_ws_enable(int on);
+/* 1 when ctts_gemm would run this descriptor on the weight-stationary kernel (no launch). */
+int ctts_gemm_takes_weight_stationary(const ctts_gemm_desc* d);
 
 /* out[b,h,t] = sum_d a[b,t,h*dh+d] * b[b,t,h*dh+d]   (a, b [B,T,H*dh] channel-last; the D vector of the fused softmax backward). */
 int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, int H, int dh, void* stream);

@@ -893,3 +893,77 @@ def test_c_abi_rejects_bad_arguments_with_messages():
         K.colsum(torch.zeros(4, 4))
     # a failed call does not poison the library: the next valid call works
     assert float(K.colsum(torch.ones(5, 3, device=DEV)).sum()) == 15.0
+
+
+@pytest.mark.parametrize("case", ["nt_plain", "nn_plain", "ff1_bias_swish_z_drop", "out_bias_drop_residual_ragged", "nn_epi_bwd_gelu_drop",
+                                  "nn_epi_bwd_plain", "relu_inference", "edge_m_n_ldc", "edge_narrow"])
+def test_weight_stationary_gemm_equals_tile_kernels_and_fp64(case):
+    """csrc/gemm_ws.hip (K = 256: the weight slice of a workgroup in registers, A tiles streamed through LDS by DMA, epilogue with
+    hardware range checks) against the other kernels of ctts_gemm on the SAME descriptor and against an fp64 computation: both operand
+    layouts, every epilogue it compiles (bias / activation / pre-activation store / dropout / residual / backward of the producer's
+    epilogue), padded-row schedule, M not a multiple of 64, N not a multiple of 128 or 32, ldc > N.  The descriptor must really take the
+    weight-stationary path (asserted), and nothing outside C[:, :N] may be written."""
+    torch.manual_seed(5)
+    B, T = 8, 640
+    M, N = B * T, 768
+    lens = torch.tensor([640, 611, 77, 300, 512, 64, 1, 257], dtype=torch.int32, device=DEV)
+    seed = torch.full((1,), 77, dtype=torch.int64, device=DEV)
+    ldc = N
+    kw, ref = {}, None
+    if case in ("edge_m_n_ldc", "edge_narrow"):
+        M, N = (4133, 200) if case == "edge_m_n_ldc" else (4100, 80)
+        ldc = N + 8
+    x = torch.randn(M, 256, device=DEV)
+    w = torch.randn(N, 256, device=DEV) * 0.05
+    bias = torch.randn(N, device=DEV) * 0.1
+    R = torch.randn(M, N, device=DEV)
+    Cbuf = torch.empty(M, ldc, device=DEV)
+    outs = [Cbuf]
+    nt = (x, w, Cbuf, M, N, 256, 256, 256, ldc, True, True)
+    nn = (x, w.t().contiguous(), Cbuf, M, N, 256, 256, N, ldc, True, False)
+    xw = x.double() @ w.double().t()
+    if case in ("nt_plain", "edge_m_n_ldc", "edge_narrow"):
+        args, ref = nt, [xw]
+    elif case == "nn_plain":
+        args, ref = nn, [xw]
+    elif case == "ff1_bias_swish_z_drop":
+        Z = torch.empty(M, N, device=DEV)
+        outs.append(Z)
+        args, kw = nt, dict(bias=bias, Z=Z, ldz=N, act=K.ACT_SWISH, p_drop=0.1, seed=seed, drop_offset=3)
+    elif case == "out_bias_drop_residual_ragged":
+        args = nt
+        kw = dict(bias=bias, alpha=0.5, p_drop=0.1, seed=seed, drop_offset=5, R=R, ldr=N, row_lens=lens, row_T=T, row_halo=0,
+                  tile_map=K.row_tile_map(lens, T, 0, M))
+    elif case == "nn_epi_bwd_gelu_drop":
+        args, kw = nn, dict(Z=R, ldz=N, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=7, epi_bwd=True)
+    elif case == "nn_epi_bwd_plain":
+        args, kw = nn, dict(alpha=0.25, epi_bwd=True)
+        ref = [0.25 * xw]
+    else:
+        args, kw = nt, dict(bias=bias, act=K.ACT_RELU)           # activation without Z: the store runs into an empty descriptor
+        ref = [torch.relu(xw + bias.double())]
+    assert K.gemm_takes_weight_stationary(*args, **kw), "the descriptor is expected to take the weight-stationary path"
+    res = []
+    try:
+        for on in (False, True):
+            K.gemm_ws_enable(on)
+            for o in outs:
+                o.fill_(float("nan"))
+            K.gemm(*args, **kw)
+            torch.cuda.synchronize()
+            res.append([o.clone() for o in outs])
+    finally:
+        K.gemm_ws_enable(True)
+    valid = slice(None)
+    for u, v in zip(res[0], res[1]):
+        if ldc > N:
+            assert torch.isnan(v[:, N:]).all(), "columns beyond N were written"
+            u, v = u[:, :N], v[:, :N]
+        if case == "out_bias_drop_residual_ragged":              # padded rows of active tiles hold unspecified finite values in both
+            rows = (torch.arange(T, device=DEV)[None, :] < lens[:, None]).reshape(M)
+            assert torch.isfinite(v).all()
+            u, v = u[rows], v[rows]
+        assert torch.isfinite(v).all()
+        close(v, u, 1e-6, "weight-stationary vs tile kernels " + case)
+    if ref is not None:
+        close(res[1][0][:, :N], ref[0], 2e-5, "weight-stationary vs fp64 " + case)
