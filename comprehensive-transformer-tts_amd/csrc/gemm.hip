@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
     act_cur = act_next;
   }
 
-  gemm_epilogue<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+  gemm_epilogue_auto<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool VEC>
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
     __syncthreads();
     act_cur = act_next;
   }
-  gemm_epilogue<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+  gemm_epilogue_auto<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>

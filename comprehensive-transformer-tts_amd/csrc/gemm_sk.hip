@@ -38,7 +38,7 @@ struct SkArgs {
   int gw;                    // n-tiles per schedule group
   int whole_tiles;           // 1: never split a tile
   int accumulate;            // 1: C += alpha * acc (weight gradients), no other epilogue
-  int debug;                 // CTTS_SK_DEBUG (tools only): 1 = no DMA after the first block, 2 = every workgroup loads tile (0,0), 16 = record shader cycles / wall ticks of workgroup 8 in the workspace header
+  int debug;                 // CTTS_SK_DEBUG (tools only): 1 = no DMA after the first block, 2 = every workgroup loads tile (0,0), 4 = no epilogue, 16 = record shader cycles / wall ticks of workgroup 8 in the workspace header
   unsigned* ws;              // workspace: SK_FLAG_WORDS words, then one slab per workgroup
 };
 
@@ -401,17 +401,9 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : ((MT * NT >= 2 || STAGES >
         }
       }
       if (p.accumulate) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n = col0 + wn0 + j * 32 + l31;
-              if (m < d.M && n < d.N) d.C[(long)m * d.ldc + n] += d.alpha * acc[i][j][r];
-            }
-      } else {
-        gemm_epilogue<MT, NT>(d, acc, d.C, 0, row0, col0, wm0, wn0, l31, h, d.M, d.N);
+        gemm_accumulate_lean<MT, NT>(d, acc, row0, col0, wm0, wn0, l31, h);
+      } else if (!(p.debug & 4)) {
+        gemm_epilogue_auto<MT, NT>(d, acc, d.C, 0, row0, col0, wm0, wn0, l31, h, d.M, d.N);
       }
     }
     // A wait hipcc can see: its scoreboard is empty when control returns to the K loop, so it never has a reason to put an

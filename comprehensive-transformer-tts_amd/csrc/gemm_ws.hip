@@ -12,8 +12,8 @@
 //   * every wave alternates between two accumulators (rows 0-31 / 32-63 of the tile) - the regime in which the matrix pipe keeps its
 //     full rate (tools/ubench/mfma_patterns.hip), fragment reads one group of 8 MFMAs ahead; 2 workgroups per CU (64 KB LDS,
 //     <= 256 VGPRs each), so that the epilogue of one (and the drain of its stores) overlaps the MFMAs of the other;
-//   * the fused epilogue of gemm.hip (bias, activation, dropout, residual, row scale, pre-activation store, epi_bwd), specialised at
-//     compile time on activation / dropout / direction (ws_epilogue).
+//   * the fused epilogue (bias, activation, dropout, residual, pre-activation store, epi_bwd) is gemm_epilogue_lean of gemm_common.h,
+//     specialised at compile time on activation / dropout / direction / gathered operand (the kernel's template parameters).
 // A-tile LDS layout: per stage K/64 sub-tiles of 64 rows x 32 floats, each exactly the K-contiguous tile of gemm_sk.hip (128-byte rows,
 // 16-byte chunks XOR-swizzled with (row >> 1) & 7 on the source address): conflict-free ds_read_b128 fragment reads.
 // Placement: workgroup b runs on XCD b % 8; the n-blocks that walk the same m-tiles are put on ONE XCD when that costs no extra round,
@@ -29,7 +29,7 @@ namespace {
 
 typedef int ws_i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int ws_u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned WS_OOB = 0x80000000u;
+constexpr unsigned WS_OOB = GEMM_OOB;
 
 __device__ __forceinline__ ws_i32x4 ws_make_rsrc(const void* base) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(base);
@@ -45,85 +45,6 @@ __device__ __forceinline__ ws_i32x4 ws_make_rsrc(const void* base) {
 __device__ __forceinline__ void ws_dma16(ws_i32x4 rsrc, unsigned lds_addr, unsigned voff) {
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc) : "memory");
-}
-
-// The epilogue of gemm_common.h (same arithmetic, bit for bit) with activation / dropout / direction as compile-time constants and
-// branch-free memory operations: raw buffer loads / stores whose descriptor ends at the last valid element, so rows >= M fall out of
-// range in hardware (loads return 0, stores are dropped) and lanes with n >= N carry an out-of-range offset - no exec masking, no 64-bit
-// address arithmetic, and hipcc batches the loads in front of the arithmetic and the stores behind it.  The generic gemm_epilogue
-// (every activation behind uniform branches per element, ~6 KB of code per accumulator), run once per 64-row tile by all 512 workgroups
-// at about the same time, took twice the MFMA time of the tile.
-struct WsEpi {
-  __amdgpu_buffer_rsrc_t c, z, aux;
-  unsigned c_lane, z_lane, aux_lane;                    // byte offset of (row 4h, column n), or out of range
-  float bv;
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* p, long bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-
-// AUX: the direction's gathered operand exists - the residual R (forward) or the stored pre-activation Z (backward, ACT != 0)
-template <int ACT, bool BWD, bool AUX>
-__device__ __forceinline__ WsEpi ws_epi_setup(const ctts_gemm_desc& d, int n, int h) {
-  WsEpi e;
-  const bool n_ok = n < d.N;
-  const long last = d.M - 1;
-  e.c = ws_rsrc(d.C, (last * d.ldc + d.N) * 4);
-  e.c_lane = n_ok ? (unsigned)((4 * h * d.ldc + n) * 4) : WS_OOB;
-  const float* aux_p = BWD ? d.Z : d.R;
-  const long aux_ld = BWD ? d.ldz : d.ldr;
-  e.aux = ws_rsrc(aux_p, AUX ? (last * aux_ld + d.N) * 4 : 0);
-  e.aux_lane = n_ok ? (unsigned)((4 * h * aux_ld + n) * 4) : WS_OOB;
-  const bool has_z = !BWD && d.Z;                       // without Z (inference) the store below runs into an empty descriptor
-  e.z = ws_rsrc(d.Z, has_z ? (last * d.ldz + d.N) * 4 : 0);
-  e.z_lane = n_ok ? (unsigned)((4 * h * d.ldz + n) * 4) : WS_OOB;
-  e.bv = (!BWD && d.bias && n_ok) ? d.bias[n] : 0.f;
-  return e;
-}
-
-template <int ACT, bool DROP, bool BWD, bool AUX>
-__device__ __forceinline__ void ws_epilogue(const ctts_gemm_desc& d, const WsEpi& e, const floatx16 (&acc)[2][1], int row0, int n, int h) {
-#pragma clang fp contract(off)
-  const float alpha = d.alpha;
-  uint32_t dkey = 0;
-  float inv_keep = 1.f;
-  if (DROP) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
-  const unsigned aux_row = (unsigned)((BWD ? d.ldz : d.ldr) * 4), z_row = (unsigned)(d.ldz * 4), c_row = (unsigned)(d.ldc * 4);
-#pragma unroll
-  for (int ib = 0; ib < 4; ++ib) {                      // batches of 8 rows: 8 gathered values in registers at a time
-    const int i = ib >> 1, rb = (ib & 1) * 8;
-    float aux[8];
-    if (AUX) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int r = rb + q, mu = row0 + i * 32 + (r & 3) + 8 * (r >> 2);      // row of h = 0 (wave-uniform)
-        aux[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(e.aux, e.aux_lane + (unsigned)mu * aux_row, 0, 0));
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = rb + q, mu = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-      const int m = mu + 4 * h;
-      float v;
-      if (BWD) {
-        v = alpha * acc[i][0][r];
-        if (DROP) v *= ctts_drop_scale(dkey, (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
-        if (ACT) v *= ctts_act_grad(aux[q], ACT);
-      } else {
-        v = alpha * (acc[i][0][r] + e.bv);
-        if (ACT) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), e.z, e.z_lane + (unsigned)mu * z_row, 0, 0);
-        v = ctts_act(v, ACT);
-        if (DROP) v *= ctts_drop_scale(dkey, (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
-        if (AUX) v += aux[q];
-      }
-#ifdef CTTS_WS_COMPACT_STORES                              // timing experiment: the workgroup's 32 KB as one contiguous block (wrong result)
-      d.C[(long)(blockIdx.x & 1023) * 8192 + (i * 16 + r) * 256 + threadIdx.x] = v;
-#else
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), e.c, e.c_lane + (unsigned)mu * c_row, 0, 0);
-#endif
-    }
-  }
 }
 
 struct WsArgs {
@@ -247,7 +168,6 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const ctts_gemm_desc d,
     }
   };
   const bool wave_has_cols = col0 + wn0 < d.N;
-  const WsEpi epi = ws_epi_setup<ACT, BWD, AUX>(d, n, h);
 
   int slot = wj;
   long long t_start = 0, t_loop = 0, t_w1 = 0, t_w2 = 0, t_epi = 0, t_c0 = 0, t_c1 = 0;
@@ -277,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const ctts_gemm_desc d,
     if (next < n_mt && !(p.debug & 4)) issue_half(next, 0);
     if (!(p.debug & 8)) compute_half(std::integral_constant<int, 1>{});
     if (p.debug & 1) { t0 = __builtin_readcyclecounter(); t_c1 += t0 - t1; }
-    if (wave_has_cols && !(p.debug & 2)) ws_epilogue<ACT, DROP, BWD, AUX>(d, epi, acc, row0, n, h);
+    if (wave_has_cols && !(p.debug & 2)) gemm_epilogue_lean<2, 1, ACT, DROP, BWD, AUX>(d, acc, row0, col0, 0, wn0, l31, h);
     if (p.debug & 1) { t1 = __builtin_readcyclecounter(); t_epi += t1 - t0; }
     ++n_done;
   }
@@ -351,8 +271,7 @@ static bool ws_plan(const ctts_gemm_desc& d, WsArgs& p) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!al16(d.A) || !al16(d.B) || ((d.lda | d.ldb) & 3)) return false;
   if ((long)(d.M + 64) * d.lda * 4 >= 0x7FFF0000L) return false;
-  auto fits = [&](const void* q, long ld) { return !q || ((long)(d.M + 64) * ld * 4 < 0x7FFF0000L && ld >= d.N); };      // 32-bit offsets
-  if (!fits(d.C, d.ldc) || !fits(d.Z, d.ldz) || !fits(d.R, d.ldr)) return false;
+  if (!gemm_fits32(d.C, d.M, d.ldc, d.N) || !gemm_fits32(d.Z, d.M, d.ldz, d.N) || !gemm_fits32(d.R, d.M, d.ldr, d.N)) return false;
   if (d.row_lens && !d.tile_map) return false;           // padded-row zeroing needs the schedule
   // combinations no K = 256 launch of the model uses are not compiled in: row scale, tanh, a pre-activation store without activation
   if (d.rowscale || d.act == 3 || (d.Z && !d.act && !d.epi_bwd)) return false;

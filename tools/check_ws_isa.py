@@ -21,9 +21,23 @@ def check(path):
         e = next(i for i in range(s, len(lines)) if "s_endpgm" in lines[i])
         L = lines[s:e]
         mf = [i for i, l in enumerate(L) if "v_mfma" in l]
-        # the explicit syncs are "s_waitcnt vmcnt(0); s_barrier" (+ the free builtin wait right behind the first one)
-        bad = [L[i].strip() for i in range(mf[0], mf[-1])
-               if "vmcnt" in L[i] and "s_barrier" not in L[i + 1] and not any("s_barrier" in x for x in L[max(0, i - 4):i])]
+        # a compiler wait hurts between the DMA of the next half and the end of the MFMA chain that follows it (the epilogue behind the
+        # chain may wait for its own loads: the DMA has had a whole half to land by then)
+        dma = [i for i, l in enumerate(L) if "buffer_load" in l and " lds" in l]
+        bad = []
+        for k, i in enumerate(dma):
+            if k + 1 < len(dma) and dma[k + 1] - i < 40:
+                continue                                  # not the last DMA instruction of its group
+            chain = [j for j in mf if j > i]
+            if not chain or chain[0] - i > 400:
+                continue
+            end = chain[0]
+            for j in chain[1:]:
+                if j - end > 30:
+                    break
+                end = j
+            bad += [L[j].strip() for j in range(i, end) if "vmcnt" in L[j] and "s_barrier" not in L[j + 1]
+                    and not any("s_barrier" in x for x in L[max(0, j - 4):j])]
         spill = any("scratch_" in l for l in L)
         report.append(dict(name=lines[s].split(":")[0], n_mfma=len(mf), stray_vmcnt=bad, scratch=spill))
     return report

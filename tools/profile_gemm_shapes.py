@@ -37,6 +37,20 @@ records = []
 orig = K.gemm
 
 
+def epi_sig(kw):
+    """epilogue signature: b(ias) a<act> z d(rop) r(esidual) s(rowscale) B(epi_bwd) E(softmax bwd)"""
+    sig = ""
+    sig += "b" if kw.get("bias") is not None else ""
+    sig += f"a{kw['act']}" if kw.get("act") else ""
+    sig += "z" if kw.get("Z") is not None else ""
+    sig += "d" if kw.get("p_drop", 0.0) > 0 else ""
+    sig += "r" if kw.get("R") is not None else ""
+    sig += "s" if kw.get("rowscale") is not None else ""
+    sig += "B" if kw.get("epi_bwd") else ""
+    sig += "E" if kw.get("E") is not None else ""
+    return sig or "-"
+
+
 def timed_gemm(A, B, Cout, M, N, Kd, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -44,7 +58,7 @@ def timed_gemm(A, B, Cout, M, N, Kd, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):
     e.record()
     nb = kw.get("nb0", 1) * kw.get("nb1", 1)
     key = (M, N, Kd, "NT" if (a_kc and b_kc) else ("NN" if a_kc else "TN"), "conv" if kw.get("conv") else "-", kw.get("split_k", 1), nb,
-           "ragged" if kw.get("row_lens") is not None else ("lens" if kw.get("lens") is not None else "-"))
+           "ragged" if kw.get("row_lens") is not None else ("lens" if kw.get("lens") is not None else "-"), epi_sig(kw))
     records.append((key, s, e))
     return r
 
@@ -64,10 +78,10 @@ print(f"# {a.block}: eager step {t0.elapsed_time(t1)/a.steps:.2f} ms (with per-G
       f"  [CTTS_SK={os.environ.get('CTTS_SK', '1')}]")
 print(f"{'M':>6} {'N':>5} {'K':>6} lay conv sk nb  pad    | calls/step  avg us   dense TF  ms/step")
 for key, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-    M, N, Kd, lay, cv, sk, nb, rg = key
+    M, N, Kd, lay, cv, sk, nb, rg, sig = key
     avg = sum(v) / len(v)
     tf = 2.0 * M * N * Kd * nb / (avg * 1e-6) / 1e12
     ms = sum(v) / a.steps / 1e3
     if ms < 0.02:
         continue
-    print(f"{M:6d} {N:5d} {Kd:6d} {lay:>3} {cv:>4} {sk:2d} {nb:3d} {rg:>6} | {len(v)/a.steps:8.1f} {avg:9.1f} {tf:9.1f} {ms:8.3f}")
+    print(f"{M:6d} {N:5d} {Kd:6d} {lay:>3} {cv:>4} {sk:2d} {nb:3d} {rg:>6} | {len(v)/a.steps:8.1f} {avg:9.1f} {tf:9.1f} {ms:8.3f}  {sig}")
