@@ -102,27 +102,30 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const void* p, long 
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
+// Batched / length-limited launches pass their batch base Cb, batch index z and limits Mv x Nv (only the combination without
+// gathered operands is dispatched for them: R, Z and rowscale are not batched).
 template <int MT, int NT, int ACT, bool DROP, bool BWD, bool AUX, bool RS = false>
-__device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, const floatx16 (&acc)[MT][NT], int row0, int col0, int wm0,
-                                                   int wn0, int l31, int h) {
+__device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, const floatx16 (&acc)[MT][NT], float* Cb, int z, int row0,
+                                                   int col0, int wm0, int wn0, int l31, int h, int Mv, int Nv) {
 #pragma clang fp contract(off)
   const float alpha = d.alpha;
   uint32_t dkey = 0;
   float inv_keep = 1.f;
   if (DROP) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
-  const long last = d.M - 1;
+  const uint32_t zoff = (uint32_t)z * (uint32_t)d.M * (uint32_t)d.N;
+  const long last = Mv - 1;
   const float* aux_p = BWD ? d.Z : d.R;
   const long aux_ld = BWD ? d.ldz : d.ldr;
   const bool has_z = !BWD && ACT && d.Z;
-  const __amdgpu_buffer_rsrc_t rc = gemm_rsrc(d.C, (last * d.ldc + d.N) * 4);
-  const __amdgpu_buffer_rsrc_t ra = gemm_rsrc(aux_p, AUX ? (last * aux_ld + d.N) * 4 : 0);
-  const __amdgpu_buffer_rsrc_t rz = gemm_rsrc(d.Z, has_z ? (last * d.ldz + d.N) * 4 : 0);
-  const __amdgpu_buffer_rsrc_t rr = gemm_rsrc(d.rowscale, RS ? (long)d.M * 4 : 0);
+  const __amdgpu_buffer_rsrc_t rc = gemm_rsrc(Cb, (last * d.ldc + Nv) * 4);
+  const __amdgpu_buffer_rsrc_t ra = gemm_rsrc(aux_p, AUX ? (last * aux_ld + Nv) * 4 : 0);
+  const __amdgpu_buffer_rsrc_t rz = gemm_rsrc(d.Z, has_z ? (last * d.ldz + Nv) * 4 : 0);
+  const __amdgpu_buffer_rsrc_t rr = gemm_rsrc(d.rowscale, RS ? (long)Mv * 4 : 0);
   const unsigned c_row = (unsigned)(d.ldc * 4), a_row = (unsigned)(aux_ld * 4), z_row = (unsigned)(d.ldz * 4);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = col0 + wn0 + j * 32 + l31;
-    const bool n_ok = n < d.N;
+    const bool n_ok = n < Nv;
     const unsigned c_lane = n_ok ? (unsigned)(4 * h) * c_row + (unsigned)n * 4u : GEMM_OOB;      // byte offset of (row 4h, column n)
     const unsigned a_lane = n_ok ? (unsigned)(4 * h) * a_row + (unsigned)n * 4u : GEMM_OOB;
     const unsigned z_lane = n_ok ? (unsigned)(4 * h) * z_row + (unsigned)n * 4u : GEMM_OOB;
@@ -152,13 +155,13 @@ __device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, cons
         float v;
         if (BWD) {
           v = alpha * acc[i][j][r];
-          if (DROP) v *= ctts_drop_scale(dkey, (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
+          if (DROP) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
           if (ACT) v *= ctts_act_grad(aux[q], ACT);
         } else {
           v = alpha * (acc[i][j][r] + bv);
           if (ACT) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rz, z_lane + (unsigned)mu * z_row, 0, 0);
           v = ctts_act(v, ACT);
-          if (DROP) v *= ctts_drop_scale(dkey, (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
+          if (DROP) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
           if (AUX) v += aux[q];
           if (RS) v *= rs[q];
         }
@@ -172,7 +175,6 @@ __device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, cons
 template <int MT, int NT>
 __device__ __forceinline__ void gemm_accumulate_lean(const ctts_gemm_desc& d, const floatx16 (&acc)[MT][NT], int row0, int col0, int wm0,
                                                      int wn0, int l31, int h) {
-#pragma clang fp contract(off)
   const __amdgpu_buffer_rsrc_t rc = gemm_rsrc(d.C, ((long)(d.M - 1) * d.ldc + d.N) * 4);
   const unsigned c_row = (unsigned)(d.ldc * 4);
 #pragma unroll
@@ -198,39 +200,102 @@ __device__ __forceinline__ void gemm_accumulate_lean(const ctts_gemm_desc& d, co
   }
 }
 
+// split-K partial: C += alpha * acc by hardware fp32 atomics (buffer_atomic_add_f32, no return value), range-checked like the stores
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_atomic_lean(const ctts_gemm_desc& d, const floatx16 (&acc)[MT][NT], float* Cb, int row0, int col0,
+                                                 int wm0, int wn0, int l31, int h, int Mv, int Nv) {
+  const __amdgpu_buffer_rsrc_t rc = gemm_rsrc(Cb, ((long)(Mv - 1) * d.ldc + Nv) * 4);
+  const unsigned c_row = (unsigned)(d.ldc * 4);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = col0 + wn0 + j * 32 + l31;
+    const unsigned c_lane = n < Nv ? (unsigned)(4 * h) * c_row + (unsigned)n * 4u : GEMM_OOB;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mu = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2);
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(d.alpha * acc[i][j][r], rc, c_lane + (unsigned)mu * c_row, 0, 0);
+      }
+  }
+}
+
+// fused softmax backward of the attention launches: C = E * (alpha * acc - rowsub[row]), E laid out like C
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_softmax_bwd_lean(const ctts_gemm_desc& d, const floatx16 (&acc)[MT][NT], float* Cb, int z, int row0,
+                                                      int col0, int wm0, int wn0, int l31, int h, int Mv, int Nv) {
+  const long bytes = ((long)(Mv - 1) * d.ldc + Nv) * 4;
+  const __amdgpu_buffer_rsrc_t rc = gemm_rsrc(Cb, bytes);
+  const __amdgpu_buffer_rsrc_t re = gemm_rsrc(d.E + (Cb - d.C), bytes);
+  const __amdgpu_buffer_rsrc_t rr = gemm_rsrc(d.rowsub + (long)z * d.M, (long)Mv * 4);
+  const unsigned c_row = (unsigned)(d.ldc * 4);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    float rs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      rs[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (unsigned)(row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 4u, 0, 0));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = col0 + wn0 + j * 32 + l31;
+      const unsigned c_lane = n < Nv ? (unsigned)(4 * h) * c_row + (unsigned)n * 4u : GEMM_OOB;
+#pragma unroll
+      for (int rb = 0; rb < 16; rb += 8) {
+        float e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = rb + q, mu = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          e[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re, c_lane + (unsigned)mu * c_row, 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = rb + q, mu = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          const float v = e[q] * (d.alpha * acc[i][j][r] - rs[r]);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, c_lane + (unsigned)mu * c_row, 0, 0);
+        }
+      }
+    }
+  }
+}
+
 // 32-bit byte offsets reach every element of an [M, ld] operand (with room for a tile of rows beyond M)
 __device__ __host__ __forceinline__ bool gemm_fits32(const void* p, long M, long ld, long N) {
   return !p || ((M + 128) * ld * 4 < 0x7FFF0000L && ld >= N);
 }
 
 // The epilogue of an unbatched tile: the lean variant of the combinations the train steps launch (tools/profile_gemm_shapes.py prints the
-// signature of every launch), the generic one for everything else (batched / length-limited launches, softmax-backward fusion,
-// split-K atomics, row scale, tanh / GELU, ...).
+// signature of every launch) - including the split-K atomics of the weight gradients, the softmax-backward fusion and the plain
+// batched / length-limited attention products - and the generic one for everything else (tanh, mixed combinations, 64-bit extents).
 template <int MT, int NT>
 __device__ __forceinline__ void gemm_epilogue_auto(const ctts_gemm_desc& d, floatx16 (&acc)[MT][NT], float* Cb, int z, int row0, int col0,
                                                    int wm0, int wn0, int l31, int h, int Mv, int Nv) {
-  const bool lean = d.nb0 * d.nb1 == 1 && !d.E && d.split_k <= 1 && Mv == d.M && Nv == d.N &&
-                    gemm_fits32(d.C, d.M, d.ldc, d.N) && gemm_fits32(d.Z, d.M, d.ldz, d.N) && gemm_fits32(d.R, d.M, d.ldr, d.N);
-#define CTTS_LEAN(ACT, DROP, BWD, AUX, RS) return gemm_epilogue_lean<MT, NT, ACT, DROP, BWD, AUX, RS>(d, acc, row0, col0, wm0, wn0, l31, h)
-  if (lean) {
+  const bool flat = d.nb0 * d.nb1 == 1 && Mv == d.M && Nv == d.N;      // the gathered operands (R, Z, rowscale) are not batched
+  const bool c_ok = gemm_fits32(Cb, Mv, d.ldc, Nv);
+  if (d.split_k > 1) {
+    if (c_ok) return gemm_atomic_lean<MT, NT>(d, acc, Cb, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+  } else if (d.E) {
+    if (c_ok) return gemm_softmax_bwd_lean<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+  } else if (c_ok && (flat ? gemm_fits32(d.Z, d.M, d.ldz, d.N) && gemm_fits32(d.R, d.M, d.ldr, d.N) : !d.Z && !d.R && !d.rowscale)) {
+#define CTTS_LEAN(ACT, DROP, BWD, AUX, RS) \
+  return gemm_epilogue_lean<MT, NT, ACT, DROP, BWD, AUX, RS>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv)
     const bool drop = d.p_drop > 0.f, res = d.R != nullptr, rs = d.rowscale != nullptr;
     if (!d.epi_bwd) {
       if (d.act == 0 && !d.Z) {
         if (!res && !rs && !drop) CTTS_LEAN(0, false, false, false, false);      // -, b
         if (res && !rs) { if (drop) CTTS_LEAN(0, true, false, true, false); else CTTS_LEAN(0, false, false, true, false); }    // bdr, br
         if (res && rs) { if (drop) CTTS_LEAN(0, true, false, true, true); else CTTS_LEAN(0, false, false, true, true); }       // bdrs, brs
-      } else if (!res && !rs) {
+      } else if (!res && !rs && flat) {
         if (d.act == 1 && !drop) CTTS_LEAN(1, false, false, false, false);       // ba1z
         if (d.act == 2) { if (drop) CTTS_LEAN(2, true, false, false, false); else CTTS_LEAN(2, false, false, false, false); }  // ba2zd, ba2z
         if (d.act == 4) { if (drop) CTTS_LEAN(4, true, false, false, false); else CTTS_LEAN(4, false, false, false, false); }  // ba4zd, ba4z
       }
-    } else if (d.Z && !rs) {
+    } else if (d.Z && !rs && flat) {
       if (d.act == 1 && !drop) CTTS_LEAN(1, false, true, true, false);           // a1zB
       if (d.act == 2 && drop) CTTS_LEAN(2, true, true, true, false);             // a2zdB
       if (d.act == 4 && drop) CTTS_LEAN(4, true, true, true, false);             // a4zdB
     }
-  }
 #undef CTTS_LEAN
+  }
   gemm_epilogue<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 

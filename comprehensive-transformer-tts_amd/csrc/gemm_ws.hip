@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const ctts_gemm_desc d,
     if (next < n_mt && !(p.debug & 4)) issue_half(next, 0);
     if (!(p.debug & 8)) compute_half(std::integral_constant<int, 1>{});
     if (p.debug & 1) { t0 = __builtin_readcyclecounter(); t_c1 += t0 - t1; }
-    if (wave_has_cols && !(p.debug & 2)) gemm_epilogue_lean<2, 1, ACT, DROP, BWD, AUX>(d, acc, row0, col0, 0, wn0, l31, h);
+    if (wave_has_cols && !(p.debug & 2)) gemm_epilogue_lean<2, 1, ACT, DROP, BWD, AUX>(d, acc, d.C, 0, row0, col0, 0, wn0, l31, h, d.M, d.N);
     if (p.debug & 1) { t1 = __builtin_readcyclecounter(); t_epi += t1 - t0; }
     ++n_done;
   }
