@@ -460,6 +460,7 @@ static int sk_try(const ctts_gemm_desc& din, hipStream_t st, bool launch) {
   static const int tile_cfg = sk_env("CTTS_SK_TILE", 22);             // 11: 64x64, 12: 64x128, 22: 128x128 workgroup tiles
   static const int max_split = sk_env("CTTS_SK_MAX_SPLIT", 2);        // tiles * max_split >= grid: a tile is cut in two or three, never more (the owner gathers serially)
   static const int debug = sk_env("CTTS_SK_DEBUG", 0);
+  static const int wg_units = sk_env("CTTS_SK_WG_UNITS", 16);         // a workgroup gets at least this many (tile, K-block) units
   const ctts_gemm_desc& d = din;
   if (!enabled || !d.sk_ws || d.sk_ws_bytes < (int64_t)ctts_gemm_workspace_bytes()) return 0;
   if (d.nb0 * d.nb1 != 1 || (d.lens && (d.lim_m || d.lim_n || d.lim_k)) || d.E) return 0;
@@ -510,11 +511,14 @@ static int sk_try(const ctts_gemm_desc& din, hipStream_t st, bool launch) {
   if (mt * nt >= 4 && per_cu > 2) per_cu = 2;
   if (mt * nt == 2 && per_cu > 3) per_cu = 3;
   long W = force_w > 0 ? force_w : per_cu * 32;
-  const long Wu = (long)p.tiles_m * p.tiles_n * p.nkb / (8 * 16);
+  const long Wu = (long)p.tiles_m * p.tiles_n * p.nkb / (8 * wg_units);
   if (W > Wu) W = Wu;
   if (W < 1) W = 1;
   const int grid = (int)W * 8;
-  if ((long)p.tiles_m * p.tiles_n * max_split < grid) return 0;
+  // a tile is cut in two (the owner gathers serially) - up to four pieces when every piece keeps a long reduction (>= 64 K-blocks: the
+  // FFN weight gradient, 144 tiles x 512 K-blocks, measured 509 -> 494 us against the tile kernels with split-K atomics)
+  const int cuts = (p.nkb >= 256 && max_split < 4) ? 4 : max_split;
+  if ((long)p.tiles_m * p.tiles_n * cuts < grid) return 0;
   if (grid > SK_MAX_WG || (long)grid * BM * BN > SK_SLAB_FLOATS_MAX) return 0;
   if (!launch) return 1;
   if (d.a_kc && d.b_kc) return conv ? sk_launch<true, true, true>(d, p, grid, stages, mt, nt, st) : sk_launch<true, true, false>(d, p, grid, stages, mt, nt, st);

@@ -12,22 +12,30 @@ only = sys.argv[2] if len(sys.argv) > 2 else None
 torch.manual_seed(0)
 
 
-def timeit(fn):
-    for _ in range(3):
+def timeit(fn, per_graph=10):
+    """GPU time per call; the calls are replayed from a graph (a Python ctts_gemm call costs more CPU time than the small kernels run)"""
+    for _ in range(5):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(per_graph):
+            fn()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    reps = max(1, iters // per_graph)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(reps):
+        g.replay()
     e.record()
     torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters * 1e-3
+    return s.elapsed_time(e) / (reps * per_graph) * 1e-3
 
 
 def err_word():
-    ws = K.gemm_workspace(torch.device(dev))
-    return int(ws.view(torch.int32)[2048].item())
+    return max(int(ws.view(torch.int32)[2048].item()) for ws in K._SK_WS.values())
 
 
 def sk_clock():
@@ -164,3 +172,24 @@ A = torch.randn(m, k, device=dev); Bm = torch.randn(n, k, device=dev) * 0.05; Cc
 R = torch.randn(m, n, device=dev); rs = (torch.rand(m, device=dev) > 0.2).float(); bb = torch.randn(n, device=dev)
 run("epilogue R/rowscale/bias, M=15000", lambda sk: (lambda: K.gemm(A, Bm, Cc, m, n, k, k, k, n, True, True, bias=bb, R=R, ldr=n, rowscale=rs,
                                                                   act=K.ACT_RELU, use_sk=sk)), 2 * m * n * k, lambda: [Cc])
+
+# ---- under-filled launches: 2048 phoneme rows x 256 outputs = 128 tiles of 64 x 64 on 256 CUs
+nve = int(lens_e.sum())
+for Kd, name in ((1024, "enc ffn2 fwd bdrs"), (1024, "enc dgrad NN"), (768, "enc qkv dgrad NN"), (512, "enc NN K=512"), (256, "enc NN K=256")):
+    a_ = torch.randn(Me, Kd, device=dev); c_ = torch.empty(Me, 256, device=dev)
+    if "bdrs" in name:
+        w_ = torch.randn(256, Kd, device=dev) * 0.03; b_ = torch.randn(256, device=dev); r_ = torch.randn(Me, 256, device=dev)
+        rs_ = (torch.arange(Te, device=dev)[None, :] < lens_e[:, None]).reshape(Me).float(); sd_ = torch.zeros(1, dtype=torch.int64, device=dev)
+        run(f"{name} 2048x256x{Kd}", lambda sk, a_=a_, w_=w_, c_=c_, b_=b_, r_=r_, rs_=rs_, sd_=sd_, Kd=Kd: (lambda: K.gemm(
+            a_, w_, c_, Me, 256, Kd, Kd, Kd, 256, True, True, bias=b_, p_drop=0.1, seed=sd_, drop_offset=9, R=r_, ldr=256, rowscale=rs_,
+            row_lens=lens_e, row_T=Te, row_halo=0, tile_map=tmap_e, use_sk=sk)), 2 * nve * 256 * Kd, lambda c_=c_: [c_])
+    else:
+        w_ = torch.randn(Kd, 256, device=dev) * 0.03
+        run(f"{name} 2048x256x{Kd}", lambda sk, a_=a_, w_=w_, c_=c_, Kd=Kd: (lambda: K.gemm(
+            a_, w_, c_, Me, 256, Kd, Kd, 256, 256, True, False, row_lens=lens_e, row_T=Te, row_halo=0, tile_map=tmap_e, use_sk=sk)),
+            2 * nve * 256 * Kd, lambda c_=c_: [c_])
+xc_ = torch.randn(B, Te, 256, device=dev); wc_ = torch.randn(256, 1280, device=dev) * 0.03; cc_ = torch.empty(B, Te, 256, device=dev)
+zc_ = torch.empty(B, Te, 256, device=dev); bc_ = torch.randn(256, device=dev)
+run("enc predictor conv k=5 ba1z 2048x256x1280", lambda sk: (lambda: K.gemm(
+    xc_, wc_, cc_, Me, 256, 1280, 256, 1280, 256, True, True, conv=(Te, 2, 256), bias=bc_, Z=zc_, ldz=256, act=K.ACT_RELU, use_sk=sk)),
+    2 * Me * 256 * 1280, lambda: [cc_, zc_])
