@@ -1,5 +1,10 @@
 #!/bin/bash
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
-cd $ROOT; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4; cd /tmp
-for i in 1 2; do timeout 300 python $ROOT/bench.py --no-cpu-baseline --no-pcie --no-secondary --no-roofline 2>/dev/null | tail -1 | cut -c80-200; done
+cd /tmp
+for cfg in "fs2:" "conformer:--block conformer"; do
+  n=${cfg%%:*}; a=${cfg#*:}; rm -rf /tmp/prof_$n
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -- python $ROOT/bench.py $a --no-graph --no-cpu-baseline --no-pcie --no-secondary --no-roofline --steps 5 --warmup 2 > /tmp/prof_$n.log 2>&1
+  python $ROOT/tools/rocpd_summary.py $(find /tmp/prof_$n -name "*results.db" | head -1) 60 > $OUT/now_${n}_eager_kernel_stats.md 2>&1
+done
