@@ -150,12 +150,18 @@ def _gemm_major(w):
 # every wgrad GEMM is issued on that stream: its workgroups fill the partially occupied last rounds ("tails") of the
 # dgrad GEMMs running on the main stream, and vice versa.  The streams are re-joined by an autograd engine callback
 # at the end of the backward pass, so callers (and hipGraph capture) see ordinary single-stream semantics.
-_WGRAD = {"stream": None, "keep": [], "main": None}
+_WGRAD = {"stream": None, "keep": [], "main": None, "max_rows": None}
 
 
-def set_wgrad_stream(stream):
-    """`stream`: a torch.cuda.Stream for weight-gradient GEMMs, or None for single-stream execution."""
+def set_wgrad_stream(stream, max_rows=None):
+    """`stream`: a torch.cuda.Stream for weight-gradient GEMMs, or None for single-stream execution.  `max_rows`: only layers whose
+    reduction (rows of the activation matrix) is at most this long use it - the under-filled launches of the phoneme-level layers
+    (2,048 rows: 128 output tiles on 256 CUs), where the data- and the weight-gradient GEMM can share the chip; None = every layer.
+    Measured under hipGraph replay (round 3, same box): fs2 23.87 ms single-stream, 24.49 ms with max_rows=4096, 25.12 ms for every
+    layer; conformer 28.8 vs 29.85 ms - every fork / join of the captured graph costs more than the overlap returns, so the train
+    step leaves it off."""
     _WGRAD["stream"] = stream
+    _WGRAD["max_rows"] = max_rows
 
 
 def _wgrad_join():
@@ -193,8 +199,12 @@ class _Inline:
         return False
 
 
-def _wgrad_scope(fused, *operands):
-    return _OnWgradStream(*operands) if (fused and _WGRAD["stream"] is not None) else _Inline()
+def _wgrad_scope(fused, *operands, rows=None):
+    if not fused or _WGRAD["stream"] is None:
+        return _Inline()
+    if _WGRAD["max_rows"] is not None and rows is not None and rows > _WGRAD["max_rows"]:
+        return _Inline()
+    return _OnWgradStream(*operands)
 
 
 import os as _os
@@ -335,12 +345,12 @@ class _LinearConv(torch.autograd.Function):
                 fused = _fusable(w)
                 gmaj = _gemm_major(_grad_of(w)) if fused else None
                 if gmaj is not None:             # GEMM-major parameter: the split-K partials are added straight into param.grad
-                    with _wgrad_scope(True, dZ, x):
+                    with _wgrad_scope(True, dZ, x, rows=M):
                         K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
                                split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, **rl)
                 else:
                     dwf = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
-                    with _wgrad_scope(fused, dZ, x, dwf):
+                    with _wgrad_scope(fused, dZ, x, dwf, rows=M):
                         K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
                                split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, **rl)
                         if fused:
@@ -370,7 +380,7 @@ class _LinearConv(torch.autograd.Function):
             elif ctx.needs_input_grad[1]:
                 fused = _fusable(w)
                 dW = _grad_of(w) if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
-                with _wgrad_scope(fused, dZ, x):
+                with _wgrad_scope(fused, dZ, x, rows=M):
                     K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha,
                            tile_map=kmap, **rl)
                 if fused:

@@ -1,10 +1,6 @@
 #!/bin/bash
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-for cfg in "fs2:" "conformer:--block conformer"; do
-  n=${cfg%%:*}; a=${cfg#*:}; rm -rf /tmp/prof_$n
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -- python $ROOT/bench.py $a --no-graph --no-cpu-baseline --no-pcie --no-secondary --no-roofline --steps 5 --warmup 2 > /tmp/prof_$n.log 2>&1
-  python $ROOT/tools/rocpd_summary.py $(find /tmp/prof_$n -name "*results.db" | head -1) 60 > $OUT/now_${n}_eager_kernel_stats.md 2>&1
-done
+for r in 0 4096 0 4096 100000; do echo "fs2 side_rows=$r"; CTTS_WGRAD_SIDE_ROWS=$r timeout 300 python $ROOT/bench.py --no-cpu-baseline --no-pcie --no-secondary --no-roofline 2>/dev/null | tail -1 | cut -c80-200; done
+for r in 0 4096 0 4096; do echo "conformer side_rows=$r"; CTTS_WGRAD_SIDE_ROWS=$r timeout 300 python $ROOT/bench.py --block conformer --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-roofline 2>/dev/null | tail -1 | cut -c80-200; done
