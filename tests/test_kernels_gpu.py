@@ -967,3 +967,78 @@ def test_weight_stationary_gemm_equals_tile_kernels_and_fp64(case):
         close(v, u, 1e-6, "weight-stationary vs tile kernels " + case)
     if ref is not None:
         close(res[1][0][:, :N], ref[0], 2e-5, "weight-stationary vs fp64 " + case)
+
+
+_LEAN = [  # (name, act, drop, residual, rowscale, bias, backward)
+    ("plain", 0, False, False, False, False, False), ("b", 0, False, False, False, True, False),
+    ("bdr", 0, True, True, False, True, False), ("br", 0, False, True, False, True, False),
+    ("bdrs", 0, True, True, True, True, False), ("brs", 0, False, True, True, True, False),
+    ("ba1z", 1, False, False, False, True, False), ("ba2zd", 2, True, False, False, True, False), ("ba2z", 2, False, False, False, True, False),
+    ("ba4zd", 4, True, False, False, True, False), ("ba4z", 4, False, False, False, True, False),
+    ("a1zB", 1, False, False, False, False, True), ("a2zdB", 2, True, False, False, False, True), ("a4zdB", 4, True, False, False, False, True)]
+
+
+@pytest.mark.parametrize("mode", _LEAN, ids=[m[0] for m in _LEAN])
+@pytest.mark.parametrize("M,N,Kd,pad", [(150, 200, 64, 0), (333, 77, 96, 5), (4200, 264, 256, 0)])
+def test_gemm_lean_epilogue_modes_vs_fp64(mode, M, N, Kd, pad):
+    """Every combination `gemm_epilogue_auto` (csrc/gemm_common.h) sends to the compile-time specialised epilogue with hardware range
+    checks, on shapes that exercise the range checks (M, N not multiples of the tile, ldc / ldz / ldr > N) and on all three kernel
+    families (tile kernels; K = 256 with >= 4096 rows: weight-stationary): C, the stored pre-activation, nothing written outside
+    [:M, :N].  Reference in float64 with the dropout mask regenerated by the standalone kernel from (seed, offset, m*N + n)."""
+    name, act, drop, res, rs, has_b, bwd = mode
+    p = 0.25 if drop else 0.0
+    ld = N + pad
+    A, B = rnd(M, Kd, seed=31).to(DEV), rnd(N, Kd, seed=32, scale=0.3).to(DEV)
+    bias = rnd(N, seed=33).to(DEV) if has_b else None
+    R = torch.randn(M, ld, device=DEV) if res else None
+    rowscale = (torch.rand(M, device=DEV) > 0.3).float() if rs else None
+    seed = torch.full((1,), 4242, dtype=torch.int64, device=DEV)
+    off, alpha = 11, 0.7
+    Cb = torch.full((M + 3, ld), float("nan"), device=DEV)
+    kw = dict(alpha=alpha, act=act, p_drop=p, seed=seed if drop else None, drop_offset=off)
+    fns = {0: lambda v: v, 1: torch.relu, 2: lambda v: F.gelu(v), 4: lambda v: v * torch.sigmoid(v)}
+    mask = torch.ones(M, N, dtype=torch.float64, device=DEV)
+    if drop:
+        mask = K.rowscale_dropout(torch.ones(M, N, device=DEV), None, p, seed, off).double()       # 0 or 1/(1-p)
+    acc = A.double() @ B.double().t()
+    if not bwd:
+        Zb = torch.full((M + 3, ld), float("nan"), device=DEV) if act else None
+        K.gemm(A, B, Cb, M, N, Kd, Kd, Kd, ld, True, True, bias=bias, Z=Zb, ldz=ld, R=R, ldr=ld, rowscale=rowscale, **kw)
+        z = alpha * (acc + (bias.double() if has_b else 0.0))
+        ref = fns[act](z) * mask
+        if res:
+            ref = ref + R[:, :N].double()
+        if rs:
+            ref = ref * rowscale.double()[:, None]
+        if act:
+            close(Zb[:M, :N], z, 1e-5, f"Z {name}")
+            assert torch.isnan(Zb[M:]).all() and (pad == 0 or torch.isnan(Zb[:, N:]).all()), "Z written out of range"
+    else:
+        Zp = torch.randn(M, ld, device=DEV)                    # the producer's stored pre-activation: an input
+        K.gemm(A, B, Cb, M, N, Kd, Kd, Kd, ld, True, True, Z=Zp, ldz=ld, epi_bwd=True, **kw)
+        zz = Zp[:, :N].double().requires_grad_()
+        fns[act](zz).sum().backward()
+        ref = alpha * acc * mask * zz.grad
+    close(Cb[:M, :N], ref, 2e-5, f"C {name}")
+    assert torch.isnan(Cb[M:]).all() and (pad == 0 or torch.isnan(Cb[:, N:]).all()), "C written out of range"
+
+
+def test_gemm_lean_split_k_atomics_and_batched_limits():
+    """The two remaining special forms: split-K partials by buffer atomics (rows / columns beyond the operand dropped in hardware) and the
+    plain epilogue of a batched launch with per-batch length limits (each batch's descriptor ends at ITS valid extent)."""
+    M, N, Kd = 130, 70, 2048
+    A, B = rnd(Kd, M, seed=41).to(DEV), rnd(Kd, N, seed=42).to(DEV)                   # TN: both reduction-major
+    Cb = torch.zeros(M + 2, N + 6, device=DEV)
+    K.gemm(A, B, Cb, M, N, Kd, M, N, N + 6, False, False, split_k=4, alpha=0.5)
+    close(Cb[:M, :N], 0.5 * (A.double().t() @ B.double()), 2e-5, "split-K atomics")
+    assert float(Cb[M:].abs().max()) == 0.0 and float(Cb[:, N:].abs().max()) == 0.0
+    nb, T, dh = 3, 90, 32
+    lens = torch.tensor([90, 41, 7], dtype=torch.int32, device=DEV)
+    q, k = rnd(nb, T, dh, seed=43).to(DEV), rnd(nb, T, dh, seed=44).to(DEV)
+    S = torch.full((nb, T, T), float("nan"), device=DEV)
+    K.gemm(q, k, S, T, T, dh, dh, dh, T, True, True, nb0=nb, nb1=1, sA=(T * dh, 0), sB=(T * dh, 0), sC=(T * T, 0), lens=lens, lim=(1, 1, 0),
+           alpha=0.25)
+    for b in range(nb):
+        L = int(lens[b])
+        close(S[b, :L, :L], 0.25 * (q[b, :L].double() @ k[b, :L].double().t()), 1e-5, f"batched limits b={b}")
+        assert torch.isnan(S[b, L:]).all() and torch.isnan(S[b, :, L:]).all(), "written beyond the batch's limits"
