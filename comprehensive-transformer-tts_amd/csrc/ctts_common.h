@@ -51,10 +51,30 @@ __device__ __forceinline__ float ctts_drop_scale(uint32_t key, uint32_t idx, flo
 }
 
 // ---------------------------------------------------------------- activations
+// erf for the GELU epilogues (F.gelu, transformer_fs2.py:228): Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 + fp32 rounding of 6 fused
+// multiply-adds - 2 ulp of a result near 1, and 3e-7 * |v| / 2 in GELU(v): three orders of magnitude inside the 1e-3 mel tolerance and
+// below the fp32 noise of the GEMM in front of it.  13 VALU instructions (one v_rcp, one v_exp) against ~35 with branches for the
+// correctly rounded library erff: the epilogue of the dominant FFN convolution runs under the other workgroup's MFMAs and still costs
+// 6 % of the launch.  CTTS_EXACT_ERF restores erff.
+__device__ __forceinline__ float ctts_erf(float x) {
+#ifdef CTTS_EXACT_ERF
+  return erff(x);
+#else
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float r = fmaf(-p * t, e, 1.0f);
+  return copysignf(r, x);
+#endif
+}
 __device__ __forceinline__ float ctts_act(float v, int act) {
   switch (act) {
     case 1: return v > 0.f ? v : 0.f;
-    case 2: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case 2: return 0.5f * v * (1.0f + ctts_erf(v * 0.70710678118654752440f));
     case 3: return tanhf(v);
     case 4: return v / (1.0f + __expf(-v));          // swish = v * sigmoid(v)
     default: return v;
@@ -65,7 +85,7 @@ __device__ __forceinline__ float ctts_act_grad(float z, int act) {
   switch (act) {
     case 1: return z > 0.f ? 1.f : 0.f;
     case 2: {
-      float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+      float cdf = 0.5f * (1.0f + ctts_erf(z * 0.70710678118654752440f));
       float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
       return cdf + z * pdf;
     }
