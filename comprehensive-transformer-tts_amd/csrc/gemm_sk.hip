@@ -38,6 +38,7 @@ struct SkArgs {
   int gw;                    // n-tiles per schedule group
   int whole_tiles;           // 1: never split a tile
   int accumulate;            // 1: C += alpha * acc (weight gradients), no other epilogue
+  int conv_chan_major;       // conv view on A: walk K as (channel block, tap) instead of (tap, channel block) - see k0_of
   int debug;                 // CTTS_SK_DEBUG (tools only): 1 = no DMA after the first block, 2 = every workgroup loads tile (0,0), 4 = no epilogue, 16 = record shader cycles / wall ticks of workgroup 8 in the workspace header
   unsigned* ws;              // workspace: SK_FLAG_WORDS words, then one slab per workgroup
 };
@@ -236,8 +237,15 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : ((MT * NT >= 2 || STAGES >
     row0 = (mmap ? mmap[1 + mslot] : mslot) * BM;
     col0 = nt * BN;
   };
+  // Conv view on A (k = tap * cin + channel): the K-blocks are walked channel block by channel block, all taps of a 32-channel block
+  // in a row.  Tap t of output row r reads input row r + t - pad, so consecutive K-blocks then read the SAME 128-byte lines shifted by
+  // one row: the activation tile comes from L2 / the vector cache instead of the fabric 9 times (tap-major, a line's next use is 8
+  // K-blocks x ~100 co-resident workgroups away - beyond the XCD's 4 MiB L2).  The sum over K is the same set of products in another
+  // order; the B operand's 128-byte segments follow the same k0.
+  const int ntap = (CONV_A && p.conv_chan_major) ? d.K / cin : 0;
   auto k0_of = [&](int kb) -> int {
     if (TN && kmap) return (kmap[1 + (kb >> 1)] * 2 + (kb & 1)) * 32;
+    if (CONV_A && ntap) { const int cb = kb / ntap; return (kb - cb * ntap) * cin + cb * 32; }
     return kb * 32;
   };
 
@@ -272,8 +280,13 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : ((MT * NT >= 2 || STAGES >
       have_l = sk_next_piece(lu, rg.lo, nkb, lp);
       if (have_l) loader_set_piece();
     } else {
-      lk0 = k0_of(lkb);
-      if (CONV_A) { lkin += 32; if (lkin >= cin) { lkin -= cin; ++ltap; } }
+      if (CONV_A && ntap) {                 // next tap of the same channel block, or tap 0 of the next channel block
+        ++ltap; lk0 += cin;
+        if (ltap == ntap) { ltap = 0; lk0 += 32 - ntap * cin; }
+      } else {
+        lk0 = k0_of(lkb);
+        if (CONV_A) { lkin += 32; if (lkin >= cin) { lkin -= cin; ++ltap; } }
+      }
     }
   };
 
@@ -497,6 +510,8 @@ static int sk_try(const ctts_gemm_desc& din, hipStream_t st, bool launch) {
   const long units = (long)p.tiles_m * p.tiles_n * p.nkb * mt * nt;  // in 64x64x32 equivalents
   if (units < min_units || p.nkb < min_nkb) return 0;
   p.whole_tiles = p.nkb < split_from ? 1 : 0;
+  static const int chan_major = sk_env("CTTS_SK_CONV_ORDER", 1);      // 1: (channel block, tap) K order for conv views on A; 0: (tap, channel)
+  p.conv_chan_major = (conv && d.a_kc && !d.conv_on_b && chan_major && d.K % d.conv_cin == 0) ? 1 : 0;
   p.accumulate = d.split_k > 1 ? 1 : 0;      // ABI: split_k > 1 means "add alpha * A B to C" (gemm.hip does it with atomics)
   p.debug = debug;
   // schedule groups: 4 groups of n-tiles when that divides (an XCD pair shares a group), else one group

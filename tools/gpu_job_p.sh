@@ -1,7 +1,6 @@
 #!/bin/bash
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
-cd /tmp
-for at in 0 1; do echo "== SK_ATOMIC=$at"; CTTS_SK_ATOMIC=$at timeout 300 python $ROOT/tools/bench_sk.py 100 "wgrad" 2>&1 | grep -v amdgpu.ids | cut -c1-150; done
-for at in 0 1 0 1; do echo "fs2 SK_ATOMIC=$at"; CTTS_SK_ATOMIC=$at timeout 300 python $ROOT/bench.py --no-cpu-baseline --no-pcie --no-secondary --no-roofline 2>/dev/null | tail -1 | cut -c80-200; done
-for at in 0 1 0 1; do echo "conformer SK_ATOMIC=$at"; CTTS_SK_ATOMIC=$at timeout 300 python $ROOT/bench.py --block conformer --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-roofline 2>/dev/null | tail -1 | cut -c80-200; done
+cd $ROOT; timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "stream_k or conv or persistent" 2>&1 | tail -3; cd /tmp
+for o in 0 1; do echo "== CONV_ORDER=$o"; CTTS_SK_CONV_ORDER=$o timeout 300 python $ROOT/tools/bench_sk.py 60 "ffn1" 2>&1 | grep -v amdgpu.ids | cut -c1-150 | head -4; CTTS_SK_CONV_ORDER=$o timeout 300 python $ROOT/tools/bench_sk.py 60 "postnet conv fwd" 2>&1 | grep -v amdgpu.ids | cut -c1-150; done
+for o in 0 1 0 1; do echo "fs2 CONV_ORDER=$o"; CTTS_SK_CONV_ORDER=$o timeout 300 python $ROOT/bench.py --no-cpu-baseline --no-pcie --no-secondary --no-roofline 2>/dev/null | tail -1 | cut -c80-200; done
