@@ -13,6 +13,9 @@ for cfg in "fs2:" "conformer:--block conformer"; do
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -- python $ROOT/bench.py $a --no-graph --no-cpu-baseline --no-pcie --no-secondary --no-roofline --steps 5 --warmup 2 > /tmp/prof_$n.log 2>&1
   python $ROOT/tools/rocpd_summary.py $(find /tmp/prof_$n -name "*results.db" | head -1) 45 > $OUT/${R}_${n}_eager_kernel_stats.md 2>&1
 done
+# the replayed graph: idle time between kernels and per-kernel totals of one step
+rm -rf /tmp/prof_g; timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_g -- python $ROOT/bench.py --no-cpu-baseline --no-pcie --no-secondary --no-roofline --steps 6 --warmup 3 > /tmp/prof_g.log 2>&1
+python $ROOT/tools/graph_gaps.py $(find /tmp/prof_g -name "*results.db" | head -1) > $OUT/${R}_fs2_graph_replay_kernels.md 2>&1
 # dominant kernel: kernel-trace summary of exactly what bench.py's roofline block launches, then PMC passes
 rm -rf /tmp/prof_dom; timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_dom -- python $ROOT/tools/bench_one.py ffn1_step 60 > /tmp/prof_dom.log 2>&1
 python $ROOT/tools/rocpd_summary.py $(find /tmp/prof_dom -name "*results.db" | head -1) 6 > $OUT/${R}_dominant_kernel_stats.md 2>&1
