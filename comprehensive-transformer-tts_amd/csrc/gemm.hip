@@ -536,7 +536,9 @@ int launch(const ctts_gemm_desc& d, hipStream_t st) {
 // Same tiling / barrier structure as gemm_kernel, operands fetched through buffer descriptors.
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV, bool PARTIAL>
 __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ctts_gemm_desc d) {
-  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+  // 4 waves as 2 x 2, or 4 x 1 for the narrow tile (BN = 32: outputs with N <= 32, e.g. the d_head = 32 attention gradients)
+  constexpr int WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, MT = WM / 32, NT = WN / 32;
   constexpr int A_LD = A_KC ? KC_LD : BM + 4;
   constexpr int B_LD = B_KC ? KC_LD : BN + 4;
   constexpr int A_SZ = A_KC ? BM * KC_LD : BK * (BM + 4);
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   floatx16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -714,6 +716,17 @@ int dispatch_buf(const ctts_gemm_desc& d, hipStream_t st) {
   if (d.a_kc && d.b_kc) return conv ? launch_buf<BM, BN, true, true, true>(d, st) : launch_buf<BM, BN, true, true, false>(d, st);
   if (d.a_kc && !d.b_kc) return conv ? launch_buf<BM, BN, true, false, true>(d, st) : launch_buf<BM, BN, true, false, false>(d, st);
   if (!d.a_kc && !d.b_kc) return conv ? launch_buf<BM, BN, false, false, true>(d, st) : launch_buf<BM, BN, false, false, false>(d, st);
+  ctts_set_error("ctts_gemm: layout a_kc=0,b_kc=1 is not instantiated");
+  return -1;
+}
+
+// 128 x 32 tiles (4 x 1 waves) for outputs at most 32 columns wide: with 64 x 64 tiles half of every workgroup's MFMAs would multiply
+// zero columns.  The three products of the conformer's attention backward that consume dS ([T, 32] = [T, T] x [T, 32] per (b, h),
+// ctts_relmha_bwd) are the users.  No conv views.
+int dispatch_buf_narrow(const ctts_gemm_desc& d, hipStream_t st) {
+  if (d.a_kc && d.b_kc) return launch_buf<128, 32, true, true, false>(d, st);
+  if (d.a_kc && !d.b_kc) return launch_buf<128, 32, true, false, false>(d, st);
+  if (!d.a_kc && !d.b_kc) return launch_buf<128, 32, false, false, false>(d, st);
   ctts_set_error("ctts_gemm: layout a_kc=0,b_kc=1 is not instantiated");
   return -1;
 }
@@ -848,6 +861,8 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
     // 4096^3, conv dgrad, conv wgrad) and make padded-row skipping effective: 64-row granularity and many waves per CU instead of two
     // rounds of 128-row tiles (fs2 train step 33.3 -> 29.8 ms).  CTTS_FORCE_TILE=128 keeps the big-tile kernel reachable for A/B runs.
     if (force_tile == 128) return dispatch_buf<128, 128>(d, st);
+    static const bool narrow = getenv("CTTS_NARROW_TILE") ? atoi(getenv("CTTS_NARROW_TILE")) != 0 : true;
+    if (narrow && d.N <= 32 && d.M >= 256 && d.conv_T <= 0 && !d.tile_map && !d.row_lens) return dispatch_buf_narrow(d, st);
     return dispatch_buf<64, 64>(d, st);
   }
 #endif

@@ -1042,3 +1042,24 @@ def test_gemm_lean_split_k_atomics_and_batched_limits():
         L = int(lens[b])
         close(S[b, :L, :L], 0.25 * (q[b, :L].double() @ k[b, :L].double().t()), 1e-5, f"batched limits b={b}")
         assert torch.isnan(S[b, L:]).all() and torch.isnan(S[b, :, L:]).all(), "written beyond the batch's limits"
+
+
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("M,N,Kd,nb", [(1000, 32, 1000, 3), (300, 20, 129, 2), (257, 8, 64, 1)])
+def test_gemm_narrow_output_tiles(layout, M, N, Kd, nb):
+    """Outputs at most 32 columns wide run on 128 x 32 tiles (4 x 1 waves; csrc/gemm.hip dispatch_buf_narrow) - the [T, d_head = 32]
+    gradients of the conformer's attention: all three operand layouts, batched with strides, ragged M / N / K, ldc > N."""
+    torch.manual_seed(3)
+    A = torch.randn(nb, M, Kd, device=DEV) if layout != "TN" else torch.randn(nb, Kd, M, device=DEV)
+    Bm = torch.randn(nb, N, Kd, device=DEV) if layout == "NT" else torch.randn(nb, Kd, N, device=DEV)
+    ldc = N + 4
+    Cb = torch.full((nb, M, ldc), float("nan"), device=DEV)
+    a_kc, b_kc = layout != "TN", layout == "NT"
+    lda = Kd if a_kc else M
+    ldb = Kd if b_kc else N
+    K.gemm(A, Bm, Cb, M, N, Kd, lda, ldb, ldc, a_kc, b_kc, nb0=nb, nb1=1, sA=(A[0].numel(), 0), sB=(Bm[0].numel(), 0), sC=(M * ldc, 0),
+           alpha=0.5)
+    Ad = A.double() if a_kc else A.double().transpose(1, 2)
+    Bd = Bm.double().transpose(1, 2) if b_kc else Bm.double()
+    close(Cb[:, :, :N], 0.5 * (Ad @ Bd), 2e-5, f"narrow {layout}")
+    assert torch.isnan(Cb[:, :, N:]).all()
