@@ -211,12 +211,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const ctts_gemm_desc d,
 template <int KB, bool B_KC, int ACT, bool DROP, bool BWD, bool AUX>
 int ws_launch(const ctts_gemm_desc& d, const WsArgs& p, hipStream_t st) {
   const size_t lds = (size_t)64 * KB * 32 * sizeof(float);             // 2 stages of one K-half
-  static bool attr_set = false;                                        // per instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KB, B_KC, ACT, DROP, BWD, AUX>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  // every call: the attribute is per device, and a process may drive several (cheap next to the launch)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KB, B_KC, ACT, DROP, BWD, AUX>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((gemm_ws_kernel<KB, B_KC, ACT, DROP, BWD, AUX>), dim3(p.n_blocks * p.wg_per_block), dim3(256), lds, st, d, p);
   CTTS_CHECK_LAUNCH("ctts_gemm(weight-stationary)");
   return 1;
