@@ -446,6 +446,10 @@ int sk_launch(const ctts_gemm_desc& d, const SkArgs& p, int grid, int stages, in
   if (mt == 1 && nt == 1) { if (stages == 3) SK_GO(3, 1, 1); else SK_GO(2, 1, 1); }
   else if (mt == 1 && nt == 2) SK_GO(2, 1, 2);
   else if (mt == 2 && nt == 2) SK_GO(2, 2, 2);
+  else if (mt == 1 && nt == 4) {
+    if constexpr (A_KC && B_KC) SK_GO(2, 1, 4);       // the wide tile is only routed for NT launches (sk_try)
+    else { ctts_set_error("ctts_gemm(stream-K): the 64x256 tile is instantiated for the NT layout only"); return -1; }
+  }
   else { ctts_set_error("ctts_gemm(stream-K): tile %dx%d not instantiated", mt, nt); return -1; }
 #undef SK_GO
   CTTS_CHECK_LAUNCH("ctts_gemm(stream-K)");
@@ -502,6 +506,11 @@ static int sk_try(const ctts_gemm_desc& din, hipStream_t st, bool launch) {
   if (mt == 2 && d.M < 128) mt = 1;
   if (mt == 2 && nt == 1) nt = (d.N >= 128) ? 2 : 1;
   if (mt == 2 && nt == 1) mt = 1;
+  // ragged rows keep 64-row tiles: make the tile 256 columns wide instead (1 x 4 MFMA tiles per wave: the same 64 MFMAs per K-block and
+  // barrier as the 128 x 128 tile, 5 fragment reads per 64 MFMAs instead of 6; 80 KB of LDS: exactly two workgroups per CU).  FFN conv
+  // forward 491 -> 467 us, its data gradient 478 -> 457 us, fs2 step -1.05 % (same box); CTTS_SK_WIDE=0 keeps 64 x 128.
+  static const int wide = sk_env("CTTS_SK_WIDE", 1);
+  if (wide && mt == 1 && nt == 2 && d.a_kc && d.b_kc && d.N % 256 == 0) nt = 4;
   const int BM = 64 * mt, BN = 64 * nt;
   SkArgs p;
   p.tiles_m = (d.M + BM - 1) / BM;
