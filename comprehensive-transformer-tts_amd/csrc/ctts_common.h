@@ -49,6 +49,14 @@ __device__ __forceinline__ float ctts_drop_scale(uint32_t key, uint32_t idx, flo
   float u = (float)(h >> 8) * (1.0f / 16777216.0f);
   return u >= p ? inv_keep : 0.0f;
 }
+// The same decision with the index hash split by the caller: pre = idx * 0x9E3779B1 + key arrives ready-made (lane constant + wave-uniform
+// SALU term: one v_add per element instead of two quarter-rate integer multiplies), and u >= p is tested on the integer:
+// (h >> 8) * 2^-24 >= p  <=>  h >= ceil(p * 2^24) << 8  (both sides exact).  Used by the GEMM epilogues and the attention kernels.
+constexpr uint32_t CTTS_DROP_G = 0x9E3779B1U;
+__device__ __forceinline__ uint32_t ctts_drop_threshold(float p) { return ((uint32_t)ceilf(p * 16777216.0f)) << 8; }
+__device__ __forceinline__ float ctts_drop_scale_pre(uint32_t pre, uint32_t thr, float inv_keep) {
+  return ctts_mix32(pre) >= thr ? inv_keep : 0.0f;
+}
 
 // ---------------------------------------------------------------- activations
 // erf for the GELU epilogues (F.gelu, transformer_fs2.py:228): Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 + fp32 rounding of 6 fused

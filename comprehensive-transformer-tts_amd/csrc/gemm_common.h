@@ -113,6 +113,9 @@ __device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, cons
   float inv_keep = 1.f;
   if (DROP) { dkey = ctts_drop_key(d.seed, d.drop_offset); inv_keep = 1.f / (1.f - d.p_drop); }
   const uint32_t zoff = (uint32_t)z * (uint32_t)d.M * (uint32_t)d.N;
+  // dropout element index zoff + m * N + n, hashed as idx * G + key: (lane constant) + (wave-uniform term of the row mu)
+  const uint32_t dthr = DROP ? ctts_drop_threshold(d.p_drop) : 0u;
+  const uint32_t drow = (uint32_t)d.N * CTTS_DROP_G;
   const long last = Mv - 1;
   const float* aux_p = BWD ? d.Z : d.R;
   const long aux_ld = BWD ? d.ldz : d.ldr;
@@ -130,6 +133,7 @@ __device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, cons
     const unsigned a_lane = n_ok ? (unsigned)(4 * h) * a_row + (unsigned)n * 4u : GEMM_OOB;
     const unsigned z_lane = n_ok ? (unsigned)(4 * h) * z_row + (unsigned)n * 4u : GEMM_OOB;
     const float bv = (!BWD && d.bias && n_ok) ? d.bias[n] : 0.f;
+    const uint32_t dlane = (zoff + (uint32_t)(4 * h) * (uint32_t)d.N + (uint32_t)n) * CTTS_DROP_G + dkey;
 #pragma unroll
     for (int ib = 0; ib < 2 * MT; ++ib) {               // batches of 8 rows: 8 gathered values in registers at a time
       const int i = ib >> 1, rb = (ib & 1) * 8;
@@ -155,13 +159,13 @@ __device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, cons
         float v;
         if (BWD) {
           v = alpha * acc[i][j][r];
-          if (DROP) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
+          if (DROP) v *= ctts_drop_scale_pre(dlane + (uint32_t)mu * drow, dthr, inv_keep);
           if (ACT) v *= ctts_act_grad(aux[q], ACT);
         } else {
           v = alpha * (acc[i][j][r] + bv);
           if (ACT) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rz, z_lane + (unsigned)mu * z_row, 0, 0);
           v = ctts_act(v, ACT);
-          if (DROP) v *= ctts_drop_scale(dkey, zoff + (uint32_t)m * (uint32_t)d.N + (uint32_t)n, d.p_drop, inv_keep);
+          if (DROP) v *= ctts_drop_scale_pre(dlane + (uint32_t)mu * drow, dthr, inv_keep);
           if (AUX) v += aux[q];
           if (RS) v *= rs[q];
         }
