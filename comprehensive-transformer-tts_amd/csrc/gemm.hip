@@ -691,6 +691,126 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   gemm_epilogue_auto<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
+// Under-filled launches (few output tiles, long reduction: the 2,048-row phoneme-level layers give 128 tiles of 64 x 64 on 256 CUs, each
+// a chain of K / 32 staged K-blocks on one workgroup per CU): 32 x 64 tiles - twice the workgroups - and the reduction split in two INSIDE
+// the workgroup.  Waves 0,1 (32 columns each) take the even 32-deep K-blocks, waves 2,3 the odd ones: one load / barrier round per 64
+// of K, half as many rounds per workgroup, every SIMD of the chip in use.  The halves are added through LDS in a fixed order and waves
+// 0,1 run the ordinary epilogue: any epilogue works (no atomics, no zero fill).  Padded 32-row tiles are zero-filled and skipped.
+template <bool A_KC, bool B_KC, bool CONV>
+__global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_k2_kernel(const ctts_gemm_desc d) {
+  constexpr int BM = 32, BN = 64;
+  constexpr int A_LD = A_KC ? KC_LD : BM + 4;
+  constexpr int B_LD = B_KC ? KC_LD : BN + 4;
+  constexpr int A_SZ = A_KC ? BM * KC_LD : BK * (BM + 4);
+  constexpr int B_SZ = B_KC ? BN * KC_LD : BK * (BN + 4);
+  static_assert(BK == 32, "the two-group kernel stages two 32-deep K-blocks per round");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];       // [group][A | B]; reused for the final reduction
+  const int z = blockIdx.z, split = blockIdx.y;
+  const int z0 = z / d.nb1, z1 = z - z0 * d.nb1;
+  const int Mv = d.M, Nv = d.N, Kv = d.K;
+  const int tiles_n = (d.N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n;
+  const int row0 = tm * BM, col0 = (blockIdx.x - tm * tiles_n) * BN;
+  if (row0 >= Mv || col0 >= Nv) return;
+  float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
+  if (A_KC && d.row_lens) {
+    const int last = min(row0 + BM, Mv) - 1;
+    const int b0 = row0 / d.row_T, b1 = last / d.row_T;
+    if (b0 == b1 && (row0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo) {
+      const int ncols = min(BN, Nv - col0), nrows = last - row0 + 1;
+      for (int e = threadIdx.x; e < nrows * ncols; e += 256) {
+        const int r = e / ncols, c = e - r * ncols;
+        Cb[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
+        if (d.Z && !d.epi_bwd) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
+      }
+      return;
+    }
+  }
+  int k_begin = 0, k_end = Kv;
+  if (d.split_k > 1) {
+    int chunk = ((Kv + d.split_k - 1) / d.split_k + 2 * BK - 1) / (2 * BK) * (2 * BK);
+    k_begin = split * chunk;
+    k_end = min(Kv, k_begin + chunk);
+    if (k_begin >= k_end) return;
+  }
+  const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
+  const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
+  const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7FFFFFFE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7FFFFFFE, 0x00020000);
+  ConvView cv{d.conv_T, d.conv_pad, d.conv_cin};
+  ConvView nocv{1, 0, 1};
+  constexpr bool CONV_A = CONV && A_KC;
+  constexpr bool CONV_B = CONV && !A_KC && !B_KC;
+  using LA = typename BLoaderSel<A_KC, BM, CONV_A, false>::type;
+  using LB = typename BLoaderSel<B_KC, BN, CONV_B, false>::type;
+  LA la; LB lb;
+  la.init(d.lda, row0, Mv, CONV_A ? cv : nocv, threadIdx.x);
+  lb.init(d.ldb, col0, Nv, CONV_B ? cv : nocv, threadIdx.x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int grp = wave >> 1, wn0 = (wave & 1) * 32;
+  float* sA = smem + grp * (A_SZ + B_SZ);
+  float* sB = sA + A_SZ;
+  floatx16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  float4 ra[2][LA::NV], rb[2][LB::NV];
+  auto load_round = [&](int k0) {                       // both 32-deep K-blocks of the round (the second may lie beyond k_end: zeros)
+    la.load(ra_src, k0, k_end, ra[0]);      lb.load(rb_src, k0, k_end, rb[0]);
+    la.load(ra_src, k0 + BK, k_end, ra[1]); lb.load(rb_src, k0 + BK, k_end, rb[1]);
+  };
+  auto store_round = [&]() {
+    la.store(smem, ra[0]);                  lb.store(smem + A_SZ, rb[0]);
+    la.store(smem + A_SZ + B_SZ, ra[1]);    lb.store(smem + 2 * A_SZ + B_SZ, rb[1]);
+  };
+  load_round(k_begin);
+  store_round();
+  __syncthreads();
+  for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
+    const bool has_next = (k0 + 2 * BK) < k_end;
+    if (has_next) load_round(k0 + 2 * BK);
+    {
+      float fa[16], fb[16];
+      fetch_frag<A_KC, A_LD>(sA, 0, l31, h, 0, fa);
+      fetch_frag<B_KC, B_LD>(sB, wn0, l31, h, 0, fb);
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc[0][0], 0, 0, 0);
+    }
+    __syncthreads();
+    if (has_next) store_round();
+    __syncthreads();
+  }
+  // waves 2,3 hand their half over through LDS (the operand tiles are dead: the loop's last barrier is behind every fragment read)
+  float* red = smem + (wave & 1) * 1024 + lane;
+  if (grp == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[r * 64] = acc[0][0][r];
+  }
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += red[r * 64];
+    gemm_epilogue_auto<1, 1>(d, acc, Cb, z, row0, col0, 0, wn0, l31, h, Mv, Nv);
+  }
+}
+
+template <bool A_KC, bool B_KC, bool CONV>
+int launch_buf_k2(const ctts_gemm_desc& d, hipStream_t st) {
+  const int tiles = ((d.M + 31) / 32) * ((d.N + 63) / 64);
+  const int nz = d.nb0 * d.nb1, ny = d.split_k > 1 ? d.split_k : 1;
+  hipLaunchKernelGGL((gemm_buf_k2_kernel<A_KC, B_KC, CONV>), dim3(tiles, ny, nz), dim3(256), 0, st, d);
+  CTTS_CHECK_LAUNCH("ctts_gemm(buf,k2)");
+  return 0;
+}
+
+int dispatch_buf_k2(const ctts_gemm_desc& d, hipStream_t st) {
+  const bool conv = d.conv_T > 0;
+  if (d.a_kc && d.b_kc) return conv ? launch_buf_k2<true, true, true>(d, st) : launch_buf_k2<true, true, false>(d, st);
+  if (d.a_kc && !d.b_kc) return conv ? launch_buf_k2<true, false, true>(d, st) : launch_buf_k2<true, false, false>(d, st);
+  ctts_set_error("ctts_gemm: the two-group kernel is instantiated for A K-contiguous only");
+  return -1;
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC, bool CONV>
 int launch_buf(const ctts_gemm_desc& d, hipStream_t st) {
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
@@ -861,6 +981,14 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
     // 4096^3, conv dgrad, conv wgrad) and make padded-row skipping effective: 64-row granularity and many waves per CU instead of two
     // rounds of 128-row tiles (fs2 train step 33.3 -> 29.8 ms).  CTTS_FORCE_TILE=128 keeps the big-tile kernel reachable for A/B runs.
     if (force_tile == 128) return dispatch_buf<128, 128>(d, st);
+    // under-filled forward / data-gradient launches (A K-contiguous, unbatched): few 64 x 64 tiles - the phoneme-level layers (2,048
+    // rows).  Routing by the step time (same box): tile limit 160 / 320 / 640 / 1024: fs2 23.36 / 23.27 / 23.17 / 23.24 ms from 23.48,
+    // conformer 27.78 / 27.84 / 27.62 / 27.90 from 28.14; K >= 256 instead of 512: another -0.03 / -0.05 ms.
+    static const int k2 = getenv("CTTS_K2_TILE") ? atoi(getenv("CTTS_K2_TILE")) : 640;          // largest 64 x 64 tile count routed here (0 = off)
+    static const int k2_mink = getenv("CTTS_K2_MIN_K") ? atoi(getenv("CTTS_K2_MIN_K")) : 256;
+    if (k2 && d.a_kc && d.nb0 * d.nb1 == 1 && !d.lens && d.N >= 64 && d.M >= 256 && d.K >= k2_mink &&
+        (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * (d.split_k > 1 ? d.split_k : 1) <= k2)
+      return dispatch_buf_k2(d, st);
     static const bool narrow = getenv("CTTS_NARROW_TILE") ? atoi(getenv("CTTS_NARROW_TILE")) != 0 : true;
     if (narrow && d.N <= 32 && d.M >= 256 && d.conv_T <= 0 && !d.tile_map && !d.row_lens) return dispatch_buf_narrow(d, st);
     return dispatch_buf<64, 64>(d, st);

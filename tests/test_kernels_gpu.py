@@ -1063,3 +1063,37 @@ def test_gemm_narrow_output_tiles(layout, M, N, Kd, nb):
     Bd = Bm.double().transpose(1, 2) if b_kc else Bm.double()
     close(Cb[:, :, :N], 0.5 * (Ad @ Bd), 2e-5, f"narrow {layout}")
     assert torch.isnan(Cb[:, :, N:]).all()
+
+
+@pytest.mark.parametrize("M,N,Kd", [(2048, 256, 1024), (1000, 200, 520), (300, 64, 2048), (2048, 1024, 256)])
+def test_gemm_under_filled_two_group_kernel(M, N, Kd):
+    """Launches with few 64 x 64 output tiles (the 2,048-row phoneme-level layers) run on 32 x 64 tiles with the reduction split between
+    two wave groups inside the workgroup (csrc/gemm.hip gemm_buf_k2_kernel): NT with bias / alpha / ldc > N, NN, K not a multiple of 64,
+    nothing written out of range; and the conv view on ragged rows (padded 32-row tiles zero-filled and skipped)."""
+    torch.manual_seed(0)
+    x = torch.randn(M, Kd, device=DEV); w = torch.randn(N, Kd, device=DEV) * 0.05; b = torch.randn(N, device=DEV)
+    C = torch.full((M + 2, N + 4), float("nan"), device=DEV)
+    K.gemm(x, w, C, M, N, Kd, Kd, Kd, N + 4, True, True, bias=b, alpha=0.5)
+    close(C[:M, :N], 0.5 * (x.double() @ w.double().t() + b.double()), 2e-5, "NT")
+    assert torch.isnan(C[M:]).all() and torch.isnan(C[:, N:]).all()
+    C2 = torch.empty(M, N, device=DEV)
+    K.gemm(x, w.t().contiguous(), C2, M, N, Kd, Kd, N, N, True, False)
+    close(C2, x.double() @ w.double().t(), 2e-5, "NN")
+
+
+def test_gemm_under_filled_conv_ragged_rows():
+    torch.manual_seed(1)
+    B, T, Cin, Cout, ks = 16, 128, 256, 256, 5
+    lens = torch.tensor([128, 123, 117, 115, 113, 112, 111, 96, 83, 82, 82, 81, 78, 63, 60, 55], dtype=torch.int32, device=DEV)
+    xc = torch.randn(B, T, Cin, device=DEV); wc = torch.randn(Cout, ks * Cin, device=DEV) * 0.03
+    bias = torch.randn(Cout, device=DEV); Z = torch.full((B, T, Cout), float("nan"), device=DEV)
+    Cc = torch.full((B, T, Cout), float("nan"), device=DEV)
+    K.gemm(xc, wc, Cc, B * T, Cout, ks * Cin, Cin, ks * Cin, Cout, True, True, conv=(T, ks // 2, Cin), bias=bias, Z=Z, ldz=Cout,
+           act=K.ACT_RELU, row_lens=lens, row_T=T, row_halo=0, tile_map=K.row_tile_map(lens, T, 0, B * T))
+    w3 = wc.view(Cout, ks, Cin).permute(0, 2, 1).contiguous()
+    ref = F.conv1d(xc.double().transpose(1, 2), w3.double(), bias.double(), padding=ks // 2).transpose(1, 2)
+    for b_ in range(B):
+        L = int(lens[b_])
+        close(Z[b_, :L], ref[b_, :L], 2e-5, f"conv Z b={b_}")
+        close(Cc[b_, :L], torch.relu(ref[b_, :L]), 2e-5, f"conv C b={b_}")
+    assert torch.isfinite(Cc).all() and torch.isfinite(Z).all()          # padded tiles are zero-filled, not left unwritten
