@@ -211,6 +211,7 @@ import os as _os
 _DGRAD_SPLIT_K = int(_os.environ.get("CTTS_DGRAD_SPLIT_K", "1"))
 _FUSE_EPILOGUE_BWD = _os.environ.get("CTTS_FUSE_EPI_BWD", "1") != "0"      # EpiLink: producer's epilogue backward inside the consumer's dgrad GEMM     # tuning knob; 0 = never split the data-gradient reduction
 _WGRAD_SPLIT_MULT = float(_os.environ.get("CTTS_WGRAD_SPLIT_MULT", "1"))
+_WGRAD_SPLIT_CAP = int(_os.environ.get("CTTS_WGRAD_SPLIT_CAP", "512"))      # a split-K piece reduces over at least this many rows
 
 
 def _split_k_for(Mo, No, Kred):
@@ -220,7 +221,7 @@ def _split_k_for(Mo, No, Kred):
     if forced and t128 >= 64:
         return forced
     want = max(1, int(-(-512 // t128) * _WGRAD_SPLIT_MULT))
-    return int(max(1, min(want, max(1, Kred // 512))))
+    return int(max(1, min(want, max(1, Kred // _WGRAD_SPLIT_CAP))))
 
 
 class EpiLink:
