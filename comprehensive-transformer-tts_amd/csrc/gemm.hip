@@ -807,7 +807,8 @@ int dispatch_buf_k2(const ctts_gemm_desc& d, hipStream_t st) {
   const bool conv = d.conv_T > 0;
   if (d.a_kc && d.b_kc) return conv ? launch_buf_k2<true, true, true>(d, st) : launch_buf_k2<true, true, false>(d, st);
   if (d.a_kc && !d.b_kc) return conv ? launch_buf_k2<true, false, true>(d, st) : launch_buf_k2<true, false, false>(d, st);
-  ctts_set_error("ctts_gemm: the two-group kernel is instantiated for A K-contiguous only");
+  if (!d.a_kc && !d.b_kc) return conv ? launch_buf_k2<false, false, true>(d, st) : launch_buf_k2<false, false, false>(d, st);
+  ctts_set_error("ctts_gemm: layout a_kc=0,b_kc=1 is not instantiated");
   return -1;
 }
 
@@ -986,7 +987,8 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
     // conformer 27.78 / 27.84 / 27.62 / 27.90 from 28.14; K >= 256 instead of 512: another -0.03 / -0.05 ms.
     static const int k2 = getenv("CTTS_K2_TILE") ? atoi(getenv("CTTS_K2_TILE")) : 640;          // largest 64 x 64 tile count routed here (0 = off)
     static const int k2_mink = getenv("CTTS_K2_MIN_K") ? atoi(getenv("CTTS_K2_MIN_K")) : 256;
-    if (k2 && d.a_kc && d.nb0 * d.nb1 == 1 && !d.lens && d.N >= 64 && d.M >= 256 && d.K >= k2_mink &&
+    static const int k2_tn = getenv("CTTS_K2_TN") ? atoi(getenv("CTTS_K2_TN")) : 1;              // the split-K weight gradients (TN) of those layers as well: conformer 27.82 -> 27.53 ms
+    if (k2 && (d.a_kc || (k2_tn && !d.b_kc)) && d.nb0 * d.nb1 == 1 && !d.lens && d.N >= 64 && d.M >= 256 && d.K >= k2_mink &&
         (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * (d.split_k > 1 ? d.split_k : 1) <= k2)
       return dispatch_buf_k2(d, st);
     static const bool narrow = getenv("CTTS_NARROW_TILE") ? atoi(getenv("CTTS_NARROW_TILE")) != 0 : true;

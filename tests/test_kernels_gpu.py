@@ -1079,6 +1079,12 @@ def test_gemm_under_filled_two_group_kernel(M, N, Kd):
     C2 = torch.empty(M, N, device=DEV)
     K.gemm(x, w.t().contiguous(), C2, M, N, Kd, Kd, N, N, True, False)
     close(C2, x.double() @ w.double().t(), 2e-5, "NN")
+    # TN with split-K partials added onto an existing value (a weight gradient accumulated into param.grad): reduction over M here
+    Mo, No = (N, 320) if N >= 256 else (320, N)            # the routed range needs at least 256 output rows
+    A = torch.randn(Kd, Mo, device=DEV); Bm = torch.randn(Kd, No, device=DEV)
+    out = torch.full((Mo, No), 0.5, device=DEV)
+    K.gemm(A, Bm, out, Mo, No, Kd, Mo, No, No, False, False, split_k=2, alpha=0.25)
+    close(out, 0.5 + 0.25 * (A.double().t() @ Bm.double()), 2e-5, "TN split-K")
 
 
 def test_gemm_under_filled_conv_ragged_rows():
