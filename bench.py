@@ -46,9 +46,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: 16 utterances per GPU; strong: 16 utterances in total, sharded r::N")
-    ap.add_argument("--shard", default="snake", choices=["snake", "strided"],
-                    help="strong scaling: how the global batch is dealt out - snake = length-balanced (default), strided = r::N like "
-                         "DistributedSampler (train.py:44); the bench line reports max/mean valid frames per rank for both")
+    ap.add_argument("--shard", default="strided", choices=["snake", "strided"],
+                    help="strong scaling: how the global batch is dealt out - strided = r::N like DistributedSampler (train.py:44), the "
+                         "reference's semantics and the default (ADVICE r03); snake = length-balanced, an optimisation to be asked for; "
+                         "the bench line reports max/mean valid frames per rank for both")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-overlap", action="store_true", help="DP: one blocking all-reduce of the whole arena after backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -343,6 +344,7 @@ def measure_secondary(dev, steps=10, warmup=3):
                 st()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+            st.check_kernels()
             v = b["valid_frames"] * steps / el
             out.append({"config": name, "value": v, "unit": "mel-frames/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
                         "valid_frames": b["valid_frames"], "padded_frames": b["padded_frames"],
@@ -423,6 +425,7 @@ def main():
         run_step()
     elapsed = timed(run_step, a.steps)
     loss_final = float(step.loss_val)
+    step.check_kernels()              # stream-K hand-off error words of every workspace (outside the timed region): raises on a failed launch
     if trace is not None and rank == 0:
         for i, t in enumerate(trace):
             print(f"[bench] step {i}: " + " ".join(f"{float(v):.4g}" for v in t), file=sys.stderr)

@@ -56,8 +56,8 @@ _SIGNATURES = {
     "ctts_relmha_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_relmha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                         _f32, _f32, _vp, _u32, _vp],
-    "ctts_weighted_colsum": [_vp, _vp, _vp, _i64, C.c_int, _f32, C.c_int, _vp],
-    "ctts_epilogue_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _u32, _f32, C.c_int, _vp],
+    "ctts_weighted_colsum": [_vp, _vp, _vp, _i64, C.c_int, _f32, C.c_int, _vp, _vp],
+    "ctts_epilogue_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _u32, _f32, C.c_int, _vp, _vp],
     "ctts_row_tile_map": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "ctts_conv_weight_repack": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_lr_index": [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
@@ -67,18 +67,18 @@ _SIGNATURES = {
     "ctts_embedding_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_positions": [_vp, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp],
     "ctts_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp, _vp],
-    "ctts_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _u32, _vp, C.c_int, _vp, _vp],
-    "ctts_colstats": [_vp, _vp, C.c_int, C.c_int, _vp],
+    "ctts_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _u32, _vp, C.c_int, _vp, _vp, _vp],
+    "ctts_colstats": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],
     "ctts_bn_finalize": [_vp, C.c_int, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "ctts_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp],
-    "ctts_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp],
+    "ctts_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp, _vp],
     "ctts_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp,
                           _u32, C.c_int, _vp],
     "ctts_softmax_fwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_softmax_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_act_dropout_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_rowscale_dropout": [_vp, _vp, _i64, C.c_int, _vp, _f32, _vp, _u32, _vp],
-    "ctts_colsum": [_vp, _vp, _i64, C.c_int, _i64, _f32, C.c_int, _vp],
+    "ctts_colsum": [_vp, _vp, _i64, C.c_int, _i64, _f32, C.c_int, _vp, _vp],
     "ctts_reflect_pad": [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_stft_magnitude": [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _vp],
     "ctts_log_clamp_transpose": [_vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],
@@ -99,7 +99,7 @@ _SIGNATURES = {
     "ctts_var_loss_bwd": [_vp] * 2 + [C.c_int] + [_vp] * 12 + [C.c_int] * 3 + [_vp, C.c_int, _vp] + [_vp] * 4 + [_vp] * 5 + [_vp],
     "ctts_bin_loss_fwd": [_vp, _vp, _i64, _vp, _vp, _vp],
     "ctts_bin_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
-    "ctts_mel_l1_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp],
+    "ctts_mel_l1_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp],
     "ctts_mel_l1_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp],
     "ctts_adam_clip_step": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     "ctts_im2col_3x3s2": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
@@ -110,7 +110,8 @@ _SIGNATURES = {
     "ctts_softmax_rect_bwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version", "ctts_mha_supported", "ctts_relmha_workspace_floats",
-                                               "ctts_mel_spectrogram_workspace_bytes", "ctts_gemm_workspace_bytes"])
+                                               "ctts_mel_spectrogram_workspace_bytes", "ctts_gemm_workspace_bytes", "ctts_workspace_bytes",
+                                               "ctts_workspace_error_word"])
 ADAM_STATE_FLOATS = 3 + 2048          # CTTS_ADAM_STATE_FLOATS of include/ctts.h
 
 _lib = None
@@ -145,6 +146,10 @@ def load():
     lib.ctts_mel_spectrogram_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.ctts_gemm_workspace_bytes.restype = C.c_size_t
     lib.ctts_gemm_workspace_bytes.argtypes = []
+    lib.ctts_workspace_bytes.restype = C.c_size_t
+    lib.ctts_workspace_bytes.argtypes = []
+    lib.ctts_workspace_error_word.restype = C.c_void_p
+    lib.ctts_workspace_error_word.argtypes = [C.c_void_p]
     lib.ctts_relmha_workspace_floats.restype = C.c_size_t
     lib.ctts_relmha_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     _lib = lib

@@ -93,12 +93,19 @@ class TacotronSTFT(nn.Module):
         self.use_fft = filter_length == 1024 and n_mel_channels <= 96
         nz = np.nonzero(np.abs(mel).sum(0))[0]
         self._kmax = int(nz.max()) + 1 if len(nz) else 0       # bins above fmax carry no filter weight: not kept on chip
-        self._range = None           # deferred range check of the FFT path: (flag in pinned host memory, event of the last launch)
+        self._range = None           # range check of the FFT path: (flag in pinned host memory, event of the last launch)
+        # strict_range = True (default): the reference's contract - the assertion is raised by the SAME call that was handed the bad
+        # waveform (one event wait per call instead of the reference's two reductions + sync).  False: the training / bulk-extraction
+        # hot path - the flag is looked at without waiting at the next call, or on demand with check_range() (call it before using the
+        # last result).
+        self.strict_range = True
 
     # ---- the reference asserts min(y) >= -1 and max(y) <= 1 on the host before computing (stft.py:177-178): two reductions and a
     # device -> host synchronisation per call, which halves the throughput of a 50 us kernel.  Here the kernel raises a flag while it
-    # loads the samples - one word of pinned host memory, written only by an offending input - and the flag is looked at, without
-    # waiting, at the NEXT call, or on demand with check_range().  Same AssertionError, raised one call later at the latest.
+    # loads the samples - one word of pinned host memory, written only by an offending input.  By default (strict_range) the call waits
+    # for its own launch and raises like the reference; with strict_range = False the flag is looked at, without waiting, at the NEXT
+    # call, or on demand with check_range() - same AssertionError, raised one call later at the latest (a single or final
+    # call must not return a mel for NaN / out-of-range audio silently, so deferral is opt-in).
     def _range_state(self, dev):
         if self._range is None:
             self._range = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
@@ -141,6 +148,8 @@ class TacotronSTFT(nn.Module):
             mel, energy, _ = K.mel_spectrogram_fft(y.float().contiguous(), self._window, self._workspace(), self.n_fft, self.hop,
                                                    self.n_mel_channels, kmax=self._kmax, range_flag=host)
             ev.record()
+            if self.strict_range:
+                self._raise_if_out_of_range(wait=True)
             return mel, energy
         lo, hi = torch.aminmax(y.detach())              # DFT-as-GEMM path (other FFT sizes): one reduction + one sync for the two asserts
         assert lo >= -1 and hi <= 1

@@ -113,3 +113,111 @@ __device__ __forceinline__ float ctts_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ---------------------------------------------------------------- bit-reproducible cross-workgroup reductions (round 4)
+// No floating-point atomics anywhere on the gradient path: the order in which workgroups reach an atomicAdd changes from run to run, so
+// two runs of the same train step from the same seed differed in the 7th digit and drifted apart (Adam amplifies: profiles/
+// r04_diag_determinism_*_before.txt).  Instead every workgroup WRITES its partial into the caller's workspace and takes a ticket; the
+// workgroup that draws the last ticket of its group sums the partials in INDEX order (never in arrival order) - two levels (groups of G
+// partials, then the group sums) so that the serial part stays ~2 x G loads deep.  The partials travel by agent-scope relaxed atomic
+// stores / loads (sc1: coherent across the 8 XCD L2s without a cache-wide write-back), the ticket is an agent-scope fetch-add after
+// `s_waitcnt vmcnt(0)` + barrier - the hand-off of gemm_sk.hip.  Tickets return to zero: the workspace is zero-filled once, by the caller.
+//
+// Workspace layout (bytes from the base; include/ctts.h ctts_workspace_bytes()): launches that share a workspace must be stream-ordered.
+constexpr size_t CTTS_WS_SK_FLAGS = 0;                              // stream-K flags + error word (gemm_sk.hip): 4096 words
+constexpr size_t CTTS_WS_GEMM_TICKETS = 16384;                      // split-K tickets, one per (batch, tile): 65536 words
+constexpr int    CTTS_WS_GEMM_TICKET_WORDS = 65536;
+constexpr size_t CTTS_WS_RED_T1 = CTTS_WS_GEMM_TICKETS + 4 * (size_t)CTTS_WS_GEMM_TICKET_WORDS;       // level-1 tickets [1024 column blocks][64 groups]
+constexpr size_t CTTS_WS_RED_T2 = CTTS_WS_RED_T1 + 4 * 65536;       // level-2 tickets [1024]
+constexpr size_t CTTS_WS_RED_P1 = CTTS_WS_RED_T2 + 4 * 1024;        // level-1 partials: 4 MiB
+constexpr size_t CTTS_WS_RED_P1_BYTES = 4u << 20;
+constexpr size_t CTTS_WS_RED_P2 = CTTS_WS_RED_P1 + CTTS_WS_RED_P1_BYTES;   // group sums: 1 MiB
+constexpr size_t CTTS_WS_RED_P2_BYTES = 1u << 20;
+constexpr size_t CTTS_WS_SLABS = CTTS_WS_RED_P2 + CTTS_WS_RED_P2_BYTES;    // GEMM slabs (stream-K hand-off, split-K partial tiles)
+constexpr size_t CTTS_WS_SLAB_FLOATS = (size_t)32 << 20;            // 128 MiB
+constexpr size_t CTTS_WS_BYTES = CTTS_WS_SLABS + 4 * CTTS_WS_SLAB_FLOATS;
+constexpr int CTTS_RED_MAX_COLBLOCKS = 1024, CTTS_RED_MAX_GROUPS = 64;
+
+template <typename T> __device__ __forceinline__ void ctts_st_agent(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ T ctts_ld_agent(const T* p) {
+  return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// All threads of the workgroup call this after their partial stores (agent-scope / write-through).  True in the workgroup that draws
+// ticket count-1 (it resets the ticket); that workgroup may then read every partial published before the others' tickets.
+__device__ __forceinline__ bool ctts_arrive_last(unsigned* ticket, unsigned count) {
+  __shared__ unsigned s_ctts_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t == count - 1;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ctts_last = last ? 1u : 0u;
+  }
+  __syncthreads();
+  const bool last = s_ctts_last != 0u;
+  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return last;
+}
+
+// Host side: groups of the two-level scheme for n partials (G = 16 up to 1024 partials)
+static inline int ctts_red_group(int n) { int g = 16; while ((n + g - 1) / g > CTTS_RED_MAX_GROUPS) g *= 2; return g; }
+
+// Ordered sum over the `nstripes` workgroups (blockIdx.y) of one 64-column block (blockIdx.x = cb) of 256 threads: thread l < 64 brings NV
+// values v[k] (its column's partial); returns true in exactly one workgroup per column block, where threads l < 64 then hold the totals.
+// Summation order: members of a group ty, ty+4, ... (ty = 0..3) in index order, the four ty-sums left to right, the groups likewise.
+template <typename T, int NV>
+__device__ __forceinline__ bool ctts_ordered_colsum(T (&v)[NV], unsigned char* ws, int cb, int stripe, int nstripes, int G) {
+  if (nstripes <= 1) return true;
+  __shared__ T s_ctts_red[4][NV * 64];
+  const int l = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  T* p1 = reinterpret_cast<T*>(ws + CTTS_WS_RED_P1);
+  T* p2 = reinterpret_cast<T*>(ws + CTTS_WS_RED_P2);
+  unsigned* t1 = reinterpret_cast<unsigned*>(ws + CTTS_WS_RED_T1);
+  unsigned* t2 = reinterpret_cast<unsigned*>(ws + CTTS_WS_RED_T2);
+  const int ngroups = (nstripes + G - 1) / G, g = stripe / G;
+  const int g0 = g * G, gn = min(G, nstripes - g0);
+  if (ty == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) ctts_st_agent(p1 + ((long)(cb * nstripes + stripe) * NV + k) * 64 + l, v[k]);
+  }
+  if (!ctts_arrive_last(t1 + cb * CTTS_RED_MAX_GROUPS + g, (unsigned)gn)) return false;
+  auto gather = [&](const T* base, int first, int n) {      // base[(first + i) * NV * 64 + k * 64 + l], i < n
+    T a[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) a[k] = (T)0;
+    for (int i0 = ty; i0 < n; i0 += 16) {            // four members in flight per thread (the loads are independent), added in index order
+      T x[4][NV];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 4 * u;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) x[u][k] = i < n ? ctts_ld_agent(base + ((long)(first + i) * NV + k) * 64 + l) : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) a[k] += x[u][k];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s_ctts_red[ty][k * 64 + l] = a[k];
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] = ((s_ctts_red[0][k * 64 + l] + s_ctts_red[1][k * 64 + l]) + s_ctts_red[2][k * 64 + l]) + s_ctts_red[3][k * 64 + l];
+    }
+    __syncthreads();
+  };
+  gather(p1 + (long)cb * nstripes * NV * 64, g0, gn);
+  if (ngroups == 1) return true;
+  if (ty == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) ctts_st_agent(p2 + ((long)(cb * ngroups + g) * NV + k) * 64 + l, v[k]);
+  }
+  if (!ctts_arrive_last(t2 + cb, (unsigned)ngroups)) return false;
+  gather(p2 + (long)cb * ngroups * NV * 64, 0, ngroups);
+  return true;
+}

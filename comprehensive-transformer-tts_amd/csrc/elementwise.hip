@@ -75,10 +75,29 @@ __global__ void rowscale_dropout_kernel(const float* __restrict__ x, float* __re
   }
 }
 
+// Final write of an ordered column sum (the one workgroup ctts_ordered_colsum elects per column block): out[c] (+)= scale * total.  A folded
+// view (C = k * creal <= 64, one column block) first adds its k copies of a channel in index order through LDS.
+__device__ __forceinline__ void ctts_colsum_emit(float tot, float* s64, float* __restrict__ out, int c, int C, int creal, float scale,
+                                                 int accumulate) {
+  const int ty = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (C != creal) {                   // uniform
+    __syncthreads();
+    if (ty == 0) s64[l] = c < C ? tot : 0.f;
+    __syncthreads();
+    if (ty == 0 && l < creal) {
+      float a = 0.f;
+      for (int j = l; j < C; j += creal) a += s64[j];
+      out[l] = accumulate ? out[l] + scale * a : scale * a;
+    }
+    return;
+  }
+  if (ty == 0 && c < C) out[c] = accumulate ? out[c] + scale * tot : scale * tot;
+}
+
 // C = row width of the (possibly folded) view; a dense narrow matrix [R, creal] (creal < 64) is read as [R/k, k*creal] so that all
 // 64 lanes carry data; view column c accumulates into channel c % creal.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C,
-                                                      int creal, long ld, float scale) {
+                                                      int creal, long ld, float scale, unsigned char* ws, int G, int accumulate) {
   __shared__ float s[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
   const long stripe = (rows + gridDim.y - 1) / gridDim.y;
@@ -90,10 +109,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
   s[ty][threadIdx.x & 63] = a;
   __syncthreads();
-  if (ty == 0 && c < C) {
-    const int l = threadIdx.x;
-    atomicAdd(out + (c % creal), scale * (s[0][l] + s[1][l] + s[2][l] + s[3][l]));
-  }
+  float tot[1] = {0.f};
+  if (ty == 0) { const int l = threadIdx.x; tot[0] = s[0][l] + s[1][l] + s[2][l] + s[3][l]; }
+  if (!ctts_ordered_colsum<float, 1>(tot, ws, blockIdx.x, blockIdx.y, gridDim.y, G)) return;
+  ctts_colsum_emit(tot[0], s[0], out, c, C, creal, scale, accumulate);
 }
 
 // Backward of the GEMM epilogue y = rowscale * (R + drop(act(alpha * (acc + bias)))) in ONE pass over dY:
@@ -102,7 +121,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ rowscale,
                                                             const float* __restrict__ z, float* __restrict__ dz, float* __restrict__ gm,
                                                             float* __restrict__ dbias, long rows, int C, int act, float p_drop,
-                                                            const uint64_t* seed, uint32_t drop_offset, float bias_scale) {
+                                                            const uint64_t* seed, uint32_t drop_offset, float bias_scale,
+                                                            unsigned char* ws, int G, int accumulate) {
   __shared__ float s[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
   const long stripe = (rows + gridDim.y - 1) / gridDim.y;
@@ -127,10 +147,10 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restri
   if (!dbias) return;
   s[ty][threadIdx.x & 63] = a;
   __syncthreads();
-  if (ty == 0 && c < C) {
-    const int l = threadIdx.x;
-    atomicAdd(dbias + c, bias_scale * (s[0][l] + s[1][l] + s[2][l] + s[3][l]));
-  }
+  float tot[1] = {0.f};
+  if (ty == 0) { const int l = threadIdx.x; tot[0] = s[0][l] + s[1][l] + s[2][l] + s[3][l]; }
+  if (!ctts_ordered_colsum<float, 1>(tot, ws, blockIdx.x, blockIdx.y, gridDim.y, G)) return;
+  ctts_colsum_emit(tot[0], s[0], dbias, c, C, C, bias_scale, accumulate);
 }
 
 // w[Cout][Cin][K] <-> GEMM-friendly layouts
@@ -234,7 +254,8 @@ extern "C" int ctts_rowscale_dropout(const float* x, float* y, int64_t rows, int
 namespace {
 // out[c] (+)= scale * sum_r w[r] * x[r,c]: weight gradient of a one-output Linear (N = 1 heads of the duration / energy predictors)
 __global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               float* __restrict__ out, long rows, int C, float scale) {
+                                                               float* __restrict__ out, long rows, int C, float scale,
+                                                               unsigned char* ws, int G, int accumulate) {
   __shared__ float s[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
   const long stripe = (rows + gridDim.y - 1) / gridDim.y;
@@ -246,56 +267,71 @@ __global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __res
   }
   s[ty][threadIdx.x & 63] = a;
   __syncthreads();
-  if (ty == 0 && c < C) {
-    const int l = threadIdx.x;
-    atomicAdd(out + c, scale * (s[0][l] + s[1][l] + s[2][l] + s[3][l]));
-  }
+  float tot[1] = {0.f};
+  if (ty == 0) { const int l = threadIdx.x; tot[0] = s[0][l] + s[1][l] + s[2][l] + s[3][l]; }
+  if (!ctts_ordered_colsum<float, 1>(tot, ws, blockIdx.x, blockIdx.y, gridDim.y, G)) return;
+  ctts_colsum_emit(tot[0], s[0], out, c, C, C, scale, accumulate);
 }
 }  // namespace
 
+// stripes (blockIdx.y) of a column-sum launch with gx column blocks: the workspace holds one 64-float partial per workgroup
+static int colsum_stripes(int gx, long want, bool have_ws) {
+  if (!have_ws) return 1;
+  const long cap = (long)(CTTS_WS_RED_P1_BYTES / (64 * sizeof(float))) / gx;
+  return (int)max((long)1, min(want, min(cap, (long)CTTS_RED_MAX_GROUPS * 64)));
+}
+
 extern "C" int ctts_weighted_colsum(const float* x, const float* w, float* out, int64_t rows, int C, float scale, int accumulate,
-                                    void* stream) {
-  CTTS_REQUIRE(x && w && out && C > 0, "ctts_weighted_colsum: bad arguments");
+                                    void* ws, void* stream) {
+  CTTS_REQUIRE(x && w && out && C > 0 && (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS, "ctts_weighted_colsum: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate && ctts_zero_async(out, sizeof(float) * C, st) != 0) { ctts_set_error("ctts_weighted_colsum: memset failed"); return -2; }
-  if (rows == 0) return 0;
+  if (rows == 0) {
+    if (!accumulate && ctts_zero_async(out, sizeof(float) * C, st) != 0) { ctts_set_error("ctts_weighted_colsum: zero fill failed"); return -2; }
+    return 0;
+  }
   const int gx = (C + 63) / 64;
-  const int gy = (int)max((long)1, min((long)max(1, 1024 / gx), (long)rows / 64));
-  hipLaunchKernelGGL(weighted_colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, w, out, (long)rows, C, scale);
+  const int gy = colsum_stripes(gx, min((long)max(1, 1024 / gx), (long)rows / 64), ws != nullptr);
+  hipLaunchKernelGGL(weighted_colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, w, out, (long)rows, C, scale, (unsigned char*)ws,
+                     ctts_red_group(gy), accumulate);
   CTTS_CHECK_LAUNCH("ctts_weighted_colsum");
   return 0;
 }
 
-extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* stream) {
-  CTTS_REQUIRE(x && out && C > 0, "ctts_colsum: bad arguments");
+extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* ws,
+                           void* stream) {
+  CTTS_REQUIRE(x && out && C > 0 && (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS, "ctts_colsum: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate && ctts_zero_async(out, sizeof(float) * C, st) != 0) { ctts_set_error("ctts_colsum: memset failed"); return -2; }
-  if (rows == 0) return 0;
+  if (rows == 0) {
+    if (!accumulate && ctts_zero_async(out, sizeof(float) * C, st) != 0) { ctts_set_error("ctts_colsum: zero fill failed"); return -2; }
+    return 0;
+  }
   int k = 1;                                   // fold narrow dense matrices so that a wave reads 64 useful floats per row
   if (ld == C)
     while (C * k * 2 <= 64 && rows % (k * 2) == 0) k *= 2;
   const int Cv = C * k, gx = (Cv + 63) / 64;
   const long Rv = rows / k;
-  const int gy = (int)max((long)1, min((long)max(1, 1024 / gx), Rv / 64));
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, out, Rv, Cv, C, (long)ld * k, scale);
+  const int gy = colsum_stripes(gx, min((long)max(1, 1024 / gx), Rv / 64), ws != nullptr);
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, out, Rv, Cv, C, (long)ld * k, scale, (unsigned char*)ws,
+                     ctts_red_group(gy), accumulate);
   CTTS_CHECK_LAUNCH("ctts_colsum");
   return 0;
 }
 
 extern "C" int ctts_epilogue_bwd(const float* dy, const float* rowscale, const float* z, float* dz, float* gm, float* dbias,
                                  int64_t rows, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, float bias_scale,
-                                 int accumulate_bias, void* stream) {
+                                 int accumulate_bias, void* ws, void* stream) {
   CTTS_REQUIRE(dy && dz && rows >= 0 && C > 0 && p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed), "ctts_epilogue_bwd: bad arguments");
+  CTTS_REQUIRE(!dbias || (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS, "ctts_epilogue_bwd: C too large for the bias-gradient reduction");
   hipStream_t st = (hipStream_t)stream;
-  if (dbias && !accumulate_bias && ctts_zero_async(dbias, sizeof(float) * C, st) != 0) {
-    ctts_set_error("ctts_epilogue_bwd: memset failed");
-    return -2;
+  if (rows == 0) {
+    if (dbias && !accumulate_bias && ctts_zero_async(dbias, sizeof(float) * C, st) != 0) { ctts_set_error("ctts_epilogue_bwd: zero fill failed"); return -2; }
+    return 0;
   }
-  if (rows == 0) return 0;
   const int gx = (C + 63) / 64;
-  const int gy = (int)max((long)1, min((long)max(1, 2048 / gx), (long)rows / 32));
+  const long want = min((long)max(1, 2048 / gx), (long)rows / 32);
+  const int gy = dbias ? colsum_stripes(gx, want, ws != nullptr) : (int)max((long)1, want);
   hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(gx, gy), dim3(256), 0, st, dy, rowscale, act ? z : nullptr, dz, gm, dbias, (long)rows, C, act,
-                     p_drop, seed, drop_offset, bias_scale);
+                     p_drop, seed, drop_offset, bias_scale, (unsigned char*)ws, ctts_red_group(gy), accumulate_bias);
   CTTS_CHECK_LAUNCH("ctts_epilogue_bwd");
   return 0;
 }

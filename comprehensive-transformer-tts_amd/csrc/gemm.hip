@@ -424,12 +424,13 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
       return;
     }
   }
-  int k_begin = 0, k_end = Kv;
+  int k_begin = 0, k_end = Kv, n_split_active = 1;
   if (d.split_k > 1) {
     int chunk = ((Kv + d.split_k - 1) / d.split_k + BK - 1) / BK * BK;
     k_begin = split * chunk;
     k_end = min(Kv, k_begin + chunk);
     if (k_begin >= k_end) return;
+    n_split_active = (Kv + chunk - 1) / chunk;           // splits with a non-empty K range: the tile's ticket count
   }
 
   const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
@@ -520,6 +521,10 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
     act_cur = act_next;
   }
 
+  if (d.split_k > 1) {       // ordered split-K sum through the workspace (gemm_common.h): no atomics
+    const int tile_lin = (z * ((d.M + BM - 1) / BM) + row0 / BM) * tiles_n + col0 / BN;
+    return gemm_splitk_finish<MT, NT, 256>(d, acc, Cb, tile_lin, split, n_split_active, threadIdx.x, true, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+  }
   gemm_epilogue_auto<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
@@ -601,12 +606,13 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
       return;
     }
   }
-  int k_begin = 0, k_end = Kv;
+  int k_begin = 0, k_end = Kv, n_split_active = 1;
   if (d.split_k > 1) {
     int chunk = ((Kv + d.split_k - 1) / d.split_k + BK - 1) / BK * BK;
     k_begin = split * chunk;
     k_end = min(Kv, k_begin + chunk);
     if (k_begin >= k_end) return;
+    n_split_active = (Kv + chunk - 1) / chunk;           // splits with a non-empty K range: the tile's ticket count
   }
   const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
   const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
@@ -688,6 +694,10 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
     __syncthreads();
     act_cur = act_next;
   }
+  if (d.split_k > 1) {       // ordered split-K sum through the workspace (gemm_common.h): no atomics
+    const int tile_lin = (z * ((d.M + BM - 1) / BM) + row0 / BM) * tiles_n + col0 / BN;
+    return gemm_splitk_finish<MT, NT, 256>(d, acc, Cb, tile_lin, split, n_split_active, threadIdx.x, true, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+  }
   gemm_epilogue_auto<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
@@ -726,12 +736,13 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_k2_kernel(const
       return;
     }
   }
-  int k_begin = 0, k_end = Kv;
+  int k_begin = 0, k_end = Kv, n_split_active = 1;
   if (d.split_k > 1) {
     int chunk = ((Kv + d.split_k - 1) / d.split_k + 2 * BK - 1) / (2 * BK) * (2 * BK);
     k_begin = split * chunk;
     k_end = min(Kv, k_begin + chunk);
     if (k_begin >= k_end) return;
+    n_split_active = (Kv + chunk - 1) / chunk;
   }
   const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
   const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
@@ -790,8 +801,12 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_k2_kernel(const
   if (grp == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] += red[r * 64];
-    gemm_epilogue_auto<1, 1>(d, acc, Cb, z, row0, col0, 0, wn0, l31, h, Mv, Nv);
   }
+  if (d.split_k > 1) {       // ordered split-K sum through the workspace: waves 0,1 hold the tile, everybody takes part in the ticket
+    const int tile_lin = (z * ((d.M + BM - 1) / BM) + tm) * tiles_n + col0 / BN;
+    return gemm_splitk_finish<1, 1, 128>(d, acc, Cb, tile_lin, split, n_split_active, threadIdx.x, grp == 0, row0, col0, 0, wn0, l31, h, Mv, Nv);
+  }
+  if (grp == 0) gemm_epilogue_auto<1, 1>(d, acc, Cb, z, row0, col0, 0, wn0, l31, h, Mv, Nv);
 }
 
 template <bool A_KC, bool B_KC, bool CONV>
@@ -975,28 +990,57 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
 #else
   const bool buf_unaligned = !aligned && chunks_ok(d) && d.conv_T <= 0 && !(d.lens && (d.lim_m || d.lim_n || d.lim_k));
 #endif
-  if (!aligned && !(buf_unaligned && buf_ok(d))) return dispatch_layout<64, 64, false>(d, st);
+  // ---- which kernel family / tile takes the launch (decided first: the ordered split-K sum needs the tile shape)
+  enum { K_SCALAR64, K_BUF128, K_BUF_K2, K_BUF_NARROW, K_BUF64, K_VEC128, K_VEC64 } kind;
+  int BMs = 64, BNs = 64;
+  if (!aligned && !(buf_unaligned && buf_ok(d))) kind = K_SCALAR64;
 #ifndef CTTS_NO_BUF
-  if (buf_ok(d)) {
+  else if (buf_ok(d)) {
     // 64x64 tiles (64 VGPRs: 8 waves/SIMD) match the 128x128 kernel on every measured shape (109 / 119 / 108 / 107 TFLOP/s on FFN conv fwd,
     // 4096^3, conv dgrad, conv wgrad) and make padded-row skipping effective: 64-row granularity and many waves per CU instead of two
     // rounds of 128-row tiles (fs2 train step 33.3 -> 29.8 ms).  CTTS_FORCE_TILE=128 keeps the big-tile kernel reachable for A/B runs.
-    if (force_tile == 128) return dispatch_buf<128, 128>(d, st);
     // under-filled forward / data-gradient launches (A K-contiguous, unbatched): few 64 x 64 tiles - the phoneme-level layers (2,048
     // rows).  Routing by the step time (same box): tile limit 160 / 320 / 640 / 1024: fs2 23.36 / 23.27 / 23.17 / 23.24 ms from 23.48,
     // conformer 27.78 / 27.84 / 27.62 / 27.90 from 28.14; K >= 256 instead of 512: another -0.03 / -0.05 ms.
     static const int k2 = getenv("CTTS_K2_TILE") ? atoi(getenv("CTTS_K2_TILE")) : 640;          // largest 64 x 64 tile count routed here (0 = off)
     static const int k2_mink = getenv("CTTS_K2_MIN_K") ? atoi(getenv("CTTS_K2_MIN_K")) : 256;
-    static const int k2_tn = getenv("CTTS_K2_TN") ? atoi(getenv("CTTS_K2_TN")) : 1;              // the split-K weight gradients (TN) of those layers as well: conformer 27.82 -> 27.53 ms
-    if (k2 && (d.a_kc || (k2_tn && !d.b_kc)) && d.nb0 * d.nb1 == 1 && !d.lens && d.N >= 64 && d.M >= 256 && d.K >= k2_mink &&
-        (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * (d.split_k > 1 ? d.split_k : 1) <= k2)
-      return dispatch_buf_k2(d, st);
+    // the split-K weight gradients (TN) of those layers as well: conformer 27.82 -> 27.53 ms.  NOTE: the two-group kernel has no K-block
+    // skipping (row_lens / tile_map are ignored for TN launches) - correct because the rows of dZ beyond a sequence's length are exactly
+    // zero (every producer of a gradient masks or zero-fills its padded rows), it merely multiplies those zeros.
+    static const int k2_tn = getenv("CTTS_K2_TN") ? atoi(getenv("CTTS_K2_TN")) : 1;
     static const bool narrow = getenv("CTTS_NARROW_TILE") ? atoi(getenv("CTTS_NARROW_TILE")) != 0 : true;
-    if (narrow && d.N <= 32 && d.M >= 256 && d.conv_T <= 0 && !d.tile_map && !d.row_lens) return dispatch_buf_narrow(d, st);
-    return dispatch_buf<64, 64>(d, st);
+    if (force_tile == 128) { kind = K_BUF128; BMs = BNs = 128; }
+    else if (k2 && (d.a_kc || (k2_tn && !d.b_kc)) && d.nb0 * d.nb1 == 1 && !d.lens && d.N >= 64 && d.M >= 256 && d.K >= k2_mink &&
+             (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * (d.split_k > 1 ? d.split_k : 1) <= k2) { kind = K_BUF_K2; BMs = 32; }
+    else if (narrow && d.N <= 32 && d.M >= 256 && d.conv_T <= 0 && !d.tile_map && !d.row_lens) { kind = K_BUF_NARROW; BMs = 128; BNs = 32; }
+    else kind = K_BUF64;
   }
 #endif
   // weight-gradient (TN) reductions measured faster on 64x64 tiles (64 VGPRs: 8 waves/SIMD): 92.6 vs 84.6 TFLOP/s on the FFN conv wgrad
-  if (tiles128 >= 256 && d.N > 64 && (d.a_kc || d.b_kc)) return dispatch_layout<128, 128, true>(d, st);
-  return dispatch_layout<64, 64, true>(d, st);
+  else if (tiles128 >= 256 && d.N > 64 && (d.a_kc || d.b_kc)) { kind = K_VEC128; BMs = BNs = 128; }
+  else kind = K_VEC64;
+
+  if (d.split_k > 1) {
+    // Ordered split-K (gemm_common.h gemm_splitk_finish): one ticket per (batch, tile), one slab per (batch, tile, split) in the caller's
+    // workspace.  split_k is an upper bound: it is lowered until the slabs fit (never below 2 - "C += alpha A B" is what split_k > 1 means).
+    CTTS_REQUIRE(d.sk_ws && d.sk_ws_bytes >= (int64_t)CTTS_WS_BYTES,
+                 "ctts_gemm: split_k > 1 needs the workspace (ctts_gemm_workspace_bytes() bytes, zero-filled once) in sk_ws - partial sums "
+                 "are added in a fixed order through it, the library has no floating-point atomics");
+    const long ntile = (long)((d.M + BMs - 1) / BMs) * ((d.N + BNs - 1) / BNs) * d.nb0 * d.nb1;
+    CTTS_REQUIRE(ntile <= CTTS_WS_GEMM_TICKET_WORDS, "ctts_gemm: %ld output tiles exceed the split-K ticket area (%d)", ntile, CTTS_WS_GEMM_TICKET_WORDS);
+    const long cap = (long)CTTS_WS_SLAB_FLOATS / (ntile * BMs * BNs);
+    CTTS_REQUIRE(cap >= 2, "ctts_gemm: split-K output of %ld tiles does not fit the workspace slabs", ntile);
+    if (d.split_k > cap) d.split_k = (int)cap;
+  }
+  switch (kind) {
+    case K_SCALAR64: return dispatch_layout<64, 64, false>(d, st);
+#ifndef CTTS_NO_BUF
+    case K_BUF128: return dispatch_buf<128, 128>(d, st);
+    case K_BUF_K2: return dispatch_buf_k2(d, st);
+    case K_BUF_NARROW: return dispatch_buf_narrow(d, st);
+    case K_BUF64: return dispatch_buf<64, 64>(d, st);
+#endif
+    case K_VEC128: return dispatch_layout<128, 128, true>(d, st);
+    default: return dispatch_layout<64, 64, true>(d, st);
+  }
 }

@@ -11,19 +11,7 @@ template <int MT, int NT>
 __device__ __forceinline__ void gemm_epilogue(const ctts_gemm_desc& d, floatx16 (&acc)[MT][NT], float* Cb, int z, int row0, int col0,
                                               int wm0, int wn0, int l31, int h, int Mv, int Nv) {
   const float alpha = d.alpha;
-  if (d.split_k > 1) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int n = col0 + wn0 + j * 32 + l31;
-          if (m < Mv && n < Nv) atomicAdd(Cb + (long)m * d.ldc + n, alpha * acc[i][j][r]);
-        }
-    return;
-  }
+  // split_k > 1 never reaches an epilogue: the kernels finish such launches through gemm_splitk_finish (ordered, no atomics)
   const bool do_drop = d.p_drop > 0.f;
   uint32_t dkey = 0;
   float inv_keep = 1.f;
@@ -97,6 +85,7 @@ __device__ __forceinline__ void gemm_epilogue(const ctts_gemm_desc& d, floatx16 
 //   RS: the row scale (non-pad mask) exists.  AUX: the gathered operand of the direction exists - the residual R (forward) or the stored pre-activation Z (backward, ACT != 0).
 //   Forward with ACT != 0 stores the pre-activation to Z; without Z (inference) that store runs into an empty descriptor.
 constexpr unsigned GEMM_OOB = 0x80000000u;
+__device__ __host__ __forceinline__ bool gemm_fits32(const void* p, long M, long ld, long N);
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const void* p, long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -175,16 +164,17 @@ __device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, cons
   }
 }
 
-// C += alpha * acc with the same addressing (weight-gradient accumulation of the persistent kernel)
+// C += alpha * acc with the same addressing (weight-gradient accumulation of the persistent kernel; last step of an ordered split-K sum).
+// Cb / Mv / Nv: the batch base and limits of batched, length-limited launches.
 template <int MT, int NT>
-__device__ __forceinline__ void gemm_accumulate_lean(const ctts_gemm_desc& d, const floatx16 (&acc)[MT][NT], int row0, int col0, int wm0,
-                                                     int wn0, int l31, int h) {
-  const __amdgpu_buffer_rsrc_t rc = gemm_rsrc(d.C, ((long)(d.M - 1) * d.ldc + d.N) * 4);
+__device__ __forceinline__ void gemm_accumulate_lean(const ctts_gemm_desc& d, const floatx16 (&acc)[MT][NT], float* Cb, int row0, int col0,
+                                                     int wm0, int wn0, int l31, int h, int Mv, int Nv) {
+  const __amdgpu_buffer_rsrc_t rc = gemm_rsrc(Cb, ((long)(Mv - 1) * d.ldc + Nv) * 4);
   const unsigned c_row = (unsigned)(d.ldc * 4);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = col0 + wn0 + j * 32 + l31;
-    const unsigned c_lane = n < d.N ? (unsigned)(4 * h) * c_row + (unsigned)n * 4u : GEMM_OOB;
+    const unsigned c_lane = n < Nv ? (unsigned)(4 * h) * c_row + (unsigned)n * 4u : GEMM_OOB;
 #pragma unroll
     for (int ib = 0; ib < 2 * MT; ++ib) {
       const int i = ib >> 1, rb = (ib & 1) * 8;
@@ -204,24 +194,69 @@ __device__ __forceinline__ void gemm_accumulate_lean(const ctts_gemm_desc& d, co
   }
 }
 
-// split-K partial: C += alpha * acc by hardware fp32 atomics (buffer_atomic_add_f32, no return value), range-checked like the stores
-template <int MT, int NT>
-__device__ __forceinline__ void gemm_atomic_lean(const ctts_gemm_desc& d, const floatx16 (&acc)[MT][NT], float* Cb, int row0, int col0,
-                                                 int wm0, int wn0, int l31, int h, int Mv, int Nv) {
-  const __amdgpu_buffer_rsrc_t rc = gemm_rsrc(Cb, ((long)(Mv - 1) * d.ldc + Nv) * 4);
-  const unsigned c_row = (unsigned)(d.ldc * 4);
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = col0 + wn0 + j * 32 + l31;
-    const unsigned c_lane = n < Nv ? (unsigned)(4 * h) * c_row + (unsigned)n * 4u : GEMM_OOB;
+// ---- split-K without atomics (round 4).  grid.y = split_k workgroups reduce disjoint K ranges of one output tile.  Each stores its
+// partial tile into the workspace slab (tile, split) with write-through stores and takes the tile's ticket; the workgroup that draws
+// the last ticket adds the slabs IN SPLIT ORDER (its own included, read back: the order never depends on who came last) and adds
+// alpha * sum into C with plain loads / stores - it is the only writer of that tile.  Bit-reproducible from run to run, which
+// buffer_atomic_add_f32 in arrival order was not (profiles/r04_diag_determinism_*_before.txt).
+//   tile_lin: linear tile index over (batch, m-tile, n-tile); nactive: splits with a non-empty K range (all others returned before);
+//   NTH threads of the workgroup hold accumulators (`active` for those; everybody calls: the ticket has barriers).
+typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
+template <int MT, int NT, int NTH>
+__device__ __forceinline__ void gemm_splitk_finish(const ctts_gemm_desc& d, floatx16 (&acc)[MT][NT], float* Cb, int tile_lin, int split,
+                                                   int nactive, int tid, bool active, int row0, int col0, int wm0, int wn0, int l31, int h,
+                                                   int Mv, int Nv) {
+  unsigned char* ws = reinterpret_cast<unsigned char*>(d.sk_ws);
+  constexpr unsigned SLAB_BYTES = MT * NT * 16 * NTH * 4;
+  const __amdgpu_buffer_rsrc_t rs = gemm_rsrc(ws + CTTS_WS_SLABS, (long)(CTTS_WS_SLAB_FLOATS * 4));
+  const unsigned tile_base = (unsigned)tile_lin * (unsigned)d.split_k * SLAB_BYTES + (unsigned)tid * 16u;
+  if (active) {
+    const unsigned base = tile_base + (unsigned)split * SLAB_BYTES;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int mu = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2);
-        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(d.alpha * acc[i][j][r], rc, c_lane + (unsigned)mu * c_row, 0, 0);
-      }
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          gemm_u32x4 v;
+          v.x = __float_as_uint(acc[i][j][4 * q + 0]); v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+          v.z = __float_as_uint(acc[i][j][4 * q + 2]); v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + (unsigned)(((i * NT + j) * 4 + q) * NTH * 16), 0, 16);      // aux 16 = sc1
+        }
   }
+  unsigned* tickets = reinterpret_cast<unsigned*>(ws + CTTS_WS_GEMM_TICKETS);
+  if (!ctts_arrive_last(tickets + tile_lin, (unsigned)nactive)) return;
+  if (!active) return;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int s = 0; s < nactive; ++s) {
+    const unsigned base = tile_base + (unsigned)s * SLAB_BYTES;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const gemm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)(((i * NT + j) * 4 + q) * NTH * 16), 0, 16);
+          acc[i][j][4 * q + 0] += __uint_as_float(v.x); acc[i][j][4 * q + 1] += __uint_as_float(v.y);
+          acc[i][j][4 * q + 2] += __uint_as_float(v.z); acc[i][j][4 * q + 3] += __uint_as_float(v.w);
+        }
+  }
+  if (gemm_fits32(Cb, Mv, d.ldc, Nv)) return gemm_accumulate_lean<MT, NT>(d, acc, Cb, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int n = col0 + wn0 + j * 32 + l31;
+        if (m < Mv && n < Nv) Cb[(long)m * d.ldc + n] += d.alpha * acc[i][j][r];
+      }
 }
 
 // fused softmax backward of the attention launches: C = E * (alpha * acc - rowsub[row]), E laid out like C
@@ -268,16 +303,14 @@ __device__ __host__ __forceinline__ bool gemm_fits32(const void* p, long M, long
 }
 
 // The epilogue of an unbatched tile: the lean variant of the combinations the train steps launch (tools/profile_gemm_shapes.py prints the
-// signature of every launch) - including the split-K atomics of the weight gradients, the softmax-backward fusion and the plain
+// signature of every launch) - including the softmax-backward fusion and the plain
 // batched / length-limited attention products - and the generic one for everything else (tanh, mixed combinations, 64-bit extents).
 template <int MT, int NT>
 __device__ __forceinline__ void gemm_epilogue_auto(const ctts_gemm_desc& d, floatx16 (&acc)[MT][NT], float* Cb, int z, int row0, int col0,
                                                    int wm0, int wn0, int l31, int h, int Mv, int Nv) {
   const bool flat = d.nb0 * d.nb1 == 1 && Mv == d.M && Nv == d.N;      // the gathered operands (R, Z, rowscale) are not batched
   const bool c_ok = gemm_fits32(Cb, Mv, d.ldc, Nv);
-  if (d.split_k > 1) {
-    if (c_ok) return gemm_atomic_lean<MT, NT>(d, acc, Cb, row0, col0, wm0, wn0, l31, h, Mv, Nv);
-  } else if (d.E) {
+  if (d.E) {
     if (c_ok) return gemm_softmax_bwd_lean<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
   } else if (c_ok && (flat ? gemm_fits32(d.Z, d.M, d.ldz, d.N) && gemm_fits32(d.R, d.M, d.ldr, d.N) : !d.Z && !d.R && !d.rowscale)) {
 #define CTTS_LEAN(ACT, DROP, BWD, AUX, RS) \

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : ((MT * NT >= 2 || STAGES >
   const sk_i32x4 rb_src = sk_make_rsrc(d.B - (CONV_B ? (long)d.conv_pad * d.ldb : 0));
   const unsigned smem_addr = (unsigned)reinterpret_cast<uintptr_t>(smem);      // low word of the flat address = LDS byte address
   unsigned* flags = p.ws;
-  float* slabs = reinterpret_cast<float*>(p.ws + SK_FLAG_WORDS);
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.ws) + CTTS_WS_SLABS);      // shared slab area of the workspace (ctts_common.h)
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, 0, 0x7FFFFFFE, 0x00020000);
   const int T = d.conv_T > 0 ? d.conv_T : 1;
   const float rcpT = 1.0f / (float)T;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : ((MT * NT >= 2 || STAGES >
         }
       }
       if (p.accumulate) {
-        gemm_accumulate_lean<MT, NT>(d, acc, row0, col0, wm0, wn0, l31, h);
+        gemm_accumulate_lean<MT, NT>(d, acc, d.C, row0, col0, wm0, wn0, l31, h, d.M, d.N);
       } else if (!(p.debug & 4)) {
         gemm_epilogue_auto<MT, NT>(d, acc, d.C, 0, row0, col0, wm0, wn0, l31, h, d.M, d.N);
       }
@@ -463,7 +463,15 @@ int sk_env(const char* name, int dflt) {
 
 }  // namespace
 
-extern "C" size_t ctts_gemm_workspace_bytes(void) { return (size_t)SK_FLAG_WORDS * 4 + (size_t)SK_SLAB_FLOATS_MAX * 4; }
+// One workspace per stream for everything that hands partial results between workgroups (layout: ctts_common.h): stream-K flags + slabs,
+// split-K tickets + slabs, tickets + partials of the ordered column reductions.
+extern "C" size_t ctts_gemm_workspace_bytes(void) { return CTTS_WS_BYTES; }
+extern "C" size_t ctts_workspace_bytes(void) { return CTTS_WS_BYTES; }
+extern "C" const uint32_t* ctts_workspace_error_word(const void* ws) {
+  return ws ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(ws) + CTTS_WS_SK_FLAGS) + SK_MAX_WG : nullptr;
+}
+static_assert((size_t)SK_FLAG_WORDS * 4 <= CTTS_WS_GEMM_TICKETS, "stream-K flag words overlap the split-K tickets");
+static_assert((size_t)SK_SLAB_FLOATS_MAX <= CTTS_WS_SLAB_FLOATS, "stream-K slabs exceed the workspace slab area");
 
 // launch == false: only answer whether the persistent kernel WOULD take this descriptor (ctts_gemm_takes_persistent)
 static int sk_try(const ctts_gemm_desc& din, hipStream_t st, bool launch) {

@@ -173,8 +173,7 @@ extern "C" int ctts_positions(const void* src, int src_is_float, int64_t stride,
 }
 
 // ---------------------------------------------------------------- embedding lookup (blocks.py:10-15 Embedding, modules.py:779-788,
-// 947,958 pitch / energy embeddings): forward gather; backward without a sort: one wave per (vocabulary row, 64-id chunk) ballots the
-// chunk for its row, sums the selected gradient rows in registers and issues one atomicAdd per channel (most waves exit at once).
+// 947,958 pitch / energy embeddings): forward gather; backward without a sort and without atomics (below).
 namespace {
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __restrict__ ids, const float4* __restrict__ w,
                                                              float4* __restrict__ out, int C4, int V, long total) {
@@ -186,34 +185,45 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __r
   }
 }
 
+// One workgroup of EMB_WAVES waves per vocabulary row v: wave w scans the 64-id chunks w, w + EMB_WAVES, ... in order, ballots each chunk
+// for its row and sums the selected gradient rows in registers; the waves' sums are then added through LDS in wave order.  The order of
+// every addition is fixed by (v, chunk, position), not by timing: the result is bit-reproducible (round 3 issued one float atomic
+// per (row, chunk, channel)).  A popular row (the unvoiced pitch bin, ~30 % of all frames) is spread over the 16 waves.
+constexpr int EMB_WAVES = 16;
 template <int NC>   // floats per lane: C <= 64 * NC
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dy,
-                                                             float* __restrict__ dw, long n, int C, int V, int padding_idx) {
-  // wave = (vocabulary row v, 64-id chunk): a popular row (e.g. the unvoiced pitch bin, ~30 % of all frames) is spread over n/64 waves
-  const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= V || v == padding_idx) return;
-  const long base = (long)blockIdx.y * 64;
-  const long p = base + lane;
-  unsigned long long m = __ballot(p < n && ids[p] == (long long)v);
-  if (!m) return;
+__global__ __launch_bounds__(64 * EMB_WAVES) void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dy,
+                                                                        float* __restrict__ dw, long n, int C, int V, int padding_idx,
+                                                                        int accumulate) {
+  __shared__ float s_acc[EMB_WAVES][NC * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int v = blockIdx.x;
+  if (v == padding_idx) return;                   // its gradient row stays as it is (zero-filled by the launcher unless accumulating)
   float acc[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) acc[i] = 0.f;
-  while (m) {
-    const int b = __builtin_ctzll(m);
-    m &= m - 1;
-    const float* row = dy + (base + b) * C;
+  for (long base = (long)wave * 64; base < n; base += 64 * EMB_WAVES) {
+    const long p = base + lane;
+    unsigned long long m = __ballot(p < n && ids[p] == (long long)v);
+    while (m) {
+      const int b = __builtin_ctzll(m);
+      m &= m - 1;
+      const float* row = dy + (base + b) * C;
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int c = lane + 64 * i;
-      if (c < C) acc[i] += row[c];
+      for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) acc[i] += row[c];
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = lane + 64 * i;
-    if (c < C) atomicAdd(dw + (long)v * C + c, acc[i]);
+  for (int i = 0; i < NC; ++i) s_acc[wave][i * 64 + lane] = acc[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 64 * EMB_WAVES) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < EMB_WAVES; ++w) a += s_acc[w][c];
+    float* o = dw + (long)v * C + c;
+    *o = accumulate ? *o + a : a;
   }
 }
 }  // namespace
@@ -233,17 +243,21 @@ extern "C" int ctts_embedding_bwd(const int64_t* ids, const float* dy, float* dw
                                   int accumulate, void* stream) {
   CTTS_REQUIRE(ids && dy && dweight && n >= 0 && C > 0 && C <= 512 && V > 0, "ctts_embedding_bwd: bad arguments (C <= 512)");
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate && ctts_zero_async(dweight, sizeof(float) * (size_t)V * C, st) != 0) {
-    ctts_set_error("ctts_embedding_bwd: memset failed");
-    return -2;
+  // every non-padding row is WRITTEN by its workgroup; only the padding row (and everything when n == 0) needs the zero fill
+  if (!accumulate) {
+    const bool pad_row = padding_idx >= 0 && padding_idx < V;
+    if (n == 0) { if (ctts_zero_async(dweight, sizeof(float) * (size_t)V * C, st) != 0) { ctts_set_error("ctts_embedding_bwd: zero fill failed"); return -2; } }
+    else if (pad_row && ctts_zero_async(dweight + (size_t)padding_idx * C, sizeof(float) * (size_t)C, st) != 0) {
+      ctts_set_error("ctts_embedding_bwd: zero fill failed");
+      return -2;
+    }
   }
   if (n == 0) return 0;
-  CTTS_REQUIRE((n + 63) / 64 <= 65535, "ctts_embedding_bwd: more than 4 M ids per call");
-  const dim3 grid((V + 3) / 4, (unsigned)((n + 63) / 64)), block(256);
+  const dim3 grid(V), block(64 * EMB_WAVES);
   const long long* idp = (const long long*)ids;
-  if (C <= 64) hipLaunchKernelGGL((embedding_bwd_kernel<1>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx);
-  else if (C <= 256) hipLaunchKernelGGL((embedding_bwd_kernel<4>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx);
-  else hipLaunchKernelGGL((embedding_bwd_kernel<8>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx);
+  if (C <= 64) hipLaunchKernelGGL((embedding_bwd_kernel<1>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx, accumulate);
+  else if (C <= 256) hipLaunchKernelGGL((embedding_bwd_kernel<4>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx, accumulate);
+  else hipLaunchKernelGGL((embedding_bwd_kernel<8>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx, accumulate);
   CTTS_CHECK_LAUNCH("ctts_embedding_bwd");
   return 0;
 }

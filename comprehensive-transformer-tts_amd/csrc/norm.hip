@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                              float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int rows, int C, float p_drop,
                                                              const uint64_t* seed, uint32_t drop_offset,
-                                                             const float* __restrict__ rowscale, const float* __restrict__ dres) {
+                                                             const float* __restrict__ rowscale, const float* __restrict__ dres,
+                                                             unsigned char* ws, int G, int accumulate) {
   __shared__ float s_red[2][4][V * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
     }
   }
-  // block reduce of the per-wave dgamma/dbeta partials, then one atomic per channel per block
+  // block reduce of the per-wave dgamma / dbeta partials, then the ordered cross-workgroup sum (ctts_common.h): thread l < 64 carries
+  // channels k * 64 + l of dgamma (k < 4 V) and of dbeta (k >= 4 V)
 #pragma unroll
   for (int i = 0; i < V; ++i)
 #pragma unroll
@@ -157,14 +159,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       s_red[1][wave][(i * 64 + lane) * 4 + e] = ab[i][e];
     }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < V * 64 * 4; idx += 256) {
-    const int v = idx >> 2, e = idx & 3;  // v = i*64 + lane -> channel vector index = lane + 64*i
-    const int cvec = (v & 63) + 64 * (v >> 6);
-    if (cvec < nvec) {
-      const float sg = s_red[0][0][idx] + s_red[0][1][idx] + s_red[0][2][idx] + s_red[0][3][idx];
-      const float sb = s_red[1][0][idx] + s_red[1][1][idx] + s_red[1][2][idx] + s_red[1][3][idx];
-      atomicAdd(dgamma + cvec * 4 + e, sg);
-      atomicAdd(dbeta + cvec * 4 + e, sb);
+  float tot[8 * V];
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < 4 * V; ++k) {
+      const int idx = k * 64 + lane;
+      tot[k] = s_red[0][0][idx] + s_red[0][1][idx] + s_red[0][2][idx] + s_red[0][3][idx];
+      tot[4 * V + k] = s_red[1][0][idx] + s_red[1][1][idx] + s_red[1][2][idx] + s_red[1][3][idx];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8 * V; ++k) tot[k] = 0.f;
+  }
+  if (!ctts_ordered_colsum<float, 8 * V>(tot, ws, 0, blockIdx.x, gridDim.x, G)) return;
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < 4 * V; ++k) {
+      const int ch = k * 64 + lane;
+      if (ch < C) {
+        dgamma[ch] = accumulate ? dgamma[ch] + tot[k] : tot[k];
+        dbeta[ch] = accumulate ? dbeta[ch] + tot[4 * V + k] : tot[4 * V + k];
+      }
     }
   }
 }
@@ -176,7 +191,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          double* __restrict__ sums, int rows, int C, int creal, int act,
-                                                         float p_drop, const uint64_t* seed, uint32_t drop_offset) {
+                                                         float p_drop, const uint64_t* seed, uint32_t drop_offset,
+                                                         unsigned char* ws, int G) {
   // C is the row width of the (possibly folded) view: a narrow matrix [R, creal] with creal < 64 is read as [R/k, k*creal] so that
   // all 64 lanes of a wave carry data; column c of the view is channel c % creal.
   __shared__ float s1[4][64], s2[4][64];
@@ -206,13 +222,28 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   }
   s1[ty][threadIdx.x & 63] = a; s2[ty][threadIdx.x & 63] = b;
   __syncthreads();
-  if (ty == 0 && c < C) {
+  double tot[2] = {0.0, 0.0};
+  if (ty == 0) {
     const int l = threadIdx.x;
-    const double A = (double)s1[0][l] + s1[1][l] + s1[2][l] + s1[3][l];
-    const double Bv = (double)s2[0][l] + s2[1][l] + s2[2][l] + s2[3][l];
-    atomicAdd(sums + ch, A);
-    atomicAdd(sums + creal + ch, Bv);
+    tot[0] = (double)s1[0][l] + s1[1][l] + s1[2][l] + s1[3][l];
+    tot[1] = (double)s2[0][l] + s2[1][l] + s2[2][l] + s2[3][l];
   }
+  if (!ctts_ordered_colsum<double, 2>(tot, ws, blockIdx.x, blockIdx.y, gridDim.y, G)) return;
+  // the elected workgroup of this column block WRITES the sums (no zero fill, no atomics); a folded view (C = k * creal <= 64, one column
+  // block) first adds the k copies of a channel in index order
+  if (C != creal) {
+    __shared__ double sf[2][64];
+    if (ty == 0) { sf[0][threadIdx.x] = c < C ? tot[0] : 0.0; sf[1][threadIdx.x] = c < C ? tot[1] : 0.0; }
+    __syncthreads();
+    if (ty == 0 && threadIdx.x < creal) {
+      double a = 0.0, b = 0.0;
+      for (int j = threadIdx.x; j < C; j += creal) { a += sf[0][j]; b += sf[1][j]; }
+      sums[threadIdx.x] = a;
+      sums[creal + threadIdx.x] = b;
+    }
+    return;
+  }
+  if (ty == 0 && c < C) { sums[c] = tot[0]; sums[creal + c] = tot[1]; }
 }
 
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -324,26 +355,34 @@ extern "C" int ctts_layernorm_fwd(const float* x, const float* gamma, const floa
 extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
                                   float p_drop, const uint64_t* seed, uint32_t drop_offset, const float* rowscale,
-                                  int accumulate, const float* dres, void* stream) {
+                                  int accumulate, const float* dres, void* ws, void* stream) {
   CTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "ctts_layernorm_bwd: null pointer");
   CTTS_REQUIRE((C % 4) == 0 && C <= 1024 && C > 0, "ctts_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate && (ctts_zero_async(dgamma, sizeof(float) * C, st) != 0 || ctts_zero_async(dbeta, sizeof(float) * C, st) != 0)) {
-    ctts_set_error("ctts_layernorm_bwd: memset failed");
-    return -2;
+  if (rows == 0) {
+    if (!accumulate && (ctts_zero_async(dgamma, sizeof(float) * C, st) != 0 || ctts_zero_async(dbeta, sizeof(float) * C, st) != 0)) {
+      ctts_set_error("ctts_layernorm_bwd: zero fill failed");
+      return -2;
+    }
+    return 0;
   }
-  if (rows == 0) return 0;
-  static const int ln_blocks = getenv("CTTS_LN_BWD_BLOCKS") ? atoi(getenv("CTTS_LN_BWD_BLOCKS")) : 256;     // tuning knob
+  static const int ln_blocks_env = getenv("CTTS_LN_BWD_BLOCKS") ? atoi(getenv("CTTS_LN_BWD_BLOCKS")) : 256;     // tuning knob
+  // the workspace keeps one partial (2 C floats) per workgroup (256 x 8 KB = 2 MiB of the 4 MiB partial area); without one: one workgroup
+  const int ln_blocks = ws ? max(1, min(ln_blocks_env, 512)) : 1;
   const int blocks = min((rows + 3) / 4, ln_blocks);
-  if (C <= 256)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<1, 4>), dim3(min((rows + 15) / 16, ln_blocks)), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx,
-                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres);
-  else if (C <= 512)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<2, 2>), dim3(min((rows + 7) / 8, ln_blocks)), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx,
-                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres);
-  else
+  unsigned char* w8 = (unsigned char*)ws;
+  if (C <= 256) {
+    const int nb = min((rows + 15) / 16, ln_blocks);
+    hipLaunchKernelGGL((layernorm_bwd_kernel<1, 4>), dim3(nb), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx,
+                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres, w8, ctts_red_group(nb), accumulate);
+  } else if (C <= 512) {
+    const int nb = min((rows + 7) / 8, ln_blocks);
+    hipLaunchKernelGGL((layernorm_bwd_kernel<2, 2>), dim3(nb), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx,
+                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres, w8, ctts_red_group(nb), accumulate);
+  } else {
     hipLaunchKernelGGL((layernorm_bwd_kernel<4, 1>), dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
-                       C, p_drop, seed, drop_offset, rowscale, dres);
+                       C, p_drop, seed, drop_offset, rowscale, dres, w8, ctts_red_group(blocks), accumulate);
+  }
   CTTS_CHECK_LAUNCH("ctts_layernorm_bwd");
   return 0;
 }
@@ -354,15 +393,20 @@ static int colreduce_fold(int rows, int C) {
   while (C * k * 2 <= 64 && rows % (k * 2) == 0) k *= 2;
   return k;
 }
-static int colreduce_grid_y(int rows, int gx) { return max(1, min(max(1, 1024 / gx), rows / 64)); }
+// stripes: the workspace holds one partial (2 x 64 doubles) per workgroup; without a workspace one stripe per column block
+static int colreduce_grid_y(int rows, int gx, bool have_ws) {
+  if (!have_ws) return 1;
+  const int cap = (int)(CTTS_WS_RED_P1_BYTES / (2 * 64 * sizeof(double))) / gx;
+  return max(1, min(min(max(1, 1024 / gx), rows / 64), min(cap, CTTS_RED_MAX_GROUPS * 64)));
+}
 
-extern "C" int ctts_colstats(const float* x, double* sums, int rows, int C, void* stream) {
-  CTTS_REQUIRE(x && sums && rows > 0 && C > 0, "ctts_colstats: bad arguments");
+extern "C" int ctts_colstats(const float* x, double* sums, int rows, int C, void* ws, void* stream) {
+  CTTS_REQUIRE(x && sums && rows > 0 && C > 0 && (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS, "ctts_colstats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (ctts_zero_async(sums, sizeof(double) * 2 * C, st) != 0) { ctts_set_error("ctts_colstats: memset failed"); return -2; }
   const int k = colreduce_fold(rows, C), Cv = C * k, Rv = rows / k, gx = (Cv + 63) / 64;
-  hipLaunchKernelGGL((colreduce_kernel<0>), dim3(gx, colreduce_grid_y(Rv, gx)), dim3(256), 0, st, x, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, sums, Rv, Cv, C, 0, 0.f, nullptr, 0u);
+  const int gy = colreduce_grid_y(Rv, gx, ws != nullptr);
+  hipLaunchKernelGGL((colreduce_kernel<0>), dim3(gx, gy), dim3(256), 0, st, x, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, sums, Rv, Cv, C, 0, 0.f, nullptr, 0u, (unsigned char*)ws, ctts_red_group(gy));
   CTTS_CHECK_LAUNCH("ctts_colstats");
   return 0;
 }
@@ -411,13 +455,14 @@ extern "C" int ctts_bn_apply(const float* x, const float* mean, const float* rst
 
 extern "C" int ctts_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                   const float* beta, double* sums, int rows, int C, int act, float p_drop,
-                                  const uint64_t* seed, uint32_t drop_offset, void* stream) {
-  CTTS_REQUIRE(dy && x && mean && rstd && gamma && beta && sums && rows > 0, "ctts_bn_bwd_reduce: bad arguments");
+                                  const uint64_t* seed, uint32_t drop_offset, void* ws, void* stream) {
+  CTTS_REQUIRE(dy && x && mean && rstd && gamma && beta && sums && rows > 0 && (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS,
+               "ctts_bn_bwd_reduce: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (ctts_zero_async(sums, sizeof(double) * 2 * C, st) != 0) { ctts_set_error("ctts_bn_bwd_reduce: memset failed"); return -2; }
   const int k = colreduce_fold(rows, C), Cv = C * k, Rv = rows / k, gx = (Cv + 63) / 64;
-  hipLaunchKernelGGL((colreduce_kernel<1>), dim3(gx, colreduce_grid_y(Rv, gx)), dim3(256), 0, st, x, dy, mean, rstd,
-                     gamma, beta, sums, Rv, Cv, C, act, p_drop, seed, drop_offset);
+  const int gy = colreduce_grid_y(Rv, gx, ws != nullptr);
+  hipLaunchKernelGGL((colreduce_kernel<1>), dim3(gx, gy), dim3(256), 0, st, x, dy, mean, rstd,
+                     gamma, beta, sums, Rv, Cv, C, act, p_drop, seed, drop_offset, (unsigned char*)ws, ctts_red_group(gy));
   CTTS_CHECK_LAUNCH("ctts_bn_bwd_reduce");
   return 0;
 }

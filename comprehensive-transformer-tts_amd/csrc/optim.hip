@@ -113,7 +113,8 @@ extern "C" int ctts_adam_clip_step(float* p, const float* g, float* m, float* v,
 namespace {
 __global__ __launch_bounds__(256) void mel_l1_fwd_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
                                                           const float* __restrict__ tgt, const unsigned char* __restrict__ pad,
-                                                          float* __restrict__ sums, float* __restrict__ roww, long rows, int C) {
+                                                          float* __restrict__ sums, float* __restrict__ roww, long rows, int C,
+                                                          unsigned char* ws, int G) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float a1 = 0.f, a2 = 0.f, aw = 0.f;
   for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
@@ -132,7 +133,14 @@ __global__ __launch_bounds__(256) void mel_l1_fwd_kernel(const float* __restrict
   __shared__ float s[3][4];
   if (lane == 0) { s[0][wave] = a1; s[1][wave] = a2; s[2][wave] = aw; }
   __syncthreads();
-  if (threadIdx.x < 3) atomicAdd(sums + threadIdx.x, s[threadIdx.x][0] + s[threadIdx.x][1] + s[threadIdx.x][2] + s[threadIdx.x][3]);
+  // ordered cross-workgroup sum (ctts_common.h): lane 0 carries the three partials; the elected workgroup WRITES sums[0..2]
+  float tot[3] = {0.f, 0.f, 0.f};
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tot[k] = s[k][0] + s[k][1] + s[k][2] + s[k][3];
+  }
+  if (!ctts_ordered_colsum<float, 3>(tot, ws, 0, blockIdx.x, gridDim.x, G)) return;
+  if (threadIdx.x == 0) { sums[0] = tot[0]; sums[1] = tot[1]; sums[2] = tot[2]; }
 }
 
 // d loss_k / d p_k = g_k * sign(p_k - t) * w[row] / (C * sum w)
@@ -151,12 +159,13 @@ __global__ void mel_l1_bwd_kernel(const float* __restrict__ p1, const float* __r
 }  // namespace
 
 extern "C" int ctts_mel_l1_fwd(const float* p1, const float* p2, const float* tgt, const uint8_t* pad, float* sums, float* roww,
-                               int64_t rows, int C, void* stream) {
+                               int64_t rows, int C, void* ws, void* stream) {
   CTTS_REQUIRE(p1 && p2 && tgt && pad && sums && roww && rows >= 0 && C > 0, "ctts_mel_l1_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (rows == 0) return 0;
-  const int blocks = (int)((rows + 3) / 4 > 1024 ? 1024 : (rows + 3) / 4);
-  hipLaunchKernelGGL(mel_l1_fwd_kernel, dim3(blocks), dim3(256), 0, st, p1, p2, tgt, pad, sums, roww, (long)rows, C);
+  if (rows == 0) return ctts_zero_async(sums, 3 * sizeof(float), st) == 0 ? 0 : -2;
+  const int blocks = !ws ? 1 : (int)((rows + 3) / 4 > 1024 ? 1024 : (rows + 3) / 4);       // sums[0..2] are WRITTEN (no zero fill needed)
+  hipLaunchKernelGGL(mel_l1_fwd_kernel, dim3(blocks), dim3(256), 0, st, p1, p2, tgt, pad, sums, roww, (long)rows, C,
+                     (unsigned char*)ws, ctts_red_group(blocks));
   CTTS_CHECK_LAUNCH("ctts_mel_l1_fwd");
   return 0;
 }

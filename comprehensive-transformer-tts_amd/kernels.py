@@ -70,18 +70,68 @@ class DropCtx:
 import os as _os
 
 SK_ENABLED = _os.environ.get("CTTS_SK", "1") != "0"      # persistent stream-K GEMM (csrc/gemm_sk.hip) for large unbatched launches
-_SK_WS = {}          # (device index, stream handle) -> zero-filled workspace of the persistent stream-K GEMM
+_SK_WS = {}          # (device index, stream handle) -> zero-filled workspace (include/ctts.h ctts_workspace_bytes)
 
 
 def gemm_workspace(device):
-    """Workspace of the persistent stream-K GEMM (include/ctts.h ctts_gemm_desc.sk_ws): one per (device, stream), because launches
-    that share it must be stream-ordered.  Zero-filled once; the kernel leaves every flag at zero when it finishes."""
+    """The per-stream workspace of the library (include/ctts.h: ctts_gemm_desc.sk_ws and every `ws` argument): stream-K flags and slabs,
+    split-K tickets and partial tiles, tickets and partials of the ordered column reductions.  One per (device, stream), because launches
+    that share it must be stream-ordered.  Zero-filled once; every kernel leaves its flag / ticket words at zero when it finishes."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     ws = _SK_WS.get(key)
     if ws is None:
-        ws = torch.zeros(_lib.load().ctts_gemm_workspace_bytes(), dtype=torch.uint8, device=device)
+        ws = torch.zeros(_lib.load().ctts_workspace_bytes(), dtype=torch.uint8, device=device)
         _SK_WS[key] = ws
     return ws
+
+
+workspace = gemm_workspace
+
+
+def _ws(t):
+    """device pointer of the current stream's workspace on t's device"""
+    return gemm_workspace(t.device).data_ptr()
+
+
+class WorkspaceErrorProbe:
+    """Host-side watch on the stream-K hand-off error word of every workspace in use (VERDICT r03 #2 / ADVICE r03: the owner of a cut
+    tile that gives up waiting writes that word and the launch's result is garbage - nobody but the tests used to read it).
+    `poll()` starts an asynchronous copy of the words into pinned memory (no sync: callable every step); `check()` waits for the last
+    copy and raises CttsError if any word is set (and re-zeroes that workspace, so a later launch does not trip over a stale flag)."""
+
+    def __init__(self):
+        self._pending = []          # (workspace, pinned host word, event)
+
+    def poll(self):
+        lib = _lib.load()
+        self._pending = []
+        for ws in list(_SK_WS.values()):
+            off = lib.ctts_workspace_error_word(C.c_void_p(ws.data_ptr())) - ws.data_ptr()
+            host = torch.empty(4, dtype=torch.uint8, pin_memory=True)
+            with torch.cuda.device(ws.device):
+                host.copy_(ws[off:off + 4], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            self._pending.append((ws, host, ev))
+
+    def check(self):
+        bad = []
+        for ws, host, ev in self._pending:
+            ev.synchronize()
+            word = int(host.view(torch.int32)[0])
+            if word != 0:
+                bad.append((ws, word))
+        self._pending = []
+        for ws, word in bad:
+            torch.cuda.synchronize(ws.device)
+            ws.zero_()
+        if bad:
+            raise _lib.CttsError("stream-K GEMM hand-off failed: an owner workgroup gave up waiting for workgroup "
+                                 f"{bad[0][1] - 1}'s partial tile - the results of that launch are invalid (workspace re-zeroed)")
+
+    def poll_and_check(self):
+        self.poll()
+        self.check()
 
 
 def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_off=0, c_off=0, nb0=1, nb1=1,
@@ -117,8 +167,9 @@ def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0
         d.tile_map = _p(tile_map)
     d.E, d.rowsub = _p(E), _p(rowsub)
     d.epi_bwd = int(bool(epi_bwd))
-    if (SK_ENABLED if use_sk is None else use_sk) and nb0 * nb1 == 1 and M * N * K >= (1 << 24):
-        # large unbatched GEMMs may run on the persistent stream-K kernel (the library decides: ctts_gemm_sk_try)
+    if int(split_k) > 1 or ((SK_ENABLED if use_sk is None else use_sk) and nb0 * nb1 == 1 and M * N * K >= (1 << 24)):
+        # split-K sums its pieces in a fixed order through the workspace (required); large unbatched GEMMs may run on the persistent
+        # stream-K kernel (the library decides: ctts_gemm_sk_try)
         ws = gemm_workspace(A.device)
         d.sk_ws, d.sk_ws_bytes = ws.data_ptr(), ws.numel()
     return d
@@ -237,7 +288,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, p_drop=0.0, seed=None, drop_offset=0
     lib = _lib.load()
     _lib.check(lib.ctts_layernorm_bwd(_p(_f32c(dy, "dy")), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
                                       _p(dbeta), rows, Cc, p_drop, _p(seed), drop_offset, _p(rowscale), int(acc_into is not None),
-                                      _p(dres), _stream()), "ctts_layernorm_bwd")
+                                      _p(dres), _ws(dy), _stream()), "ctts_layernorm_bwd")
     return dx, dgamma, dbeta
 
 
@@ -245,7 +296,7 @@ def colstats(x2d):
     rows, Cc = x2d.shape
     sums = torch.empty(2 * Cc, dtype=torch.float64, device=x2d.device)
     lib = _lib.load()
-    _lib.check(lib.ctts_colstats(_p(_f32c(x2d, "x")), _p(sums), rows, Cc, _stream()), "ctts_colstats")
+    _lib.check(lib.ctts_colstats(_p(_f32c(x2d, "x")), _p(sums), rows, Cc, _ws(x2d), _stream()), "ctts_colstats")
     return sums
 
 
@@ -283,7 +334,7 @@ def bn_bwd(dy, x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, bat
         dbeta = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
     lib = _lib.load()
     _lib.check(lib.ctts_bn_bwd_reduce(_p(_f32c(dy, "dy")), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), rows,
-                                      Cc, act, p_drop, _p(seed), drop_offset, _stream()), "ctts_bn_bwd_reduce")
+                                      Cc, act, p_drop, _p(seed), drop_offset, _ws(dy), _stream()), "ctts_bn_bwd_reduce")
     _lib.check(lib.ctts_bn_bwd_apply(_p(dy), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), _p(dx), _p(dgamma),
                                      _p(dbeta), rows, Cc, act, p_drop, _p(seed), drop_offset, int(batch_stats), _stream()),
                "ctts_bn_bwd_apply")
@@ -328,7 +379,7 @@ def colsum(x2d, ld=None, scale=1.0, acc_into=None):
     out = torch.empty(Cc, dtype=torch.float32, device=x2d.device) if acc_into is None else acc_into
     lib = _lib.load()
     _lib.check(lib.ctts_colsum(_p(x2d), _p(out), rows, Cc, ld if ld is not None else Cc, float(scale), int(acc_into is not None),
-                               _stream()), "ctts_colsum")
+                               _ws(x2d), _stream()), "ctts_colsum")
     return out
 
 
@@ -577,7 +628,7 @@ def epilogue_bwd(dy, rowscale=None, z=None, act=0, p_drop=0.0, seed=None, drop_o
     lib = _lib.load()
     _lib.check(lib.ctts_epilogue_bwd(_p(_f32c(dy, "dy")), _p(rowscale), _p(z if act else None), _p(dz), _p(gm), _p(dbias), rows, Cc,
                                      int(act), float(p_drop), _p(seed), int(drop_offset), float(bias_scale),
-                                     int(bias_acc_into is not None), _stream()), "ctts_epilogue_bwd")
+                                     int(bias_acc_into is not None), _ws(dy) if want_bias else None, _stream()), "ctts_epilogue_bwd")
     return dz, gm, dbias
 
 
@@ -678,7 +729,7 @@ def weighted_colsum(x2d, w, scale=1.0, acc_into=None):
     out = torch.empty(Cc, dtype=torch.float32, device=x2d.device) if acc_into is None else acc_into
     lib = _lib.load()
     _lib.check(lib.ctts_weighted_colsum(_p(_f32c(x2d, "x")), _p(_f32c(w, "w")), _p(out), rows, Cc, float(scale),
-                                        int(acc_into is not None), _stream()), "ctts_weighted_colsum")
+                                        int(acc_into is not None), _ws(x2d), _stream()), "ctts_weighted_colsum")
     return out
 
 
@@ -686,11 +737,11 @@ def mel_l1_fwd(p1, p2, tgt, pad_u8):
     """-> (sums [3] = {sum w|p1-t|, sum w|p2-t|, sum w}, roww [rows])"""
     Cc = tgt.shape[-1]
     rows = tgt.numel() // Cc
-    sums = torch.zeros(3, dtype=torch.float32, device=tgt.device)        # accumulated into by the kernel
+    sums = torch.empty(3, dtype=torch.float32, device=tgt.device)        # written by the workgroup that finishes the ordered sum
     roww = torch.empty(rows, dtype=torch.float32, device=tgt.device)
     lib = _lib.load()
     _lib.check(lib.ctts_mel_l1_fwd(_p(_f32c(p1, "p1")), _p(_f32c(p2, "p2")), _p(_f32c(tgt, "tgt")), _p(pad_u8), _p(sums), _p(roww), rows,
-                                   Cc, _stream()), "ctts_mel_l1_fwd")
+                                   Cc, _ws(tgt), _stream()), "ctts_mel_l1_fwd")
     return sums, roww
 
 

@@ -234,12 +234,21 @@ class EpiLink:
     def __init__(self):
         self.Z = self.seed = None
         self.act, self.p_drop, self.drop_offset = ACT_NONE, 0.0, 0
-        self.armed = False          # producer forward has run with this link
-        self.done = False           # consumer backward has delivered dZ instead of dY
+        self.armed = False          # producer forward has run with this link and no consumer has taken it yet
+        self.gen = 0                # every producer forward is a new generation: a link object reused across forwards (or re-armed before
+        self.done = set()           # backward) pairs each consumer backward with ITS producer; `done`: generations whose dZ was delivered
 
     def arm(self, Z, act, p_drop, seed, drop_offset):
         self.Z, self.act, self.p_drop, self.seed, self.drop_offset = Z, act, p_drop, seed, drop_offset
-        self.armed, self.done = True, False
+        self.gen += 1
+        self.armed = True
+        return self.gen
+
+    def take(self):
+        """consumer forward: snapshot of the producer's epilogue (the consumer's backward must not read the mutable link: ADVICE r03) -
+        one consumer per producer forward"""
+        self.armed = False
+        return (self.Z, self.act, self.p_drop, self.seed, self.drop_offset, self.gen)
 
 
 class _LinearConv(torch.autograd.Function):
@@ -275,13 +284,13 @@ class _LinearConv(torch.autograd.Function):
         ctx.save_for_backward(x, w, Z, rowscale, seed, row_lens, b)
         ctx.cfg = (act, alpha, p_drop, drop_offset, ksize, b is not None, residual is not None, row_T)
         ctx.pr = pr
-        ctx.link, ctx.link_role = None, 0
+        ctx.link, ctx.link_role, ctx.link_snap = None, 0, None
         if link is not None and _FUSE_EPILOGUE_BWD:
             if link_role == 1 and rowscale is None and residual is None and (act != ACT_NONE or p_drop > 0):
-                link.arm(Z, act, p_drop, seed, drop_offset)
+                ctx.link_gen = link.arm(Z, act, p_drop, seed, drop_offset)
                 ctx.link, ctx.link_role = link, 1
             elif link_role == 2 and link.armed and not ksize:
-                ctx.link, ctx.link_role = link, 2
+                ctx.link, ctx.link_role, ctx.link_snap = link, 2, link.take()
         return out
 
     @staticmethod
@@ -299,9 +308,9 @@ class _LinearConv(torch.autograd.Function):
         dX = dW = dB = None
         want_bias = has_bias and ctx.needs_input_grad[2]
         fuse_bias = want_bias and _fusable(b)
-        if ctx.link_role == 1 and ctx.link.done:
+        if ctx.link_role == 1 and ctx.link_gen in ctx.link.done:
             # the consumer's data-gradient GEMM already applied this layer's epilogue backward: dY IS dZ (EpiLink)
-            ctx.link.done = False
+            ctx.link.done.discard(ctx.link_gen)
             dZ, d_res = dY, None
             if want_bias:
                 if fuse_bias:
@@ -364,12 +373,12 @@ class _LinearConv(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[0]:
                 dX = torch.empty_like(x)
-                lk = ctx.link if ctx.link_role == 2 else None
-                if lk is not None:       # hand the producer its dZ: mask / (1-p) * act'(Z_producer) applied in this GEMM's epilogue
-                    K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha, epi_bwd=True, Z=lk.Z, ldz=Cin, act=lk.act,
-                           p_drop=lk.p_drop, seed=lk.seed, drop_offset=lk.drop_offset,
+                if ctx.link_role == 2:   # hand the producer its dZ: mask / (1-p) * act'(Z_producer) applied in this GEMM's epilogue
+                    lZ, lact, lp, lseed, loff, lgen = ctx.link_snap           # the producer's epilogue as it was at THIS forward
+                    K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha, epi_bwd=True, Z=lZ, ldz=Cin, act=lact,
+                           p_drop=lp, seed=lseed, drop_offset=loff,
                            tile_map=pr.tile_map(0, M) if pr is not None else None, **rl)
-                    lk.done = True
+                    ctx.link.done.add(lgen)
                 else:
                     K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha,
                            tile_map=pr.tile_map(0, M) if pr is not None else None, **rl)

@@ -51,6 +51,12 @@ class TrainStep:
         self.g_opt = None
         self.loss_val = None
         self.static_buffer = None
+        # the stream-K hand-off reports a failed wait into its workspace; watch that word (async copy every `probe_every` steps, checked
+        # one step later: no sync on the hot path) and at the end of capture - a failed launch must not go unnoticed
+        from . import kernels as _K
+        self.ws_probe = _K.WorkspaceErrorProbe()
+        self.probe_every = 100
+        self._calls = 0
 
     # ---- pieces
     def _forward_loss(self):
@@ -128,6 +134,7 @@ class TrainStep:
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=pool, stream=side, capture_error_mode="thread_local"):
                 self._optimizer_step()
+        self.ws_probe.poll_and_check()                    # the warm-up steps ran every kernel of the step once
 
     # ---- inputs as views of one packed device buffer (data.PackedBatch layout)
     def bind_static_buffer(self, buf):
@@ -137,7 +144,14 @@ class TrainStep:
         """refresh every model input with ONE device-to-device copy (same PackedBatch layout as the static buffer)"""
         self.static_buffer.copy_(device_buffer, non_blocking=True)
 
+    def check_kernels(self):
+        """synchronous check of the workspace error words (end of an epoch / before a checkpoint); raises CttsError"""
+        self.ws_probe.poll_and_check()
+
     def __call__(self):
+        self._calls += 1
+        if self._calls % self.probe_every == 1:
+            self.ws_probe.check()                       # the copy started `probe_every` steps ago has long landed: no stall
         self.optim.update_learning_rate()               # host scalar -> device lr tensor (outside the graphs)
         if self.graphs is not None:
             for s, g in enumerate(self.graphs):
@@ -150,4 +164,6 @@ class TrainStep:
                 self._optimizer_step()
         else:
             self._eager()
+        if self._calls % self.probe_every == 0:
+            self.ws_probe.poll()
         self.step_no += 1

@@ -49,7 +49,7 @@ typedef struct ctts_gemm_desc {
   const int32_t* lens;                    /* [nb0] valid length per z0, or NULL                       */
   int32_t lim_m, lim_n, lim_k;            /* clamp that dim to lens[z0]                               */
   int32_t conv_T, conv_pad, conv_cin, conv_on_b; /* conv_T=0: plain; conv_on_b=1 applies to B (b_kc=0) */
-  int32_t split_k;                        /* >1: atomicAdd partials into pre-zeroed C, no epilogue    */
+  int32_t split_k;                        /* >1: C += alpha * A B, K cut into <= split_k pieces summed in a FIXED order through sk_ws (no atomics, no epilogue) */
   float alpha;
   const float* bias;                      /* [N] or NULL                                              */
   float* Z; int64_t ldz;                  /* optional store of the pre-activation                     */
@@ -76,8 +76,10 @@ typedef struct ctts_gemm_desc {
    * batch strides) and rowsub indexed [batch * M + row]:  dS = P * (dP - D), D = rowsum(dO * O), straight out of the dP = dO V^T GEMM -
    * no separate pass over the [T,T] maps.  NULL = off; not combinable with bias / act / dropout / R / rowscale / split_k. */
   const float* E; const float* rowsub;
-  /* Optional workspace of the persistent stream-K kernel (csrc/gemm_sk.hip): ctts_gemm_workspace_bytes() bytes, zero-filled ONCE by the
-   * caller, private to the stream the launch goes to (launches that share it must be stream-ordered).  With it, large unbatched GEMMs
+  /* Workspace (ctts_workspace_bytes() bytes, zero-filled ONCE by the caller, private to the stream the launch goes to: launches that
+   * share it must be stream-ordered; every kernel leaves its flag / ticket words at zero).  REQUIRED when split_k > 1: the partial tiles
+   * of the K pieces are written to it and summed in split order by the workgroup that finishes last - bit-reproducible, unlike float
+   * atomics in arrival order.  It also enables the persistent stream-K kernel (csrc/gemm_sk.hip): with it, large unbatched GEMMs
    * run on a persistent grid that cuts the (tile, K-block) space evenly over the CUs and sums cut tiles in a fixed order; split_k > 1
    * then only means "C += alpha * A B" (no atomics).  NULL = tile-per-workgroup kernels only. */
   void* sk_ws; int64_t sk_ws_bytes;
@@ -88,7 +90,14 @@ typedef struct ctts_gemm_desc {
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
+/* Size of the per-stream workspace shared by ctts_gemm (sk_ws) and by every entry point below that takes a `ws` argument (ordered
+ * cross-workgroup reductions: column sums, LayerNorm / BatchNorm parameter sums, loss sums).  `ws` = NULL is legal for those: the
+ * reduction then runs on ONE workgroup per column block (slow, still deterministic).  ctts_gemm_workspace_bytes is the older name. */
+size_t ctts_workspace_bytes(void);
 size_t ctts_gemm_workspace_bytes(void);
+/* Error word of the stream-K hand-off in a workspace (0 = clean; n > 0: an owner gave up waiting for workgroup n - 1 and the launch's
+ * result is invalid).  DEVICE pointer to one uint32 inside `ws`: copy it to the host (asynchronously, e.g. every N steps) and raise. */
+const uint32_t* ctts_workspace_error_word(const void* ws);
 /* 1 when ctts_gemm would run this descriptor on the persistent stream-K kernel (sk_ws given, shape / alignment eligible, enough tiles
  * for the grid), else 0.  Callers that otherwise split the reduction (split_k > 1 + zero fill) ask first: the persistent kernel balances
  * the reduction itself and wants split_k = 1. */
@@ -104,14 +113,14 @@ int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, 
 
 /* out[c] (+)= scale * sum_r w[r] * x[r,c] (x [rows,C] dense): the weight gradient of a one-output Linear - the N = 1 heads of the
  * duration / energy predictors (modules.py:1296,1349) - as one streaming pass instead of a degenerate 1 x C GEMM. */
-int ctts_weighted_colsum(const float* x, const float* w, float* out, int64_t rows, int C, float scale, int accumulate, void* stream);
+int ctts_weighted_colsum(const float* x, const float* w, float* out, int64_t rows, int C, float scale, int accumulate, void* ws, void* stream);
 
 /* Backward of the ctts_gemm epilogue in one pass over dY [rows,C]:  gm = dY * rowscale[row] (optional output = gradient of the
  * residual R), dZ = gm * dropout_mask(seed, drop_offset, element) / (1-p) * act'(Z) (act as in ctts_gemm_desc; Z NULL or act 0: factor 1),
  * dbias[c] (+)= bias_scale * sum_rows dZ[.,c] (optional; bias_scale = the epilogue's alpha).  Any of rowscale, z, gm, dbias may be NULL. */
 int ctts_epilogue_bwd(const float* dy, const float* rowscale, const float* z, float* dz, float* gm, float* dbias, int64_t rows, int C,
                       int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, float bias_scale, int accumulate_bias,
-                      void* stream);
+                      void* ws, void* stream);
 
 /* m-tile schedule for padded-row skipping (see ctts_gemm_desc.tile_map): a 64-row tile is inactive when all its rows (b,t) belong to one
  * utterance b and t >= row_lens[b] + row_halo.  tile_map: 1 + ceil(M/64) int32. */
@@ -151,7 +160,7 @@ int ctts_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
                        const float* rowscale, void* stream);
 int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx, float* dgamma, float* dbeta, int rows, int C, float p_drop, const uint64_t* seed,
-                       uint32_t drop_offset, const float* rowscale, int accumulate, const float* dres, void* stream);
+                       uint32_t drop_offset, const float* rowscale, int accumulate, const float* dres, void* ws, void* stream);
 /* accumulate != 0: dgamma / dbeta (and ctts_colsum's out) are ADDED to - gradient-accumulation fusion straight into param.grad.
  * dres (optional, [rows,C]): added to dx - the gradient arriving through the residual connection around the pre-LN sub-layer
  * (x -> LN -> f -> + x), so the autograd sum of the two paths costs no extra pass. */
@@ -163,7 +172,7 @@ int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
  * bwd_reduce: sums[0..C) = sum dt, sums[C..2C) = sum dt*xhat with dt = dy*dropmask*act'(u).
  * bwd_apply: dx = gamma*rstd*(dt - sum_dt/rows - xhat*sum_dtxhat/rows); dgamma/dbeta from sums.
  *   batch_stats bit 0: train-mode statistics (the two correction terms above), bit 1: ADD to dgamma / dbeta instead of storing. */
-int ctts_colstats(const float* x, double* sums, int rows, int C, void* stream);
+int ctts_colstats(const float* x, double* sums, int rows, int C, void* ws, void* stream);
 /* mean / rstd of the batch from ctts_colstats sums, plus the nn.BatchNorm train-mode bookkeeping (running_mean / running_var with
  * momentum and the unbiased variance, num_batches_tracked += 1; NULL pointers skip) - one launch instead of a dozen [C]-sized ops. */
 int ctts_bn_finalize(const double* sums, int rows, int C, float eps, float momentum, float* mean, float* rstd, float* running_mean,
@@ -173,7 +182,7 @@ int ctts_bn_apply(const float* x, const float* mean, const float* rstd, const fl
                   void* stream);
 int ctts_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        const float* beta, double* sums, int rows, int C, int act, float p_drop, const uint64_t* seed,
-                       uint32_t drop_offset, void* stream);
+                       uint32_t drop_offset, void* ws, void* stream);
 int ctts_bn_bwd_apply(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const double* sums, float* dx, float* dgamma, float* dbeta, int rows, int C,
                       int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, int batch_stats, void* stream);
@@ -193,7 +202,7 @@ int ctts_act_dropout_bwd(const float* dg, const float* z, float* dz, int64_t row
                          float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream);
 int ctts_rowscale_dropout(const float* x, float* y, int64_t rows, int C, const float* rowscale, float p_drop,
                           const uint64_t* seed, uint32_t drop_offset, void* stream);
-int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* stream);
+int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Mel front end (audio/stft.py:59-88,166-185): reflect-pad, |DFT| from the [F, 2*nbins]
@@ -389,7 +398,7 @@ int ctts_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n,
  *   sums must be ZERO on entry (the kernel accumulates into it)
  * bwd: d1, d2 = g[k] * sign(p_k - t) * w / (C * sums[2]) with g the two upstream scalars (device). */
 int ctts_mel_l1_fwd(const float* p1, const float* p2, const float* tgt, const uint8_t* pad, float* sums, float* roww, int64_t rows,
-                    int C, void* stream);
+                    int C, void* ws, void* stream);
 int ctts_mel_l1_bwd(const float* p1, const float* p2, const float* tgt, const float* roww, const float* sums, const float* g, float* d1,
                     float* d2, int64_t rows, int C, void* stream);
 

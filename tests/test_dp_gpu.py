@@ -65,13 +65,15 @@ def _trajectory(c5, block, use_graph, staged, n=5):
 @pytest.mark.parametrize("c5", [False, True])
 def test_hipgraph_replay_matches_eager_training(c5):
     """Five full train steps (fwd + loss + bwd + fused clip/Adam, dropout on) replayed from the two hipGraphs vs launched eagerly
-    from the same initial state and dropout seed: the loss trajectories must agree (this is the check that exposed the stale-bytes
-    problem of memset nodes inside replayed graphs)."""
+    from the same initial state and dropout seed: the loss trajectories must be IDENTICAL (this is the check that exposed the
+    stale-bytes problem of memset nodes inside replayed graphs).  Round 3 allowed 1e-4 here and the driver's run failed at 1.05e-4:
+    the kernels were not reproducible from run to run (fp32 atomics; eager differed from eager by as much,
+    profiles/r04_diag_determinism_c5_before.txt).  Since round 4 every cross-workgroup sum has a fixed order, so the same kernels
+    on the same inputs give the same bits whether launched eagerly or replayed."""
     eager, _ = _trajectory(c5, "transformer_fs2", False, False)
     graph, _ = _trajectory(c5, "transformer_fs2", True, False)
     print("eager", eager, "graph", graph)
-    for a, b in zip(eager, graph):
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (eager, graph)       # observed ~1e-7: same kernels, same dropout stream
+    assert eager == graph, (eager, graph)
 
 
 @pytest.mark.parametrize("block,c5", [("transformer_fs2", False), ("conformer", False), ("transformer_fs2", True)])
@@ -82,8 +84,8 @@ def test_staged_backward_graphs_match_monolithic_eager(block, c5):
     staged, st = _trajectory(c5, block, True, True)
     assert st.staged and st.n_stages == 4 and len(st.graphs) == 4 and st.g_opt is not None
     print("mono", mono, "staged", staged)
-    for a, b in zip(mono, staged):
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (mono, staged)
+    for a, b in zip(mono, staged):       # the cuts change where autograd adds the branches of a fan-out, not which kernels run: rounding only
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (mono, staged)
 
 
 def _run_ranks(world, block, n_steps, use_graph, tmp_path):

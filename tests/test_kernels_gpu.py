@@ -353,20 +353,30 @@ def test_mel_spectrogram_vs_reference_golden(path):
     assert all_vs_ref <= 4e-3, all_vs_ref
 
 
-def test_mel_spectrogram_range_assert_is_deferred_not_dropped():
-    """audio/stft.py:177-178 asserts min(y) >= -1 and max(y) <= 1 before computing.  The FFT kernel raises a device flag instead of a
-    reduction + host sync per call: a waveform outside [-1, 1] still raises AssertionError - at check_range(), or at the next call once
-    the flag has arrived - and a valid waveform raises nothing; NaN input is caught as well."""
+def test_mel_spectrogram_range_assert_strict_by_default_deferred_on_request():
+    """audio/stft.py:177-178 asserts min(y) >= -1 and max(y) <= 1 before computing.  The FFT kernel raises a flag in pinned host memory
+    instead of two reductions.  Default (strict_range): the SAME call raises AssertionError for an out-of-range or NaN waveform - also
+    when it is the only or the last call.  strict_range = False (training hot path): no wait; the assertion arrives at
+    check_range(), or at the next call once the flag has landed.  A valid waveform raises nothing either way."""
     st = ctts_amd.TacotronSTFT(1024, 256, 1024, 80, 22050, 0, 8000).to(DEV)
     y = (torch.rand(2, 8192, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    bad = y.clone(); bad[1, 4000] = 1.5
+    nan = y.clone(); nan[0, 100] = float("nan")
+    assert st.strict_range
+    st.mel_spectrogram(y)                              # valid input: silent
+    with pytest.raises(AssertionError, match="outside"):
+        st.mel_spectrogram(bad)                        # raised by the offending call itself
+    st.mel_spectrogram(y)                              # flag was cleared
+    with pytest.raises(AssertionError):
+        st.mel_spectrogram(nan)
+    st.mel_spectrogram(y)
+    st.strict_range = False
     st.mel_spectrogram(y)
     st.check_range()                                   # valid input: silent
-    bad = y.clone(); bad[1, 4000] = 1.5
     st.mel_spectrogram(bad)                            # launch succeeds (no sync) ...
     with pytest.raises(AssertionError, match="outside"):
         st.check_range()                               # ... the assertion arrives here
     st.mel_spectrogram(y); st.check_range()            # flag was cleared
-    nan = y.clone(); nan[0, 100] = float("nan")
     st.mel_spectrogram(nan)
     torch.cuda.synchronize()
     with pytest.raises(AssertionError):
@@ -588,7 +598,19 @@ def test_epilogue_backward_in_the_consumer_gemm_equals_the_separate_pass(ksize, 
         y = ops.linear(h, ts[3], ts[4], residual=ts[0], rowscale=nonpad, p_drop=p, drop=drop, pad_rows=pr, link=link, link_role=2)
         y.backward(go)
         if linked:
-            assert link.armed and not link.done              # armed in the forward, consumed by the producer's backward
+            assert not link.armed and not link.done          # taken by the consumer's forward, delivered dZ consumed by the producer's backward
+            # a link object reused by a SECOND forward before the first backward: each backward uses the snapshot of its own
+            # forward, so both passes still reproduce the unlinked gradients
+            drop2 = K.DropCtx(DEV, seed=5)
+            ts2 = [t.to(DEV).requires_grad_() for t in (x0, w1, b1, w2, b2)]
+            ha = f1(ts2[0], ts2[1], ts2[2], act=a, alpha=0.5, p_drop=p, drop=drop2, pad_rows=pr, link=link, link_role=1)
+            ya = ops.linear(ha, ts2[3], ts2[4], residual=ts2[0], rowscale=nonpad, p_drop=p, drop=drop2, pad_rows=pr, link=link, link_role=2)
+            hb = f1(ts2[0], ts2[1], ts2[2], act=a, alpha=0.5, p_drop=0.5, drop=drop2, pad_rows=pr, link=link, link_role=1)     # re-arms the link
+            yb = ops.linear(hb, ts2[3], ts2[4], residual=ts2[0], rowscale=nonpad, p_drop=p, drop=drop2, pad_rows=pr, link=link, link_role=2)
+            ya.backward(go)
+            for n, u, v in zip(("dx", "dw1", "db1", "dw2", "db2"), res[0][1:], [t.grad for t in ts2]):
+                close(v, u, 2e-5, "EpiLink reused link, first pass " + n)
+            del yb
         res.append([y.detach()] + [t.grad for t in ts])
     for n, u, v in zip(("y", "dx", "dw1", "db1", "dw2", "db2"), res[0], res[1]):
         close(v, u, 2e-5, "EpiLink " + n)

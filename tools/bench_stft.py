@@ -14,8 +14,11 @@ g = torch.Generator().manual_seed(1)
 from ctts_amd import kernels as K
 for B in (16, 64):
     y = (torch.rand(B, 262144, generator=g) - 0.5).to(dev)
-    for path in ("fft_kernel_only", "fft", "dft_gemm"):
+    # "fft": TacotronSTFT.mel_spectrogram with the range assertion deferred (strict_range = False, the training / bulk path);
+    # "fft_strict": the default - the call waits for its own launch and raises like the reference (audio/stft.py:177-178)
+    for path in ("fft_kernel_only", "fft", "fft_strict", "dft_gemm"):
         st.use_fft = path != "dft_gemm"
+        st.strict_range = path == "fft_strict"
         if path == "fft_kernel_only":         # the C entry point alone (ctts_mel_spectrogram), without the reference's host-side range assert
             ws = st._workspace()
             run = lambda: K.mel_spectrogram_fft(y, st._window, ws, 1024, 256, 80, kmax=st._kmax)[:2]          # noqa: E731
