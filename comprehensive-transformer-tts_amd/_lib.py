@@ -52,7 +52,7 @@ _SIGNATURES = {
     "ctts_mel_prepare": [_vp, C.c_int, C.c_int, _vp, _vp],
     "ctts_mel_spectrogram": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp],
     "ctts_mha_fwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _vp],
-    "ctts_mha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp],
+    "ctts_mha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp],
     "ctts_relmha_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_relmha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                         _f32, _f32, _vp, _u32, _vp],

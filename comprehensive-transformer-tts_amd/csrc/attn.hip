@@ -661,7 +661,8 @@ extern "C" int ctts_mha_fwd(const float* qkv, const int32_t* lens, float* out, f
 }
 
 extern "C" int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* out, const float* dout, const float* lse, float* Dws,
-                            float* dS, float* kv_part, float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* stream) {
+                            float* dS, float* kv_part, float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* ws,
+                            void* stream) {
   CTTS_REQUIRE(qkv && out && dout && lse && Dws && dS && dqkv && B > 0 && T > 0, "ctts_mha_bwd: bad arguments");
   CTTS_REQUIRE(q_split <= 1 || kv_part, "ctts_mha_bwd: q_split > 1 needs the kv_part scratch [q_split, B, T, 2C]");
   CTTS_REQUIRE((long)T * T * 4 < 0x7FFFFFFFL && (long)T * C * 12 < 0x7FFFFFFFL, "ctts_mha_bwd: one utterance exceeds the 32-bit byte offsets of the kernel");
@@ -700,7 +701,9 @@ extern "C" int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* 
   g.lens = lens; g.lim_m = lens ? 1 : 0; g.lim_k = lens ? 1 : 0;
   g.alpha = 1.f;
   const long tiles = (long)((T + 63) / 64) * ((dh + 63) / 64) * B * H;
-  g.split_k = (tiles < 1536 && T >= 512) ? 2 : 1;
+  // (the two pieces are summed in a fixed order through the caller's workspace; without one: no split)
+  g.split_k = (ws && tiles < 1536 && T >= 512) ? 2 : 1;
+  if (g.split_k > 1) { g.sk_ws = ws; g.sk_ws_bytes = (int64_t)CTTS_WS_BYTES; }
   return ctts_gemm(&g, stream);
 }
 

@@ -424,18 +424,18 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
       return;
     }
   }
-  int k_begin = 0, k_end = Kv, n_split_active = 1;
+  int k_begin = 0, k_end = Kv;
   if (d.split_k > 1) {
     int chunk = ((Kv + d.split_k - 1) / d.split_k + BK - 1) / BK * BK;
     k_begin = split * chunk;
     k_end = min(Kv, k_begin + chunk);
     if (k_begin >= k_end) return;
-    n_split_active = (Kv + chunk - 1) / chunk;           // splits with a non-empty K range: the tile's ticket count
   }
 
   const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
   const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
   float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
+  if (d.split_k > 1) Cb += (long)split * d.M * d.ldc;      // split-K: C is the partial matrix P_split of the workspace (ctts_gemm rewrote the descriptor)
   const float* Asafe = Ab;   // in-bounds, 16-B aligned dummy addresses for masked-out chunks (VEC loaders)
   const float* Bsafe = Bb;
   ConvView cv{d.conv_T, d.conv_pad, d.conv_cin};
@@ -521,10 +521,6 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
     act_cur = act_next;
   }
 
-  if (d.split_k > 1) {       // ordered split-K sum through the workspace (gemm_common.h): no atomics
-    const int tile_lin = (z * ((d.M + BM - 1) / BM) + row0 / BM) * tiles_n + col0 / BN;
-    return gemm_splitk_finish<MT, NT, 256>(d, acc, Cb, tile_lin, split, n_split_active, threadIdx.x, true, row0, col0, wm0, wn0, l31, h, Mv, Nv);
-  }
   gemm_epilogue_auto<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
@@ -593,6 +589,7 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   const int row0 = tm * BM, col0 = (wg % tiles_n) * BN;
   if (row0 >= Mv || col0 >= Nv) return;
   float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
+  if (d.split_k > 1) Cb += (long)split * d.M * d.ldc;      // split-K: C is the partial matrix P_split of the workspace (ctts_gemm rewrote the descriptor)
   if (A_KC && d.row_lens && !scheduled_active) {
     const int last = min(row0 + BM, Mv) - 1;
     const int b0 = row0 / d.row_T, b1 = last / d.row_T;
@@ -606,13 +603,12 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
       return;
     }
   }
-  int k_begin = 0, k_end = Kv, n_split_active = 1;
+  int k_begin = 0, k_end = Kv;
   if (d.split_k > 1) {
     int chunk = ((Kv + d.split_k - 1) / d.split_k + BK - 1) / BK * BK;
     k_begin = split * chunk;
     k_end = min(Kv, k_begin + chunk);
     if (k_begin >= k_end) return;
-    n_split_active = (Kv + chunk - 1) / chunk;           // splits with a non-empty K range: the tile's ticket count
   }
   const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
   const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
@@ -694,10 +690,6 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
     __syncthreads();
     act_cur = act_next;
   }
-  if (d.split_k > 1) {       // ordered split-K sum through the workspace (gemm_common.h): no atomics
-    const int tile_lin = (z * ((d.M + BM - 1) / BM) + row0 / BM) * tiles_n + col0 / BN;
-    return gemm_splitk_finish<MT, NT, 256>(d, acc, Cb, tile_lin, split, n_split_active, threadIdx.x, true, row0, col0, wm0, wn0, l31, h, Mv, Nv);
-  }
   gemm_epilogue_auto<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
@@ -723,6 +715,7 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_k2_kernel(const
   const int row0 = tm * BM, col0 = (blockIdx.x - tm * tiles_n) * BN;
   if (row0 >= Mv || col0 >= Nv) return;
   float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
+  if (d.split_k > 1) Cb += (long)split * d.M * d.ldc;      // split-K: C is the partial matrix P_split of the workspace
   if (A_KC && d.row_lens) {
     const int last = min(row0 + BM, Mv) - 1;
     const int b0 = row0 / d.row_T, b1 = last / d.row_T;
@@ -736,13 +729,12 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_k2_kernel(const
       return;
     }
   }
-  int k_begin = 0, k_end = Kv, n_split_active = 1;
+  int k_begin = 0, k_end = Kv;
   if (d.split_k > 1) {
     int chunk = ((Kv + d.split_k - 1) / d.split_k + 2 * BK - 1) / (2 * BK) * (2 * BK);
     k_begin = split * chunk;
     k_end = min(Kv, k_begin + chunk);
     if (k_begin >= k_end) return;
-    n_split_active = (Kv + chunk - 1) / chunk;
   }
   const float* Ab = d.A + z0 * d.sA0 + z1 * d.sA1;
   const float* Bb = d.B + z0 * d.sB0 + z1 * d.sB1;
@@ -801,10 +793,6 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_k2_kernel(const
   if (grp == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] += red[r * 64];
-  }
-  if (d.split_k > 1) {       // ordered split-K sum through the workspace: waves 0,1 hold the tile, everybody takes part in the ticket
-    const int tile_lin = (z * ((d.M + BM - 1) / BM) + tm) * tiles_n + col0 / BN;
-    return gemm_splitk_finish<1, 1, 128>(d, acc, Cb, tile_lin, split, n_split_active, threadIdx.x, grp == 0, row0, col0, 0, wn0, l31, h, Mv, Nv);
   }
   if (grp == 0) gemm_epilogue_auto<1, 1>(d, acc, Cb, z, row0, col0, 0, wn0, l31, h, Mv, Nv);
 }
@@ -929,6 +917,66 @@ __global__ __launch_bounds__(64) void row_tile_map_kernel(const int32_t* __restr
 }
 }  // namespace
 
+namespace {
+// Second launch of a split-K GEMM: C[m, n] += alpha * (P_0 + P_1 + ... )[m, n] in split order (fixed: bit-reproducible), for the rows /
+// columns / batches the GEMM kernels computed - per-batch length limits, tiles of padded rows (zero-filled by the GEMM, skipped here) and
+// splits whose K range was empty (never written) follow the kernels' own predicates.  One thread per 4 columns, all splits' loads in flight.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ctts_gemm_desc d, int BM, int kround) {
+  const int z = blockIdx.z, z0 = z / d.nb1, z1 = z - z0 * d.nb1;
+  int Mv = d.M, Nv = d.N, Kv = d.K;
+  if (d.lens) {
+    const int L = d.lens[z0];
+    if (d.lim_m) Mv = min(Mv, L);
+    if (d.lim_n) Nv = min(Nv, L);
+    if (d.lim_k) Kv = min(Kv, L);
+  }
+  if (Kv <= 0) return;
+  const int chunk = ((Kv + d.split_k - 1) / d.split_k + kround - 1) / kround * kround;
+  const int nact = (Kv + chunk - 1) / chunk;
+  const long ldp = gemm_partial_ld(d.N);
+  const int n4 = (int)(ldp >> 2);
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const int m = (int)(e / n4), n = (int)(e - (long)m * n4) * 4;
+  if (m >= Mv || n >= Nv) return;
+  if (d.a_kc && d.row_lens) {             // the GEMM zero-filled whole tiles of padded rows and wrote no partials for them
+    const int row0 = m / BM * BM, last = min(row0 + BM, Mv) - 1;
+    const int b0 = row0 / d.row_T, b1 = last / d.row_T;
+    if (b0 == b1 && (row0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo) return;
+  }
+  const float4* P = reinterpret_cast<const float4*>(gemm_partial_base(d, z, 0) + (long)m * ldp + n);
+  const long sstride = (long)d.M * ldp / 4;          // P_s of a batch are consecutive [M, ldp] matrices
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 4 <= nact; s += 4) {
+    const float4 v0 = P[(long)s * sstride], v1 = P[(long)(s + 1) * sstride], v2 = P[(long)(s + 2) * sstride], v3 = P[(long)(s + 3) * sstride];
+    a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+    a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+    a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+  }
+  for (; s < nact; ++s) { const float4 v = P[(long)s * sstride]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  float* Cr = d.C + z0 * d.sC0 + z1 * d.sC1 + (long)m * d.ldc + n;
+  const float al = d.alpha;
+  if (n + 4 <= Nv && ((reinterpret_cast<uintptr_t>(Cr) & 15) == 0)) {
+    float4 c = *reinterpret_cast<float4*>(Cr);
+    c.x += al * a.x; c.y += al * a.y; c.z += al * a.z; c.w += al * a.w;
+    *reinterpret_cast<float4*>(Cr) = c;
+  } else {
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (n + q < Nv) Cr[q] += al * av[q];
+  }
+}
+
+int splitk_reduce(const ctts_gemm_desc& d, int BM, int kround, hipStream_t st) {
+  const long e = (long)d.M * (gemm_partial_ld(d.N) / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((e + 255) / 256), 1, d.nb0 * d.nb1), dim3(256), 0, st, d, BM, kround);
+  CTTS_CHECK_LAUNCH("ctts_gemm(split-K reduce)");
+  return 0;
+}
+}  // namespace
+
 extern "C" int ctts_row_tile_map(const int32_t* row_lens, int row_T, int row_halo, int M, int32_t* tile_map, void* stream) {
   CTTS_REQUIRE(row_lens && tile_map && row_T > 0 && M >= 0, "ctts_row_tile_map: bad arguments");
   hipLaunchKernelGGL(row_tile_map_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, row_lens, row_T, row_halo, M, tile_map);
@@ -1021,26 +1069,44 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   else kind = K_VEC64;
 
   if (d.split_k > 1) {
-    // Ordered split-K (gemm_common.h gemm_splitk_finish): one ticket per (batch, tile), one slab per (batch, tile, split) in the caller's
-    // workspace.  split_k is an upper bound: it is lowered until the slabs fit (never below 2 - "C += alpha A B" is what split_k > 1 means).
+    // Ordered split-K (gemm_common.h; splitk_reduce_kernel above): one partial matrix [M, N] per (batch, split) in the
+    // caller's workspace.  split_k is an upper bound: it is lowered until the partials fit (never below 2 - "C += alpha A B" is what
+    // split_k > 1 means).
     CTTS_REQUIRE(d.sk_ws && d.sk_ws_bytes >= (int64_t)CTTS_WS_BYTES,
-                 "ctts_gemm: split_k > 1 needs the workspace (ctts_gemm_workspace_bytes() bytes, zero-filled once) in sk_ws - partial sums "
+                 "ctts_gemm: split_k > 1 needs the workspace (ctts_workspace_bytes() bytes, zero-filled once) in sk_ws - partial sums "
                  "are added in a fixed order through it, the library has no floating-point atomics");
-    const long ntile = (long)((d.M + BMs - 1) / BMs) * ((d.N + BNs - 1) / BNs) * d.nb0 * d.nb1;
-    CTTS_REQUIRE(ntile <= CTTS_WS_GEMM_TICKET_WORDS, "ctts_gemm: %ld output tiles exceed the split-K ticket area (%d)", ntile, CTTS_WS_GEMM_TICKET_WORDS);
-    const long cap = (long)CTTS_WS_SLAB_FLOATS / (ntile * BMs * BNs);
-    CTTS_REQUIRE(cap >= 2, "ctts_gemm: split-K output of %ld tiles does not fit the workspace slabs", ntile);
+    const long per_split = (long)d.nb0 * d.nb1 * d.M * gemm_partial_ld(d.N);
+    const long cap = (long)CTTS_WS_SLAB_FLOATS / per_split;
+    CTTS_REQUIRE(cap >= 2 && (long)d.M * gemm_partial_ld(d.N) * 4 < 0x7FFF0000L, "ctts_gemm: split-K output [%d, %d] x %d batches does not fit the workspace",
+                 d.M, d.N, d.nb0 * d.nb1);
     if (d.split_k > cap) d.split_k = (int)cap;
   }
-  switch (kind) {
-    case K_SCALAR64: return dispatch_layout<64, 64, false>(d, st);
-#ifndef CTTS_NO_BUF
-    case K_BUF128: return dispatch_buf<128, 128>(d, st);
-    case K_BUF_K2: return dispatch_buf_k2(d, st);
-    case K_BUF_NARROW: return dispatch_buf_narrow(d, st);
-    case K_BUF64: return dispatch_buf<64, 64>(d, st);
-#endif
-    case K_VEC128: return dispatch_layout<128, 128, true>(d, st);
-    default: return dispatch_layout<64, 64, true>(d, st);
+  const bool split = d.split_k > 1;
+  const ctts_gemm_desc d_user = d;                 // what the reduce launch accumulates into
+  if (split) {
+    // the tile kernels see the partial matrices as their output: C = P [z][split][M][ldp], plain stores (alpha = 1, no epilogue terms);
+    // workgroup (z, split) adds split * M * ldc itself.  Whole tiles of padded rows are "zero-filled" into P_0 and skipped by the reduce.
+    const long ldp = gemm_partial_ld(d.N);
+    d.C = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(d.sk_ws) + CTTS_WS_SLABS);
+    d.ldc = ldp;
+    d.sC1 = (long)d.split_k * d.M * ldp;
+    d.sC0 = (long)d.nb1 * d.sC1;
+    d.alpha = 1.f; d.bias = nullptr; d.Z = nullptr; d.act = 0; d.p_drop = 0.f; d.R = nullptr; d.rowscale = nullptr;
   }
+  int rc;
+  switch (kind) {
+    case K_SCALAR64: rc = dispatch_layout<64, 64, false>(d, st); break;
+#ifndef CTTS_NO_BUF
+    case K_BUF128: rc = dispatch_buf<128, 128>(d, st); break;
+    case K_BUF_K2: rc = dispatch_buf_k2(d, st); break;
+    case K_BUF_NARROW: rc = dispatch_buf_narrow(d, st); break;
+    case K_BUF64: rc = dispatch_buf<64, 64>(d, st); break;
+#endif
+    case K_VEC128: rc = dispatch_layout<128, 128, true>(d, st); break;
+    default: rc = dispatch_layout<64, 64, true>(d, st); break;
+  }
+  if (rc != 0 || !split) return rc;
+  ctts_gemm_desc dr = d_user;
+  dr.split_k = d.split_k;                          // (possibly lowered above)
+  return splitk_reduce(dr, BMs, kind == K_BUF_K2 ? 2 * BK : BK, st);      // kround: the K granularity of the kernel's split (its `chunk`)
 }

@@ -194,69 +194,19 @@ __device__ __forceinline__ void gemm_accumulate_lean(const ctts_gemm_desc& d, co
   }
 }
 
-// ---- split-K without atomics (round 4).  grid.y = split_k workgroups reduce disjoint K ranges of one output tile.  Each stores its
-// partial tile into the workspace slab (tile, split) with write-through stores and takes the tile's ticket; the workgroup that draws
-// the last ticket adds the slabs IN SPLIT ORDER (its own included, read back: the order never depends on who came last) and adds
-// alpha * sum into C with plain loads / stores - it is the only writer of that tile.  Bit-reproducible from run to run, which
-// buffer_atomic_add_f32 in arrival order was not (profiles/r04_diag_determinism_*_before.txt).
-//   tile_lin: linear tile index over (batch, m-tile, n-tile); nactive: splits with a non-empty K range (all others returned before);
-//   NTH threads of the workgroup hold accumulators (`active` for those; everybody calls: the ticket has barriers).
-typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
-template <int MT, int NT, int NTH>
-__device__ __forceinline__ void gemm_splitk_finish(const ctts_gemm_desc& d, floatx16 (&acc)[MT][NT], float* Cb, int tile_lin, int split,
-                                                   int nactive, int tid, bool active, int row0, int col0, int wm0, int wn0, int l31, int h,
-                                                   int Mv, int Nv) {
-  unsigned char* ws = reinterpret_cast<unsigned char*>(d.sk_ws);
-  constexpr unsigned SLAB_BYTES = MT * NT * 16 * NTH * 4;
-  const __amdgpu_buffer_rsrc_t rs = gemm_rsrc(ws + CTTS_WS_SLABS, (long)(CTTS_WS_SLAB_FLOATS * 4));
-  const unsigned tile_base = (unsigned)tile_lin * (unsigned)d.split_k * SLAB_BYTES + (unsigned)tid * 16u;
-  if (active) {
-    const unsigned base = tile_base + (unsigned)split * SLAB_BYTES;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          gemm_u32x4 v;
-          v.x = __float_as_uint(acc[i][j][4 * q + 0]); v.y = __float_as_uint(acc[i][j][4 * q + 1]);
-          v.z = __float_as_uint(acc[i][j][4 * q + 2]); v.w = __float_as_uint(acc[i][j][4 * q + 3]);
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + (unsigned)(((i * NT + j) * 4 + q) * NTH * 16), 0, 16);      // aux 16 = sc1
-        }
-  }
-  unsigned* tickets = reinterpret_cast<unsigned*>(ws + CTTS_WS_GEMM_TICKETS);
-  if (!ctts_arrive_last(tickets + tile_lin, (unsigned)nactive)) return;
-  if (!active) return;
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  for (int s = 0; s < nactive; ++s) {
-    const unsigned base = tile_base + (unsigned)s * SLAB_BYTES;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const gemm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)(((i * NT + j) * 4 + q) * NTH * 16), 0, 16);
-          acc[i][j][4 * q + 0] += __uint_as_float(v.x); acc[i][j][4 * q + 1] += __uint_as_float(v.y);
-          acc[i][j][4 * q + 2] += __uint_as_float(v.z); acc[i][j][4 * q + 3] += __uint_as_float(v.w);
-        }
-  }
-  if (gemm_fits32(Cb, Mv, d.ldc, Nv)) return gemm_accumulate_lean<MT, NT>(d, acc, Cb, row0, col0, wm0, wn0, l31, h, Mv, Nv);
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int n = col0 + wn0 + j * 32 + l31;
-        if (m < Mv && n < Nv) Cb[(long)m * d.ldc + n] += d.alpha * acc[i][j][r];
-      }
+// ---- split-K without atomics (round 4).  grid.y = split_k workgroups reduce disjoint K ranges of one output tile.  Each STORES its
+// partial tile into the partial matrix P_s [M, ldp] of its split in the caller's workspace - ctts_gemm hands the tile kernels a rewritten
+// descriptor whose C is that area, so this is their ordinary plain epilogue; a second launch (splitk_reduce_kernel, gemm.hip) adds the
+// P_s in split order and accumulates alpha * sum into the caller's C.  The sum
+// has a fixed order, so it is bit-reproducible from run to run - buffer_atomic_add_f32 in arrival order was not (profiles/
+// r04_diag_determinism_*_before.txt) - and the GEMM kernels carry no tickets, flags or extra registers for it (a first version gathered
+// the slabs inside the GEMM's epilogue: 65 - 69 VGPRs instead of <= 64 on the 64 x 64 kernels, i.e. 7 instead of 8 waves per SIMD for
+// EVERY launch, and a 25 us serial gather at the tail of every 31-way split).
+// P_s of (batch z, split s): the partial matrices live in the slab area of the workspace, [z][s][M][ldp], ldp = N rounded up to 4
+__device__ __host__ __forceinline__ long gemm_partial_ld(int N) { return (long)((N + 3) / 4) * 4; }
+__device__ __forceinline__ float* gemm_partial_base(const ctts_gemm_desc& d, int z, int split) {
+  float* P = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(d.sk_ws) + CTTS_WS_SLABS);
+  return P + ((long)z * d.split_k + split) * (long)d.M * gemm_partial_ld(d.N);
 }
 
 // fused softmax backward of the attention launches: C = E * (alpha * acc - rowsub[row]), E laid out like C

@@ -669,7 +669,7 @@ def mha_bwd(qkv, lens, out, dout, lse, n_heads, scale, q_split=1):
     part = torch.empty(q_split, B, T, 2 * Cc, dtype=torch.float32, device=dev) if q_split > 1 else None
     lib = _lib.load()
     _lib.check(lib.ctts_mha_bwd(_p(qkv), _p(lens), _p(_f32c(out, "out")), _p(_f32c(dout, "dout")), _p(lse), _p(Dws), _p(dS), _p(part), _p(dqkv),
-                                B, T, n_heads, Cc, float(scale), int(q_split), _stream()), "ctts_mha_bwd")
+                                B, T, n_heads, Cc, float(scale), int(q_split), _ws(qkv), _stream()), "ctts_mha_bwd")
     return dqkv
 
 

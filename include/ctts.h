@@ -343,7 +343,9 @@ int ctts_mel_spectrogram(const float* y, const int32_t* lens, const float* windo
 int ctts_mha_supported(int C, int H);
 int ctts_mha_fwd(const float* qkv, const int32_t* lens, float* out, float* lse, int B, int T, int H, int C, float scale, void* stream);
 int ctts_mha_bwd(const float* qkv, const int32_t* lens, const float* out, const float* dout, const float* lse, float* Dws, float* dS,
-                 float* kv_part, float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* stream);
+                 float* kv_part, float* dqkv, int B, int T, int H, int C, float scale, int q_split, void* ws, void* stream);
+/* ws: the per-stream workspace (ctts_workspace_bytes()) - the dQ = dS K reduction is split in two when the launch would not fill the
+ * chip, and the pieces are summed through it in a fixed order; NULL = never split. */
 size_t ctts_relmha_workspace_floats(int B, int T, int H);
 int ctts_relmha_fwd(const float* qu, const float* qv, const float* kv, const float* pos, float* out, float* lse, int B, int T,
                     int H, int C, float scale, float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream);

@@ -2,7 +2,7 @@
 round-3 product was not - fp32 atomics (split-K weight gradients, LayerNorm / BatchNorm / bias column sums, embedding backward, the mel
 L1 sums) added in arrival order, and two runs of the same step differed in the 7th digit and drifted apart under Adam
 (profiles/r04_diag_determinism_*_before.txt).  Every cross-workgroup sum now goes through a workspace in a fixed order
-(csrc/ctts_common.h, csrc/gemm_common.h gemm_splitk_finish).  These tests repeat each reduction several times from the same inputs -
+(csrc/ctts_common.h; split-K: csrc/gemm.hip splitk_reduce_kernel).  These tests repeat each reduction several times from the same inputs -
 with other work in between, so that the arrival order of the workgroups changes - and demand bit-identical results, plus agreement with
 float64; the train step is repeated from the same seed (eager twice, hipGraph replay) and must reproduce losses AND the whole gradient
 arena bit for bit."""
@@ -68,8 +68,6 @@ def test_split_k_gemm_is_bit_reproducible_and_matches_fp64(M, N, Kd, split, layo
     out = _repeat_equal(run, name=f"split-K {layout} {M}x{N}x{Kd}/{split}")[0]
     _close(out[:M, :N] - base[:M, :N], ref, 3e-6 * max(1, Kd / 16), "split-K vs fp64")
     assert torch.equal(out[M:], base[M:]) and torch.equal(out[:, N:], base[:, N:]), "written outside [:M, :N]"
-    ws = K.gemm_workspace(A.device)
-    assert int(ws[16384:16384 + 4 * 65536].view(torch.int32).abs().max()) == 0, "split-K tickets not returned to zero"
 
 
 def test_split_k_batched_attention_gradient_is_reproducible():
@@ -90,6 +88,19 @@ def test_split_k_batched_attention_gradient_is_reproducible():
         L = int(lens[b])
         _close(out[b, :L], dS[b, :L, :L].double() @ Km[b, :L].double(), 2e-5, f"dQ b={b}")
         assert float(out[b, L:].abs().max()) == 0.0 if L < T else True
+
+
+def test_reduction_tickets_return_to_zero():
+    """every ordered reduction leaves its ticket words at zero (the workspace is zero-filled once, by the caller)"""
+    x = torch.randn(16384, 1024, device=DEV)
+    K.colsum(x); K.colstats(x); K.epilogue_bwd(x, want_bias=True)
+    g = torch.ones(1024, device=DEV)
+    y, mean, rstd = K.layernorm_fwd(x, g, g, 1e-5)
+    K.layernorm_bwd(x, x, g, mean, rstd)
+    torch.cuda.synchronize()
+    ws = K.gemm_workspace(x.device)
+    lo, hi = 16384, 16384 + 4 * 65536 + 4 * 65536 + 4 * 1024           # csrc/ctts_common.h: GEMM ticket area (unused), level-1 and level-2 tickets
+    assert int(ws[lo:hi].view(torch.int32).abs().max()) == 0
 
 
 @pytest.mark.parametrize("rows,C", [(16384, 256), (2048, 256), (16384, 1024), (999, 80), (16384, 1), (655360, 32), (37, 512)])

@@ -574,6 +574,56 @@ def test_persistent_stream_k_gemm_equals_tile_kernels(case):
         close(v, u, 3e-6 if case != "wgrad_tn_accumulate" else 2e-5, "stream-K vs tiles " + case)
 
 
+def test_dominant_stream_k_kernel_vs_fp64_at_the_bench_shape():
+    """the kernel bench.py's roofline block times - gemm_sk_kernel<NT layout, conv, 64 x 256 tiles> on the decoder FFN
+    Conv1d k = 9 at its train-step arguments: M = 16,384 rows (B = 16, T = 1024, canonical ragged lengths, device-built tile schedule),
+    N = 1024, K = 2304, bias + GELU + dropout epilogue with pre-activation store - DIRECTLY against float64 (it was only compared with
+    the tile kernels at N = 512, a self-comparison).  The float64 reference is computed for a sample of rows spread over every
+    utterance (first / last valid rows, tile edges, the conv's time boundary) and ALL 1024 columns; padded rows must be exactly zero."""
+    from ctts_amd.synthetic import CANONICAL_SRC_LENS
+    B, T, Cin, N, ks = 16, 1024, 256, 1024, 9
+    M, Kd, pad = B * T, ks * Cin, 4
+    lens_l = [8 * n for n in CANONICAL_SRC_LENS]
+    lens = torch.tensor(lens_l, dtype=torch.int32, device=DEV)
+    g = torch.Generator().manual_seed(77)
+    x = (torch.rand(B, T, Cin, generator=g) - 0.5).to(DEV)
+    w = ((torch.rand(N, Kd, generator=g) - 0.5) * 0.1).to(DEV)               # GEMM-major conv weight [Cout][k][Cin]
+    bias = (torch.rand(N, generator=g) - 0.5).to(DEV)
+    seed = torch.full((1,), 99, dtype=torch.int64, device=DEV)
+    p, off, alpha = 0.1, 5, 1.0
+    out = torch.full((B, T, N), float("nan"), device=DEV)
+    Z = torch.full((B, T, N), float("nan"), device=DEV)
+    args = (x, w, out, M, N, Kd, Cin, Kd, N, True, True)
+    kw = dict(conv=(T, pad, Cin), alpha=alpha, bias=bias, Z=Z, ldz=N, act=K.ACT_GELU, p_drop=p, seed=seed, drop_offset=off,
+              row_lens=lens, row_T=T, row_halo=0, tile_map=K.row_tile_map(lens, T, 0, M))
+    assert K.gemm_takes_persistent(*args, **kw), "expected on the persistent stream-K kernel"
+    K.gemm(*args, **kw)
+    torch.cuda.synchronize()
+    assert _sk_error_word() == 0
+    mask = K.rowscale_dropout(torch.ones(M, N, device=DEV), None, p, seed, off).view(B, T, N)        # 0 or 1/(1-p), from (seed, offset, m*N+n)
+    xd, wd = x.double().cpu(), w.double().cpu().view(N, ks, Cin)
+    worst_c = worst_z = 0.0
+    for b in range(B):
+        L = lens_l[b]
+        rows = sorted({0, 1, 3, 4, 5, 63, 64, 65, L // 2, L - 65, L - 5, L - 4, L - 1} & set(range(L)))
+        for t in rows:
+            acc = torch.zeros(N, dtype=torch.float64)
+            for kk in range(ks):
+                tt = t - pad + kk
+                if 0 <= tt < T:                                  # the conv pads with zeros at the utterance tensor's edges
+                    acc += wd[:, kk, :] @ xd[b, tt]
+            z = alpha * (acc + bias.double().cpu())
+            ref = F.gelu(z) * mask[b, t].double().cpu()
+            worst_z = max(worst_z, float((Z[b, t].double().cpu() - z).abs().max()))
+            worst_c = max(worst_c, float((out[b, t].double().cpu() - ref).abs().max()))
+        tail0 = (L + 63) // 64 * 64                              # rows of wholly padded 64-row tiles are defined as zero
+        if tail0 < T:
+            assert float(out[b, tail0:].abs().max()) == 0.0 and float(Z[b, tail0:].abs().max()) == 0.0
+    assert torch.isfinite(out).all() and torch.isfinite(Z).all()
+    print(f"stream-K 64x256 conv fwd vs fp64: pre-activation {worst_z:.2e}, output {worst_c:.2e}")
+    assert worst_z <= 2e-5 and worst_c <= 2e-5, (worst_z, worst_c)
+
+
 @pytest.mark.parametrize("ksize,act", [(9, "gelu"), (0, "swish")])
 def test_epilogue_backward_in_the_consumer_gemm_equals_the_separate_pass(ksize, act):
     """ops.EpiLink: producer (Conv1d k=9 + GELU + dropout, or Linear + Swish + dropout) -> consumer Linear.  With the link the consumer's
@@ -1045,14 +1095,15 @@ def test_gemm_lean_epilogue_modes_vs_fp64(mode, M, N, Kd, pad):
     assert torch.isnan(Cb[M:]).all() and (pad == 0 or torch.isnan(Cb[:, N:]).all()), "C written out of range"
 
 
-def test_gemm_lean_split_k_atomics_and_batched_limits():
-    """The two remaining special forms: split-K partials by buffer atomics (rows / columns beyond the operand dropped in hardware) and the
-    plain epilogue of a batched launch with per-batch length limits (each batch's descriptor ends at ITS valid extent)."""
+def test_gemm_lean_split_k_partials_and_batched_limits():
+    """The two remaining special forms: split-K (partial matrices in the workspace + the ordered reduce launch; rows / columns beyond the
+    operand never touched) and the plain epilogue of a batched launch with per-batch length limits (each batch's descriptor ends at ITS
+    valid extent)."""
     M, N, Kd = 130, 70, 2048
     A, B = rnd(Kd, M, seed=41).to(DEV), rnd(Kd, N, seed=42).to(DEV)                   # TN: both reduction-major
     Cb = torch.zeros(M + 2, N + 6, device=DEV)
     K.gemm(A, B, Cb, M, N, Kd, M, N, N + 6, False, False, split_k=4, alpha=0.5)
-    close(Cb[:M, :N], 0.5 * (A.double().t() @ B.double()), 2e-5, "split-K atomics")
+    close(Cb[:M, :N], 0.5 * (A.double().t() @ B.double()), 2e-5, "split-K")
     assert float(Cb[M:].abs().max()) == 0.0 and float(Cb[:, N:].abs().max()) == 0.0
     nb, T, dh = 3, 90, 32
     lens = torch.tensor([90, 41, 7], dtype=torch.int32, device=DEV)
