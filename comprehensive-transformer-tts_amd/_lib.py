@@ -39,11 +39,20 @@ class GemmDesc(C.Structure):
         ("E", _vp), ("rowsub", _vp),
         ("sk_ws", _vp), ("sk_ws_bytes", _i64),
         ("epi_bwd", _i32),
+        ("split_out", _vp), ("split_out_floats", _i64),
     ]
+
+
+class PsumTask(C.Structure):
+    """ctts_psum_task of include/ctts.h"""
+    _fields_ = [("src", _vp), ("dst", _vp), ("n", _i64), ("stride", _i64), ("count", _i32), ("alpha", _f32)]
 
 
 # name -> argtypes (every function returns int status except the two listed below)
 _SIGNATURES = {
+    "ctts_gemm_split_plan": [C.POINTER(GemmDesc), C.POINTER(_i32), C.POINTER(_i64)],
+    "ctts_partial_sums": [C.POINTER(PsumTask), C.c_int, _vp],
+    "ctts_reduce_parts": [C.c_int, _i64, C.c_int],
     "ctts_gemm": [C.POINTER(GemmDesc), _vp],
     "ctts_gemm_takes_persistent": [C.POINTER(GemmDesc)],
     "ctts_gemm_ws_enable": [C.c_int],
@@ -56,18 +65,18 @@ _SIGNATURES = {
     "ctts_relmha_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_relmha_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
                         _f32, _f32, _vp, _u32, _vp],
-    "ctts_weighted_colsum": [_vp, _vp, _vp, _i64, C.c_int, _f32, C.c_int, _vp, _vp],
-    "ctts_epilogue_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _u32, _f32, C.c_int, _vp, _vp],
+    "ctts_weighted_colsum": [_vp, _vp, _vp, _i64, C.c_int, _f32, C.c_int, _vp, _vp, _vp],
+    "ctts_epilogue_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _vp, _u32, _f32, C.c_int, _vp, _vp, _vp],
     "ctts_row_tile_map": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "ctts_conv_weight_repack": [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_lr_index": [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
     "ctts_lr_gather_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_lr_gather_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_embedding_fwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp],
-    "ctts_embedding_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_embedding_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "ctts_positions": [_vp, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp],
     "ctts_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp, _vp],
-    "ctts_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _u32, _vp, C.c_int, _vp, _vp, _vp],
+    "ctts_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _u32, _vp, C.c_int, _vp, _vp, _vp, _vp],
     "ctts_colstats": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],
     "ctts_bn_finalize": [_vp, C.c_int, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     "ctts_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp],
@@ -78,7 +87,7 @@ _SIGNATURES = {
     "ctts_softmax_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_act_dropout_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],
     "ctts_rowscale_dropout": [_vp, _vp, _i64, C.c_int, _vp, _f32, _vp, _u32, _vp],
-    "ctts_colsum": [_vp, _vp, _i64, C.c_int, _i64, _f32, C.c_int, _vp, _vp],
+    "ctts_colsum": [_vp, _vp, _i64, C.c_int, _i64, _f32, C.c_int, _vp, _vp, _vp],
     "ctts_reflect_pad": [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_stft_magnitude": [_vp, _i64, _vp, _i64, _vp, _i64, C.c_int, _vp],
     "ctts_log_clamp_transpose": [_vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp],

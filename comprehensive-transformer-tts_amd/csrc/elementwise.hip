@@ -97,7 +97,8 @@ __device__ __forceinline__ void ctts_colsum_emit(float tot, float* s64, float* _
 // C = row width of the (possibly folded) view; a dense narrow matrix [R, creal] (creal < 64) is read as [R/k, k*creal] so that all
 // 64 lanes carry data; view column c accumulates into channel c % creal.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C,
-                                                      int creal, long ld, float scale, unsigned char* ws, int G, int accumulate) {
+                                                      int creal, long ld, float scale, unsigned char* ws, int G, int accumulate,
+                                                      float* __restrict__ parts) {
   __shared__ float s[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
   const long stripe = (rows + gridDim.y - 1) / gridDim.y;
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   __syncthreads();
   float tot[1] = {0.f};
   if (ty == 0) { const int l = threadIdx.x; tot[0] = s[0][l] + s[1][l] + s[2][l] + s[3][l]; }
+  if (parts) {                 // deferred: this stripe's partial row; ctts_partial_sums adds the stripes in order later
+    if (ty == 0 && c < C) parts[(long)blockIdx.y * C + c] = tot[0];
+    return;
+  }
   if (!ctts_ordered_colsum<float, 1>(tot, ws, blockIdx.x, blockIdx.y, gridDim.y, G)) return;
   ctts_colsum_emit(tot[0], s[0], out, c, C, creal, scale, accumulate);
 }
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restri
                                                             const float* __restrict__ z, float* __restrict__ dz, float* __restrict__ gm,
                                                             float* __restrict__ dbias, long rows, int C, int act, float p_drop,
                                                             const uint64_t* seed, uint32_t drop_offset, float bias_scale,
-                                                            unsigned char* ws, int G, int accumulate) {
+                                                            unsigned char* ws, int G, int accumulate, float* __restrict__ parts) {
   __shared__ float s[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
   const long stripe = (rows + gridDim.y - 1) / gridDim.y;
@@ -144,11 +149,15 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restri
       a += g;
     }
   }
-  if (!dbias) return;
+  if (!dbias && !parts) return;
   s[ty][threadIdx.x & 63] = a;
   __syncthreads();
   float tot[1] = {0.f};
   if (ty == 0) { const int l = threadIdx.x; tot[0] = s[0][l] + s[1][l] + s[2][l] + s[3][l]; }
+  if (parts) {
+    if (ty == 0 && c < C) parts[(long)blockIdx.y * C + c] = tot[0];
+    return;
+  }
   if (!ctts_ordered_colsum<float, 1>(tot, ws, blockIdx.x, blockIdx.y, gridDim.y, G)) return;
   ctts_colsum_emit(tot[0], s[0], dbias, c, C, C, bias_scale, accumulate);
 }
@@ -255,7 +264,7 @@ namespace {
 // out[c] (+)= scale * sum_r w[r] * x[r,c]: weight gradient of a one-output Linear (N = 1 heads of the duration / energy predictors)
 __global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                float* __restrict__ out, long rows, int C, float scale,
-                                                               unsigned char* ws, int G, int accumulate) {
+                                                               unsigned char* ws, int G, int accumulate, float* __restrict__ parts) {
   __shared__ float s[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
   const long stripe = (rows + gridDim.y - 1) / gridDim.y;
@@ -269,6 +278,10 @@ __global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __res
   __syncthreads();
   float tot[1] = {0.f};
   if (ty == 0) { const int l = threadIdx.x; tot[0] = s[0][l] + s[1][l] + s[2][l] + s[3][l]; }
+  if (parts) {
+    if (ty == 0 && c < C) parts[(long)blockIdx.y * C + c] = tot[0];
+    return;
+  }
   if (!ctts_ordered_colsum<float, 1>(tot, ws, blockIdx.x, blockIdx.y, gridDim.y, G)) return;
   ctts_colsum_emit(tot[0], s[0], out, c, C, C, scale, accumulate);
 }
@@ -281,45 +294,67 @@ static int colsum_stripes(int gx, long want, bool have_ws) {
   return (int)max((long)1, min(want, min(cap, (long)CTTS_RED_MAX_GROUPS * 64)));
 }
 
+int ctts_layernorm_bwd_blocks(int rows, int C);      // norm.hip
+
+// Deferred mode of the column-sum entry points (`parts` != NULL): every stripe writes its partial row [C] to parts[stripe][C] and nothing
+// else happens - no tickets, no tail; the caller adds the stripes in order later, many reductions in one launch (ctts_partial_sums).
+// ctts_reduce_parts(kind, rows, C) = the number of partial rows the launch will write (0: this shape has no deferred mode).
+//   kind 0: ctts_colsum   1: ctts_weighted_colsum   2: ctts_epilogue_bwd (bias gradient)   3: ctts_layernorm_bwd (rows of 2 C: dgamma | dbeta)
+extern "C" int ctts_reduce_parts(int kind, int64_t rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  const int gx = (C + 63) / 64;
+  if (gx > CTTS_RED_MAX_COLBLOCKS) return 0;
+  switch (kind) {
+    case 0: if (C * 2 <= 64 && rows % 2 == 0) return 0;           // narrow matrices are folded: immediate mode only
+            return colsum_stripes(gx, min((long)max(1, 1024 / gx), (long)rows / 64), true);
+    case 1: return colsum_stripes(gx, min((long)max(1, 1024 / gx), (long)rows / 64), true);
+    case 2: return colsum_stripes(gx, min((long)max(1, 2048 / gx), (long)rows / 32), true);
+    case 3: return ctts_layernorm_bwd_blocks((int)rows, C);
+    default: return 0;
+  }
+}
+
 extern "C" int ctts_weighted_colsum(const float* x, const float* w, float* out, int64_t rows, int C, float scale, int accumulate,
-                                    void* ws, void* stream) {
-  CTTS_REQUIRE(x && w && out && C > 0 && (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS, "ctts_weighted_colsum: bad arguments");
+                                    void* ws, float* parts, void* stream) {
+  CTTS_REQUIRE(x && w && (out || parts) && C > 0 && (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS, "ctts_weighted_colsum: bad arguments");
+  CTTS_REQUIRE(!parts || rows > 0, "ctts_weighted_colsum: deferred mode needs rows > 0");
   hipStream_t st = (hipStream_t)stream;
   if (rows == 0) {
     if (!accumulate && ctts_zero_async(out, sizeof(float) * C, st) != 0) { ctts_set_error("ctts_weighted_colsum: zero fill failed"); return -2; }
     return 0;
   }
   const int gx = (C + 63) / 64;
-  const int gy = colsum_stripes(gx, min((long)max(1, 1024 / gx), (long)rows / 64), ws != nullptr);
+  const int gy = colsum_stripes(gx, min((long)max(1, 1024 / gx), (long)rows / 64), ws != nullptr || parts != nullptr);
   hipLaunchKernelGGL(weighted_colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, w, out, (long)rows, C, scale, (unsigned char*)ws,
-                     ctts_red_group(gy), accumulate);
+                     ctts_red_group(gy), accumulate, parts);
   CTTS_CHECK_LAUNCH("ctts_weighted_colsum");
   return 0;
 }
 
 extern "C" int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* ws,
-                           void* stream) {
-  CTTS_REQUIRE(x && out && C > 0 && (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS, "ctts_colsum: bad arguments");
+                           float* parts, void* stream) {
+  CTTS_REQUIRE(x && (out || parts) && C > 0 && (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS, "ctts_colsum: bad arguments");
+  CTTS_REQUIRE(!parts || ctts_reduce_parts(0, rows, C) > 0, "ctts_colsum: this shape has no deferred mode (ctts_reduce_parts = 0)");
   hipStream_t st = (hipStream_t)stream;
   if (rows == 0) {
     if (!accumulate && ctts_zero_async(out, sizeof(float) * C, st) != 0) { ctts_set_error("ctts_colsum: zero fill failed"); return -2; }
     return 0;
   }
   int k = 1;                                   // fold narrow dense matrices so that a wave reads 64 useful floats per row
-  if (ld == C)
+  if (ld == C && !parts)
     while (C * k * 2 <= 64 && rows % (k * 2) == 0) k *= 2;
   const int Cv = C * k, gx = (Cv + 63) / 64;
   const long Rv = rows / k;
-  const int gy = colsum_stripes(gx, min((long)max(1, 1024 / gx), Rv / 64), ws != nullptr);
+  const int gy = colsum_stripes(gx, min((long)max(1, 1024 / gx), Rv / 64), ws != nullptr || parts != nullptr);
   hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, st, x, out, Rv, Cv, C, (long)ld * k, scale, (unsigned char*)ws,
-                     ctts_red_group(gy), accumulate);
+                     ctts_red_group(gy), accumulate, parts);
   CTTS_CHECK_LAUNCH("ctts_colsum");
   return 0;
 }
 
 extern "C" int ctts_epilogue_bwd(const float* dy, const float* rowscale, const float* z, float* dz, float* gm, float* dbias,
                                  int64_t rows, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, float bias_scale,
-                                 int accumulate_bias, void* ws, void* stream) {
+                                 int accumulate_bias, void* ws, float* parts, void* stream) {
   CTTS_REQUIRE(dy && dz && rows >= 0 && C > 0 && p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed), "ctts_epilogue_bwd: bad arguments");
   CTTS_REQUIRE(!dbias || (C + 63) / 64 <= CTTS_RED_MAX_COLBLOCKS, "ctts_epilogue_bwd: C too large for the bias-gradient reduction");
   hipStream_t st = (hipStream_t)stream;
@@ -329,9 +364,10 @@ extern "C" int ctts_epilogue_bwd(const float* dy, const float* rowscale, const f
   }
   const int gx = (C + 63) / 64;
   const long want = min((long)max(1, 2048 / gx), (long)rows / 32);
-  const int gy = dbias ? colsum_stripes(gx, want, ws != nullptr) : (int)max((long)1, want);
+  CTTS_REQUIRE(!parts || rows > 0, "ctts_epilogue_bwd: deferred bias gradient needs rows > 0");
+  const int gy = (dbias || parts) ? colsum_stripes(gx, want, ws != nullptr || parts != nullptr) : (int)max((long)1, want);
   hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(gx, gy), dim3(256), 0, st, dy, rowscale, act ? z : nullptr, dz, gm, dbias, (long)rows, C, act,
-                     p_drop, seed, drop_offset, bias_scale, (unsigned char*)ws, ctts_red_group(gy), accumulate_bias);
+                     p_drop, seed, drop_offset, bias_scale, (unsigned char*)ws, ctts_red_group(gy), accumulate_bias, parts);
   CTTS_CHECK_LAUNCH("ctts_epilogue_bwd");
   return 0;
 }
@@ -373,5 +409,85 @@ extern "C" int ctts_log_clamp_transpose(const float* mel_fm, float* out, int B, 
   hipLaunchKernelGGL(log_clamp_transpose_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mel_fm, out, F, n_mel,
                      clip, total);
   CTTS_CHECK_LAUNCH("ctts_log_clamp_transpose");
+  return 0;
+}
+
+
+// ---------------------------------------------------------------- deferred ordered reductions, many per launch (round 4)
+// dst[i] += alpha * (src[0*stride + i] + src[1*stride + i] + ... + src[(count-1)*stride + i]), partials added in index order: the second
+// half of every split-K weight gradient, bias / LayerNorm column sum of a backward stage, finished by ONE launch per PSUM_BATCH tasks
+// instead of one tail (or one reduce launch) per layer.  Workgroup b works on 1024 consecutive elements of the task whose block range
+// contains b.
+namespace {
+constexpr int PSUM_BATCH = 24;
+struct PsumBatch {
+  const float* src[PSUM_BATCH];
+  float* dst[PSUM_BATCH];
+  long n[PSUM_BATCH];
+  long stride[PSUM_BATCH];
+  int count[PSUM_BATCH];
+  float alpha[PSUM_BATCH];
+  int first_block[PSUM_BATCH + 1];
+  int ntasks;
+};
+
+__global__ __launch_bounds__(256) void partial_sums_kernel(const PsumBatch b) {
+  int t = 0;
+  while (t + 1 < b.ntasks && (int)blockIdx.x >= b.first_block[t + 1]) ++t;        // uniform; <= 24 steps
+  const float* src = b.src[t];
+  float* dst = b.dst[t];
+  const long n = b.n[t], stride = b.stride[t];
+  const int count = b.count[t];
+  const float alpha = b.alpha[t];
+  const long i0 = ((long)(blockIdx.x - b.first_block[t]) * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  const bool vec = i0 + 4 <= n && !(stride & 3) && !((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15);
+  if (vec) {
+    const float4* p = reinterpret_cast<const float4*>(src + i0);
+    const long s4 = stride >> 2;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= count; s += 4) {
+      const float4 v0 = p[(long)s * s4], v1 = p[(long)(s + 1) * s4], v2 = p[(long)(s + 2) * s4], v3 = p[(long)(s + 3) * s4];
+      a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+      a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+      a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+      a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+    }
+    for (; s < count; ++s) { const float4 v = p[(long)s * s4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    float4 c = *reinterpret_cast<float4*>(dst + i0);
+    c.x += alpha * a.x; c.y += alpha * a.y; c.z += alpha * a.z; c.w += alpha * a.w;
+    *reinterpret_cast<float4*>(dst + i0) = c;
+  } else {
+    for (int q = 0; q < 4 && i0 + q < n; ++q) {
+      float a = 0.f;
+      for (int s = 0; s < count; ++s) a += src[(long)s * stride + i0 + q];
+      dst[i0 + q] += alpha * a;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ctts_partial_sums(const ctts_psum_task* tasks, int ntasks, void* stream) {
+  CTTS_REQUIRE(ntasks >= 0 && (tasks || ntasks == 0), "ctts_partial_sums: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < ntasks; t0 += PSUM_BATCH) {
+    PsumBatch b;
+    b.ntasks = 0;
+    int blocks = 0;
+    for (int t = t0; t < ntasks && t < t0 + PSUM_BATCH; ++t) {
+      const ctts_psum_task& k = tasks[t];
+      CTTS_REQUIRE(k.src && k.dst && k.n >= 0 && k.count >= 0 && k.stride >= k.n, "ctts_partial_sums: bad task %d", t);
+      if (k.n == 0 || k.count == 0) continue;
+      const int i = b.ntasks++;
+      b.src[i] = k.src; b.dst[i] = k.dst; b.n[i] = k.n; b.stride[i] = k.stride; b.count[i] = k.count; b.alpha[i] = k.alpha;
+      b.first_block[i] = blocks;
+      blocks += (int)((k.n + 1023) / 1024);
+    }
+    if (b.ntasks == 0) continue;
+    b.first_block[b.ntasks] = blocks;
+    hipLaunchKernelGGL(partial_sums_kernel, dim3(blocks), dim3(256), 0, st, b);
+    CTTS_CHECK_LAUNCH("ctts_partial_sums");
+  }
   return 0;
 }

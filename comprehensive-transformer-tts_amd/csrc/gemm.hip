@@ -984,7 +984,11 @@ extern "C" int ctts_row_tile_map(const int32_t* row_lens, int row_T, int row_hal
   return 0;
 }
 
-extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
+namespace {
+struct GemmSplitPlan { int deferred_ok; int count; long stride; };
+}
+// plan != nullptr: no launch - only answer how a split-K launch of this descriptor would lay out its partial matrices
+static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan) {
   CTTS_REQUIRE(dp != nullptr, "ctts_gemm: null descriptor");
   ctts_gemm_desc d = *dp;
   CTTS_REQUIRE(d.A && d.B && d.C, "ctts_gemm: null operand pointer");
@@ -1002,11 +1006,12 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
   CTTS_REQUIRE(!d.E || (d.rowsub && d.split_k <= 1 && !d.bias && !d.act && d.p_drop == 0.f && !d.R && !d.rowscale && !d.Z),
                "ctts_gemm: the E/rowsub epilogue excludes bias, activation, dropout, residual, rowscale and split-K");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  {
+  if (plan) {
+    plan->deferred_ok = 0;
+    if (d.split_k <= 1 || ctts_gemm_takes_weight_stationary(&d) || ctts_gemm_takes_persistent(&d)) return 0;
+  } else {
     const int ws = ctts_gemm_ws_try(d, st);      // weight-stationary kernel (gemm_ws.hip) for K = 256 linears with many rows
     if (ws != 0) return ws > 0 ? 0 : ws;
-  }
-  {
     const int sk = ctts_gemm_sk_try(d, st);      // persistent stream-K kernel (gemm_sk.hip) when the descriptor is eligible
     if (sk != 0) return sk > 0 ? 0 : sk;
   }
@@ -1072,22 +1077,34 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
     // Ordered split-K (gemm_common.h; splitk_reduce_kernel above): one partial matrix [M, N] per (batch, split) in the
     // caller's workspace.  split_k is an upper bound: it is lowered until the partials fit (never below 2 - "C += alpha A B" is what
     // split_k > 1 means).
-    CTTS_REQUIRE(d.sk_ws && d.sk_ws_bytes >= (int64_t)CTTS_WS_BYTES,
+    CTTS_REQUIRE(plan || d.split_out || (d.sk_ws && d.sk_ws_bytes >= (int64_t)CTTS_WS_BYTES),
                  "ctts_gemm: split_k > 1 needs the workspace (ctts_workspace_bytes() bytes, zero-filled once) in sk_ws - partial sums "
                  "are added in a fixed order through it, the library has no floating-point atomics");
     const long per_split = (long)d.nb0 * d.nb1 * d.M * gemm_partial_ld(d.N);
-    const long cap = (long)CTTS_WS_SLAB_FLOATS / per_split;
-    CTTS_REQUIRE(cap >= 2 && (long)d.M * gemm_partial_ld(d.N) * 4 < 0x7FFF0000L, "ctts_gemm: split-K output [%d, %d] x %d batches does not fit the workspace",
-                 d.M, d.N, d.nb0 * d.nb1);
+    // split_out: the caller keeps the partial matrices and adds them itself later (ctts_partial_sums, many GEMMs per launch) - no reduce launch
+    const long room = plan ? (1L << 60) : (d.split_out ? d.split_out_floats : (long)CTTS_WS_SLAB_FLOATS);
+    const long cap = room / per_split;
+    CTTS_REQUIRE(cap >= 2 && (long)d.M * gemm_partial_ld(d.N) * 4 < 0x7FFF0000L, "ctts_gemm: split-K output [%d, %d] x %d batches does not fit the %s",
+                 d.M, d.N, d.nb0 * d.nb1, d.split_out ? "caller's split_out buffer" : "workspace");
     if (d.split_k > cap) d.split_k = (int)cap;
   }
   const bool split = d.split_k > 1;
+  const int kround = kind == K_BUF_K2 ? 2 * BK : BK;          // the K granularity of the kernel's split (its `chunk`)
+  if (plan) {
+    if (split && d.nb0 * d.nb1 == 1 && !d.lens && d.K > 0 && !(d.a_kc && d.row_lens)) {
+      const int chunk = ((d.K + d.split_k - 1) / d.split_k + kround - 1) / kround * kround;
+      plan->deferred_ok = 1;
+      plan->count = (d.K + chunk - 1) / chunk;
+      plan->stride = (long)d.M * gemm_partial_ld(d.N);
+    }
+    return 0;
+  }
   const ctts_gemm_desc d_user = d;                 // what the reduce launch accumulates into
   if (split) {
     // the tile kernels see the partial matrices as their output: C = P [z][split][M][ldp], plain stores (alpha = 1, no epilogue terms);
     // workgroup (z, split) adds split * M * ldc itself.  Whole tiles of padded rows are "zero-filled" into P_0 and skipped by the reduce.
     const long ldp = gemm_partial_ld(d.N);
-    d.C = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(d.sk_ws) + CTTS_WS_SLABS);
+    d.C = d.split_out ? d.split_out : reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(d.sk_ws) + CTTS_WS_SLABS);
     d.ldc = ldp;
     d.sC1 = (long)d.split_k * d.M * ldp;
     d.sC0 = (long)d.nb1 * d.sC1;
@@ -1105,8 +1122,24 @@ extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) {
     case K_VEC128: rc = dispatch_layout<128, 128, true>(d, st); break;
     default: rc = dispatch_layout<64, 64, true>(d, st); break;
   }
-  if (rc != 0 || !split) return rc;
+  if (rc != 0 || !split || d_user.split_out) return rc;
   ctts_gemm_desc dr = d_user;
   dr.split_k = d.split_k;                          // (possibly lowered above)
-  return splitk_reduce(dr, BMs, kind == K_BUF_K2 ? 2 * BK : BK, st);      // kround: the K granularity of the kernel's split (its `chunk`)
+  return splitk_reduce(dr, BMs, kround, st);
+}
+
+extern "C" int ctts_gemm(const ctts_gemm_desc* dp, void* stream) { return gemm_impl(dp, stream, nullptr); }
+
+// Deferred split-K (ctts_gemm_desc.split_out): would ctts_gemm run this descriptor as a split-K launch of the tile kernels whose partial
+// matrices the caller may keep and add later?  Returns 1 and fills *count (partial matrices that will be written: P_0 .. P_count-1) and
+// *stride (floats between them; each is [M, N rounded up to 4] row-major), else 0 (stream-K / weight-stationary take it, split_k <= 1,
+// batched or length-limited launches).  Give ctts_gemm a split_out buffer of at least split_k * stride floats.
+extern "C" int ctts_gemm_split_plan(const ctts_gemm_desc* dp, int32_t* count, int64_t* stride) {
+  GemmSplitPlan pl = {0, 0, 0};
+  ctts_gemm_desc d = *dp;
+  d.split_out = nullptr;
+  if (gemm_impl(&d, nullptr, &pl) != 0 || !pl.deferred_ok) return 0;
+  if (count) *count = pl.count;
+  if (stride) *stride = pl.stride;
+  return 1;
 }

@@ -185,43 +185,71 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __r
   }
 }
 
-// One workgroup of EMB_WAVES waves per vocabulary row v: wave w scans the 64-id chunks w, w + EMB_WAVES, ... in order, ballots each chunk
-// for its row and sums the selected gradient rows in registers; the waves' sums are then added through LDS in wave order.  The order of
-// every addition is fixed by (v, chunk, position), not by timing: the result is bit-reproducible (round 3 issued one float atomic
-// per (row, chunk, channel)).  A popular row (the unvoiced pitch bin, ~30 % of all frames) is spread over the 16 waves.
+// Workgroup (v, g) of EMB_WAVES waves: vocabulary row v, group g of the 64-id chunks.  Wave w scans the chunks c0 + w, c0 + w + EMB_WAVES,
+// ... of its group in order, ballots each chunk for its row and sums the selected gradient rows in registers (four rows in flight); the
+// waves' sums are added through LDS in wave order, the groups' sums through the workspace in group order by the workgroup that takes the
+// row's last ticket (ctts_common.h).  The order of every addition is fixed by (v, chunk, position), not by timing: bit-reproducible
+// (round 3 issued one float atomic per (row, chunk, channel)).  A popular row (the unvoiced pitch bin, ~30 % of all frames) is spread
+// over NG x 16 waves.
 constexpr int EMB_WAVES = 16;
 template <int NC>   // floats per lane: C <= 64 * NC
 __global__ __launch_bounds__(64 * EMB_WAVES) void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dy,
                                                                         float* __restrict__ dw, long n, int C, int V, int padding_idx,
-                                                                        int accumulate) {
+                                                                        int accumulate, unsigned char* ws) {
   __shared__ float s_acc[EMB_WAVES][NC * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int v = blockIdx.x;
+  const int v = blockIdx.x, g = blockIdx.y, NG = gridDim.y;
   if (v == padding_idx) return;                   // its gradient row stays as it is (zero-filled by the launcher unless accumulating)
+  const long chunks = (n + 63) / 64, cpg = (chunks + NG - 1) / NG;
+  const long c_end = min(chunks, (long)(g + 1) * cpg);
   float acc[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) acc[i] = 0.f;
-  for (long base = (long)wave * 64; base < n; base += 64 * EMB_WAVES) {
-    const long p = base + lane;
+  for (long ch = (long)g * cpg + wave; ch < c_end; ch += EMB_WAVES) {
+    const long base = ch * 64, p = base + lane;
     unsigned long long m = __ballot(p < n && ids[p] == (long long)v);
     while (m) {
-      const int b = __builtin_ctzll(m);
-      m &= m - 1;
-      const float* row = dy + (base + b) * C;
+      int bpos[4];
+      float x[4][NC];
 #pragma unroll
-      for (int i = 0; i < NC; ++i) {
-        const int c = lane + 64 * i;
-        if (c < C) acc[i] += row[c];
+      for (int u = 0; u < 4; ++u) {                // up to four selected rows in flight, added in position order
+        bpos[u] = m ? __builtin_ctzll(m) : -1;
+        if (m) m &= m - 1;
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* row = dy + (base + (bpos[u] < 0 ? 0 : bpos[u])) * C;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          const int c = lane + 64 * i;
+          x[u][i] = (bpos[u] >= 0 && c < C) ? row[c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < NC; ++i) acc[i] += x[u][i];
     }
   }
 #pragma unroll
   for (int i = 0; i < NC; ++i) s_acc[wave][i * 64 + lane] = acc[i];
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 64 * EMB_WAVES) {
-    float a = 0.f;
+  float a = 0.f;
+  const int c = threadIdx.x;                      // C <= 512 < 1024 threads: thread c finishes channel c
+  if (c < C) {
 #pragma unroll
     for (int w = 0; w < EMB_WAVES; ++w) a += s_acc[w][c];
+  }
+  if (NG > 1) {
+    float* p1 = reinterpret_cast<float*>(ws + CTTS_WS_RED_P1);
+    unsigned* t1 = reinterpret_cast<unsigned*>(ws + CTTS_WS_RED_T1);
+    if (c < C) ctts_st_agent(p1 + ((long)v * NG + g) * C + c, a);
+    if (!ctts_arrive_last(t1 + v * CTTS_RED_MAX_GROUPS, (unsigned)NG)) return;
+    a = 0.f;
+    if (c < C)
+      for (int gg = 0; gg < NG; ++gg) a += ctts_ld_agent(p1 + ((long)v * NG + gg) * C + c);
+  }
+  if (c < C) {
     float* o = dw + (long)v * C + c;
     *o = accumulate ? *o + a : a;
   }
@@ -240,7 +268,7 @@ extern "C" int ctts_embedding_fwd(const int64_t* ids, const float* weight, float
 }
 
 extern "C" int ctts_embedding_bwd(const int64_t* ids, const float* dy, float* dweight, int64_t n, int C, int V, int padding_idx,
-                                  int accumulate, void* stream) {
+                                  int accumulate, void* ws, void* stream) {
   CTTS_REQUIRE(ids && dy && dweight && n >= 0 && C > 0 && C <= 512 && V > 0, "ctts_embedding_bwd: bad arguments (C <= 512)");
   hipStream_t st = (hipStream_t)stream;
   // every non-padding row is WRITTEN by its workgroup; only the padding row (and everything when n == 0) needs the zero fill
@@ -253,11 +281,20 @@ extern "C" int ctts_embedding_bwd(const int64_t* ids, const float* dy, float* dw
     }
   }
   if (n == 0) return 0;
-  const dim3 grid(V), block(64 * EMB_WAVES);
+  // groups of chunks per vocabulary row: enough workgroups to fill the chip and to spread a popular row, within the workspace's partial
+  // area (one C-float partial per workgroup) and ticket rows; without a workspace: one workgroup per row
+  int NG = 1;
+  if (ws && V <= CTTS_RED_MAX_COLBLOCKS) {
+    const long chunks = (n + 63) / 64;
+    const long cap = (long)(CTTS_WS_RED_P1_BYTES / sizeof(float)) / ((long)V * C);
+    NG = (int)max(1L, min(min(8L, cap), chunks / (2 * EMB_WAVES)));
+  }
+  const dim3 grid(V, NG), block(64 * EMB_WAVES);
   const long long* idp = (const long long*)ids;
-  if (C <= 64) hipLaunchKernelGGL((embedding_bwd_kernel<1>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx, accumulate);
-  else if (C <= 256) hipLaunchKernelGGL((embedding_bwd_kernel<4>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx, accumulate);
-  else hipLaunchKernelGGL((embedding_bwd_kernel<8>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx, accumulate);
+  unsigned char* w8 = (unsigned char*)ws;
+  if (C <= 64) hipLaunchKernelGGL((embedding_bwd_kernel<1>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx, accumulate, w8);
+  else if (C <= 256) hipLaunchKernelGGL((embedding_bwd_kernel<4>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx, accumulate, w8);
+  else hipLaunchKernelGGL((embedding_bwd_kernel<8>), grid, block, 0, st, idp, dy, dweight, (long)n, C, V, padding_idx, accumulate, w8);
   CTTS_CHECK_LAUNCH("ctts_embedding_bwd");
   return 0;
 }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                              float* __restrict__ dbeta, int rows, int C, float p_drop,
                                                              const uint64_t* seed, uint32_t drop_offset,
                                                              const float* __restrict__ rowscale, const float* __restrict__ dres,
-                                                             unsigned char* ws, int G, int accumulate) {
+                                                             unsigned char* ws, int G, int accumulate, float* __restrict__ parts) {
   __shared__ float s_red[2][4][V * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
@@ -170,6 +170,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   } else {
 #pragma unroll
     for (int k = 0; k < 8 * V; ++k) tot[k] = 0.f;
+  }
+  if (parts) {                 // deferred: this workgroup's partial row [dgamma (C) | dbeta (C)]; ctts_partial_sums adds the rows in order later
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < 4 * V; ++k) {
+        const int ch = k * 64 + lane;
+        if (ch < C) { parts[(long)blockIdx.x * 2 * C + ch] = tot[k]; parts[(long)blockIdx.x * 2 * C + C + ch] = tot[4 * V + k]; }
+      }
+    }
+    return;
   }
   if (!ctts_ordered_colsum<float, 8 * V>(tot, ws, 0, blockIdx.x, gridDim.x, G)) return;
   if (wave == 0) {
@@ -352,12 +362,24 @@ extern "C" int ctts_layernorm_fwd(const float* x, const float* gamma, const floa
   return 0;
 }
 
+// workgroups of a ctts_layernorm_bwd launch with a workspace (or in deferred mode) = partial rows it produces
+static int ln_bwd_block_cap() {
+  static const int ln_blocks_env = getenv("CTTS_LN_BWD_BLOCKS") ? atoi(getenv("CTTS_LN_BWD_BLOCKS")) : 256;     // tuning knob
+  return max(1, min(ln_blocks_env, 512));       // the workspace keeps one partial (2 C floats) per workgroup: 512 x 8 KB = the 4 MiB partial area
+}
+int ctts_layernorm_bwd_blocks(int rows, int C) {
+  if (rows <= 0) return 0;
+  const int cap = ln_bwd_block_cap();
+  return C <= 256 ? min((rows + 15) / 16, cap) : (C <= 512 ? min((rows + 7) / 8, cap) : min((rows + 3) / 4, cap));
+}
+
 extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                   const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int C,
                                   float p_drop, const uint64_t* seed, uint32_t drop_offset, const float* rowscale,
-                                  int accumulate, const float* dres, void* ws, void* stream) {
-  CTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "ctts_layernorm_bwd: null pointer");
+                                  int accumulate, const float* dres, void* ws, float* parts, void* stream) {
+  CTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && ((dgamma && dbeta) || parts), "ctts_layernorm_bwd: null pointer");
   CTTS_REQUIRE((C % 4) == 0 && C <= 1024 && C > 0, "ctts_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
+  CTTS_REQUIRE(!parts || rows > 0, "ctts_layernorm_bwd: deferred mode needs rows > 0");
   hipStream_t st = (hipStream_t)stream;
   if (rows == 0) {
     if (!accumulate && (ctts_zero_async(dgamma, sizeof(float) * C, st) != 0 || ctts_zero_async(dbeta, sizeof(float) * C, st) != 0)) {
@@ -366,23 +388,18 @@ extern "C" int ctts_layernorm_bwd(const float* dy, const float* x, const float* 
     }
     return 0;
   }
-  static const int ln_blocks_env = getenv("CTTS_LN_BWD_BLOCKS") ? atoi(getenv("CTTS_LN_BWD_BLOCKS")) : 256;     // tuning knob
-  // the workspace keeps one partial (2 C floats) per workgroup (256 x 8 KB = 2 MiB of the 4 MiB partial area); without one: one workgroup
-  const int ln_blocks = ws ? max(1, min(ln_blocks_env, 512)) : 1;
-  const int blocks = min((rows + 3) / 4, ln_blocks);
+  // without a workspace (and not deferred): one workgroup - slow, still deterministic
+  const int nb = (ws || parts) ? ctts_layernorm_bwd_blocks(rows, C) : 1;
   unsigned char* w8 = (unsigned char*)ws;
-  if (C <= 256) {
-    const int nb = min((rows + 15) / 16, ln_blocks);
+  if (C <= 256)
     hipLaunchKernelGGL((layernorm_bwd_kernel<1, 4>), dim3(nb), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx,
-                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres, w8, ctts_red_group(nb), accumulate);
-  } else if (C <= 512) {
-    const int nb = min((rows + 7) / 8, ln_blocks);
+                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres, w8, ctts_red_group(nb), accumulate, parts);
+  else if (C <= 512)
     hipLaunchKernelGGL((layernorm_bwd_kernel<2, 2>), dim3(nb), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx,
-                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres, w8, ctts_red_group(nb), accumulate);
-  } else {
-    hipLaunchKernelGGL((layernorm_bwd_kernel<4, 1>), dim3(blocks), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
-                       C, p_drop, seed, drop_offset, rowscale, dres, w8, ctts_red_group(blocks), accumulate);
-  }
+                       dgamma, dbeta, rows, C, p_drop, seed, drop_offset, rowscale, dres, w8, ctts_red_group(nb), accumulate, parts);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_kernel<4, 1>), dim3(nb), dim3(256), 0, st, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
+                       C, p_drop, seed, drop_offset, rowscale, dres, w8, ctts_red_group(nb), accumulate, parts);
   CTTS_CHECK_LAUNCH("ctts_layernorm_bwd");
   return 0;
 }

@@ -134,6 +134,54 @@ class WorkspaceErrorProbe:
         self.check()
 
 
+class PartialSink:
+    """Deferred ordered reductions of a backward stage (include/ctts.h ctts_partial_sums).  While a sink is installed
+    (`set_partial_sink`; trainer.TrainStep does it around every backward stage), the wrappers below that accumulate a cross-workgroup sum
+    into `param.grad` - split-K weight gradients (`gemm(..., defer=True)`), bias / LayerNorm column sums - only have their kernels WRITE
+    the per-workgroup partials into a scratch tensor and register (partials, count, destination) here; `flush()` then finishes all of
+    them with one launch per 24 tasks, each sum in index order (bit-reproducible).  Replaces one reduce launch or one ticket tail per
+    layer (fs2: ~160 per step).  The destination must not be READ before flush() - TrainStep flushes at the end of every stage, before
+    the stage's gradient bucket is all-reduced."""
+
+    def __init__(self):
+        self.tasks = []
+        self.keep = []
+
+    def add(self, src, count, stride, n, dst, alpha, src_off=0, dst_off=0):
+        self.tasks.append((src.data_ptr() + 4 * int(src_off), dst.data_ptr() + 4 * int(dst_off), int(n), int(stride), int(count), float(alpha)))
+        self.keep.append((src, dst))
+
+    def flush(self):
+        if not self.tasks:
+            return
+        arr = (_lib.PsumTask * len(self.tasks))()
+        for t, (src, dst, n, stride, count, alpha) in zip(arr, self.tasks):
+            t.src, t.dst, t.n, t.stride, t.count, t.alpha = src, dst, n, stride, count, alpha
+        self.tasks = []
+        try:
+            _lib.check(_lib.load().ctts_partial_sums(arr, len(arr), _stream()), "ctts_partial_sums")
+        finally:
+            self.keep = []
+
+
+_SINK = None
+DEFER_ENABLED = _os.environ.get("CTTS_DEFER_SUMS", "1") != "0"       # A/B switch: 0 = every reduction finishes inside its own call
+
+
+def set_partial_sink(sink):
+    """install (or remove: None) the PartialSink of the current backward stage; returns the previous one"""
+    global _SINK
+    prev, _SINK = _SINK, (sink if DEFER_ENABLED else None)
+    return prev
+
+
+def _sink_for(dst):
+    """the active sink if `dst` (a tensor the caller wants a sum ADDED to) is dense in memory, else None"""
+    if _SINK is None or dst is None or not dst.is_contiguous():
+        return None
+    return _SINK
+
+
 def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_off=0, c_off=0, nb0=1, nb1=1,
                sA=(0, 0), sB=(0, 0), sC=(0, 0), lens=None, lim=(0, 0, 0), conv=None, conv_on_b=False, split_k=1, alpha=1.0,
                bias=None, Z=None, ldz=0, act=ACT_NONE, p_drop=0.0, seed=None, drop_offset=0, R=None, ldr=0, rowscale=None,
@@ -175,10 +223,20 @@ def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0
     return d
 
 
-def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):
-    """C = epi(alpha * (opA @ opB + bias)); see include/ctts.h ctts_gemm_desc (keyword arguments: _gemm_desc)."""
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, defer=False, **kw):
+    """C = epi(alpha * (opA @ opB + bias)); see include/ctts.h ctts_gemm_desc (keyword arguments: _gemm_desc).
+    defer=True (split_k > 1, C a dense [M, N] accumulation target such as param.grad): with a PartialSink installed the split-K partial
+    matrices stay in a scratch tensor and are added to C at the sink's flush instead of by a reduce launch of their own."""
     d = _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc, b_kc, **kw)
     lib = _lib.load()
+    if defer and _SINK is not None and d.split_k > 1 and d.nb0 * d.nb1 == 1 and ldc == N and N % 4 == 0:
+        cnt, stride = C.c_int32(0), C.c_int64(0)
+        if lib.ctts_gemm_split_plan(C.byref(d), C.byref(cnt), C.byref(stride)) == 1:
+            P = torch.empty(d.split_k * stride.value, dtype=torch.float32, device=A.device)
+            d.split_out, d.split_out_floats = P.data_ptr(), P.numel()
+            _lib.check(lib.ctts_gemm(C.byref(d), _stream()), "ctts_gemm")
+            _SINK.add(P, cnt.value, stride.value, M * N, Cout, d.alpha, dst_off=kw.get("c_off", 0))
+            return Cout
     _lib.check(lib.ctts_gemm(C.byref(d), _stream()), "ctts_gemm")
     return Cout
 
@@ -286,9 +344,18 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, p_drop=0.0, seed=None, drop_offset=0
     else:
         dgamma, dbeta = acc_into
     lib = _lib.load()
+    sink = _sink_for(dgamma) if (acc_into is not None and dbeta.is_contiguous()) else None
+    nparts = lib.ctts_reduce_parts(3, rows, Cc) if sink is not None else 0
+    if nparts > 1:              # deferred: the kernel only writes its per-workgroup partial rows [dgamma | dbeta]
+        parts = torch.empty(nparts, 2 * Cc, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ctts_layernorm_bwd(_p(_f32c(dy, "dy")), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), None, None, rows, Cc, p_drop,
+                                          _p(seed), drop_offset, _p(rowscale), 1, _p(dres), None, _p(parts), _stream()), "ctts_layernorm_bwd")
+        sink.add(parts, nparts, 2 * Cc, Cc, dgamma, 1.0)
+        sink.add(parts, nparts, 2 * Cc, Cc, dbeta, 1.0, src_off=Cc)
+        return dx, dgamma, dbeta
     _lib.check(lib.ctts_layernorm_bwd(_p(_f32c(dy, "dy")), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma),
                                       _p(dbeta), rows, Cc, p_drop, _p(seed), drop_offset, _p(rowscale), int(acc_into is not None),
-                                      _p(dres), _ws(dy), _stream()), "ctts_layernorm_bwd")
+                                      _p(dres), _ws(dy), None, _stream()), "ctts_layernorm_bwd")
     return dx, dgamma, dbeta
 
 
@@ -378,8 +445,15 @@ def colsum(x2d, ld=None, scale=1.0, acc_into=None):
     rows, Cc = x2d.shape
     out = torch.empty(Cc, dtype=torch.float32, device=x2d.device) if acc_into is None else acc_into
     lib = _lib.load()
+    sink = _sink_for(acc_into)
+    nparts = lib.ctts_reduce_parts(0, rows, Cc) if sink is not None else 0
+    if nparts > 1:
+        parts = torch.empty(nparts, Cc, dtype=torch.float32, device=x2d.device)
+        _lib.check(lib.ctts_colsum(_p(x2d), None, rows, Cc, ld if ld is not None else Cc, 1.0, 1, None, _p(parts), _stream()), "ctts_colsum")
+        sink.add(parts, nparts, Cc, Cc, out, scale)
+        return out
     _lib.check(lib.ctts_colsum(_p(x2d), _p(out), rows, Cc, ld if ld is not None else Cc, float(scale), int(acc_into is not None),
-                               _ws(x2d), _stream()), "ctts_colsum")
+                               _ws(x2d), None, _stream()), "ctts_colsum")
     return out
 
 
@@ -611,7 +685,7 @@ def embedding_bwd(ids, dy, V, padding_idx=-1, acc_into=None):
     dw = torch.empty(V, Cc, dtype=torch.float32, device=dy.device) if acc_into is None else acc_into
     lib = _lib.load()
     _lib.check(lib.ctts_embedding_bwd(_p(ids), _p(_f32c(dy, "dy")), _p(dw), ids.numel(), Cc, V, int(padding_idx),
-                                      int(acc_into is not None), _stream()), "ctts_embedding_bwd")
+                                      int(acc_into is not None), _ws(dy), _stream()), "ctts_embedding_bwd")
     return dw
 
 
@@ -626,9 +700,18 @@ def epilogue_bwd(dy, rowscale=None, z=None, act=0, p_drop=0.0, seed=None, drop_o
     if want_bias:
         dbias = bias_acc_into if bias_acc_into is not None else torch.empty(Cc, dtype=torch.float32, device=dy.device)
     lib = _lib.load()
+    sink = _sink_for(bias_acc_into) if want_bias else None
+    nparts = lib.ctts_reduce_parts(2, rows, Cc) if sink is not None else 0
+    if nparts > 1:              # deferred bias gradient: per-stripe partial rows, added at the sink's flush
+        parts = torch.empty(nparts, Cc, dtype=torch.float32, device=dy.device)
+        _lib.check(lib.ctts_epilogue_bwd(_p(_f32c(dy, "dy")), _p(rowscale), _p(z if act else None), _p(dz), _p(gm), None, rows, Cc,
+                                         int(act), float(p_drop), _p(seed), int(drop_offset), 1.0, 1, None, _p(parts), _stream()),
+                   "ctts_epilogue_bwd")
+        sink.add(parts, nparts, Cc, Cc, dbias, bias_scale)
+        return dz, gm, dbias
     _lib.check(lib.ctts_epilogue_bwd(_p(_f32c(dy, "dy")), _p(rowscale), _p(z if act else None), _p(dz), _p(gm), _p(dbias), rows, Cc,
                                      int(act), float(p_drop), _p(seed), int(drop_offset), float(bias_scale),
-                                     int(bias_acc_into is not None), _ws(dy) if want_bias else None, _stream()), "ctts_epilogue_bwd")
+                                     int(bias_acc_into is not None), _ws(dy) if want_bias else None, None, _stream()), "ctts_epilogue_bwd")
     return dz, gm, dbias
 
 
@@ -728,8 +811,16 @@ def weighted_colsum(x2d, w, scale=1.0, acc_into=None):
     rows, Cc = x2d.shape
     out = torch.empty(Cc, dtype=torch.float32, device=x2d.device) if acc_into is None else acc_into
     lib = _lib.load()
+    sink = _sink_for(acc_into)
+    nparts = lib.ctts_reduce_parts(1, rows, Cc) if sink is not None else 0
+    if nparts > 1:
+        parts = torch.empty(nparts, Cc, dtype=torch.float32, device=x2d.device)
+        _lib.check(lib.ctts_weighted_colsum(_p(_f32c(x2d, "x")), _p(_f32c(w, "w")), None, rows, Cc, 1.0, 1, None, _p(parts), _stream()),
+                   "ctts_weighted_colsum")
+        sink.add(parts, nparts, Cc, Cc, out, scale)
+        return out
     _lib.check(lib.ctts_weighted_colsum(_p(_f32c(x2d, "x")), _p(_f32c(w, "w")), _p(out), rows, Cc, float(scale),
-                                        int(acc_into is not None), _ws(x2d), _stream()), "ctts_weighted_colsum")
+                                        int(acc_into is not None), _ws(x2d), None, _stream()), "ctts_weighted_colsum")
     return out
 
 

@@ -357,7 +357,7 @@ class _LinearConv(torch.autograd.Function):
                 if gmaj is not None:             # GEMM-major parameter: the split-K partials are added straight into param.grad
                     with _wgrad_scope(True, dZ, x, rows=M):
                         K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, **rl)
+                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, defer=True, **rl)
                 else:
                     dwf = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
                     with _wgrad_scope(fused, dZ, x, dwf, rows=M):
@@ -392,7 +392,7 @@ class _LinearConv(torch.autograd.Function):
                 dW = _grad_of(w) if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
                 with _wgrad_scope(fused, dZ, x, rows=M):
                     K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha,
-                           tile_map=kmap, **rl)
+                           tile_map=kmap, defer=fused, **rl)
                 if fused:
                     dW = None
         return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None, None, None
@@ -493,7 +493,7 @@ class _PackedLinear(torch.autograd.Function):
         sk = max(2, _split_k_for(N, Kd, M))
         if all(g is not None for g in gs) and _adjacent(gs):
             G = torch.as_strided(gs[0], (N, Kd), (Kd, 1))
-            K.gemm(dY, x, G, N, Kd, M, N, Kd, Kd, False, False, split_k=sk)
+            K.gemm(dY, x, G, N, Kd, M, N, Kd, Kd, False, False, split_k=sk, defer=True)
             return (dX,) + (None,) * len(ws)
         dW = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
         K.gemm(dY, x, dW, N, Kd, M, N, Kd, Kd, False, False, split_k=sk)

@@ -72,12 +72,26 @@ class TrainStep:
         return losses[0]
 
     def _stages(self):
-        """generator over backward stages; forward + loss + stage 0 run on the first next()"""
+        """generator over backward stages; forward + loss + stage 0 run on the first next().  During every stage a kernels.PartialSink
+        collects the deferred ordered sums into the arena (split-K weight gradients, bias / LayerNorm column sums) and finishes them
+        with one launch per 24 sums at the END of the stage - before the stage's bucket is all-reduced / the optimizer reads it."""
+        from . import kernels as _K
         rec = ops.CutRecorder(self.cut_names)
         with rec:
             loss = self._forward_loss()
         self.flat_grad.zero_()
-        yield from rec.backward_stages(loss)
+        sink = _K.PartialSink()
+        gen = rec.backward_stages(loss)
+        while True:
+            prev = _K.set_partial_sink(sink)
+            try:
+                s = next(gen)
+                sink.flush()
+            except StopIteration:
+                return
+            finally:
+                _K.set_partial_sink(prev)
+            yield s
 
     def _optimizer_step(self):
         if self.fadam is not None:

@@ -87,9 +87,23 @@ typedef struct ctts_gemm_desc {
    * pre-activation, laid out like C with ldz) and  C = drop_mask(seed, drop_offset, m*N+n)/(1-p) * act'(Z) * alpha * acc : the data-gradient
    * GEMM of layer k+1 hands layer k its dZ directly, no separate pass over the [M,N] gradient.  Excludes bias / R / rowscale / E / split_k. */
   int32_t epi_bwd;
+  /* Deferred split-K (split_k > 1, tile kernels): the partial matrices P_0 .. P_count-1 ([M, N rounded up to 4] each, `stride` floats apart -
+   * ctts_gemm_split_plan) are written HERE and left for the caller, who adds them in order later with ctts_partial_sums - the second
+   * halves of all weight gradients of a backward stage in one launch instead of one reduce launch per GEMM.  NULL = the library adds them
+   * itself (through sk_ws) before ctts_gemm returns control of the stream. */
+  float* split_out; int64_t split_out_floats;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
+/* 1 (+ *count, *stride) when ctts_gemm would run `d` as a split-K launch whose partials the caller may keep (split_out); else 0. */
+int ctts_gemm_split_plan(const ctts_gemm_desc* d, int32_t* count, int64_t* stride);
+/* Deferred ordered reductions, many per launch: for every task  dst[i] += alpha * (src[i] + src[stride + i] + ... + src[(count-1)*stride + i]),
+ * i < n, partials added in index order (bit-reproducible).  `tasks` is a HOST array (copied into kernel arguments, 24 tasks per launch).
+ * Producers: ctts_gemm with split_out; ctts_colsum / ctts_weighted_colsum / ctts_epilogue_bwd / ctts_layernorm_bwd with `parts`
+ * (ctts_reduce_parts(kind, rows, C) partial rows of C floats - 2 C for kind 3 - written, nothing else). */
+typedef struct ctts_psum_task { const float* src; float* dst; int64_t n; int64_t stride; int32_t count; float alpha; } ctts_psum_task;
+int ctts_partial_sums(const ctts_psum_task* tasks, int ntasks, void* stream);
+int ctts_reduce_parts(int kind, int64_t rows, int C);     /* kind 0 colsum, 1 weighted_colsum, 2 epilogue_bwd bias, 3 layernorm_bwd; 0 = no deferred mode */
 /* Size of the per-stream workspace shared by ctts_gemm (sk_ws) and by every entry point below that takes a `ws` argument (ordered
  * cross-workgroup reductions: column sums, LayerNorm / BatchNorm parameter sums, loss sums).  `ws` = NULL is legal for those: the
  * reduction then runs on ONE workgroup per column block (slow, still deterministic).  ctts_gemm_workspace_bytes is the older name. */
@@ -113,14 +127,15 @@ int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, 
 
 /* out[c] (+)= scale * sum_r w[r] * x[r,c] (x [rows,C] dense): the weight gradient of a one-output Linear - the N = 1 heads of the
  * duration / energy predictors (modules.py:1296,1349) - as one streaming pass instead of a degenerate 1 x C GEMM. */
-int ctts_weighted_colsum(const float* x, const float* w, float* out, int64_t rows, int C, float scale, int accumulate, void* ws, void* stream);
+int ctts_weighted_colsum(const float* x, const float* w, float* out, int64_t rows, int C, float scale, int accumulate, void* ws, float* parts,
+                         void* stream);
 
 /* Backward of the ctts_gemm epilogue in one pass over dY [rows,C]:  gm = dY * rowscale[row] (optional output = gradient of the
  * residual R), dZ = gm * dropout_mask(seed, drop_offset, element) / (1-p) * act'(Z) (act as in ctts_gemm_desc; Z NULL or act 0: factor 1),
  * dbias[c] (+)= bias_scale * sum_rows dZ[.,c] (optional; bias_scale = the epilogue's alpha).  Any of rowscale, z, gm, dbias may be NULL. */
 int ctts_epilogue_bwd(const float* dy, const float* rowscale, const float* z, float* dz, float* gm, float* dbias, int64_t rows, int C,
                       int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, float bias_scale, int accumulate_bias,
-                      void* ws, void* stream);
+                      void* ws, float* parts, void* stream);
 
 /* m-tile schedule for padded-row skipping (see ctts_gemm_desc.tile_map): a 64-row tile is inactive when all its rows (b,t) belong to one
  * utterance b and t >= row_lens[b] + row_halo.  tile_map: 1 + ceil(M/64) int32. */
@@ -160,7 +175,8 @@ int ctts_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
                        const float* rowscale, void* stream);
 int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx, float* dgamma, float* dbeta, int rows, int C, float p_drop, const uint64_t* seed,
-                       uint32_t drop_offset, const float* rowscale, int accumulate, const float* dres, void* ws, void* stream);
+                       uint32_t drop_offset, const float* rowscale, int accumulate, const float* dres, void* ws, float* parts,
+                       void* stream);
 /* accumulate != 0: dgamma / dbeta (and ctts_colsum's out) are ADDED to - gradient-accumulation fusion straight into param.grad.
  * dres (optional, [rows,C]): added to dx - the gradient arriving through the residual connection around the pre-LN sub-layer
  * (x -> LN -> f -> + x), so the autograd sum of the two paths costs no extra pass. */
@@ -202,7 +218,7 @@ int ctts_act_dropout_bwd(const float* dg, const float* z, float* dz, int64_t row
                          float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream);
 int ctts_rowscale_dropout(const float* x, float* y, int64_t rows, int C, const float* rowscale, float p_drop,
                           const uint64_t* seed, uint32_t drop_offset, void* stream);
-int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* ws, void* stream);
+int ctts_colsum(const float* x, float* out, int64_t rows, int C, int64_t ld, float scale, int accumulate, void* ws, float* parts, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Mel front end (audio/stft.py:59-88,166-185): reflect-pad, |DFT| from the [F, 2*nbins]
@@ -247,7 +263,7 @@ int ctts_relshift_bwd(const float* dS, float* dPS, int nbatch, int T, void* stre
  *      one wave per (vocabulary row, 64-id chunk), register partial sums + one atomicAdd per channel.  padding_idx < 0: none. */
 int ctts_embedding_fwd(const int64_t* ids, const float* weight, float* out, int64_t n, int C, int V, void* stream);
 int ctts_embedding_bwd(const int64_t* ids, const float* dy, float* dweight, int64_t n, int C, int V, int padding_idx, int accumulate,
-                       void* stream);
+                       void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Unsupervised duration modelling.

@@ -184,6 +184,50 @@ def test_embedding_backward_is_bit_reproducible(V, C, n):
     assert float(dw[0].abs().max()) == 0.0
 
 
+def test_deferred_sums_through_a_partial_sink_match_fp64_and_are_reproducible():
+    """kernels.PartialSink (what trainer.TrainStep installs around every backward stage): the producers only write per-workgroup partials,
+    ONE ctts_partial_sums launch adds them - in index order - into the destinations.  Against float64, against the immediate mode
+    (rounding only: the association differs), bit-reproducible, and nothing is added before flush()."""
+    g = torch.Generator().manual_seed(11)
+    rows, C, N = 16384, 256, 1024
+    x = (torch.rand(rows, C, generator=g) - 0.5).to(DEV)
+    dyb = (torch.rand(rows, N, generator=g) - 0.5).to(DEV)
+    w = (torch.rand(rows, generator=g) - 0.5).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    y, mean, rstd = K.layernorm_fwd(x, gamma, torch.zeros(C, device=DEV), 1e-5)
+    A = (torch.rand(rows, N, generator=g) - 0.5).to(DEV)             # dZ [rows, N]: weight gradient dW[N, C] = dZ^T x over the rows
+
+    def run(deferred):
+        outs = [torch.full((C,), 0.25, device=DEV), torch.full((N,), 0.25, device=DEV), torch.full((C,), 0.25, device=DEV),
+                torch.full((C,), 0.25, device=DEV), torch.full((C,), 0.25, device=DEV), torch.full((N, C), 0.25, device=DEV)]
+        sink = K.PartialSink()
+        prev = K.set_partial_sink(sink if deferred else None)
+        try:
+            K.colsum(x, scale=0.5, acc_into=outs[0])
+            K.epilogue_bwd(dyb, want_bias=True, bias_scale=2.0, bias_acc_into=outs[1])
+            K.weighted_colsum(x, w, scale=0.5, acc_into=outs[2])
+            K.layernorm_bwd(x, x, gamma, mean, rstd, acc_into=(outs[3], outs[4]))
+            K.gemm(A, x, outs[5], N, C, rows, N, C, C, False, False, split_k=31, alpha=0.5, defer=True)
+            if deferred:
+                assert len(sink.tasks) == 6
+                torch.cuda.synchronize()
+                assert all(float((o - 0.25).abs().max()) == 0.0 for o in outs), "a destination changed before flush()"
+                sink.flush()
+                assert not sink.tasks and not sink.keep
+        finally:
+            K.set_partial_sink(prev)
+        return outs
+    d = _repeat_equal(lambda: run(True), name="deferred sums")
+    i = run(False)
+    xh = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    refs = [0.25 + 0.5 * x.double().sum(0), 0.25 + 2.0 * dyb.double().sum(0), 0.25 + 0.5 * (w.double()[:, None] * x.double()).sum(0),
+            0.25 + (x.double() * xh).sum(0), 0.25 + x.double().sum(0), 0.25 + 0.5 * (A.double().t() @ x.double())]
+    for k, (a, b, r) in enumerate(zip(d, i, refs)):
+        tol = 3e-6 * rows ** 0.5 if k < 5 else 3e-6 * rows / 16
+        _close(a, r, tol, f"deferred sum {k} vs fp64")
+        _close(a, b, tol, f"deferred vs immediate {k}")
+
+
 def _train(c5, block, use_graph, n=3, canonical=False):
     from ctts_amd.configs import get_configs
     from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
