@@ -52,6 +52,9 @@ def parse():
                          "the bench line reports max/mean valid frames per rank for both")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-overlap", action="store_true", help="DP: one blocking all-reduce of the whole arena after backward")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="DP over RCCL: capture the whole step - backward stages, bucketed all-reduces, optimizer - as ONE hipGraph (no host "
+                         "work between the stages); default: one graph per stage, eager collectives between the replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="full", choices=["full", "primary"],
                     help="primary: only C2 at physical cores; full: C1 and C2 at physical cores and at 8 threads")
@@ -247,7 +250,8 @@ def cpu_baseline(mode="full"):
             "runs": runs, "reference_over_port_time_ratio": ratio}
 
 
-def build_step(dev, rank, world, dataset, block, prosody, learn_alignment, batch, scaling, use_graph=True, overlap=True, shard_order="snake"):
+def build_step(dev, rank, world, dataset, block, prosody, learn_alignment, batch, scaling, use_graph=True, overlap=True, shard_order="strided",
+               graph_collectives=False):
     """model + loss + optimizer + synthetic batch + (captured) TrainStep of one BASELINE configuration"""
     import ctts_amd
     from ctts_amd.configs import get_configs
@@ -293,7 +297,8 @@ def build_step(dev, rank, world, dataset, block, prosody, learn_alignment, batch
     model_args = views[2:]
 
     step = TrainStep(model, loss_fn, optim, model_args, world=world, use_graph=use_graph, overlap=overlap,
-                     adam_step=optim.current_step)   # steady state: both the Noam schedule and Adam's bias correction at step 50,000
+                     adam_step=optim.current_step,   # steady state: both the Noam schedule and Adam's bias correction at step 50,000
+                     graph_collectives=graph_collectives)
     step.bind_static_buffer(packed.device_buffer)
     if prosody != "none" or learn_alignment:
         step.step_no = 100001                                 # every loss term on: bin-loss weight 1, prosody loss enabled
@@ -313,9 +318,11 @@ def build_step(dev, rank, world, dataset, block, prosody, learn_alignment, batch
         if ok:
             mode = (f"hipgraph({step.n_stages} backward stages, bucketed all-reduce between replays | clip+adam)" if step.staged
                     else "hipgraph(fwd+bwd | clip+adam)")
+            if step.g_all is not None:
+                mode = f"hipgraph(whole step: {step.n_stages} backward stages + bucketed all-reduces on a side stream + clip+adam in ONE graph)"
         else:
             print("[bench] running eager", file=sys.stderr)
-            step.graphs = step.g_opt = None
+            step.graphs = step.g_opt = step.g_all = None
     return {"step": step, "mode": mode, "batch_cpu": batch_cpu, "collated": collated, "packed": packed,
             "valid_frames": valid_frames, "padded_frames": padded_frames, "shard_balance": balance}
 
@@ -384,7 +391,7 @@ def main():
     from ctts_amd.synthetic import make_batch
 
     built = build_step(dev, rank, world, a.dataset, a.block, a.prosody, a.learn_alignment, a.batch, a.scaling,
-                       use_graph=not a.no_graph, overlap=not a.no_overlap, shard_order=a.shard)
+                       use_graph=not a.no_graph, overlap=not a.no_overlap, shard_order=a.shard, graph_collectives=a.graph_collectives)
     step, mode, batch_cpu, collated, packed = built["step"], built["mode"], built["batch_cpu"], built["collated"], built["packed"]
     valid_frames, padded_frames = built["valid_frames"], built["padded_frames"]
     if world > 1 and rank == 0:       # evidence for a SCALE run that N ranks and RCCL were really in play

@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("sk_ws", _vp), ("sk_ws_bytes", _i64),
         ("epi_bwd", _i32),
         ("split_out", _vp), ("split_out_floats", _i64),
+        ("split_overwrite", _i32),
     ]
 
 
@@ -53,6 +54,7 @@ _SIGNATURES = {
     "ctts_gemm_split_plan": [C.POINTER(GemmDesc), C.POINTER(_i32), C.POINTER(_i64)],
     "ctts_partial_sums": [C.POINTER(PsumTask), C.c_int, _vp],
     "ctts_reduce_parts": [C.c_int, _i64, C.c_int],
+    "ctts_xcd_probe": [_vp, C.c_int, _vp],
     "ctts_gemm": [C.POINTER(GemmDesc), _vp],
     "ctts_gemm_takes_persistent": [C.POINTER(GemmDesc)],
     "ctts_gemm_ws_enable": [C.c_int],

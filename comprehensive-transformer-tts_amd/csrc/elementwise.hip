@@ -446,15 +446,13 @@ __global__ __launch_bounds__(256) void partial_sums_kernel(const PsumBatch b) {
     const float4* p = reinterpret_cast<const float4*>(src + i0);
     const long s4 = stride >> 2;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0;
-    for (; s + 4 <= count; s += 4) {
-      const float4 v0 = p[(long)s * s4], v1 = p[(long)(s + 1) * s4], v2 = p[(long)(s + 2) * s4], v3 = p[(long)(s + 3) * s4];
-      a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
-      a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
-      a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
-      a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+    for (int s = 0; s < count; s += 8) {       // eight partials in flight (HBM latency, not bandwidth, bounds this loop), added in index order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (s + u < count) ? p[(long)(s + u) * s4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
     }
-    for (; s < count; ++s) { const float4 v = p[(long)s * s4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
     float4 c = *reinterpret_cast<float4*>(dst + i0);
     c.x += alpha * a.x; c.y += alpha * a.y; c.z += alpha * a.z; c.w += alpha * a.w;
     *reinterpret_cast<float4*>(dst + i0) = c;

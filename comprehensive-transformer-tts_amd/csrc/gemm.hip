@@ -930,42 +930,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ctts_gemm_desc
     if (d.lim_n) Nv = min(Nv, L);
     if (d.lim_k) Kv = min(Kv, L);
   }
-  if (Kv <= 0) return;
-  const int chunk = ((Kv + d.split_k - 1) / d.split_k + kround - 1) / kround * kround;
-  const int nact = (Kv + chunk - 1) / chunk;
+  const bool ow = d.split_overwrite != 0;      // C = alpha * sum (and ZERO outside the limits / in padded tiles) instead of C += : no pre-zeroed C
+  int nact = 0;
+  if (Kv > 0) {
+    const int chunk = ((Kv + d.split_k - 1) / d.split_k + kround - 1) / kround * kround;
+    nact = (Kv + chunk - 1) / chunk;
+  }
+  if (nact == 0 && !ow) return;
   const long ldp = gemm_partial_ld(d.N);
   const int n4 = (int)(ldp >> 2);
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   const int m = (int)(e / n4), n = (int)(e - (long)m * n4) * 4;
-  if (m >= Mv || n >= Nv) return;
-  if (d.a_kc && d.row_lens) {             // the GEMM zero-filled whole tiles of padded rows and wrote no partials for them
+  if (m >= d.M || n >= d.N) return;
+  bool live = m < Mv && n < Nv && nact > 0;
+  if (live && d.a_kc && d.row_lens) {          // the GEMM wrote no partials for whole tiles of padded rows (their result is defined as zero)
     const int row0 = m / BM * BM, last = min(row0 + BM, Mv) - 1;
     const int b0 = row0 / d.row_T, b1 = last / d.row_T;
-    if (b0 == b1 && (row0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo) return;
+    if (b0 == b1 && (row0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo) live = false;
   }
-  const float4* P = reinterpret_cast<const float4*>(gemm_partial_base(d, z, 0) + (long)m * ldp + n);
-  const long sstride = (long)d.M * ldp / 4;          // P_s of a batch are consecutive [M, ldp] matrices
+  if (!live && !ow) return;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  int s = 0;
-  for (; s + 4 <= nact; s += 4) {
-    const float4 v0 = P[(long)s * sstride], v1 = P[(long)(s + 1) * sstride], v2 = P[(long)(s + 2) * sstride], v3 = P[(long)(s + 3) * sstride];
-    a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
-    a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
-    a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
-    a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+  if (live) {
+    const float4* P = reinterpret_cast<const float4*>(gemm_partial_base(d, z, 0) + (long)m * ldp + n);
+    const long sstride = (long)d.M * ldp / 4;          // P_s of a batch are consecutive [M, ldp] matrices
+    for (int s = 0; s < nact; s += 8) {          // eight partials in flight, added in split order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (s + u < nact) ? P[(long)(s + u) * sstride] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
   }
-  for (; s < nact; ++s) { const float4 v = P[(long)s * sstride]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
   float* Cr = d.C + z0 * d.sC0 + z1 * d.sC1 + (long)m * d.ldc + n;
   const float al = d.alpha;
+  const int ncols = ow ? d.N : Nv;              // overwrite mode also zeroes the columns between the batch's limit and N
   if (n + 4 <= Nv && ((reinterpret_cast<uintptr_t>(Cr) & 15) == 0)) {
-    float4 c = *reinterpret_cast<float4*>(Cr);
+    float4 c = ow ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(Cr);
     c.x += al * a.x; c.y += al * a.y; c.z += al * a.z; c.w += al * a.w;
     *reinterpret_cast<float4*>(Cr) = c;
   } else {
     const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (n + q < Nv) Cr[q] += al * av[q];
+      if (n + q < ncols) Cr[q] = (ow ? 0.f : Cr[q]) + ((live && n + q < Nv) ? al * av[q] : 0.f);
   }
 }
 

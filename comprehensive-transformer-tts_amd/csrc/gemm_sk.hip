@@ -467,6 +467,26 @@ int sk_env(const char* name, int dflt) {
 // split-K tickets + slabs, tickets + partials of the ordered column reductions.
 extern "C" size_t ctts_gemm_workspace_bytes(void) { return CTTS_WS_BYTES; }
 extern "C" size_t ctts_workspace_bytes(void) { return CTTS_WS_BYTES; }
+
+// The persistent kernel's schedule and its slab hand-off assume the default (SPX) dispatch: workgroup b of a launch runs on XCD b % 8
+// (sk_plan.h cuts the unit space per XCD; a cut tile's owner and its contributors share an XCD and therefore an L2).  This probe makes
+// that checkable: workgroup b writes the hardware's XCC_ID into out[b]; the host compares with b % 8 (kernels.gemm_workspace does it
+// once per device and refuses to enable the persistent kernel under any other partition mode).
+namespace {
+__global__ void xcd_probe_kernel(int32_t* out) {
+  if (threadIdx.x == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    out[blockIdx.x] = (int32_t)(id & 0xF);
+  }
+}
+}  // namespace
+extern "C" int ctts_xcd_probe(int32_t* out, int nblocks, void* stream) {
+  CTTS_REQUIRE(out && nblocks > 0, "ctts_xcd_probe: bad arguments");
+  hipLaunchKernelGGL(xcd_probe_kernel, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, out);
+  CTTS_CHECK_LAUNCH("ctts_xcd_probe");
+  return 0;
+}
 extern "C" const uint32_t* ctts_workspace_error_word(const void* ws) {
   return ws ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(ws) + CTTS_WS_SK_FLAGS) + SK_MAX_WG : nullptr;
 }
@@ -529,7 +549,8 @@ static int sk_try(const ctts_gemm_desc& din, hipStream_t st, bool launch) {
   p.whole_tiles = p.nkb < split_from ? 1 : 0;
   static const int chan_major = sk_env("CTTS_SK_CONV_ORDER", 1);      // 1: (channel block, tap) K order for conv views on A; 0: (tap, channel)
   p.conv_chan_major = (conv && d.a_kc && !d.conv_on_b && chan_major && d.K % d.conv_cin == 0) ? 1 : 0;
-  p.accumulate = d.split_k > 1 ? 1 : 0;      // ABI: split_k > 1 means "add alpha * A B to C" (gemm.hip does it with atomics)
+  // ABI: split_k > 1 means "add alpha * A B to C" (plain read-modify-write by the tile's owner) - unless split_overwrite asks for C = ...
+  p.accumulate = (d.split_k > 1 && !d.split_overwrite) ? 1 : 0;
   p.debug = debug;
   // schedule groups: 4 groups of n-tiles when that divides (an XCD pair shares a group), else one group
   p.gw = (p.tiles_n % 4 == 0) ? p.tiles_n / 4 : p.tiles_n;

@@ -140,17 +140,21 @@ class BucketedReducer:
     """All-reduce(sum)/world of the arena, one bucket per backward stage, on a side stream (overlaps the following stages).
 
     launch(s): call right after backward stage s has been ISSUED on the current stream; finish(): current stream waits for all
-    buckets.  With world == 1 both are no-ops."""
+    buckets.  With world == 1 both are no-ops - unless `always_reduce` asks for the collectives anyway (a one-rank RCCL group on a
+    single GPU: the only way to run the RCCL code path, its stream ordering and ReduceOp.AVG on a 1-GPU box).
+    Both calls are capture-safe: under hipGraph capture the side stream forks from and re-joins the capturing stream, so a step
+    captured with its collectives inside replays them without any host involvement (trainer.TrainStep graph_collectives)."""
 
-    def __init__(self, arena, stage_of, n_stages, world=None, group=None):
+    def __init__(self, arena, stage_of, n_stages, world=None, group=None, always_reduce=False):
         self.arena, self.group = arena, group
         self.world = (dist.get_world_size(group) if dist.is_initialized() else 1) if world is None else int(world)
+        self.active = self.world > 1 or (bool(always_reduce) and dist.is_initialized())
         by_stage = [[] for _ in range(n_stages)]
         for i, n in enumerate(arena.names):
             by_stage[stage_of(n)].append(i)
         self.ranges = [arena.ranges_of(ix) for ix in by_stage]
         self.is_cuda = arena.flat.is_cuda
-        self.comm = torch.cuda.Stream(device=arena.flat.device) if (self.is_cuda and self.world > 1) else None
+        self.comm = torch.cuda.Stream(device=arena.flat.device) if (self.is_cuda and self.active) else None
         self.launched = 0
 
     def bucket_bytes(self):
@@ -171,7 +175,7 @@ class BucketedReducer:
 
     def launch(self, s):
         self.launched += 1
-        if self.world <= 1 or not self.ranges[s]:
+        if not self.active or not self.ranges[s]:
             return
         if self.comm is None:
             self._reduce(s)

@@ -80,9 +80,35 @@ def gemm_workspace(device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     ws = _SK_WS.get(key)
     if ws is None:
+        if SK_ENABLED and not torch.cuda.is_current_stream_capturing():
+            check_xcd_dispatch(device)
         ws = torch.zeros(_lib.load().ctts_workspace_bytes(), dtype=torch.uint8, device=device)
         _SK_WS[key] = ws
     return ws
+
+
+_XCD_OK = {}
+
+
+def check_xcd_dispatch(device):
+    """Once per device: workgroup b of a launch must run on XCD b % 8 (SPX, the default compute partition of an MI355X) - the schedule
+    and the slab hand-off of the persistent stream-K GEMM are built on it (nothing asserted the mode).  Any other mapping
+    switches that kernel OFF for the process (the tile kernels take its launches) and says so once."""
+    global SK_ENABLED
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _XCD_OK:
+        return _XCD_OK[idx]
+    out = torch.full((64,), -1, dtype=torch.int32, device=device)
+    _lib.check(_lib.load().ctts_xcd_probe(_p(out), 64, _stream()), "ctts_xcd_probe")
+    got = out.cpu().tolist()
+    ok = got == [b % 8 for b in range(64)]
+    _XCD_OK[idx] = ok
+    if not ok:
+        import warnings
+        SK_ENABLED = False
+        warnings.warn(f"ctts_amd: workgroups are not dispatched round-robin over 8 XCDs on cuda:{idx} (XCC_ID of workgroups 0..15: {got[:16]}) - "
+                      "not the SPX partition mode; the persistent stream-K GEMM is disabled, the tile kernels take its launches")
+    return ok
 
 
 workspace = gemm_workspace
@@ -185,7 +211,7 @@ def _sink_for(dst):
 def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_off=0, c_off=0, nb0=1, nb1=1,
                sA=(0, 0), sB=(0, 0), sC=(0, 0), lens=None, lim=(0, 0, 0), conv=None, conv_on_b=False, split_k=1, alpha=1.0,
                bias=None, Z=None, ldz=0, act=ACT_NONE, p_drop=0.0, seed=None, drop_offset=0, R=None, ldr=0, rowscale=None,
-               row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None, use_sk=None, epi_bwd=False):
+               row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None, use_sk=None, epi_bwd=False, split_overwrite=False):
     d = GemmDesc()
     d.A, d.B, d.C = _p(A, a_off), _p(B, b_off), _p(Cout, c_off)
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -215,6 +241,7 @@ def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0
         d.tile_map = _p(tile_map)
     d.E, d.rowsub = _p(E), _p(rowsub)
     d.epi_bwd = int(bool(epi_bwd))
+    d.split_overwrite = int(bool(split_overwrite) and int(split_k) > 1)
     if int(split_k) > 1 or ((SK_ENABLED if use_sk is None else use_sk) and nb0 * nb1 == 1 and M * N * K >= (1 << 24)):
         # split-K sums its pieces in a fixed order through the workspace (required); large unbatched GEMMs may run on the persistent
         # stream-K kernel (the library decides: ctts_gemm_sk_try)

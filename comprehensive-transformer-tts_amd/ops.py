@@ -348,8 +348,8 @@ class _LinearConv(torch.autograd.Function):
                 dg = dict(conv=(T, pad, N), alpha=alpha, row_halo=pad, tile_map=pr.tile_map(pad, M) if pr is not None else None, **rl)
                 if sk > 1 and K.gemm_takes_persistent(dZ, wd, x, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=1, **dg):
                     sk = 1          # the persistent stream-K kernel balances the reduction itself: no split, no zero fill, no atomics
-                dX = torch.zeros_like(x) if sk > 1 else torch.empty_like(x)
-                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=sk, **dg)
+                dX = torch.empty_like(x)             # split: the ordered reduce launch writes every element (zeros in padded tiles)
+                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=sk, split_overwrite=True, **dg)
             if ctx.needs_input_grad[1]:
                 Kd = ksize * Cin
                 fused = _fusable(w)
@@ -632,10 +632,11 @@ class _SelfAttention(torch.autograd.Function):
         K.gemm(qkv, qkv, S, T, T, dh, C3, C3, T, True, True, a_off=0, b_off=C, nb0=B, nb1=n_heads,
                sA=(T * C3, dh), sB=(T * C3, dh), sC=(n_heads * T * T, T * T), lens=lens, lim=(1, 1, 0), alpha=scale)
         K.softmax_fwd(S, lens, B, n_heads, T)
-        out = torch.zeros(B, T, C, dtype=torch.float32, device=qkv.device)
         sk = _attn_split_k(B * n_heads, T, dh)
+        # split: the ordered reduce launch WRITES every element (zeros for query rows >= len); unsplit: the kernel leaves those rows alone
+        out = (torch.empty if sk > 1 else torch.zeros)(B, T, C, dtype=torch.float32, device=qkv.device)
         K.gemm(S, qkv, out, T, dh, T, T, C3, C, True, False, b_off=2 * C, nb0=B, nb1=n_heads,
-               sA=(n_heads * T * T, T * T), sB=(T * C3, dh), sC=(T * C, dh), lens=lens, lim=(1, 0, 1), split_k=sk)
+               sA=(n_heads * T * T, T * T), sB=(T * C3, dh), sC=(T * C, dh), lens=lens, lim=(1, 0, 1), split_k=sk, split_overwrite=True)
         ctx.save_for_backward(qkv, S, lens, out)
         ctx.n_heads = n_heads
         return out
@@ -650,11 +651,11 @@ class _SelfAttention(torch.autograd.Function):
         dh = C // H
         scale = dh ** -0.5
         sP = (H * T * T, T * T)
-        dqkv = torch.zeros_like(qkv)
         sk = _attn_split_k(B * H, T, dh)
+        dqkv = torch.empty_like(qkv) if sk > 1 else torch.zeros_like(qkv)      # split: the three reduce launches below write all of it
         # dV[key,d] = sum_q P[q,key] dO[q,d]
         K.gemm(P, dO, dqkv, T, dh, T, T, C, C3, False, False, c_off=2 * C, nb0=B, nb1=H, sA=sP, sB=(T * C, dh),
-               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), split_k=sk)
+               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), split_k=sk, split_overwrite=True)
         # dS[q,key] = P * (dO V^T - D),  D[q] = sum_key dP P = sum_d dO[q,d] O[q,d]: the softmax backward rides in the epilogue of the
         # dP GEMM (one read of P) instead of a separate pass that re-reads P and dP and rewrites dS
         Dv = K.rowdot_heads(dO, O, H)
@@ -663,10 +664,10 @@ class _SelfAttention(torch.autograd.Function):
                sC=sP, lens=lens, lim=(1, 1, 0), E=P, rowsub=Dv)
         # dQ[q,d] = scale * sum_key dS[q,key] K[key,d]
         K.gemm(dP, qkv, dqkv, T, dh, T, T, C3, C3, True, False, b_off=C, c_off=0, nb0=B, nb1=H, sA=sP, sB=(T * C3, dh),
-               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale, split_k=sk)
+               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale, split_k=sk, split_overwrite=True)
         # dK[key,d] = scale * sum_q dS[q,key] Q[q,d]
         K.gemm(dP, qkv, dqkv, T, dh, T, T, C3, C3, False, False, b_off=0, c_off=C, nb0=B, nb1=H, sA=sP, sB=(T * C3, dh),
-               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale, split_k=sk)
+               sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), alpha=scale, split_k=sk, split_overwrite=True)
         return dqkv, None, None
 
 

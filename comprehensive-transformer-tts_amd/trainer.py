@@ -20,11 +20,16 @@ from .dp import FlatGradArena, FlatAdam, BucketedReducer, stage_plan
 
 class TrainStep:
     def __init__(self, model, loss_fn, optim, model_args, world=1, group=None, use_graph=True, overlap=True, n_cuts=3,
-                 step_no=50001, fused_optimizer=True, max_norm=1.0, adam_step=0, force_staged=False):
+                 step_no=50001, fused_optimizer=True, max_norm=1.0, adam_step=0, force_staged=False, graph_collectives=None,
+                 always_reduce=False):
         """`model_args`: positional arguments of CompTransTTS.forward (static device tensors; the graphs read them in place).
         `optim`: loss.ScheduledOptim(..., capturable=True) - owns the Noam schedule and the device-resident lr.
         `adam_step`: Adam's bias-correction step count to start from (a resumed run: the restore step; `FlatAdam.load_state_dict`
-        sets it from a checkpoint).  `force_staged`: stage the backward pass even with world == 1 (tests)."""
+        sets it from a checkpoint).  `force_staged`: stage the backward pass even with world == 1 (tests).
+        `graph_collectives` (None = env CTTS_GRAPH_COLLECTIVES, default off): capture the WHOLE step - the backward stages, the bucketed
+        all-reduces on their side stream (RCCL collectives are capturable) and the optimizer - as ONE hipGraph, so a replayed step has
+        no host work at all between its stages; off: one graph per stage with eager collectives between the replays (works with every
+        backend; the only mode gloo supports).  `always_reduce`: issue the collectives with world == 1 too (1-GPU RCCL tests)."""
         self.model, self.loss_fn, self.optim, self.world = model, loss_fn, optim, int(world)
         self.args = list(model_args)
         self.loss_inputs = [None, None] + list(self.args)
@@ -40,15 +45,20 @@ class TrainStep:
             oc = optim._optimizer.defaults
             self.fadam = FlatAdam(self.arena, optim.lr_tensor, betas=tuple(oc["betas"]), eps=oc["eps"],
                                   weight_decay=oc["weight_decay"], max_norm=max_norm, current_step=adam_step)
-        self.staged = (self.world > 1 and overlap) or force_staged
+        self.staged = ((self.world > 1 or always_reduce) and overlap) or force_staged
         self.cut_names, stage_of = stage_plan(model, n_cuts)
         self.n_stages = len(self.cut_names) + 1
         if not self.staged:
             self.cut_names, self.n_stages = [], 1
             stage_of = lambda name: 0                                         # noqa: E731
-        self.reducer = BucketedReducer(self.arena, stage_of, self.n_stages, world=self.world, group=group)
+        self.reducer = BucketedReducer(self.arena, stage_of, self.n_stages, world=self.world, group=group, always_reduce=always_reduce)
+        if graph_collectives is None:
+            import os
+            graph_collectives = os.environ.get("CTTS_GRAPH_COLLECTIVES", "0") == "1"
+        self.graph_collectives = bool(graph_collectives) and self.reducer.active
         self.graphs = None              # [stage graphs], then the optimizer graph
         self.g_opt = None
+        self.g_all = None               # graph_collectives: the whole step in one graph
         self.loss_val = None
         self.static_buffer = None
         # the stream-K hand-off reports a failed wait into its workspace; watch that word (async copy every `probe_every` steps, checked
@@ -131,6 +141,15 @@ class TrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.graph_collectives:
+            # ONE graph: stages, collectives (forked onto the reducer's side stream inside the capture, joined by finish()) and optimizer
+            if self.fadam is None:
+                raise RuntimeError("graph_collectives needs the fused optimizer (torch's foreach clip + Adam are not capture-safe here)")
+            self.g_all = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_all, stream=side, capture_error_mode="thread_local"):
+                self._eager()
+            self.ws_probe.poll_and_check()
+            return
         # every stage is captured on the SAME stream (autograd runs a node's backward on the stream of its forward) and into one pool;
         # thread_local capture mode: the RCCL watchdog / a prefetch thread may touch the runtime while this thread captures
         graphs, gen, pool = [], self._stages(), None
@@ -167,7 +186,9 @@ class TrainStep:
         if self._calls % self.probe_every == 1:
             self.ws_probe.check()                       # the copy started `probe_every` steps ago has long landed: no stall
         self.optim.update_learning_rate()               # host scalar -> device lr tensor (outside the graphs)
-        if self.graphs is not None:
+        if self.g_all is not None:
+            self.g_all.replay()
+        elif self.graphs is not None:
             for s, g in enumerate(self.graphs):
                 g.replay()
                 self.reducer.launch(s)

@@ -92,6 +92,10 @@ typedef struct ctts_gemm_desc {
    * halves of all weight gradients of a backward stage in one launch instead of one reduce launch per GEMM.  NULL = the library adds them
    * itself (through sk_ws) before ctts_gemm returns control of the stream. */
   float* split_out; int64_t split_out_floats;
+  /* split_k > 1 (library-side sum only): C = alpha * A B instead of C += - every element of the [M, N] block of every batch is WRITTEN,
+   * zero where the per-batch limits (lens) or a whole tile of padded rows (row_lens) leave nothing to compute: the caller needs no
+   * pre-zeroed C (one fill launch per attention / convolution data gradient saved). */
+  int32_t split_overwrite;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
@@ -112,6 +116,9 @@ size_t ctts_gemm_workspace_bytes(void);
 /* Error word of the stream-K hand-off in a workspace (0 = clean; n > 0: an owner gave up waiting for workgroup n - 1 and the launch's
  * result is invalid).  DEVICE pointer to one uint32 inside `ws`: copy it to the host (asynchronously, e.g. every N steps) and raise. */
 const uint32_t* ctts_workspace_error_word(const void* ws);
+/* out[b] = XCC_ID (the XCD) workgroup b of an nblocks-wide launch ran on.  The persistent stream-K kernel assumes b % 8 (the default SPX
+ * dispatch of an MI355X): callers verify once per device before handing ctts_gemm a workspace. */
+int ctts_xcd_probe(int32_t* out, int nblocks, void* stream);
 /* 1 when ctts_gemm would run this descriptor on the persistent stream-K kernel (sk_ws given, shape / alignment eligible, enough tiles
  * for the grid), else 0.  Callers that otherwise split the reduction (split_k > 1 + zero fill) ask first: the persistent kernel balances
  * the reduction itself and wants split_k = 1. */

@@ -70,8 +70,11 @@ def test_split_k_gemm_is_bit_reproducible_and_matches_fp64(M, N, Kd, split, layo
     assert torch.equal(out[M:], base[M:]) and torch.equal(out[:, N:], base[:, N:]), "written outside [:M, :N]"
 
 
-def test_split_k_batched_attention_gradient_is_reproducible():
-    """dQ = dS K with per-batch length limits and split_k = 2 (ops.self_attention's backward)"""
+@pytest.mark.parametrize("overwrite", [False, True])
+def test_split_k_batched_attention_gradient_is_reproducible(overwrite):
+    """dQ = dS K with per-batch length limits and split_k = 2 (ops.self_attention's backward).  split_overwrite: the reduce launch WRITES
+    the whole [T, dh] block of every batch - zeros for the query rows beyond the batch's length - so the caller passes an uninitialised
+    tensor (here: NaN) instead of a zero-filled one."""
     nb, T, dh = 6, 640, 128
     g = torch.Generator().manual_seed(5)
     lens = torch.tensor([640, 512, 333, 64, 7, 600], dtype=torch.int32, device=DEV)
@@ -79,15 +82,48 @@ def test_split_k_batched_attention_gradient_is_reproducible():
     Km = (torch.rand(nb, T, dh, generator=g) - 0.5).to(DEV)
 
     def run():
-        dQ = torch.zeros(nb, T, dh, device=DEV)
+        dQ = torch.full((nb, T, dh), float("nan"), device=DEV) if overwrite else torch.zeros(nb, T, dh, device=DEV)
         K.gemm(dS, Km, dQ, T, dh, T, T, dh, dh, True, False, nb0=nb, nb1=1, sA=(T * T, 0), sB=(T * dh, 0), sC=(T * dh, 0), lens=lens,
-               lim=(1, 0, 1), split_k=2)
+               lim=(1, 0, 1), split_k=2, split_overwrite=overwrite)
         return [dQ]
     out = _repeat_equal(run, name="batched split-K")[0]
+    assert torch.isfinite(out).all()
     for b in range(nb):
         L = int(lens[b])
         _close(out[b, :L], dS[b, :L, :L].double() @ Km[b, :L].double(), 2e-5, f"dQ b={b}")
-        assert float(out[b, L:].abs().max()) == 0.0 if L < T else True
+        assert L == T or float(out[b, L:].abs().max()) == 0.0
+
+
+def test_split_k_overwrite_conv_data_gradient_writes_padded_tiles_as_zero():
+    """Conv1d data gradient with ragged rows, split_k = 3 + split_overwrite into a NaN-filled dX: valid rows vs float64 through autograd of
+    F.conv1d, whole 64-row tiles of padding exactly zero, everything finite (ops._LinearConv.backward no longer zero-fills dX)."""
+    import torch.nn.functional as F
+    B, T, Cin, N, ks = 3, 256, 64, 128, 9
+    pad = (ks - 1) // 2
+    lens = torch.tensor([256, 100, 37], dtype=torch.int32, device=DEV)
+    g = torch.Generator().manual_seed(9)
+    w = ((torch.rand(N, Cin, ks, generator=g) - 0.5) * 0.2).to(DEV)
+    mask = (torch.arange(T, device=DEV)[None, :] < lens[:, None]).float()[..., None]
+    dZ = (torch.rand(B, T, N, generator=g) - 0.5).to(DEV) * mask
+    wd = torch.empty(Cin, ks * N, device=DEV)
+    K.conv_weight_repack(w.contiguous(), wd, N, Cin, ks, 1)
+    M = B * T
+
+    def run():
+        dX = torch.full((B, T, Cin), float("nan"), device=DEV)
+        K.gemm(dZ, wd, dX, M, Cin, ks * N, N, ks * N, Cin, True, True, conv=(T, pad, N), row_lens=lens, row_T=T, row_halo=pad,
+               tile_map=K.row_tile_map(lens, T, pad, M), split_k=3, split_overwrite=True, use_sk=False)
+        return [dX]
+    dX = _repeat_equal(run, name="conv dgrad split overwrite")[0]
+    assert torch.isfinite(dX).all()
+    x = torch.zeros(B, Cin, T, dtype=torch.float64, device=DEV, requires_grad=True)
+    F.conv1d(x, w.double(), padding=pad).backward(dZ.double().transpose(1, 2))
+    ref = x.grad.transpose(1, 2)
+    for b in range(B):
+        L = int(lens[b])
+        _close(dX[b, :L], ref[b, :L], 2e-5, f"conv dgrad b={b}")
+        t0 = (L + pad + 63) // 64 * 64
+        assert t0 >= T or float(dX[b, t0:].abs().max()) == 0.0
 
 
 def test_reduction_tickets_return_to_zero():

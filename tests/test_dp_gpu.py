@@ -207,3 +207,15 @@ def test_single_gpu_bench_line_has_roofline_and_pcie_rates():
     d = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
     assert d["n_gpus"] == 1 and d["roofline"]["frac"] > 0.3 and d["roofline"]["bound"] == "mfma"
     assert d["pcie_inclusive"]["value"] > 0.8 * d["value"]                  # one 8 MB H2D per step hides behind the previous step
+
+
+def test_rccl_one_rank_group_runs_the_collective_path_on_this_gpu():
+    """a 1-GPU box cannot host two RCCL ranks, but a ONE-rank RCCL group is legal - backend "nccl" (= RCCL),
+    world_size 1, the bucketed all-reduces with ReduceOp.AVG on their side stream: launched eagerly between eager stages, eagerly between
+    the replays of the four stage graphs, and captured INSIDE one whole-step hipGraph (trainer.TrainStep graph_collectives).  Each mode
+    must reproduce the loss trajectory and the final parameters of the step without collectives bit for bit (tools/try_rccl_world1.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "try_rccl_world1.py")], env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "backend=nccl" in r.stdout and r.stdout.count("identical to no-collective run: True") == 3
