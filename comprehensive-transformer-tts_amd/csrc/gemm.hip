@@ -587,8 +587,27 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
     tm = (int)(((long)tm * P) % tiles_m);
   }
   const int row0 = tm * BM, col0 = (wg % tiles_n) * BN;
-  if (row0 >= Mv || col0 >= Nv) return;
   float* Cb = d.C + z0 * d.sC0 + z1 * d.sC1;
+  // overwrite mode of an unsplit batched launch with per-batch limits: everything of the batch's [M, N] block outside the limits is
+  // WRITTEN as zero by the tile that covers it (the caller passes an uninitialised C: no fill launch per attention product)
+  const bool zero_outside = PARTIAL && d.split_overwrite && d.split_k <= 1;
+  if (row0 >= Mv || col0 >= Nv) {
+    if (zero_outside && row0 < d.M && col0 < d.N) {
+      const int nrows = min(BM, d.M - row0), ncols = min(BN, d.N - col0);
+      for (int e = threadIdx.x; e < nrows * ncols; e += 256) {
+        const int r = e / ncols, c = e - r * ncols;
+        Cb[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
+      }
+    }
+    return;
+  }
+  if (zero_outside && (row0 + BM > Mv || col0 + BN > Nv)) {      // the part of a straddling tile beyond the limits (the epilogue never stores there)
+    const int nrows = min(BM, d.M - row0), ncols = min(BN, d.N - col0);
+    for (int e = threadIdx.x; e < nrows * ncols; e += 256) {
+      const int r = e / ncols, c = e - r * ncols;
+      if (row0 + r >= Mv || col0 + c >= Nv) Cb[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
+    }
+  }
   if (d.split_k > 1) Cb += (long)split * d.M * d.ldc;      // split-K: C is the partial matrix P_split of the workspace (ctts_gemm rewrote the descriptor)
   if (A_KC && d.row_lens && !scheduled_active) {
     const int last = min(row0 + BM, Mv) - 1;
@@ -1096,6 +1115,8 @@ static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan
     if (d.split_k > cap) d.split_k = (int)cap;
   }
   const bool split = d.split_k > 1;
+  CTTS_REQUIRE(!(d.split_overwrite && !split && d.lens && (d.lim_m || d.lim_n)) || kind == K_BUF64 || kind == K_BUF_NARROW || kind == K_BUF128,
+               "ctts_gemm: split_overwrite on an unsplit length-limited launch needs the buffer-loader kernels (aligned operands)");
   const int kround = kind == K_BUF_K2 ? 2 * BK : BK;          // the K granularity of the kernel's split (its `chunk`)
   if (plan) {
     if (split && d.nb0 * d.nb1 == 1 && !d.lens && d.K > 0 && !(d.a_kc && d.row_lens)) {

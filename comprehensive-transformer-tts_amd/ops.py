@@ -561,7 +561,9 @@ def layer_norm(x, gamma, beta, eps, rowscale=None, p_drop=0.0, drop=None):
     return _LayerNorm.apply(x, gamma, beta, eps, rowscale, p_drop if seed is not None else 0.0, seed, off)
 
 
-_ATTN_SPLIT_K = int(_os.environ.get("CTTS_ATTN_SPLIT_K", "2"))      # tuning knob; 1 = off
+# tuning knob; 1 = off (default since round 4: with the ordered reduce launch a 2-way split of the [T, T] x [T, dh] products costs more
+# than the under-filled launch it avoids - fs2 step 23.73 -> 23.50 ms, same box)
+_ATTN_SPLIT_K = int(_os.environ.get("CTTS_ATTN_SPLIT_K", "1"))
 
 
 def _attn_split_k(nbatch, T, dh):
@@ -633,8 +635,8 @@ class _SelfAttention(torch.autograd.Function):
                sA=(T * C3, dh), sB=(T * C3, dh), sC=(n_heads * T * T, T * T), lens=lens, lim=(1, 1, 0), alpha=scale)
         K.softmax_fwd(S, lens, B, n_heads, T)
         sk = _attn_split_k(B * n_heads, T, dh)
-        # split: the ordered reduce launch WRITES every element (zeros for query rows >= len); unsplit: the kernel leaves those rows alone
-        out = (torch.empty if sk > 1 else torch.zeros)(B, T, C, dtype=torch.float32, device=qkv.device)
+        # "write everything" (split_overwrite): the query rows >= len are written as zeros by the launch itself - no fill launch
+        out = torch.empty(B, T, C, dtype=torch.float32, device=qkv.device)
         K.gemm(S, qkv, out, T, dh, T, T, C3, C, True, False, b_off=2 * C, nb0=B, nb1=n_heads,
                sA=(n_heads * T * T, T * T), sB=(T * C3, dh), sC=(T * C, dh), lens=lens, lim=(1, 0, 1), split_k=sk, split_overwrite=True)
         ctx.save_for_backward(qkv, S, lens, out)
@@ -652,7 +654,7 @@ class _SelfAttention(torch.autograd.Function):
         scale = dh ** -0.5
         sP = (H * T * T, T * T)
         sk = _attn_split_k(B * H, T, dh)
-        dqkv = torch.empty_like(qkv) if sk > 1 else torch.zeros_like(qkv)      # split: the three reduce launches below write all of it
+        dqkv = torch.empty_like(qkv)            # the three launches below write all of it ("write everything": zeros beyond each utterance's length)
         # dV[key,d] = sum_q P[q,key] dO[q,d]
         K.gemm(P, dO, dqkv, T, dh, T, T, C, C3, False, False, c_off=2 * C, nb0=B, nb1=H, sA=sP, sB=(T * C, dh),
                sC=(T * C3, dh), lens=lens, lim=(1, 0, 1), split_k=sk, split_overwrite=True)

@@ -92,9 +92,10 @@ typedef struct ctts_gemm_desc {
    * halves of all weight gradients of a backward stage in one launch instead of one reduce launch per GEMM.  NULL = the library adds them
    * itself (through sk_ws) before ctts_gemm returns control of the stream. */
   float* split_out; int64_t split_out_floats;
-  /* split_k > 1 (library-side sum only): C = alpha * A B instead of C += - every element of the [M, N] block of every batch is WRITTEN,
-   * zero where the per-batch limits (lens) or a whole tile of padded rows (row_lens) leave nothing to compute: the caller needs no
-   * pre-zeroed C (one fill launch per attention / convolution data gradient saved). */
+  /* "Write everything": every element of the [M, N] block of every batch is WRITTEN, zero where the per-batch limits (lens) or a whole
+   * tile of padded rows (row_lens) leave nothing to compute - the caller needs no pre-zeroed C (one fill launch per attention product /
+   * convolution data gradient saved).  With split_k > 1 (library-side sum only) this also turns C += alpha * A B into C = alpha * A B;
+   * with split_k <= 1 it only adds the zeros outside the limits of a batched, length-limited launch (buffer-loader kernels). */
   int32_t split_overwrite;
 } ctts_gemm_desc;
 

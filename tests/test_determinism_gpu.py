@@ -70,11 +70,12 @@ def test_split_k_gemm_is_bit_reproducible_and_matches_fp64(M, N, Kd, split, layo
     assert torch.equal(out[M:], base[M:]) and torch.equal(out[:, N:], base[:, N:]), "written outside [:M, :N]"
 
 
-@pytest.mark.parametrize("overwrite", [False, True])
-def test_split_k_batched_attention_gradient_is_reproducible(overwrite):
+@pytest.mark.parametrize("split,overwrite", [(2, False), (2, True), (1, True)])
+def test_split_k_batched_attention_gradient_is_reproducible(split, overwrite):
     """dQ = dS K with per-batch length limits and split_k = 2 (ops.self_attention's backward).  split_overwrite: the reduce launch WRITES
     the whole [T, dh] block of every batch - zeros for the query rows beyond the batch's length - so the caller passes an uninitialised
-    tensor (here: NaN) instead of a zero-filled one."""
+    tensor (here: NaN) instead of a zero-filled one; unsplit (split 1, the default of ops.self_attention since round 4) the tile kernel
+    writes those zeros itself."""
     nb, T, dh = 6, 640, 128
     g = torch.Generator().manual_seed(5)
     lens = torch.tensor([640, 512, 333, 64, 7, 600], dtype=torch.int32, device=DEV)
@@ -84,7 +85,7 @@ def test_split_k_batched_attention_gradient_is_reproducible(overwrite):
     def run():
         dQ = torch.full((nb, T, dh), float("nan"), device=DEV) if overwrite else torch.zeros(nb, T, dh, device=DEV)
         K.gemm(dS, Km, dQ, T, dh, T, T, dh, dh, True, False, nb0=nb, nb1=1, sA=(T * T, 0), sB=(T * dh, 0), sC=(T * dh, 0), lens=lens,
-               lim=(1, 0, 1), split_k=2, split_overwrite=overwrite)
+               lim=(1, 0, 1), split_k=split, split_overwrite=overwrite)
         return [dQ]
     out = _repeat_equal(run, name="batched split-K")[0]
     assert torch.isfinite(out).all()
@@ -237,6 +238,7 @@ def test_deferred_sums_through_a_partial_sink_match_fp64_and_are_reproducible():
         outs = [torch.full((C,), 0.25, device=DEV), torch.full((N,), 0.25, device=DEV), torch.full((C,), 0.25, device=DEV),
                 torch.full((C,), 0.25, device=DEV), torch.full((C,), 0.25, device=DEV), torch.full((N, C), 0.25, device=DEV)]
         sink = K.PartialSink()
+        sink.FLUSH_BYTES = 0                             # this test looks at the sink before its end-of-stage flush
         prev = K.set_partial_sink(sink if deferred else None)
         try:
             K.colsum(x, scale=0.5, acc_into=outs[0])
