@@ -408,7 +408,21 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_kernel(const ctts_g
     tm = (int)(((long)tm * P) % tiles_m);
   }
   const int row0 = tm * BM, col0 = (wg % tiles_n) * BN;
-  if (row0 >= Mv || col0 >= Nv) return;
+  {
+    // "write everything" (split_overwrite) on an unsplit launch with per-batch limits: the part of the batch's [M, N] block outside the
+    // limits is written as zero by the tile that covers it (same rule as gemm_buf_kernel)
+    const bool zero_outside = d.lens && d.split_overwrite && d.split_k <= 1;
+    const bool beyond = row0 >= Mv || col0 >= Nv;
+    if (zero_outside && row0 < d.M && col0 < d.N && (beyond || row0 + BM > Mv || col0 + BN > Nv)) {
+      float* Cz = d.C + z0 * d.sC0 + z1 * d.sC1;
+      const int nrows = min(BM, d.M - row0), ncols = min(BN, d.N - col0);
+      for (int e = threadIdx.x; e < nrows * ncols; e += 256) {
+        const int r = e / ncols, c = e - r * ncols;
+        if (row0 + r >= Mv || col0 + c >= Nv) Cz[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
+      }
+    }
+    if (beyond) return;
+  }
 
   if (A_KC && d.row_lens) {  // whole tile of padded rows -> zeros, no operand traffic, no MFMA
     const int last = min(row0 + BM, Mv) - 1;
@@ -1115,8 +1129,6 @@ static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan
     if (d.split_k > cap) d.split_k = (int)cap;
   }
   const bool split = d.split_k > 1;
-  CTTS_REQUIRE(!(d.split_overwrite && !split && d.lens && (d.lim_m || d.lim_n)) || kind == K_BUF64 || kind == K_BUF_NARROW || kind == K_BUF128,
-               "ctts_gemm: split_overwrite on an unsplit length-limited launch needs the buffer-loader kernels (aligned operands)");
   const int kround = kind == K_BUF_K2 ? 2 * BK : BK;          // the K granularity of the kernel's split (its `chunk`)
   if (plan) {
     if (split && d.nb0 * d.nb1 == 1 && !d.lens && d.K > 0 && !(d.a_kc && d.row_lens)) {

@@ -95,7 +95,7 @@ typedef struct ctts_gemm_desc {
   /* "Write everything": every element of the [M, N] block of every batch is WRITTEN, zero where the per-batch limits (lens) or a whole
    * tile of padded rows (row_lens) leave nothing to compute - the caller needs no pre-zeroed C (one fill launch per attention product /
    * convolution data gradient saved).  With split_k > 1 (library-side sum only) this also turns C += alpha * A B into C = alpha * A B;
-   * with split_k <= 1 it only adds the zeros outside the limits of a batched, length-limited launch (buffer-loader kernels). */
+   * with split_k <= 1 it only adds the zeros outside the limits of a batched, length-limited launch. */
   int32_t split_overwrite;
 } ctts_gemm_desc;
 

@@ -36,7 +36,7 @@ from torch.utils._python_dispatch import TorchDispatchMode
 agg = collections.defaultdict(int)
 VIEW = ("view", "reshape", "transpose", "permute", "expand", "slice", "select", "unsqueeze", "squeeze", "as_strided", "detach", "alias",
         "t.default", "_unsafe_view", "split", "unbind", "narrow", "empty", "size", "stride", "is_", "_local_scalar", "item", "numel", "dim",
-        "storage_offset", "sym_", "lift_fresh", "new_empty", "_to_copy" )
+        "storage_offset", "sym_", "lift_fresh", "new_empty")
 
 
 class Rec(TorchDispatchMode):
