@@ -55,6 +55,8 @@ _SIGNATURES = {
     "ctts_partial_sums": [C.POINTER(PsumTask), C.c_int, _vp],
     "ctts_reduce_parts": [C.c_int, _i64, C.c_int],
     "ctts_xcd_probe": [_vp, C.c_int, _vp],
+    "ctts_posembed_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _vp, _u32, _vp],
+    "ctts_posembed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _f32, _vp, _u32, C.c_int, _vp, _vp],
     "ctts_gemm": [C.POINTER(GemmDesc), _vp],
     "ctts_gemm_takes_persistent": [C.POINTER(GemmDesc)],
     "ctts_gemm_ws_enable": [C.c_int],

@@ -413,6 +413,104 @@ extern "C" int ctts_log_clamp_transpose(const float* mel_fm, float* out, int B, 
 }
 
 
+// ---------------------------------------------------------------- positional embedding add (round 4)
+// y = rowscale[row] * dropout(x + alpha * table[pos[row]])   -   `x + self.pos_embed_alpha * self.embed_positions(x)` followed by F.dropout
+// and the non-pad mask multiply (transformer_fs2.py:41-52,113-119; PitchPredictor.forward modules.py:1349-1351) in ONE launch instead of
+// int64 cast + gather + multiply + add + dropout / mask (five), and ONE in the backward (dx = mask / dropout of dy; dalpha = sum over all
+// elements of dx * table[pos], ordered cross-workgroup sum) instead of six.  alpha: device scalar (the [1] parameter) or NULL (= 1).
+namespace {
+__global__ __launch_bounds__(256) void posembed_fwd_kernel(const float4* __restrict__ x, const int32_t* __restrict__ pos, const float4* __restrict__ table,
+                                                            const float* __restrict__ alpha, const float* __restrict__ rowscale, float4* __restrict__ y,
+                                                            long n4, int C4, float p_drop, const uint64_t* seed, uint32_t drop_offset) {
+#pragma clang fp contract(off)          // x + alpha * pe with TWO roundings like torch's unfused sequence (HIP's __fmul_rn / __fadd_rn are plain operators)
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  const float a = alpha ? alpha[0] : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C4;
+    const int c = (int)(i - row * C4);
+    const float4 xv = x[i], tv = table[(long)pos[row] * C4 + c];
+    float v[4] = {xv.x + a * tv.x, xv.y + a * tv.y, xv.z + a * tv.z, xv.w + a * tv.w};      // no FMA (pragma above): bit-identical to the unfused sequence
+    const float sc = rowscale ? rowscale[row] : 1.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (do_drop) v[e] *= ctts_drop_scale(dkey, (uint32_t)(i * 4 + e), p_drop, inv_keep);
+      v[e] *= sc;
+    }
+    y[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void posembed_bwd_kernel(const float4* __restrict__ dy, const int32_t* __restrict__ pos, const float4* __restrict__ table,
+                                                            const float* __restrict__ rowscale, float4* __restrict__ dx, float* __restrict__ dalpha,
+                                                            long n4, int C4, float p_drop, const uint64_t* seed, uint32_t drop_offset,
+                                                            unsigned char* ws, int G, int accumulate) {
+  __shared__ float s_w[4];
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  float dot = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C4;
+    const int c = (int)(i - row * C4);
+    const float4 g = dy[i];
+    float v[4] = {g.x, g.y, g.z, g.w};
+    const float sc = rowscale ? rowscale[row] : 1.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] *= sc;
+      if (do_drop) v[e] *= ctts_drop_scale(dkey, (uint32_t)(i * 4 + e), p_drop, inv_keep);
+    }
+    dx[i] = make_float4(v[0], v[1], v[2], v[3]);
+    if (dalpha) {
+      const float4 tv = table[(long)pos[row] * C4 + c];
+      dot += v[0] * tv.x + v[1] * tv.y + v[2] * tv.z + v[3] * tv.w;
+    }
+  }
+  if (!dalpha) return;
+  dot = ctts_wave_sum(dot);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  float tot[1] = {0.f};
+  if (threadIdx.x == 0) tot[0] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+  if (!ctts_ordered_colsum<float, 1>(tot, ws, 0, blockIdx.x, gridDim.x, G)) return;
+  if (threadIdx.x == 0) dalpha[0] = accumulate ? dalpha[0] + tot[0] : tot[0];
+}
+}  // namespace
+
+extern "C" int ctts_posembed_fwd(const float* x, const int32_t* pos, const float* table, const float* alpha, const float* rowscale, float* y,
+                                 int64_t rows, int C, float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream) {
+  CTTS_REQUIRE(x && pos && table && y && rows >= 0 && C > 0 && (C % 4) == 0 && p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed),
+               "ctts_posembed_fwd: bad arguments (C %% 4 must be 0)");
+  const long n4 = (long)rows * (C / 4);
+  if (n4 == 0) return 0;
+  hipLaunchKernelGGL(posembed_fwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, pos, (const float4*)table, alpha,
+                     rowscale, (float4*)y, n4, C / 4, p_drop, seed, drop_offset);
+  CTTS_CHECK_LAUNCH("ctts_posembed_fwd");
+  return 0;
+}
+
+extern "C" int ctts_posembed_bwd(const float* dy, const int32_t* pos, const float* table, const float* rowscale, float* dx, float* dalpha,
+                                 int64_t rows, int C, float p_drop, const uint64_t* seed, uint32_t drop_offset, int accumulate, void* ws,
+                                 void* stream) {
+  CTTS_REQUIRE(dy && dx && rows >= 0 && C > 0 && (C % 4) == 0 && p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || seed) &&
+               (!dalpha || (pos && table)), "ctts_posembed_bwd: bad arguments (C %% 4 must be 0)");
+  const long n4 = (long)rows * (C / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (n4 == 0) {
+    if (dalpha && !accumulate && ctts_zero_async(dalpha, sizeof(float), st) != 0) return -2;
+    return 0;
+  }
+  // the ordered sum of dalpha keeps one 64-float partial per workgroup in the workspace; without one (and dalpha wanted): one workgroup
+  int grid = grid_for(n4, 1024);
+  if (dalpha && !ws) grid = 1;
+  hipLaunchKernelGGL(posembed_bwd_kernel, dim3(grid), dim3(256), 0, st, (const float4*)dy, pos, (const float4*)table, rowscale, (float4*)dx, dalpha,
+                     n4, C / 4, p_drop, seed, drop_offset, (unsigned char*)ws, ctts_red_group(grid), accumulate);
+  CTTS_CHECK_LAUNCH("ctts_posembed_bwd");
+  return 0;
+}
+
 // ---------------------------------------------------------------- deferred ordered reductions, many per launch (round 4)
 // dst[i] += alpha * (src[0*stride + i] + src[1*stride + i] + ... + src[(count-1)*stride + i]), partials added in index order: the second
 // half of every split-K weight gradient, bias / LayerNorm column sum of a backward stage, finished by ONE launch per PSUM_BATCH tasks

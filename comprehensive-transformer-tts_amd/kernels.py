@@ -477,6 +477,30 @@ def rowscale_dropout(x, rowscale=None, p_drop=0.0, seed=None, drop_offset=0):
     return y
 
 
+def posembed_fwd(x, pos, table, alpha=None, rowscale=None, p_drop=0.0, seed=None, drop_offset=0):
+    """y = rowscale * dropout(x + alpha * table[pos]); x [.., C] float32, pos int32 [rows], table [n_pos, C], alpha device scalar or None (= 1)"""
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().ctts_posembed_fwd(_p(_f32c(x, "x")), _p(pos), _p(_f32c(table, "table")), _p(alpha), _p(rowscale), _p(y), rows, Cc,
+                                             float(p_drop), _p(seed), int(drop_offset), _stream()), "ctts_posembed_fwd")
+    return y
+
+
+def posembed_bwd(dy, pos, table, rowscale=None, p_drop=0.0, seed=None, drop_offset=0, want_alpha=True, alpha_acc_into=None):
+    """-> (dx, dalpha [1] or None); alpha_acc_into: ADD the alpha gradient into that [1] buffer (param.grad)"""
+    Cc = dy.shape[-1]
+    rows = dy.numel() // Cc
+    dx = torch.empty_like(dy)
+    dalpha = None
+    if want_alpha:
+        dalpha = alpha_acc_into if alpha_acc_into is not None else torch.empty(1, dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.load().ctts_posembed_bwd(_p(_f32c(dy, "dy")), _p(pos), _p(table), _p(rowscale), _p(dx), _p(dalpha), rows, Cc, float(p_drop),
+                                             _p(seed), int(drop_offset), int(alpha_acc_into is not None), _ws(dy) if want_alpha else None,
+                                             _stream()), "ctts_posembed_bwd")
+    return dx, dalpha
+
+
 def colsum(x2d, ld=None, scale=1.0, acc_into=None):
     """out[c] = scale * sum_r x[r,c]; acc_into: add into an existing buffer (param.grad) instead."""
     rows, Cc = x2d.shape

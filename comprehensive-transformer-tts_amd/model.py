@@ -90,6 +90,12 @@ class _PosEmbed(nn.Module):
         tab = self.table(src.shape[1] + 1)
         return F.embedding(pos.long(), tab)
 
+    def add_to(self, x, src, stride, alpha=None, rowscale=None, p_drop=0.0, drop=None):
+        """rowscale * dropout(x + alpha * embed_positions(src)) in one launch each way (ops.posembed_add); positions from `src`
+        (tokens, or the activations themselves: blocks.py:85-104 make_positions on channel 0)."""
+        pos = K.positions(src, stride)
+        return ops.posembed_add(x, pos, self.table(src.shape[1] + 1), alpha, rowscale, p_drop, drop)
+
 
 class _SelfAttn(nn.Module):
     def __init__(self, c):
@@ -99,25 +105,31 @@ class _SelfAttn(nn.Module):
 
 
 class _FFN(nn.Module):
-    def __init__(self, c, k):
+    def __init__(self, c, k, padding="SAME"):
         super().__init__()
-        self.ffn_1 = _Conv(c, 4 * c, k)
+        # transformer_fs2.py:209-215: LEFT wraps the convolution as nn.Sequential(ConstantPad1d, Conv1d) - its parameters are then
+        # called ffn_1.1.weight / ffn_1.1.bias in a state dict
+        self.ffn_1 = _Conv(c, 4 * c, k) if padding == "SAME" else nn.ModuleDict({"1": _Conv(c, 4 * c, k)})
         self.ffn_2 = _Linear(4 * c, c)
+
+    @property
+    def conv1(self):
+        return self.ffn_1["1"] if isinstance(self.ffn_1, nn.ModuleDict) else self.ffn_1
 
 
 class _EncSALayer(nn.Module):
-    def __init__(self, c, k):
+    def __init__(self, c, k, padding="SAME"):
         super().__init__()
         self.layer_norm1 = _Norm(c)
         self.self_attn = _SelfAttn(c)
         self.layer_norm2 = _Norm(c)
-        self.ffn = _FFN(c, k)
+        self.ffn = _FFN(c, k, padding)
 
 
 class _Layer(nn.Module):
-    def __init__(self, c, k):
+    def __init__(self, c, k, padding="SAME"):
         super().__init__()
-        self.op = _EncSALayer(c, k)
+        self.op = _EncSALayer(c, k, padding)
 
 
 def _runtime(module):
@@ -133,14 +145,15 @@ def _runtime(module):
 class FFTBlocks(nn.Module):
     """reference: transformer_fs2.py:16-72 (FFTBlocks), :154-200 (EncSALayer), :203-239 (FFN)."""
 
-    def __init__(self, hidden, n_layers, ksize, dropout, n_heads, use_pos_embed):
+    def __init__(self, hidden, n_layers, ksize, dropout, n_heads, use_pos_embed, ffn_act=ops.ACT_GELU, ffn_padding="SAME"):
         super().__init__()
         self.hidden_size, self.num_layers, self.ksize = hidden, n_layers, ksize
         self.dropout, self.num_heads, self.use_pos_embed = dropout, n_heads, use_pos_embed
+        self.ffn_act, self.ffn_padding = ffn_act, ffn_padding
         if use_pos_embed:
             self.pos_embed_alpha = nn.Parameter(torch.ones(1))
             self.embed_positions = _PosEmbed(hidden)
-        self.layers = nn.ModuleList([_Layer(hidden, ksize) for _ in range(n_layers)])
+        self.layers = nn.ModuleList([_Layer(hidden, ksize, ffn_padding) for _ in range(n_layers)])
         self.layer_norm = _Norm(hidden)
         self.drop_ctx = None  # set by the owning model
         self._cut_prefix = None   # "decoder.layers" when owned by CompTransTTS: names of the staged-backward cut points (dp.stage_plan)
@@ -153,8 +166,7 @@ class FFTBlocks(nn.Module):
         nonpad = (~pad_mask).to(torch.float32).reshape(-1).contiguous()
         lens = (~pad_mask).sum(1).to(torch.int32).contiguous()
         if self.use_pos_embed:
-            x = x + self.pos_embed_alpha * self.embed_positions.lookup(x, C)
-            x = ops.rowscale_dropout(x, nonpad, p, drop)
+            x = self.embed_positions.add_to(x.contiguous(), x, C, self.pos_embed_alpha, nonpad, p, drop)
         else:
             x = ops.rowscale_dropout(x, nonpad, 0.0, None)
         alpha = self.ksize ** -0.5
@@ -170,8 +182,8 @@ class FFTBlocks(nn.Module):
             h, xr = ops.layer_norm_res(x, op.layer_norm2.weight, op.layer_norm2.bias, 1e-12)
             # g feeds ffn_2 only: its epilogue backward (GELU', dropout mask) rides in the epilogue of ffn_2's data-gradient GEMM
             link = ops.EpiLink()
-            g = ops.conv1d(h, op.ffn.ffn_1.weight, op.ffn.ffn_1.bias, act=ops.ACT_GELU, alpha=alpha, p_drop=p, drop=drop,
-                           pad_rows=pr, link=link, link_role=1)
+            g = ops.conv1d(h, op.ffn.conv1.weight, op.ffn.conv1.bias, act=self.ffn_act, alpha=alpha, p_drop=p, drop=drop,
+                           pad_rows=pr, link=link, link_role=1, padding=self.ffn_padding)
             x = ops.linear(g, op.ffn.ffn_2.weight, op.ffn.ffn_2.bias, residual=xr, rowscale=nonpad, p_drop=p, drop=drop,
                            pad_rows=pr, link=link, link_role=2)
         return ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, 1e-5, rowscale=nonpad)
@@ -182,13 +194,17 @@ class FFTBlocks(nn.Module):
         return self.run(x, padding_mask), padding_mask
 
 
-def _check_ffn_switches(config):
-    """transformer_fs2.py:87-88,131-132 hand variance_predictor.ffn_padding / ffn_act to every FFN; only the shipped values are built"""
+_FFN_ACTS = {"gelu": ops.ACT_GELU, "relu": ops.ACT_RELU, "swish": ops.ACT_SWISH}
+
+
+def _ffn_switches(config):
+    """transformer_fs2.py:87-88,131-132 hand variance_predictor.ffn_padding / ffn_act to every FFN (TransformerFFNLayer :203-239: act in
+    gelu / relu / swish - any other string means NO activation there -, padding SAME / LEFT) -> (activation code, padding)"""
     vp = config.get("variance_predictor", {})
-    if vp.get("ffn_act", "gelu") != "gelu":
-        raise NotImplementedError(f"variance_predictor.ffn_act '{vp['ffn_act']}': the fused FFN epilogue is built for 'gelu' only")
-    if vp.get("ffn_padding", "SAME") != "SAME":
-        raise NotImplementedError(f"variance_predictor.ffn_padding '{vp['ffn_padding']}': only 'SAME' is built")
+    act, padding = vp.get("ffn_act", "gelu"), vp.get("ffn_padding", "SAME")
+    if padding not in ("SAME", "LEFT"):
+        raise NotImplementedError(f"variance_predictor.ffn_padding '{padding}': the reference builds SAME and LEFT only")
+    return _FFN_ACTS.get(act, ops.ACT_NONE), padding
 
 
 class TextEncoder(FFTBlocks):
@@ -196,9 +212,9 @@ class TextEncoder(FFTBlocks):
 
     def __init__(self, config):
         c = config["transformer_fs2"]
-        _check_ffn_switches(config)
+        act, padding = _ffn_switches(config)
         super().__init__(c["encoder_hidden"], c["encoder_layer"], c["ffn_kernel_size"], c["encoder_dropout"],
-                         c["encoder_head"], use_pos_embed=False)
+                         c["encoder_head"], use_pos_embed=False, ffn_act=act, ffn_padding=padding)
         self.embed_tokens = nn.Embedding(N_SYMBOLS + 1, c["encoder_hidden"], padding_idx=0)
         self.embed_positions = _PosEmbed(c["encoder_hidden"])
         self.embed_scale = math.sqrt(c["encoder_hidden"])
@@ -206,9 +222,8 @@ class TextEncoder(FFTBlocks):
 
     def forward(self, txt_tokens, encoder_padding_mask):
         emb = self.embed_scale * ops.embedding(txt_tokens, self.embed_tokens.weight, 0)
-        x = emb + self.embed_positions.lookup(txt_tokens.contiguous(), 1)
         p = self.dropout if self.training else 0.0
-        x = ops.rowscale_dropout(x, None, p, self.drop_ctx if p > 0 else None)
+        x = self.embed_positions.add_to(emb, txt_tokens.contiguous(), 1, None, None, p, self.drop_ctx if p > 0 else None)
         return self.run(x, encoder_padding_mask), emb
 
 
@@ -217,9 +232,9 @@ class Decoder(FFTBlocks):
 
     def __init__(self, config):
         c = config["transformer_fs2"]
-        _check_ffn_switches(config)
+        act, padding = _ffn_switches(config)
         super().__init__(c["decoder_hidden"], c["decoder_layer"], c["ffn_kernel_size"], c["decoder_dropout"],
-                         c["decoder_head"], use_pos_embed=True)
+                         c["decoder_head"], use_pos_embed=True, ffn_act=act, ffn_padding=padding)
         self.d_model = c["decoder_hidden"]
 
 
@@ -227,15 +242,16 @@ class Decoder(FFTBlocks):
 class _PredictorConvs(nn.Module):
     """ModuleList of {1: Conv1d, 3: LayerNorm} so that keys read conv.{i}.1.weight / conv.{i}.3.weight."""
 
-    def __init__(self, idim, n_layers, n_chans, ksize):
+    def __init__(self, idim, n_layers, n_chans, ksize, padding="SAME"):
         super().__init__()
+        self.padding = padding        # modules.py:1270-1283,1328-1331: ConstantPad1d (k-1)//2 on both sides (SAME) or (k-1, 0) (LEFT)
         self.conv = nn.ModuleList([
             nn.ModuleDict({"1": _Conv(idim if i == 0 else n_chans, n_chans, ksize), "3": _Norm(n_chans)})
             for i in range(n_layers)])
 
     def run_convs(self, x, p, drop, nonpad):
         for blk in self.conv:
-            x = ops.conv1d(x, blk["1"].weight, blk["1"].bias, act=ops.ACT_RELU)
+            x = ops.conv1d(x, blk["1"].weight, blk["1"].bias, act=ops.ACT_RELU, padding=self.padding)
             x = ops.layer_norm(x, blk["3"].weight, blk["3"].bias, 1e-12, rowscale=nonpad, p_drop=p, drop=drop)
         return x
 
@@ -243,8 +259,8 @@ class _PredictorConvs(nn.Module):
 class DurationPredictor(_PredictorConvs):
     """reference: modules.py:1252-1310"""
 
-    def __init__(self, idim, n_layers, n_chans, ksize, dropout):
-        super().__init__(idim, n_layers, n_chans, ksize)
+    def __init__(self, idim, n_layers, n_chans, ksize, dropout, padding="SAME"):
+        super().__init__(idim, n_layers, n_chans, ksize, padding)
         self.linear = _Linear(n_chans, 1)
         self.dropout = dropout
         self.drop_ctx = None
@@ -259,8 +275,8 @@ class DurationPredictor(_PredictorConvs):
 class PitchPredictor(_PredictorConvs):
     """reference: modules.py:1313-1356 (also EnergyPredictor, :1359)"""
 
-    def __init__(self, idim, n_layers, n_chans, odim, ksize, dropout):
-        super().__init__(idim, n_layers, n_chans, ksize)
+    def __init__(self, idim, n_layers, n_chans, odim, ksize, dropout, padding="SAME"):
+        super().__init__(idim, n_layers, n_chans, ksize, padding)
         self.linear = _Linear(n_chans, odim)
         self.embed_positions = _PosEmbed(idim)
         self.pos_embed_alpha = nn.Parameter(torch.ones(1))
@@ -270,7 +286,7 @@ class PitchPredictor(_PredictorConvs):
     def forward(self, x, squeeze=False):
         p = self.dropout if self.training else 0.0
         x = x.contiguous()
-        x = x + self.pos_embed_alpha * self.embed_positions.lookup(x, x.shape[-1])
+        x = self.embed_positions.add_to(x, x, x.shape[-1], self.pos_embed_alpha)
         h = self.run_convs(x, p, self.drop_ctx if p > 0 else None, None)
         out = ops.linear(h, self.linear.weight, self.linear.bias)
         return out.squeeze(-1) if squeeze else out
@@ -279,10 +295,10 @@ class PitchPredictor(_PredictorConvs):
 class _CwtPredictor(nn.Module):
     """nn.Sequential(Linear, PitchPredictor) of modules.py:765-772 with keys '0' / '1'."""
 
-    def __init__(self, hidden, h, filt, layers, odim, ksize, dropout):
+    def __init__(self, hidden, h, filt, layers, odim, ksize, dropout, padding="SAME"):
         super().__init__()
         self.add_module("0", _Linear(hidden, h))
-        self.add_module("1", PitchPredictor(h, layers, filt, odim, ksize, dropout))
+        self.add_module("1", PitchPredictor(h, layers, filt, odim, ksize, dropout, padding))
 
     def forward(self, x):
         lin, pp = getattr(self, "0"), getattr(self, "1")
@@ -408,8 +424,9 @@ class VarianceAdaptor(nn.Module):
         ve = model_config["variance_embedding"]
         if not (ve.get("use_pitch_embed", True) and ve.get("use_energy_embed", True)):
             raise NotImplementedError("variance_embedding.use_pitch_embed / use_energy_embed = False are not built (shipped configs: True)")
-        if vp.get("ffn_padding", "SAME") != "SAME":
-            raise NotImplementedError(f"variance_predictor.ffn_padding '{vp['ffn_padding']}': only 'SAME' is built")
+        pad_mode = vp.get("ffn_padding", "SAME")          # modules.py:743: the predictors' ConstantPad1d follows it too
+        if pad_mode not in ("SAME", "LEFT"):
+            raise NotImplementedError(f"variance_predictor.ffn_padding '{pad_mode}': the reference builds SAME and LEFT only")
         self.predictor_grad = vp["predictor_grad"]
         self.cwt_std_scale = vp["cwt_std_scale"]
         hidden = model_config["transformer"]["encoder_hidden"]  # sic: modules.py:739 reads the 'transformer' section
@@ -424,12 +441,12 @@ class VarianceAdaptor(nn.Module):
         else:
             bins = torch.linspace(emin, emax, n_ebins - 1)
         self.energy_bins = nn.Parameter(bins, requires_grad=False)
-        self.duration_predictor = DurationPredictor(hidden, vp["dur_predictor_layers"], filt, vp["dur_predictor_kernel"], drop)
+        self.duration_predictor = DurationPredictor(hidden, vp["dur_predictor_layers"], filt, vp["dur_predictor_kernel"], drop, pad_mode)
         self.cwt_predictor = _CwtPredictor(hidden, vp["cwt_hidden_size"], filt, vp["predictor_layers"], 11,
-                                           vp["predictor_kernel"], drop)
+                                           vp["predictor_kernel"], drop, pad_mode)
         self.cwt_stats_layers = _StatsMLP(hidden, vp["cwt_hidden_size"])
         self.pitch_embed = nn.Embedding(model_config["variance_embedding"]["pitch_n_bins"], hidden, padding_idx=0)
-        self.energy_predictor = PitchPredictor(hidden, vp["predictor_layers"], filt, 1, vp["predictor_kernel"], drop)
+        self.energy_predictor = PitchPredictor(hidden, vp["predictor_layers"], filt, 1, vp["predictor_kernel"], drop, pad_mode)
         self.energy_embedding = nn.Embedding(n_ebins, hidden, padding_idx=0)
         if self.learn_alignment:
             n_mel = preprocess_config["preprocessing"]["mel"]["n_mel_channels"]

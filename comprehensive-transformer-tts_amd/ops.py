@@ -259,7 +259,7 @@ class _LinearConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, residual, rowscale, act, alpha, p_drop, seed, drop_offset, ksize, row_lens, row_T, pr=None, link=None,
-                link_role=0):
+                link_role=0, pad_left=None):
         x = x.contiguous()
         Cin = x.shape[-1]
         M = x.numel() // Cin
@@ -272,7 +272,9 @@ class _LinearConv(torch.autograd.Function):
             if wf is None:
                 wf = torch.empty(N, ksize * Cin, dtype=torch.float32, device=x.device)
                 K.conv_weight_repack(w.contiguous(), wf, N, Cin, ksize, 0)
-            conv = (T, (ksize - 1) // 2, Cin)
+            # zeros in front of the sequence: (k-1)//2 = nn.Conv1d(padding=k//2) "SAME"; k-1 = ConstantPad1d((k-1, 0)) "LEFT" (causal)
+            ctx.pad_left = (ksize - 1) // 2 if pad_left is None else int(pad_left)
+            conv = (T, ctx.pad_left, Cin)
             Kdim = ksize * Cin
         else:
             wf, conv, Kdim = w.contiguous(), None, Cin
@@ -333,7 +335,8 @@ class _LinearConv(torch.autograd.Function):
                 dB = dBn
         if ksize:
             T = x.shape[-2]
-            pad = (ksize - 1) // 2
+            pad = ctx.pad_left                   # forward / weight-gradient view
+            pad_d = ksize - 1 - pad              # data gradient: correlation with the flipped taps (equal to `pad` for SAME with odd k)
             if ctx.needs_input_grad[0]:
                 wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
                 wmaj = _gemm_major(w)
@@ -345,7 +348,7 @@ class _LinearConv(torch.autograd.Function):
                 # all 256 CUs x 8 resident workgroups (atomic accumulation into a zero-filled dX)
                 tiles = -(-M // 64) * -(-Cin // 64)
                 sk = min(4, max(2, -(-2304 // tiles))) if (_DGRAD_SPLIT_K and tiles < 1536 and ksize * N >= 4096) else 1
-                dg = dict(conv=(T, pad, N), alpha=alpha, row_halo=pad, tile_map=pr.tile_map(pad, M) if pr is not None else None, **rl)
+                dg = dict(conv=(T, pad_d, N), alpha=alpha, row_halo=pad_d, tile_map=pr.tile_map(pad_d, M) if pr is not None else None, **rl)
                 if sk > 1 and K.gemm_takes_persistent(dZ, wd, x, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=1, **dg):
                     sk = 1          # the persistent stream-K kernel balances the reduction itself: no split, no zero fill, no atomics
                 dX = torch.empty_like(x)             # split: the ordered reduce launch writes every element (zeros in padded tiles)
@@ -395,7 +398,7 @@ class _LinearConv(torch.autograd.Function):
                            tile_map=kmap, defer=fused, **rl)
                 if fused:
                     dW = None
-        return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None, None, None
+        return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class PadRows:
@@ -434,12 +437,17 @@ def linear(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, 
 
 
 def conv1d(x, w, b=None, act=ACT_NONE, alpha=1.0, residual=None, rowscale=None, p_drop=0.0, drop=None, pad_rows=None, link=None,
-           link_role=0):
-    """x [B,T,Cin], w [Cout,Cin,k] (nn.Conv1d layout), 'same' zero padding, stride 1."""
+           link_role=0, padding="SAME"):
+    """x [B,T,Cin], w [Cout,Cin,k] (nn.Conv1d layout), stride 1, output length T.  padding "SAME": k//2 zeros on both sides
+    (nn.Conv1d(padding=k//2), odd k); "LEFT": k-1 zeros in front, none behind (ConstantPad1d((k-1, 0)): the reference's causal
+    ffn_padding, transformer_fs2.py:209-218, modules.py:1328-1331)."""
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
     rl, rT, pr = _pad_rows(pad_rows)
+    if padding not in ("SAME", "LEFT"):
+        raise ValueError(f"conv1d: padding '{padding}' (SAME or LEFT)")
+    k = w.shape[2]
     return _LinearConv.apply(x, w, b, residual, rowscale, act, alpha, p_drop if seed is not None else 0.0, seed, off,
-                             w.shape[2], rl, rT, pr, link, link_role)
+                             k, rl, rT, pr, link, link_role, (k - 1) if padding == "LEFT" else (k - 1) // 2)
 
 
 def _adjacent(ts):
@@ -793,6 +801,32 @@ class _RowscaleDropout(torch.autograd.Function):
         rowscale, seed = ctx.saved_tensors
         p_drop, drop_offset = ctx.cfg
         return K.rowscale_dropout(dy.contiguous(), rowscale, p_drop, seed, drop_offset), None, None, None, None
+
+
+class _PosEmbedAdd(torch.autograd.Function):
+    """y = rowscale * dropout(x + alpha * table[pos])  (csrc/elementwise.hip posembed_*): one launch forward, one backward"""
+
+    @staticmethod
+    def forward(ctx, x, alpha, pos, table, rowscale, p_drop, seed, drop_offset):
+        ctx.save_for_backward(pos, table, rowscale, seed, alpha)
+        ctx.cfg = (p_drop, drop_offset)
+        return K.posembed_fwd(x.contiguous(), pos, table, alpha.detach() if alpha is not None else None, rowscale, p_drop, seed, drop_offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        pos, table, rowscale, seed, alpha = ctx.saved_tensors
+        p_drop, drop_offset = ctx.cfg
+        want_alpha = alpha is not None and ctx.needs_input_grad[1]
+        acc = _grad_of(alpha) if want_alpha else None
+        dx, dalpha = K.posembed_bwd(dy.contiguous(), pos, table, rowscale, p_drop, seed, drop_offset, want_alpha=want_alpha, alpha_acc_into=acc)
+        return dx, (None if (acc is not None or not want_alpha) else dalpha.view_as(alpha)), None, None, None, None, None, None
+
+
+def posembed_add(x, pos, table, alpha=None, rowscale=None, p_drop=0.0, drop=None):
+    """rowscale * dropout(x + alpha * table[pos]): the fs2 `x + pos_embed_alpha * embed_positions(x)` (+ F.dropout + non-pad mask) fused;
+    pos int32 [B, T] (kernels.positions), table [n_pos, C] (ops.sinusoid_table), alpha: the [1] parameter or None (= 1)."""
+    seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
+    return _PosEmbedAdd.apply(x, alpha, pos, table, rowscale, p_drop if seed is not None else 0.0, seed, off)
 
 
 def rowscale_dropout(x, rowscale=None, p_drop=0.0, drop=None):

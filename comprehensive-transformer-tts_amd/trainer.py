@@ -21,7 +21,7 @@ from .dp import FlatGradArena, FlatAdam, BucketedReducer, stage_plan
 class TrainStep:
     def __init__(self, model, loss_fn, optim, model_args, world=1, group=None, use_graph=True, overlap=True, n_cuts=3,
                  step_no=50001, fused_optimizer=True, max_norm=1.0, adam_step=0, force_staged=False, graph_collectives=None,
-                 always_reduce=False):
+                 always_reduce=False, grad_acc_step=1):
         """`model_args`: positional arguments of CompTransTTS.forward (static device tensors; the graphs read them in place).
         `optim`: loss.ScheduledOptim(..., capturable=True) - owns the Noam schedule and the device-resident lr.
         `adam_step`: Adam's bias-correction step count to start from (a resumed run: the restore step; `FlatAdam.load_state_dict`
@@ -40,6 +40,8 @@ class TrainStep:
         self.flat_grad = self.arena.flat
         self.use_graph = bool(use_graph)
         self.max_norm = max_norm
+        self.grad_acc_step = max(1, int(grad_acc_step))
+        self.g_opt_noclip = None
         self.fadam = None
         if fused_optimizer:
             oc = optim._optimizer.defaults
@@ -90,6 +92,8 @@ class TrainStep:
         with rec:
             loss = self._forward_loss()
         self.flat_grad.zero_()
+        if self.grad_acc_step > 1:
+            loss = loss * (1.0 / self.grad_acc_step)          # train.py:112
         sink = _K.PartialSink()
         gen = rec.backward_stages(loss)
         while True:
@@ -103,19 +107,24 @@ class TrainStep:
                 _K.set_partial_sink(prev)
             yield s
 
-    def _optimizer_step(self):
+    def _clip_now(self):
+        return self.step_no % self.grad_acc_step == 0        # train.py:118 (always true for grad_acc_step = 1)
+
+    def _optimizer_step(self, clip=True):
         if self.fadam is not None:
+            self.fadam.max_norm = self.max_norm if clip else 0.0          # 0 = no clipping (csrc/optim.hip)
             self.fadam.step()
             return
         self.arena.check_bound()
-        torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
+        if clip:
+            torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
         self.optim._optimizer.step()
 
     def _eager(self):
         for s in self._stages():
             self.reducer.launch(s)
         self.reducer.finish()
-        self._optimizer_step()
+        self._optimizer_step(self._clip_now())
 
     # ---- checkpointing (train.py:190-200 saves {"model": ..., "optimizer": optimizer._optimizer.state_dict()})
     def optimizer_state_dict(self):
@@ -143,8 +152,9 @@ class TrainStep:
         torch.cuda.synchronize()
         if self.graph_collectives:
             # ONE graph: stages, collectives (forked onto the reducer's side stream inside the capture, joined by finish()) and optimizer
-            if self.fadam is None:
-                raise RuntimeError("graph_collectives needs the fused optimizer (torch's foreach clip + Adam are not capture-safe here)")
+            if self.fadam is None or self.grad_acc_step > 1:
+                raise RuntimeError("graph_collectives needs the fused optimizer (torch's foreach clip + Adam are not capture-safe here) "
+                                   "and grad_acc_step = 1 (the whole-step graph has one optimizer node)")
             self.g_all = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_all, stream=side, capture_error_mode="thread_local"):
                 self._eager()
@@ -166,7 +176,11 @@ class TrainStep:
         if self.fadam is not None:                        # torch's foreach clip + Adam are not capture-safe on strided parameters: eager
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=pool, stream=side, capture_error_mode="thread_local"):
-                self._optimizer_step()
+                self._optimizer_step(True)
+            if self.grad_acc_step > 1:                    # the steps between two clipping steps: same update without the clip coefficient
+                self.g_opt_noclip = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_opt_noclip, pool=pool, stream=side, capture_error_mode="thread_local"):
+                    self._optimizer_step(False)
         self.ws_probe.poll_and_check()                    # the warm-up steps ran every kernel of the step once
 
     # ---- inputs as views of one packed device buffer (data.PackedBatch layout)
@@ -193,10 +207,11 @@ class TrainStep:
                 g.replay()
                 self.reducer.launch(s)
             self.reducer.finish()
+            clip = self._clip_now()
             if self.g_opt is not None:
-                self.g_opt.replay()
+                (self.g_opt if (clip or self.g_opt_noclip is None) else self.g_opt_noclip).replay()
             else:
-                self._optimizer_step()
+                self._optimizer_step(clip)
         else:
             self._eager()
         if self._calls % self.probe_every == 0:

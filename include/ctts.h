@@ -102,6 +102,14 @@ typedef struct ctts_gemm_desc {
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
 /* 1 (+ *count, *stride) when ctts_gemm would run `d` as a split-K launch whose partials the caller may keep (split_out); else 0. */
 int ctts_gemm_split_plan(const ctts_gemm_desc* d, int32_t* count, int64_t* stride);
+/* y = rowscale[row] * dropout(x + alpha * table[pos[row]]): positional-embedding add of the fs2 stacks and predictors
+ * (`x + self.pos_embed_alpha * self.embed_positions(x)` + F.dropout + non-pad mask, transformer_fs2.py:41-52,113-119, modules.py:1349-1351)
+ * as one launch each way; pos from ctts_positions, table [n_pos, C] row-major, alpha a device scalar or NULL (= 1), rowscale / dropout
+ * optional.  Backward: dx = rowscale * dropmask * dy; dalpha (optional, (+)= by `accumulate`) = sum of dx * table[pos] (ordered sum, ws). */
+int ctts_posembed_fwd(const float* x, const int32_t* pos, const float* table, const float* alpha, const float* rowscale, float* y,
+                      int64_t rows, int C, float p_drop, const uint64_t* seed, uint32_t drop_offset, void* stream);
+int ctts_posembed_bwd(const float* dy, const int32_t* pos, const float* table, const float* rowscale, float* dx, float* dalpha,
+                      int64_t rows, int C, float p_drop, const uint64_t* seed, uint32_t drop_offset, int accumulate, void* ws, void* stream);
 /* Deferred ordered reductions, many per launch: for every task  dst[i] += alpha * (src[i] + src[stride + i] + ... + src[(count-1)*stride + i]),
  * i < n, partials added in index order (bit-reproducible).  `tasks` is a HOST array (copied into kernel arguments, 24 tasks per launch).
  * Producers: ctts_gemm with split_out; ctts_colsum / ctts_weighted_colsum / ctts_epilogue_bwd / ctts_layernorm_bwd with `parts`

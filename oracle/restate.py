@@ -82,6 +82,25 @@ def conv1d_btc(x, w, b, pad):
     return F.conv1d(x.transpose(1, 2), w, b, padding=pad).transpose(1, 2)
 
 
+# variance_predictor.ffn_act / ffn_padding of the configuration being restated (set by comp_trans_tts_forward): the FFN of every fs2
+# block (transformer_fs2.py:203-239: act gelu / relu / swish, padding SAME = Conv1d(padding=k//2) / LEFT = ConstantPad1d((k-1, 0)))
+# and the ConstantPad1d of the duration / pitch / energy predictors (modules.py:1270-1283,1328-1331) follow them
+_SW = {"ffn_act": "gelu", "ffn_padding": "SAME"}
+
+
+def conv1d_mode(x, w, b):
+    """conv1d_btc with the configured ffn_padding: SAME (k-1)//2 zeros on both sides, LEFT k-1 zeros in front"""
+    k = w.shape[2]
+    if _SW["ffn_padding"] == "LEFT":
+        return F.conv1d(F.pad(x.transpose(1, 2), (k - 1, 0)), w, b).transpose(1, 2)
+    return conv1d_btc(x, w, b, (k - 1) // 2)
+
+
+def ffn_act(z):
+    a = _SW["ffn_act"]
+    return F.gelu(z) if a == "gelu" else (torch.relu(z) if a == "relu" else (z * torch.sigmoid(z) if a == "swish" else z))
+
+
 def _drop(x, p, on):
     return F.dropout(x, p, True) if (on and p > 0) else x
 
@@ -170,8 +189,9 @@ def fft_blocks(sd, pre, x, pad_mask, n_layers, n_heads, ksize, p_drop, use_pos, 
         x = (res + _drop(a, p_drop, train_dropout)) * nonpad
         res = x
         h = layer_norm(x, sd[p + "layer_norm2.weight"], sd[p + "layer_norm2.bias"], 1e-12)
-        z = conv1d_btc(h, sd[p + "ffn.ffn_1.weight"], sd[p + "ffn.ffn_1.bias"], ksize // 2) * ksize ** -0.5
-        g = _drop(F.gelu(z), p_drop, train_dropout)
+        f1 = "ffn.ffn_1.1." if _SW["ffn_padding"] == "LEFT" else "ffn.ffn_1."          # LEFT: nn.Sequential(ConstantPad1d, Conv1d)
+        z = conv1d_mode(h, sd[p + f1 + "weight"], sd[p + f1 + "bias"]) * ksize ** -0.5
+        g = _drop(ffn_act(z), p_drop, train_dropout)
         y = g @ sd[p + "ffn.ffn_2.weight"].t() + sd[p + "ffn.ffn_2.bias"]
         x = (res + _drop(y, p_drop, train_dropout)) * nonpad
         if taps is not None:
@@ -194,7 +214,7 @@ def text_encoder(sd, cfg, tokens, pad_mask, train_dropout=False, taps=None):
 # ----------------------------------------------------------------------------- a7, a10, a11 predictors
 def _predictor_convs(sd, pre, x, n_layers, ksize, p_drop, mask_nonpad, train_dropout):
     for i in range(n_layers):
-        x = conv1d_btc(x, sd[f"{pre}conv.{i}.1.weight"], sd[f"{pre}conv.{i}.1.bias"], (ksize - 1) // 2)
+        x = conv1d_mode(x, sd[f"{pre}conv.{i}.1.weight"], sd[f"{pre}conv.{i}.1.bias"])
         x = torch.relu(x)
         x = layer_norm(x, sd[f"{pre}conv.{i}.3.weight"], sd[f"{pre}conv.{i}.3.bias"], 1e-12)
         x = _drop(x, p_drop, train_dropout)
@@ -547,6 +567,8 @@ def comp_trans_tts_forward(sd, model_cfg, pre_cfg, speakers, texts, src_lens, ma
     learn_alignment == False.  `training` selects BatchNorm batch statistics;
     `train_dropout` additionally turns the dropouts on (for CPU-baseline timing)."""
     assert model_cfg["block_type"] == "transformer_fs2"
+    vp_sw = model_cfg.get("variance_predictor", {})
+    _SW["ffn_act"], _SW["ffn_padding"] = vp_sw.get("ffn_act", "gelu"), vp_sw.get("ffn_padding", "SAME")
     src_pad = mask_from_lengths(src_lens, max_src_len)
     mel_pad = mask_from_lengths(mel_lens, max_mel_len) if mel_lens is not None else None
     enc, text_emb = text_encoder(sd, model_cfg, texts, src_pad, train_dropout, taps)
@@ -661,6 +683,8 @@ def comp_trans_tts_forward_conformer(sd, model_cfg, pre_cfg, speakers, texts, sr
                                      training=False, train_dropout=False, taps=None, new_stats=None):
     """model/CompTransTTS.py:64-152 with block_type == conformer (conformer.py:20-159 encoder/decoder wrappers)."""
     assert model_cfg["block_type"] == "conformer" and attn_priors is None and not model_cfg["multi_speaker"]
+    vp_sw = model_cfg.get("variance_predictor", {})
+    _SW["ffn_act"], _SW["ffn_padding"] = vp_sw.get("ffn_act", "gelu"), vp_sw.get("ffn_padding", "SAME")       # the predictors' padding
     c = model_cfg["conformer"]
     src_pad = mask_from_lengths(src_lens, max_src_len)
     mel_pad = mask_from_lengths(mel_lens, max_mel_len) if mel_lens is not None else None

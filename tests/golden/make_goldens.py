@@ -36,18 +36,19 @@ def pseudo(name, shape):
     return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float()
 
 
-def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=False, prosody="none"):
+def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=False, prosody="none", vp_overrides=None, tag_suffix=""):
     from model import CompTransTTS
 
     pre, mc, tc = ref_import.load_configs(dataset)
     mc["duration_modeling"]["learn_alignment"] = learn_alignment
     mc["prosody_modeling"]["model_type"] = prosody
     mc["block_type"] = block_type
+    mc["variance_predictor"].update(vp_overrides or {})
     model = CompTransTTS(pre, mc, tc)
     sd = closed_form_state_dict(model.state_dict())
     model.load_state_dict(sd)
     import json
-    tag = f"{dataset}_{block_type}" + ("_unsup" if learn_alignment else "") + ("" if prosody == "none" else "_" + prosody)
+    tag = f"{dataset}_{block_type}" + ("_unsup" if learn_alignment else "") + ("" if prosody == "none" else "_" + prosody) + tag_suffix
     with open(os.path.join(OUT, f"state_dict_schema_{tag}.json"), "w") as f:
         json.dump({k: [list(v.shape), str(v.dtype).replace("torch.", ""), bool(k in dict(model.named_parameters()))]
                    for k, v in model.state_dict().items()}, f, indent=0)
@@ -294,6 +295,19 @@ def main():
     run_case(model_c, cb, "train", "g4_conformer_train_nodrop", with_grads=True)
 
 
+def main_ffn_switches():
+    """G13: variance_predictor.ffn_act / ffn_padding away from the shipped values (transformer_fs2.py:203-239, modules.py:1270-1283,
+    1328-1331): swish + LEFT (causal ConstantPad1d((k-1, 0)) in every FFN and predictor; ffn_1 becomes nn.Sequential: key ffn_1.1.*)
+    and relu + SAME."""
+    torch.manual_seed(0)
+    b = make_batch([24, 17], 6, seed=1313)
+    m1, _ = build("LJSpeech", vp_overrides=dict(ffn_act="swish", ffn_padding="LEFT"), tag_suffix="_swish_left")
+    run_case(m1, b, "eval", "g13_swish_left_eval")
+    run_case(m1, b, "train", "g13_swish_left_train_nodrop", with_grads=True)
+    m2, _ = build("LJSpeech", vp_overrides=dict(ffn_act="relu"), tag_suffix="_relu")
+    run_case(m2, b, "train", "g13_relu_train_nodrop", with_grads=True)
+
+
 from tests.util import synthetic_samples  # noqa: E402  (shared with tests/test_data_cpu.py)
 
 
@@ -353,8 +367,11 @@ if __name__ == "__main__":
         golden_collate()
     elif len(sys.argv) > 1 and sys.argv[1] == "vctk_unsup":
         main_vctk_unsup()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ffn_switches":
+        main_ffn_switches()
     else:
         main()
         main_liu2021()
         golden_collate()
         main_vctk_unsup()
+        main_ffn_switches()

@@ -338,3 +338,49 @@ def test_workspace_error_probe_reads_clean_and_raises_on_a_set_word():
         probe.poll_and_check()
     assert int(ws.view(torch.int32)[2048]) == 0          # re-zeroed
     probe.poll_and_check()
+
+
+def test_grad_acc_step_follows_the_reference_loop():
+    """train.py:112-125 with optimizer.grad_acc_step = k > 1 (VERDICT r03 missing #5; TrainStep used to ignore it): the loss is divided
+    by k (so every gradient is EXACTLY the k = 1 gradient times 1/k - a power of two here), clipping happens only on steps with
+    step % k == 0, the optimizer steps and the arena is zeroed on every step (the reference's `step_and_update_lr` / `zero_grad` sit
+    outside its `if`: it never sums gradients over batches).  Eager and hipGraph replay (two optimizer graphs: with / without the clip
+    coefficient) are bit-identical over four steps."""
+    from ctts_amd.configs import get_configs
+    from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
+    from ctts_amd.synthetic import make_batch, to_device, as_model_args
+    from ctts_amd.trainer import TrainStep
+
+    def run(k, use_graph, n, warm):
+        torch.manual_seed(1234)
+        pre, mc, tc = get_configs()
+        model = ctts_amd.CompTransTTS(pre, mc, tc).to(DEV)
+        model.train()
+        loss_fn, optim = CompTransTTSLoss(pre, mc, tc).to(DEV), ScheduledOptim(model, tc, mc, 50000, capturable=True)
+        batch = to_device(make_batch([60, 41, 33, 17], 8, seed=3), DEV)
+        step = TrainStep(model, loss_fn, optim, as_model_args(batch), world=1, use_graph=use_graph, grad_acc_step=k)
+        if use_graph:
+            step.capture(warmup=warm)        # `warm` REAL eager steps (lazy tables, workspaces), then the graphs
+            assert (step.g_opt_noclip is not None) == (k > 1)
+        else:
+            for _ in range(warm):
+                step.optim.update_learning_rate()
+                step._eager()
+        losses, clips, g1 = [], [], None
+        for i in range(n):
+            clips.append(step._clip_now())
+            step()
+            losses.append(float(step.loss_val))
+            if i == 0:
+                torch.cuda.synchronize()
+                g1 = step.flat_grad.clone()
+        torch.cuda.synchronize()
+        return losses, g1, step.fadam.flat_param.clone(), clips
+    l1, g1, _, c1 = run(1, False, 1, 0)
+    l2, g2, p2, c2 = run(2, False, 4, 0)
+    assert c1 == [True] and c2 == [False, True, False, True]           # step_no starts at 50001
+    # scaling by a power of two commutes with every rounding (short of the subnormal range): the k = 2 gradients are the k = 1 gradients / 2
+    assert l1[0] == l2[0] and torch.allclose(g2, 0.5 * g1, rtol=1e-6, atol=1e-20), "gradients of step 1 are not half the k = 1 gradients"
+    le, ge, pe, _ = run(2, False, 4, 2)
+    lg, gg, pg, _ = run(2, True, 4, 2)
+    assert lg == le and torch.equal(gg, ge) and torch.equal(pg, pe), "hipGraph replay differs from eager with grad_acc_step = 2"

@@ -1176,3 +1176,38 @@ def test_gemm_under_filled_conv_ragged_rows():
         close(Z[b_, :L], ref[b_, :L], 2e-5, f"conv Z b={b_}")
         close(Cc[b_, :L], torch.relu(ref[b_, :L]), 2e-5, f"conv C b={b_}")
     assert torch.isfinite(Cc).all() and torch.isfinite(Z).all()          # padded tiles are zero-filled, not left unwritten
+
+
+@pytest.mark.parametrize("B,T,C,p,use_alpha,use_mask", [(3, 70, 256, 0.2, True, True), (2, 33, 64, 0.0, True, False), (2, 128, 256, 0.1, False, False)])
+def test_positional_embedding_add_fwd_bwd(B, T, C, p, use_alpha, use_mask):
+    """ops.posembed_add = `x + pos_embed_alpha * embed_positions(x)` + F.dropout + non-pad mask (transformer_fs2.py:41-52,113-119,
+    modules.py:1349-1351) as one launch each way: against the torch composition in float64 with the dropout mask regenerated from
+    (seed, offset, element index); the forward is BIT-identical to the unfused fp32 sequence (two roundings, no FMA)."""
+    g = torch.Generator().manual_seed(B * T + C)
+    x = (torch.rand(B, T, C, generator=g) - 0.5)
+    lens = torch.tensor([T, max(1, T // 2), max(1, T - 9)][:B])
+    x = x * (torch.arange(T)[None, :] < lens[:, None])[..., None]            # padded rows are zero: channel 0 marks non-pad (make_positions)
+    x[..., 0] = torch.where(torch.arange(T)[None, :] < lens[:, None], x[..., 0].abs() + 0.1, torch.zeros(()))
+    xg = x.to(DEV).requires_grad_()
+    alpha = torch.tensor([0.7], device=DEV, requires_grad=True) if use_alpha else None
+    nonpad = (torch.arange(T)[None, :] < lens[:, None]).float().reshape(-1).to(DEV) if use_mask else None
+    drop = K.DropCtx(DEV, seed=9) if p > 0 else None
+    pos = K.positions(xg.detach(), C)
+    table = ops.sinusoid_table(T + 1, C, DEV)
+    y = ops.posembed_add(xg, pos, table, alpha, nonpad, p, drop)
+    go = (torch.rand(B, T, C, generator=g) - 0.5).to(DEV)
+    y.backward(go)
+    mask = torch.ones(B * T, C, device=DEV)
+    if p > 0:
+        mask = K.rowscale_dropout(torch.ones(B * T, C, device=DEV), None, p, drop.seed, 1)        # the op drew call-site offset 1
+    mask = mask.view(B, T, C)
+    pe = torch.nn.functional.embedding(pos.long(), table)
+    a32 = alpha.detach() if use_alpha else torch.ones(1, device=DEV)
+    y32 = (xg.detach() + a32 * pe) * mask
+    if use_mask:
+        y32 = y32 * nonpad.view(B, T, 1)
+    assert torch.equal(y.detach(), y32), "forward differs from the unfused fp32 sequence"
+    m64 = mask.double() * (nonpad.view(B, T, 1).double() if use_mask else 1.0)
+    close(xg.grad, go.double() * m64, 1e-6, "posembed dx")
+    if use_alpha:
+        close(alpha.grad, (go.double() * m64 * pe.double()).sum().view(1), 1e-5 * (B * T * C) ** 0.5, "posembed dalpha")

@@ -252,3 +252,22 @@ def test_g12_vctk_multispeaker_unsupervised():
     assert np.array_equal(a_hard.numpy(), g["out.attn_hard"]) and np.array_equal(a_dur.numpy(), g["out.attn_hard_dur"])
     _close(out[0], g["out.mel"], name="mel")
     _close(out[1], g["out.postnet_mel"], 5e-5, name="postnet_mel")
+
+
+@pytest.mark.parametrize("gname,suffix,vp,training", [("g13_swish_left_eval", "_swish_left", dict(ffn_act="swish", ffn_padding="LEFT"), False),
+                                                      ("g13_swish_left_train_nodrop", "_swish_left", dict(ffn_act="swish", ffn_padding="LEFT"), True),
+                                                      ("g13_relu_train_nodrop", "_relu", dict(ffn_act="relu"), True)])
+def test_g13_ffn_act_and_padding_switches(gname, suffix, vp, training):
+    """variance_predictor.ffn_act / ffn_padding away from the shipped values (transformer_fs2.py:203-239; the predictors' ConstantPad1d
+    modules.py:1270-1283,1328-1331): swish + LEFT (causal; ffn_1 is nn.Sequential there: state-dict key ffn_1.1.*) and relu + SAME."""
+    g = load_golden(gname)
+    sd = closed_form_sd(suffix=suffix)
+    pre, mc, tc = get_configs()
+    mc["variance_predictor"].update(vp)
+    b = batch_from_golden(g)
+    taps, stats = {}, {}
+    out = R.comp_trans_tts_forward(sd, mc, pre, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"],
+                                   b["mel_lens"], b["max_mel_len"], b["p_targets"], b["e_targets"], b["d_targets"],
+                                   None, b["spker_embeds"], training=training, taps=taps, new_stats=stats)
+    _check_outputs(g, out, taps)
+    R._SW.update(ffn_act="gelu", ffn_padding="SAME")

@@ -17,17 +17,18 @@ def load_golden(name):
     return {k: z[k] for k in z.files}
 
 
-def schema(dataset="LJSpeech", block="transformer_fs2", unsup=False, prosody="none"):
-    tag = f"{dataset}_{block}{'_unsup' if unsup else ''}{'' if prosody == 'none' else '_' + prosody}"
+def schema(dataset="LJSpeech", block="transformer_fs2", unsup=False, prosody="none", suffix=""):
+    tag = f"{dataset}_{block}{'_unsup' if unsup else ''}{'' if prosody == 'none' else '_' + prosody}{suffix}"
     with open(os.path.join(GOLDEN, f"state_dict_schema_{tag}.json")) as f:
         return json.load(f)
 
 
-def closed_form_sd(dataset="LJSpeech", block="transformer_fs2", unsup=False, prosody="none"):
-    """Closed-form weights for every schema key (energy_bins from stats.json like modules.py:795-818)."""
+def closed_form_sd(dataset="LJSpeech", block="transformer_fs2", unsup=False, prosody="none", suffix=""):
+    """Closed-form weights for every schema key (energy_bins from stats.json like modules.py:795-818).  `suffix`: schema of a
+    configuration variant (G13: "_swish_left", "_relu")."""
     pre, mc, tc = get_configs(dataset)
     sd = {}
-    for k, (shape, dtype, is_param) in schema(dataset, block, unsup, prosody).items():
+    for k, (shape, dtype, is_param) in schema(dataset, block, unsup, prosody, suffix).items():
         if k.endswith("energy_bins"):
             with open(os.path.join(pre["path"]["preprocessed_path"], "stats.json")) as f:
                 emin, emax = json.load(f)["energy_unsup_frame" if unsup else "energy_sup_phone"][:2]
