@@ -169,7 +169,8 @@ class _ConformerStack(nn.Module):
         return self.position_enc[0, :T]
 
     def run(self, x, mask, pos_table):
-        nonpad = (~mask).to(torch.float32).reshape(-1).contiguous()
+        from .model import mask_aux
+        nonpad = mask_aux(mask)[0]
         pos_table = pos_table.contiguous()
         cut = getattr(self, "_cut_prefix", None)
         for li, blk in enumerate(self.layer_stack):

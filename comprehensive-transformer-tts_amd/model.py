@@ -132,6 +132,22 @@ class _Layer(nn.Module):
         self.op = _EncSALayer(c, k, padding)
 
 
+def mask_aux(pad_mask, lens=None):
+    """(non-pad row scale float32 [B*T], valid lengths int32 [B]) of a padding mask [B,T] (True = pad), computed ONCE per mask object:
+    the encoder / decoder stack, the predictors and the variance adaptor all ask for the same two tensors (4 small launches each time)."""
+    aux = getattr(pad_mask, "_ctts_aux", None)
+    if aux is None:
+        valid = ~pad_mask
+        nonpad = valid.to(torch.float32).reshape(-1).contiguous()
+        li = (lens if lens is not None else valid.sum(1)).to(torch.int32).contiguous()
+        aux = (nonpad, li)
+        try:
+            pad_mask._ctts_aux = aux
+        except Exception:        # noqa: BLE001   (a tensor subclass without a __dict__)
+            pass
+    return aux
+
+
 def _runtime(module):
     """dropout context shared by the whole model (device-resident seed, see kernels.DropCtx)."""
     ctx = getattr(module, "_drop_ctx", None)
@@ -163,8 +179,7 @@ class FFTBlocks(nn.Module):
         B, T, C = x.shape
         p = self.dropout if self.training else 0.0
         drop = self.drop_ctx if p > 0 else None
-        nonpad = (~pad_mask).to(torch.float32).reshape(-1).contiguous()
-        lens = (~pad_mask).sum(1).to(torch.int32).contiguous()
+        nonpad, lens = mask_aux(pad_mask)
         if self.use_pos_embed:
             x = self.embed_positions.add_to(x.contiguous(), x, C, self.pos_embed_alpha, nonpad, p, drop)
         else:
@@ -267,7 +282,7 @@ class DurationPredictor(_PredictorConvs):
 
     def forward(self, x, src_pad):
         p = self.dropout if self.training else 0.0
-        nonpad = (~src_pad).to(torch.float32).reshape(-1).contiguous()
+        nonpad = mask_aux(src_pad)[0]
         h = self.run_convs(x, p, self.drop_ctx if p > 0 else None, nonpad)
         return ops.linear(h, self.linear.weight, self.linear.bias, rowscale=nonpad).squeeze(-1)
 
@@ -467,8 +482,8 @@ class VarianceAdaptor(nn.Module):
         up_emb = pp_emb = pp_attn = None
         if self.training:
             assert mel is not None and mel_mask is not None, "liu2021 prosody encoders need the reference mel in training"
-            mel_nonpad = (~mel_mask).to(torch.float32).reshape(-1).contiguous()
-            src_nonpad = (~src_mask).to(torch.float32).reshape(-1).contiguous()
+            mel_nonpad = mask_aux(mel_mask)[0]
+            src_nonpad = mask_aux(src_mask)[0]
             ue, pe = self.utterance_prosody_encoder, self.phoneme_prosody_encoder
             gi_u, whh_u, bhh_u = ue.encoder.features(mel, mel_nonpad)
             gi_p, whh_p, bhh_p = pe.encoder.features(mel, mel_nonpad)
@@ -687,6 +702,9 @@ class CompTransTTS(nn.Module):
         dev = texts.device
         src_masks = torch.arange(max_src_len, device=dev)[None, :] >= src_lens[:, None]
         mel_masks = (torch.arange(max_mel_len, device=dev)[None, :] >= mel_lens[:, None]) if mel_lens is not None else None
+        mask_aux(src_masks, src_lens.clamp(max=max_src_len))          # the lengths are known here: no row sums of the masks later
+        if mel_masks is not None:
+            mask_aux(mel_masks, mel_lens.clamp(max=max_mel_len))
         enc, text_embeds = self.encoder(texts, src_masks)
         speaker_embeds = None
         if self.speaker_emb is not None:

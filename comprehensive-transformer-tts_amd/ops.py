@@ -362,10 +362,10 @@ class _LinearConv(torch.autograd.Function):
                         K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
                                split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, defer=True, **rl)
                 else:
-                    dwf = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
+                    dwf = torch.empty(N, Kd, dtype=torch.float32, device=x.device)
                     with _wgrad_scope(fused, dZ, x, dwf, rows=M):
                         K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, **rl)
+                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, split_overwrite=True, **rl)
                         if fused:
                             K.conv_weight_repack(dwf, _grad_of(w), N, Cin, ksize, 3)
                         elif _gemm_major(w) is not None:
@@ -392,10 +392,12 @@ class _LinearConv(torch.autograd.Function):
                 dW = None if fused else got.view(1, Cin)
             elif ctx.needs_input_grad[1]:
                 fused = _fusable(w)
-                dW = _grad_of(w) if fused else torch.zeros_like(w)      # split-K partials are atomically ADDED to the target
+                # fused: the ordered split-K sum is ADDED to param.grad (deferred to the stage's PartialSink); else it is WRITTEN into a fresh
+                # tensor (split_overwrite: no zero fill)
+                dW = _grad_of(w) if fused else torch.empty_like(w)
                 with _wgrad_scope(fused, dZ, x, rows=M):
                     K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha,
-                           tile_map=kmap, defer=fused, **rl)
+                           tile_map=kmap, defer=fused, split_overwrite=not fused, **rl)
                 if fused:
                     dW = None
         return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None, None, None, None
@@ -503,8 +505,8 @@ class _PackedLinear(torch.autograd.Function):
             G = torch.as_strided(gs[0], (N, Kd), (Kd, 1))
             K.gemm(dY, x, G, N, Kd, M, N, Kd, Kd, False, False, split_k=sk, defer=True)
             return (dX,) + (None,) * len(ws)
-        dW = torch.zeros(N, Kd, dtype=torch.float32, device=x.device)
-        K.gemm(dY, x, dW, N, Kd, M, N, Kd, Kd, False, False, split_k=sk)
+        dW = torch.empty(N, Kd, dtype=torch.float32, device=x.device)
+        K.gemm(dY, x, dW, N, Kd, M, N, Kd, Kd, False, False, split_k=sk, split_overwrite=True)
         return (dX,) + tuple(dW.split(ctx.sizes, 0))
 
 
@@ -1138,10 +1140,10 @@ class _GRU(torch.autograd.Function):
         B, T = out.shape[0], out.shape[1]
         dgi, dgh, hprev = K.gru_bwd(dout.contiguous(), out, gates, whh, H, ndir, rev_mask)
         rows = B * T
-        dwhh = torch.zeros_like(whh)
+        dwhh = torch.empty_like(whh)
         for d in range(ndir):              # dW_hh[d] = dgh_d^T h_prev_d : [3H, H], reduction over all B*T steps (split-K on MFMA)
             K.gemm(dgh, hprev, dwhh, 3 * H, H, rows, ndir * 3 * H, ndir * H, H, False, False, a_off=d * 3 * H, b_off=d * H,
-                   c_off=d * 3 * H * H, split_k=max(2, _split_k_for(3 * H, H, rows)))
+                   c_off=d * 3 * H * H, split_k=max(2, _split_k_for(3 * H, H, rows)), split_overwrite=True)
         dbhh = K.colsum(dgh.view(rows, ndir * 3 * H)).view(ndir, 3 * H)
         return dgi, dwhh, dbhh, None, None, None
 

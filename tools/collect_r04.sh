@@ -1,0 +1,47 @@
+#!/bin/bash
+# Round-3 artefacts in one GPU-box call:  bash tools/collect_r04.sh  -> gpurun_out/r04_*  (copy the ones to keep into profiles/)
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out; R=r04
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+# headline + secondary configs (driver-style invocation)
+timeout 900 python $ROOT/bench.py > $OUT/${R}_bench_fs2.json 2> $OUT/${R}_bench.err
+# eager kernel traces
+for cfg in "fs2:" "conformer:--block conformer"; do
+  n=${cfg%%:*}; a=${cfg#*:}; rm -rf /tmp/prof_$n
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -- python $ROOT/bench.py $a --no-graph --no-cpu-baseline --no-pcie --no-secondary --no-roofline --steps 5 --warmup 2 > /tmp/prof_$n.log 2>&1
+  python $ROOT/tools/rocpd_summary.py $(find /tmp/prof_$n -name "*results.db" | head -1) 45 > $OUT/${R}_${n}_eager_kernel_stats.md 2>&1
+done
+# the replayed graph: idle time between kernels and per-kernel totals of one step
+rm -rf /tmp/prof_g; timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_g -- python $ROOT/bench.py --no-cpu-baseline --no-pcie --no-secondary --no-roofline --steps 6 --warmup 3 > /tmp/prof_g.log 2>&1
+python $ROOT/tools/graph_gaps.py $(find /tmp/prof_g -name "*results.db" | head -1) > $OUT/${R}_fs2_graph_replay_kernels.md 2>&1
+rm -rf /tmp/prof_g; timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_g -- python $ROOT/bench.py --block conformer --no-cpu-baseline --no-pcie --no-secondary --no-roofline --steps 6 --warmup 3 > /tmp/prof_g.log 2>&1
+python $ROOT/tools/graph_gaps.py $(find /tmp/prof_g -name "*results.db" | head -1) > $OUT/${R}_conformer_graph_replay_kernels.md 2>&1
+rm -rf /tmp/prof_g; timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_g -- python $ROOT/bench.py --prosody liu2021 --learn-alignment --no-cpu-baseline --no-pcie --no-secondary --no-roofline --steps 6 --warmup 3 > /tmp/prof_g.log 2>&1
+python $ROOT/tools/graph_gaps.py $(find /tmp/prof_g -name "*results.db" | head -1) > $OUT/${R}_c5_graph_replay_kernels.md 2>&1
+# dominant kernel: kernel-trace summary of exactly what bench.py's roofline block launches, then PMC passes
+rm -rf /tmp/prof_dom; timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_dom -- python $ROOT/tools/bench_one.py ffn1_step 60 > /tmp/prof_dom.log 2>&1
+python $ROOT/tools/rocpd_summary.py $(find /tmp/prof_dom -name "*results.db" | head -1) 6 > $OUT/${R}_dominant_kernel_stats.md 2>&1
+grep TFLOP /tmp/prof_dom.log >> $OUT/${R}_dominant_kernel_stats.md
+: > $OUT/${R}_pmc_traffic_gemm_shapes.md
+for w in ffn1_step dgrad wgrad; do
+  for p in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc; timeout 200 rocprofv3 --kernel-trace --pmc $p -d /tmp/pmc -- python $ROOT/tools/bench_one.py $w 30 > /tmp/pmc.log 2>&1
+    echo "## $w  ($p, KiB per launch; FETCH_SIZE counts 128-B requests at 64 B on gfx950: double it)" >> $OUT/${R}_pmc_traffic_gemm_shapes.md
+    python $ROOT/tools/rocpd_pmc_summary.py $(find /tmp/pmc -name "*results.db" | head -1) 2>&1 | grep -E "^\| kernel|gemm_" | cut -c1-300 >> $OUT/${R}_pmc_traffic_gemm_shapes.md
+    grep TFLOP /tmp/pmc.log >> $OUT/${R}_pmc_traffic_gemm_shapes.md
+  done
+done
+P1="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"
+P2="SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS"
+: > $OUT/${R}_pmc_sq_gemm.md
+for P in "$P1" "$P2"; do
+  rm -rf /tmp/pmc; timeout 200 rocprofv3 --kernel-trace --pmc $P -d /tmp/pmc -- python $ROOT/tools/bench_one.py ffn1_step 30 > /tmp/pmc.log 2>&1
+  python $ROOT/tools/rocpd_pmc_summary.py $(find /tmp/pmc -name "*results.db" | head -1) 2>&1 < /dev/null | grep -E "^\| kernel|gemm_" | cut -c1-400 >> $OUT/${R}_pmc_sq_gemm.md
+done
+# micro-benchmarks
+timeout 200 python $ROOT/tools/profile_gemm_shapes.py > $OUT/${R}_gemm_shapes_in_step_fs2.txt 2>&1
+timeout 200 python $ROOT/tools/profile_gemm_shapes.py --block conformer > $OUT/${R}_gemm_shapes_in_step_conformer.txt 2>&1
+timeout 100 python $ROOT/tools/bench_stft.py > $OUT/${R}_bench_stft.jsonl 2>/dev/null
+ls -la $OUT | grep ${R}_ | head -40

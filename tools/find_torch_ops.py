@@ -14,6 +14,7 @@ from ctts_amd.trainer import TrainStep
 ap = argparse.ArgumentParser()
 ap.add_argument("--block", default="transformer_fs2")
 ap.add_argument("--shapes", action="store_true")
+ap.add_argument("--c5", action="store_true", help="BASELINE configs[4]: liu2021 prosody + learn_alignment (built through bench.build_step)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 pre, mc, tc = get_configs("LJSpeech")
@@ -27,6 +28,9 @@ packed = PackedBatch.pack(as_collated_tuple(batch))
 views, ev = packed.to_device(dev)
 torch.cuda.current_stream().wait_event(ev)
 step = TrainStep(model, loss_fn, optim, views[2:], use_graph=False, adam_step=optim.current_step)
+if a.c5:
+    import bench
+    step = bench.build_step(dev, 0, 1, "LJSpeech", "transformer_fs2", "liu2021", True, "canonical", "weak", use_graph=False)["step"]
 for _ in range(2):
     step()
 torch.cuda.synchronize()
