@@ -93,14 +93,28 @@ class CompTransTTSLoss(nn.Module):
         energy_loss = zero
         if step > self.var_start_steps:
             # loss.py:123-243 in one fused launch: terms = (pdur, wdur, sdur, C, uv, f0_mean, f0_std, energy), lambda-weighted
-            t = ops.variance_losses(log_d, p_pred["cwt"], p_pred["f0_mean"], p_pred["f0_std"], e_pred, duration_targets, texts, src_masks,
-                                    pitch_targets["cwt_spec"], pitch_targets["uv"], mel_masks, pitch_targets["f0_mean"],
-                                    pitch_targets["f0_std"], energy_targets, self._lambdas, self._cwt_l2, self._sil)
+            # variance_embedding.use_pitch_embed / use_energy_embed = False (loss.py:331-334 skips the term, get_init_losses keeps its
+            # zero): the fused kernel is fed zero predictions AND zero targets for that branch - the term and its gradients are exactly 0
+            B, Tm = mel_masks.shape
+            dev = mel_targets.device
+            if self.use_pitch_embed:
+                cwt_p, f0m_p, f0s_p = p_pred["cwt"], p_pred["f0_mean"], p_pred["f0_std"]
+                cwt_t, uv_t, f0m_t, f0s_t = pitch_targets["cwt_spec"], pitch_targets["uv"], pitch_targets["f0_mean"], pitch_targets["f0_std"]
+            else:
+                cwt_p, cwt_t = torch.zeros(B, Tm, 11, device=dev), torch.zeros(B, Tm, 10, device=dev)
+                uv_t = torch.full((B, Tm), 0.5, device=dev)       # BCE-with-logits of logit 0 against 0.5 has zero gradient; its value is dropped below
+                f0m_p = f0s_p = f0m_t = f0s_t = torch.zeros(B, device=dev)
+            e_p, e_t = (e_pred, energy_targets) if self.use_energy_embed else (torch.zeros_like(log_d), torch.zeros_like(log_d))
+            t = ops.variance_losses(log_d, cwt_p, f0m_p, f0s_p, e_p, duration_targets, texts, src_masks,
+                                    cwt_t, uv_t, mel_masks, f0m_t, f0s_t, e_t, self._lambdas, self._cwt_l2, self._sil)
             duration_loss = {"pdur": t[0], "wdur": t[1] if self.loss_config["lambda_word_dur"] > 0 else zero,
                              "sdur": t[2] if self.loss_config["lambda_sent_dur"] > 0 else zero}
-            pitch_loss = {"C": t[3], "uv": t[4], "f0_mean": t[5], "f0_std": t[6]}
-            energy_loss = t[7]
-            total = total + t.sum()
+            if self.use_pitch_embed:
+                pitch_loss = {"C": t[3], "uv": t[4], "f0_mean": t[5], "f0_std": t[6]}
+            if self.use_energy_embed:
+                energy_loss = t[7]
+            keep = torch.tensor([1.0, 1.0, 1.0] + [float(self.use_pitch_embed)] * 4 + [float(self.use_energy_embed)], device=dev)
+            total = total + (t if (self.use_pitch_embed and self.use_energy_embed) else t * keep).sum()
         return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, prosody_loss)
 
 

@@ -437,8 +437,8 @@ class VarianceAdaptor(nn.Module):
         self.pitch_cfg = pitch
         vp = model_config["variance_predictor"]
         ve = model_config["variance_embedding"]
-        if not (ve.get("use_pitch_embed", True) and ve.get("use_energy_embed", True)):
-            raise NotImplementedError("variance_embedding.use_pitch_embed / use_energy_embed = False are not built (shipped configs: True)")
+        # modules.py:735-736,754-821: the pitch / energy branches (predictors, embeddings, energy_bins) only exist when switched on
+        self.use_pitch_embed, self.use_energy_embed = bool(ve.get("use_pitch_embed", True)), bool(ve.get("use_energy_embed", True))
         pad_mode = vp.get("ffn_padding", "SAME")          # modules.py:743: the predictors' ConstantPad1d follows it too
         if pad_mode not in ("SAME", "LEFT"):
             raise NotImplementedError(f"variance_predictor.ffn_padding '{pad_mode}': the reference builds SAME and LEFT only")
@@ -451,18 +451,21 @@ class VarianceAdaptor(nn.Module):
         with open(os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")) as f:
             emin, emax = json.load(f)[stats_key][:2]
         n_ebins = model_config["variance_embedding"]["energy_n_bins"]
-        if model_config["variance_embedding"]["energy_quantization"] == "log":
-            bins = torch.exp(torch.linspace(math.log(emin), math.log(emax), n_ebins - 1))
-        else:
-            bins = torch.linspace(emin, emax, n_ebins - 1)
-        self.energy_bins = nn.Parameter(bins, requires_grad=False)
+        if self.use_energy_embed:
+            if model_config["variance_embedding"]["energy_quantization"] == "log":
+                bins = torch.exp(torch.linspace(math.log(emin), math.log(emax), n_ebins - 1))
+            else:
+                bins = torch.linspace(emin, emax, n_ebins - 1)
+            self.energy_bins = nn.Parameter(bins, requires_grad=False)
         self.duration_predictor = DurationPredictor(hidden, vp["dur_predictor_layers"], filt, vp["dur_predictor_kernel"], drop, pad_mode)
-        self.cwt_predictor = _CwtPredictor(hidden, vp["cwt_hidden_size"], filt, vp["predictor_layers"], 11,
-                                           vp["predictor_kernel"], drop, pad_mode)
-        self.cwt_stats_layers = _StatsMLP(hidden, vp["cwt_hidden_size"])
-        self.pitch_embed = nn.Embedding(model_config["variance_embedding"]["pitch_n_bins"], hidden, padding_idx=0)
-        self.energy_predictor = PitchPredictor(hidden, vp["predictor_layers"], filt, 1, vp["predictor_kernel"], drop, pad_mode)
-        self.energy_embedding = nn.Embedding(n_ebins, hidden, padding_idx=0)
+        if self.use_pitch_embed:
+            self.cwt_predictor = _CwtPredictor(hidden, vp["cwt_hidden_size"], filt, vp["predictor_layers"], 11,
+                                               vp["predictor_kernel"], drop, pad_mode)
+            self.cwt_stats_layers = _StatsMLP(hidden, vp["cwt_hidden_size"])
+            self.pitch_embed = nn.Embedding(model_config["variance_embedding"]["pitch_n_bins"], hidden, padding_idx=0)
+        if self.use_energy_embed:
+            self.energy_predictor = PitchPredictor(hidden, vp["predictor_layers"], filt, 1, vp["predictor_kernel"], drop, pad_mode)
+            self.energy_embedding = nn.Embedding(n_ebins, hidden, padding_idx=0)
         if self.learn_alignment:
             n_mel = preprocess_config["preprocessing"]["mel"]["n_mel_channels"]
             self.aligner = AlignmentEncoder(n_mel, n_mel, d_model, model_config["duration_modeling"]["aligner_temperature"],
@@ -522,7 +525,8 @@ class VarianceAdaptor(nn.Module):
             d_rounded = attn_hard_dur
             mel2ph, _, _ = K.lr_index(d_rounded, int(max_len), pad=src_mask, round_mode=1)    # dur_to_mel2ph(...)[:, :max_len]
             pitch_target["mel2ph"] = mel2ph.long()
-            energy_target = phoneme_level_mean(energy_target, attn_hard_dur, src_len)
+            if self.use_energy_embed:        # modules.py:1095-1097
+                energy_target = phoneme_level_mean(energy_target, attn_hard_dur, src_len)
             mel2ph = None
         elif duration_target is not None:
             assert not self.learn_alignment
@@ -535,36 +539,42 @@ class VarianceAdaptor(nn.Module):
             ids = torch.arange(x.shape[1], device=x.device)[None, :]
             mel_mask = ids >= mel_len[:, None]
             mel2ph = ops.dur_to_mel2ph(d_rounded, src_mask)
-        # ---- pitch (cwt)   modules.py:890-948
-        cwt = self.cwt_predictor(ops.grad_scale(x, self.predictor_grad)) * p_control
-        stats = self.cwt_stats_layers(x_org[:, 0, :].contiguous())
-        f0_mean, f0_std = stats[:, 0], stats[:, 1]
-        eps = self.pitch_cfg["pitch_norm_eps"]
-        with torch.no_grad():
-            if pitch_target is not None:
-                mel2ph = pitch_target["mel2ph"]
-                pitch_target["f0"] = cwt2f0_norm(pitch_target["cwt_spec"], pitch_target["f0_mean"], pitch_target["f0_std"],
-                                                 mel2ph.shape[1], eps)
-                pitch_target.update({"f0_cwt": pitch_target["f0"]})
-                f0, uv = pitch_target["f0"], pitch_target["uv"]
+        pitch_prediction = energy_prediction = None          # modules.py:982: stay None when the branch is switched off
+        out = x
+        if self.use_pitch_embed:
+            # ---- pitch (cwt)   modules.py:890-948,1071-1091
+            cwt = self.cwt_predictor(ops.grad_scale(x, self.predictor_grad)) * p_control
+            stats = self.cwt_stats_layers(x_org[:, 0, :].contiguous())
+            f0_mean, f0_std = stats[:, 0], stats[:, 1]
+            eps = self.pitch_cfg["pitch_norm_eps"]
+            with torch.no_grad():
+                if pitch_target is not None:
+                    mel2ph = pitch_target["mel2ph"]
+                    pitch_target["f0"] = cwt2f0_norm(pitch_target["cwt_spec"], pitch_target["f0_mean"], pitch_target["f0_std"],
+                                                     mel2ph.shape[1], eps)
+                    pitch_target.update({"f0_cwt": pitch_target["f0"]})
+                    f0, uv = pitch_target["f0"], pitch_target["uv"]
+                else:
+                    f0 = cwt2f0_norm(cwt[:, :, :10], f0_mean, f0_std * self.cwt_std_scale, mel2ph.shape[1], eps)
+                    uv = cwt[:, :, -1] > 0
+                f0_denorm = 2 ** f0
+                f0_denorm = torch.where(uv > 0, torch.zeros_like(f0_denorm), f0_denorm)
+                pitch_ids = f0_to_coarse(f0_denorm)
+            pitch_embedding = ops.embedding(pitch_ids, self.pitch_embed.weight, 0)
+            pitch_prediction = {"pitch_pred": None, "f0_denorm": f0_denorm, "cwt": cwt, "f0_mean": f0_mean, "f0_std": f0_std}
+            out = out + pitch_embedding
+        if self.use_energy_embed:
+            # ---- energy (phoneme level)   modules.py:950-960,1095-1099 (no gradient scaling: :951 is a no-op)
+            energy_prediction = self.energy_predictor(x_org, squeeze=True)
+            if energy_target is not None:
+                e_ids = torch.bucketize(energy_target, self.energy_bins)
             else:
-                f0 = cwt2f0_norm(cwt[:, :, :10], f0_mean, f0_std * self.cwt_std_scale, mel2ph.shape[1], eps)
-                uv = cwt[:, :, -1] > 0
-            f0_denorm = 2 ** f0
-            f0_denorm = torch.where(uv > 0, torch.zeros_like(f0_denorm), f0_denorm)
-            pitch_ids = f0_to_coarse(f0_denorm)
-        pitch_embedding = ops.embedding(pitch_ids, self.pitch_embed.weight, 0)
-        pitch_prediction = {"pitch_pred": None, "f0_denorm": f0_denorm, "cwt": cwt, "f0_mean": f0_mean, "f0_std": f0_std}
-        # ---- energy (phoneme level)   modules.py:950-960,1095-1099 (no gradient scaling: :951 is a no-op)
-        energy_prediction = self.energy_predictor(x_org, squeeze=True)
-        if energy_target is not None:
-            e_ids = torch.bucketize(energy_target, self.energy_bins)
-        else:
-            energy_prediction = energy_prediction * e_control
-            e_ids = torch.bucketize(energy_prediction.detach(), self.energy_bins)
-        energy_embedding = ops.embedding(e_ids, self.energy_embedding.weight, 0)
-        e_frames, _, _ = ops.length_regulate(energy_embedding, d_rounded, max_len)
-        x = x + pitch_embedding + e_frames
+                energy_prediction = energy_prediction * e_control
+                e_ids = torch.bucketize(energy_prediction.detach(), self.energy_bins)
+            energy_embedding = ops.embedding(e_ids, self.energy_embedding.weight, 0)
+            e_frames, _, _ = ops.length_regulate(energy_embedding, d_rounded, max_len)
+            out = out + e_frames
+        x = out
         return (x, pitch_target, pitch_prediction, energy_target, energy_prediction, log_d, d_rounded, mel_len, mel_mask,
                 attn_out, prosody_info)
 

@@ -491,42 +491,48 @@ def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pa
     if taps is not None:
         taps["lr_out"] = x
 
-    # pitch (cwt)
-    dec_inp = _grad_scale(x, vp["predictor_grad"])
-    h = dec_inp @ sd[va + "cwt_predictor.0.weight"].t() + sd[va + "cwt_predictor.0.bias"]
-    cwt = pitch_like_predictor(sd, va + "cwt_predictor.1.", cfg, h, train_dropout) * p_control
-    s = x_org[:, 0, :]
-    s = torch.relu(s @ sd[va + "cwt_stats_layers.0.weight"].t() + sd[va + "cwt_stats_layers.0.bias"])
-    s = torch.relu(s @ sd[va + "cwt_stats_layers.2.weight"].t() + sd[va + "cwt_stats_layers.2.bias"])
-    stats = s @ sd[va + "cwt_stats_layers.4.weight"].t() + sd[va + "cwt_stats_layers.4.bias"]
-    f0_mean, f0_std = stats[:, 0], stats[:, 1]
-    if p_targets is not None:
-        p_targets = dict(p_targets)
-        mel2ph = p_targets["mel2ph"]
-        p_targets["f0"] = cwt2f0_norm(p_targets["cwt_spec"], p_targets["f0_mean"], p_targets["f0_std"],
-                                      mel2ph.shape[1], pitch_cfg["pitch_norm_eps"])
-        p_targets["f0_cwt"] = p_targets["f0"]
-        f0, uv = p_targets["f0"], p_targets["uv"]
-    else:
-        f0 = cwt2f0_norm(cwt[:, :, :10], f0_mean, f0_std * vp["cwt_std_scale"], mel2ph_inf.shape[1],
-                         pitch_cfg["pitch_norm_eps"])
-        uv = cwt[:, :, -1] > 0
-    f0_denorm = 2 ** f0
-    f0_denorm = torch.where(uv > 0, torch.zeros_like(f0_denorm), f0_denorm)
-    pitch_emb = F.embedding(f0_to_coarse(f0_denorm), sd[va + "pitch_embed.weight"], padding_idx=0)
-    p_pred = {"pitch_pred": None, "f0_denorm": f0_denorm, "cwt": cwt, "f0_mean": f0_mean, "f0_std": f0_std}
-
-    # energy (phoneme level; NOTE modules.py:951 discards the grad-scaled tensor -> full gradient)
-    e_pred = pitch_like_predictor(sd, va + "energy_predictor.", cfg, x_org, train_dropout).squeeze(-1)
-    bins = sd[va + "energy_bins"]
-    if e_targets is not None:
-        e_idx = torch.bucketize(e_targets, bins)
-    else:
-        e_pred = e_pred * e_control
-        e_idx = torch.bucketize(e_pred, bins)
-    e_emb = F.embedding(e_idx, sd[va + "energy_embedding.weight"], padding_idx=0)
-    e_emb_frames, _ = length_regulate(e_emb, d_rounded, max_mel_len)
-    out = x + pitch_emb + e_emb_frames
+    ve = cfg.get("variance_embedding", {})
+    use_pitch, use_energy = ve.get("use_pitch_embed", True), ve.get("use_energy_embed", True)      # modules.py:735-736,1071,1092-1095
+    out = x
+    p_pred = e_pred = None
+    if use_pitch:
+        # pitch (cwt)
+        dec_inp = _grad_scale(x, vp["predictor_grad"])
+        h = dec_inp @ sd[va + "cwt_predictor.0.weight"].t() + sd[va + "cwt_predictor.0.bias"]
+        cwt = pitch_like_predictor(sd, va + "cwt_predictor.1.", cfg, h, train_dropout) * p_control
+        s = x_org[:, 0, :]
+        s = torch.relu(s @ sd[va + "cwt_stats_layers.0.weight"].t() + sd[va + "cwt_stats_layers.0.bias"])
+        s = torch.relu(s @ sd[va + "cwt_stats_layers.2.weight"].t() + sd[va + "cwt_stats_layers.2.bias"])
+        stats = s @ sd[va + "cwt_stats_layers.4.weight"].t() + sd[va + "cwt_stats_layers.4.bias"]
+        f0_mean, f0_std = stats[:, 0], stats[:, 1]
+        if p_targets is not None:
+            p_targets = dict(p_targets)
+            mel2ph = p_targets["mel2ph"]
+            p_targets["f0"] = cwt2f0_norm(p_targets["cwt_spec"], p_targets["f0_mean"], p_targets["f0_std"],
+                                          mel2ph.shape[1], pitch_cfg["pitch_norm_eps"])
+            p_targets["f0_cwt"] = p_targets["f0"]
+            f0, uv = p_targets["f0"], p_targets["uv"]
+        else:
+            f0 = cwt2f0_norm(cwt[:, :, :10], f0_mean, f0_std * vp["cwt_std_scale"], mel2ph_inf.shape[1],
+                             pitch_cfg["pitch_norm_eps"])
+            uv = cwt[:, :, -1] > 0
+        f0_denorm = 2 ** f0
+        f0_denorm = torch.where(uv > 0, torch.zeros_like(f0_denorm), f0_denorm)
+        pitch_emb = F.embedding(f0_to_coarse(f0_denorm), sd[va + "pitch_embed.weight"], padding_idx=0)
+        p_pred = {"pitch_pred": None, "f0_denorm": f0_denorm, "cwt": cwt, "f0_mean": f0_mean, "f0_std": f0_std}
+        out = out + pitch_emb
+    if use_energy:
+        # energy (phoneme level; NOTE modules.py:951 discards the grad-scaled tensor -> full gradient)
+        e_pred = pitch_like_predictor(sd, va + "energy_predictor.", cfg, x_org, train_dropout).squeeze(-1)
+        bins = sd[va + "energy_bins"]
+        if e_targets is not None:
+            e_idx = torch.bucketize(e_targets, bins)
+        else:
+            e_pred = e_pred * e_control
+            e_idx = torch.bucketize(e_pred, bins)
+        e_emb = F.embedding(e_idx, sd[va + "energy_embedding.weight"], padding_idx=0)
+        e_emb_frames, _ = length_regulate(e_emb, d_rounded, max_mel_len)
+        out = out + e_emb_frames
     if taps is not None:
         taps["va_out"] = out
     return out, p_targets, p_pred, e_targets, e_pred, log_d, d_rounded, mel_len, mel_pad

@@ -36,7 +36,8 @@ def pseudo(name, shape):
     return torch.from_numpy(_hash_uniform("probe." + name, int(np.prod(shape))).reshape(shape)).float()
 
 
-def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=False, prosody="none", vp_overrides=None, tag_suffix=""):
+def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=False, prosody="none", vp_overrides=None, tag_suffix="",
+          ve_overrides=None):
     from model import CompTransTTS
 
     pre, mc, tc = ref_import.load_configs(dataset)
@@ -44,6 +45,7 @@ def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=Fals
     mc["prosody_modeling"]["model_type"] = prosody
     mc["block_type"] = block_type
     mc["variance_predictor"].update(vp_overrides or {})
+    mc["variance_embedding"].update(ve_overrides or {})
     model = CompTransTTS(pre, mc, tc)
     sd = closed_form_state_dict(model.state_dict())
     model.load_state_dict(sd)
@@ -58,14 +60,16 @@ def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=Fals
 def flatten_outputs(out, prefix="out."):
     (mel, post, p_pred, e_pred, log_d, d_rounded, src_mask, mel_mask, src_lens, mel_lens, attn, pros, p_t, e_t) = out
     d = {
-        "mel": _np(mel), "postnet_mel": _np(post), "e_pred": _np(e_pred), "log_d": _np(log_d),
+        "mel": _np(mel), "postnet_mel": _np(post), "e_pred": _np(e_pred) if e_pred is not None else None, "log_d": _np(log_d),
         "d_rounded": _np(d_rounded), "src_mask": _np(src_mask), "mel_mask": _np(mel_mask),
         "src_lens": _np(src_lens), "mel_lens": _np(mel_lens),
-        "cwt": _np(p_pred["cwt"]), "f0_denorm": _np(p_pred["f0_denorm"]), "f0_mean": _np(p_pred["f0_mean"]),
-        "f0_std": _np(p_pred["f0_std"]),
     }
+    if p_pred is not None:                   # None with variance_embedding.use_pitch_embed = False (G14)
+        d.update({"cwt": _np(p_pred["cwt"]), "f0_denorm": _np(p_pred["f0_denorm"]), "f0_mean": _np(p_pred["f0_mean"]),
+                  "f0_std": _np(p_pred["f0_std"])})
     if p_t is not None:
-        d["pt_f0"] = _np(p_t["f0"])
+        if "f0" in p_t:
+            d["pt_f0"] = _np(p_t["f0"])
         d["pt_mel2ph"] = _np(p_t["mel2ph"])
     if attn is not None and attn[0] is not None:
         d["attn_soft"], d["attn_hard"], d["attn_hard_dur"], d["attn_logprob"] = [_np(a) for a in attn]
@@ -127,9 +131,12 @@ def run_case(model, batch, mode, name, with_grads=False, extra_kwargs=None):
     if with_grads:
         mel, post, p_pred, e_pred, log_d = out[0], out[1], out[2], out[3], out[4]
         loss = ((post * pseudo("post", post.shape)).sum() + (mel * pseudo("mel", mel.shape)).sum()
-                + (log_d * pseudo("logd", log_d.shape)).sum() + (e_pred * pseudo("e", e_pred.shape)).sum()
-                + (p_pred["cwt"] * pseudo("cwt", p_pred["cwt"].shape)).sum()
-                + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum())
+                + (log_d * pseudo("logd", log_d.shape)).sum())
+        if e_pred is not None:
+            loss = loss + (e_pred * pseudo("e", e_pred.shape)).sum()
+        if p_pred is not None:
+            loss = loss + ((p_pred["cwt"] * pseudo("cwt", p_pred["cwt"].shape)).sum()
+                           + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum())
         if out[10][0] is not None:      # unsupervised: attention outputs enter the loss too
             a_soft, _, _, a_logp = out[10]
             loss = loss + (a_soft * pseudo("asoft", a_soft.shape)).sum() * 10 + (a_logp * pseudo("alogp", a_logp.shape)).sum() * 0.1
@@ -308,6 +315,20 @@ def main_ffn_switches():
     run_case(m2, b, "train", "g13_relu_train_nodrop", with_grads=True)
 
 
+def main_embed_switches():
+    """G14: variance_embedding.use_pitch_embed / use_energy_embed = False (modules.py:735-736,754-821,1071-1099; loss.py:331-334): the
+    pitch / energy branches and their parameters do not exist, predictions[2] / [3] are None, the loss keeps the initial zeros."""
+    torch.manual_seed(0)
+    b = make_batch([24, 17], 6, seed=1414)
+    m, cfgs = build("LJSpeech", ve_overrides=dict(use_pitch_embed=False, use_energy_embed=False), tag_suffix="_noembed")
+    run_case(m, b, "eval", "g14_noembed_eval")
+    out = run_case(m, b, "train", "g14_noembed_train_nodrop", with_grads=True)
+    golden_loss(out, b, cfgs, "g14_noembed_loss")
+    m2, cfgs2 = build("LJSpeech", ve_overrides=dict(use_pitch_embed=False), tag_suffix="_nopitch")
+    out2 = run_case(m2, b, "train", "g14_nopitch_train_nodrop", with_grads=True)
+    golden_loss(out2, b, cfgs2, "g14_nopitch_loss")
+
+
 from tests.util import synthetic_samples  # noqa: E402  (shared with tests/test_data_cpu.py)
 
 
@@ -369,9 +390,12 @@ if __name__ == "__main__":
         main_vctk_unsup()
     elif len(sys.argv) > 1 and sys.argv[1] == "ffn_switches":
         main_ffn_switches()
+    elif len(sys.argv) > 1 and sys.argv[1] == "embed_switches":
+        main_embed_switches()
     else:
         main()
         main_liu2021()
         golden_collate()
         main_vctk_unsup()
         main_ffn_switches()
+        main_embed_switches()

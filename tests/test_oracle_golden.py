@@ -271,3 +271,29 @@ def test_g13_ffn_act_and_padding_switches(gname, suffix, vp, training):
                                    None, b["spker_embeds"], training=training, taps=taps, new_stats=stats)
     _check_outputs(g, out, taps)
     R._SW.update(ffn_act="gelu", ffn_padding="SAME")
+
+
+@pytest.mark.parametrize("gname,suffix,ve,training", [("g14_noembed_eval", "_noembed", dict(use_pitch_embed=False, use_energy_embed=False), False),
+                                                      ("g14_noembed_train_nodrop", "_noembed", dict(use_pitch_embed=False, use_energy_embed=False), True),
+                                                      ("g14_nopitch_train_nodrop", "_nopitch", dict(use_pitch_embed=False), True)])
+def test_g14_pitch_and_energy_embedding_switches(gname, suffix, ve, training):
+    """variance_embedding.use_pitch_embed / use_energy_embed = False (modules.py:735-736,754-821,1071-1099): the branch, its parameters
+    and its prediction (None) disappear."""
+    g = load_golden(gname)
+    sd = closed_form_sd(suffix=suffix)
+    pre, mc, tc = get_configs()
+    mc["variance_embedding"].update(ve)
+    b = batch_from_golden(g)
+    taps, stats = {}, {}
+    out = R.comp_trans_tts_forward(sd, mc, pre, b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"],
+                                   b["mel_lens"], b["max_mel_len"], b["p_targets"], b["e_targets"], b["d_targets"],
+                                   None, b["spker_embeds"], training=training, taps=taps, new_stats=stats)
+    mel, post, p_pred, e_pred, log_d = out[:5]
+    assert p_pred is None and (e_pred is None) == (not ve.get("use_energy_embed", True))
+    assert "out.cwt" not in g and ("out.e_pred" in g) == (e_pred is not None)
+    for name, a, key in (("encoder_out", taps["encoder_out"], "tap.encoder_out"), ("va_out", taps["va_out"], "tap.va_out"),
+                         ("decoder_out", taps["decoder_out"], "tap.decoder_out"), ("mel", mel, "out.mel"), ("log_d", log_d, "out.log_d")):
+        _close(a, g[key], name=name)
+    _close(post, g["out.postnet_mel"], 5e-5, name="postnet_mel")
+    if e_pred is not None:
+        _close(e_pred, g["out.e_pred"], name="e_pred")
