@@ -153,6 +153,8 @@ def _gemm_major(w):
 _WGRAD = {"stream": None, "keep": [], "main": None, "max_rows": None}
 
 
+# (With a side stream set the weight gradients are NOT deferred to the stage's PartialSink: their partials would be written on one stream
+#  and summed on another.)
 def set_wgrad_stream(stream, max_rows=None):
     """`stream`: a torch.cuda.Stream for weight-gradient GEMMs, or None for single-stream execution.  `max_rows`: only layers whose
     reduction (rows of the activation matrix) is at most this long use it - the under-filled launches of the phoneme-level layers
@@ -360,7 +362,7 @@ class _LinearConv(torch.autograd.Function):
                 if gmaj is not None:             # GEMM-major parameter: the split-K partials are added straight into param.grad
                     with _wgrad_scope(True, dZ, x, rows=M):
                         K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, defer=True, **rl)
+                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, defer=_WGRAD["stream"] is None, **rl)
                 else:
                     dwf = torch.empty(N, Kd, dtype=torch.float32, device=x.device)
                     with _wgrad_scope(fused, dZ, x, dwf, rows=M):
@@ -397,7 +399,7 @@ class _LinearConv(torch.autograd.Function):
                 dW = _grad_of(w) if fused else torch.empty_like(w)
                 with _wgrad_scope(fused, dZ, x, rows=M):
                     K.gemm(dZ, x, dW, N, Cin, M, N, Cin, Cin, False, False, split_k=max(2, _split_k_for(N, Cin, M)), alpha=alpha,
-                           tile_map=kmap, defer=fused, split_overwrite=not fused, **rl)
+                           tile_map=kmap, defer=fused and _WGRAD["stream"] is None, split_overwrite=not fused, **rl)
                 if fused:
                     dW = None
         return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None, None, None, None
@@ -503,7 +505,7 @@ class _PackedLinear(torch.autograd.Function):
         sk = max(2, _split_k_for(N, Kd, M))
         if all(g is not None for g in gs) and _adjacent(gs):
             G = torch.as_strided(gs[0], (N, Kd), (Kd, 1))
-            K.gemm(dY, x, G, N, Kd, M, N, Kd, Kd, False, False, split_k=sk, defer=True)
+            K.gemm(dY, x, G, N, Kd, M, N, Kd, Kd, False, False, split_k=sk, defer=_WGRAD["stream"] is None)
             return (dX,) + (None,) * len(ws)
         dW = torch.empty(N, Kd, dtype=torch.float32, device=x.device)
         K.gemm(dY, x, dW, N, Kd, M, N, Kd, Kd, False, False, split_k=sk, split_overwrite=True)
