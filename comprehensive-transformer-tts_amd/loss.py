@@ -113,8 +113,14 @@ class CompTransTTSLoss(nn.Module):
                 pitch_loss = {"C": t[3], "uv": t[4], "f0_mean": t[5], "f0_std": t[6]}
             if self.use_energy_embed:
                 energy_loss = t[7]
-            keep = torch.tensor([1.0, 1.0, 1.0] + [float(self.use_pitch_embed)] * 4 + [float(self.use_energy_embed)], device=dev)
-            total = total + (t if (self.use_pitch_embed and self.use_energy_embed) else t * keep).sum()
+            if self.use_pitch_embed and self.use_energy_embed:
+                total = total + t.sum()
+            else:                        # only the terms of the branches that exist (no host tensor here: the step is graph-captured)
+                total = total + t[0] + t[1] + t[2]
+                if self.use_pitch_embed:
+                    total = total + t[3] + t[4] + t[5] + t[6]
+                if self.use_energy_embed:
+                    total = total + t[7]
         return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, prosody_loss)
 
 
