@@ -49,8 +49,14 @@ class PsumTask(C.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("n", _i64), ("stride", _i64), ("count", _i32), ("alpha", _f32)]
 
 
+class RepackTask(C.Structure):
+    """ctts_repack_task of include/ctts.h"""
+    _fields_ = [("src", _vp), ("dst", _vp), ("cout", _i32), ("cin", _i32), ("k", _i32)]
+
+
 # name -> argtypes (every function returns int status except the two listed below)
 _SIGNATURES = {
+    "ctts_conv_dgrad_weights": [C.POINTER(RepackTask), C.c_int, _vp],
     "ctts_gemm_split_plan": [C.POINTER(GemmDesc), C.POINTER(_i32), C.POINTER(_i64)],
     "ctts_partial_sums": [C.POINTER(PsumTask), C.c_int, _vp],
     "ctts_reduce_parts": [C.c_int, _i64, C.c_int],

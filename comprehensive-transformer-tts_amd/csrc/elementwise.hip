@@ -413,6 +413,71 @@ extern "C" int ctts_log_clamp_transpose(const float* mel_fm, float* out, int B, 
 }
 
 
+// ---------------------------------------------------------------- data-gradient weights of all Conv1d layers, one launch (round 4)
+// The data gradient of a Conv1d is a convolution with the flipped, transposed taps: dst[ci][kk][co] = src[co][k-1-kk][ci] (src = the
+// GEMM-major forward layout [Cout][K][Cin] of model._Conv).  Round 3 repacked each layer's weight inside its own backward - 21 launches
+// of an uncoalesced gather (threads walked co with a stride of K*Cin floats: 10 us for 9.4 MB).  Now ONE launch at the start of the step
+// transposes 32 x 32 (co, ci) tiles of every layer through LDS (both sides coalesced), tasks packed 32 per launch like ctts_partial_sums.
+namespace {
+constexpr int RPK_BATCH = 32;
+struct RepackBatch {
+  const float* src[RPK_BATCH];
+  float* dst[RPK_BATCH];
+  int cout[RPK_BATCH], cin[RPK_BATCH], k[RPK_BATCH];
+  int first_block[RPK_BATCH + 1];
+  int ntasks;
+};
+
+__global__ __launch_bounds__(256) void conv_dgrad_weights_kernel(const RepackBatch b) {
+  __shared__ float tile[32][33];
+  int t = 0;
+  while (t + 1 < b.ntasks && (int)blockIdx.x >= b.first_block[t + 1]) ++t;
+  const float* __restrict__ src = b.src[t];
+  float* __restrict__ dst = b.dst[t];
+  const int cout = b.cout[t], cin = b.cin[t], k = b.k[t];
+  const int tco = (cout + 31) / 32, tci = (cin + 31) / 32;
+  int blk = (int)blockIdx.x - b.first_block[t];
+  const int kk = blk / (tco * tci);
+  blk -= kk * tco * tci;
+  const int co0 = (blk / tci) * 32, ci0 = (blk % tci) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < cout && ci < cin) ? src[((long)co * k + (k - 1 - kk)) * cin + ci] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < cin && co < cout) dst[((long)ci * k + kk) * cout + co] = tile[tx][r];
+  }
+}
+}  // namespace
+
+extern "C" int ctts_conv_dgrad_weights(const ctts_repack_task* tasks, int ntasks, void* stream) {
+  CTTS_REQUIRE(ntasks >= 0 && (tasks || ntasks == 0), "ctts_conv_dgrad_weights: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < ntasks; t0 += RPK_BATCH) {
+    RepackBatch b;
+    b.ntasks = 0;
+    int blocks = 0;
+    for (int t = t0; t < ntasks && t < t0 + RPK_BATCH; ++t) {
+      const ctts_repack_task& q = tasks[t];
+      CTTS_REQUIRE(q.src && q.dst && q.cout > 0 && q.cin > 0 && q.k > 0, "ctts_conv_dgrad_weights: bad task %d", t);
+      const int i = b.ntasks++;
+      b.src[i] = q.src; b.dst[i] = q.dst; b.cout[i] = q.cout; b.cin[i] = q.cin; b.k[i] = q.k;
+      b.first_block[i] = blocks;
+      blocks += ((q.cout + 31) / 32) * ((q.cin + 31) / 32) * q.k;
+    }
+    if (b.ntasks == 0) continue;
+    b.first_block[b.ntasks] = blocks;
+    hipLaunchKernelGGL(conv_dgrad_weights_kernel, dim3(blocks), dim3(256), 0, st, b);
+    CTTS_CHECK_LAUNCH("ctts_conv_dgrad_weights");
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------- positional embedding add (round 4)
 // y = rowscale[row] * dropout(x + alpha * table[pos[row]])   -   `x + self.pos_embed_alpha * self.embed_positions(x)` followed by F.dropout
 // and the non-pad mask multiply (transformer_fs2.py:41-52,113-119; PitchPredictor.forward modules.py:1349-1351) in ONE launch instead of

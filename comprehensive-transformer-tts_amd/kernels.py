@@ -305,6 +305,19 @@ def row_tile_map(row_lens, row_T, row_halo, M):
     return tm
 
 
+def conv_dgrad_weights(weights):
+    """Data-gradient operands [Cin, K * Cout] of many Conv1d weights (GEMM-major forward layout, viewed [Cout, K * Cin]) in one launch
+    per 32 layers: `weights` = list of (wmaj [Cout, K*Cin], cout, cin, k) -> list of wd tensors (include/ctts.h ctts_conv_dgrad_weights)."""
+    if not weights:
+        return []
+    outs = [torch.empty(cin, k * cout, dtype=torch.float32, device=w.device) for w, cout, cin, k in weights]
+    arr = (_lib.RepackTask * len(weights))()
+    for t, (w, cout, cin, k), o in zip(arr, weights, outs):
+        t.src, t.dst, t.cout, t.cin, t.k = _p(_f32c(w, "conv weight (GEMM-major)")), _p(o), int(cout), int(cin), int(k)
+    _lib.check(_lib.load().ctts_conv_dgrad_weights(arr, len(arr), _stream()), "ctts_conv_dgrad_weights")
+    return outs
+
+
 def conv_weight_repack(src, dst, cout, cin, k, mode):
     lib = _lib.load()
     _lib.check(lib.ctts_conv_weight_repack(_p(src), _p(dst), cout, cin, k, mode, _stream()), "ctts_conv_weight_repack")

@@ -340,12 +340,14 @@ class _LinearConv(torch.autograd.Function):
             pad = ctx.pad_left                   # forward / weight-gradient view
             pad_d = ksize - 1 - pad              # data gradient: correlation with the flipped taps (equal to `pad` for SAME with odd k)
             if ctx.needs_input_grad[0]:
-                wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
-                wmaj = _gemm_major(w)
-                if wmaj is not None:
-                    K.conv_weight_repack(wmaj, wd, N, Cin, ksize, 4)
-                else:
-                    K.conv_weight_repack(w.contiguous(), wd, N, Cin, ksize, 1)
+                wd = _DGRAD_W.pop(w.data_ptr(), None)          # prepared for the whole model at the start of the step (prepare_dgrad_weights)
+                if wd is None or tuple(wd.shape) != (Cin, ksize * N):
+                    wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
+                    wmaj = _gemm_major(w)
+                    if wmaj is not None:
+                        K.conv_weight_repack(wmaj, wd, N, Cin, ksize, 4)
+                    else:
+                        K.conv_weight_repack(w.contiguous(), wd, N, Cin, ksize, 1)
                 # few output tiles but a long reduction (FFN conv dgrad: 1024 tiles, K = 9216): split K so that the launch fills
                 # all 256 CUs x 8 resident workgroups (atomic accumulation into a zero-filled dX)
                 tiles = -(-M // 64) * -(-Cin // 64)
@@ -403,6 +405,29 @@ class _LinearConv(torch.autograd.Function):
                 if fused:
                     dW = None
         return dX, dW, dB, d_res, None, None, None, None, None, None, None, None, None, None, None, None, None
+
+
+# data-gradient operands of the Conv1d weights, keyed by the weight's device address; filled by prepare_dgrad_weights at the start of a
+# train step (ONE launch for all layers instead of one repack inside every layer's backward), consumed by _LinearConv.backward
+_DGRAD_W = {}
+
+
+def prepare_dgrad_weights(params):
+    """`params`: Conv1d weights in the GEMM-major layout of model._Conv (others are ignored).  Valid until the weights change - call it
+    once per step, after the optimizer update and before the backward pass (trainer.TrainStep does, in front of the forward)."""
+    _DGRAD_W.clear()
+    todo = []
+    for w in params:
+        wm = _gemm_major(w) if w.dim() == 3 else None
+        if wm is not None and w.requires_grad:
+            N, Cin, k = w.shape
+            todo.append((w, (wm.detach(), N, Cin, k)))
+    for (w, _), wd in zip(todo, K.conv_dgrad_weights([t for _, t in todo])):
+        _DGRAD_W[w.data_ptr()] = wd
+
+
+def clear_dgrad_weights():
+    _DGRAD_W.clear()
 
 
 class PadRows:

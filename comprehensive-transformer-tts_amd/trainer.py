@@ -42,6 +42,9 @@ class TrainStep:
         self.max_norm = max_norm
         self.grad_acc_step = max(1, int(grad_acc_step))
         self.g_opt_noclip = None
+        import os as _os          # CTTS_BATCH_REPACK=0: every conv layer repacks its own data-gradient weight inside its backward (A/B switch)
+        self._conv_weights = ([p for p in model.parameters() if p.dim() == 3 and p.requires_grad and ops._gemm_major(p) is not None]
+                              if _os.environ.get("CTTS_BATCH_REPACK", "1") != "0" else [])
         self.fadam = None
         if fused_optimizer:
             oc = optim._optimizer.defaults
@@ -88,6 +91,8 @@ class TrainStep:
         collects the deferred ordered sums into the arena (split-K weight gradients, bias / LayerNorm column sums) and finishes them
         with one launch per 24 sums at the END of the stage - before the stage's bucket is all-reduced / the optimizer reads it."""
         from . import kernels as _K
+        if self._conv_weights:
+            ops.prepare_dgrad_weights(self._conv_weights)         # one launch: the transposed / flipped taps every conv's data gradient needs
         rec = ops.CutRecorder(self.cut_names)
         with rec:
             loss = self._forward_loss()
@@ -102,6 +107,7 @@ class TrainStep:
                 s = next(gen)
                 sink.flush()
             except StopIteration:
+                ops.clear_dgrad_weights()
                 return
             finally:
                 _K.set_partial_sink(prev)

@@ -102,6 +102,11 @@ typedef struct ctts_gemm_desc {
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
 /* 1 (+ *count, *stride) when ctts_gemm would run `d` as a split-K launch whose partials the caller may keep (split_out); else 0. */
 int ctts_gemm_split_plan(const ctts_gemm_desc* d, int32_t* count, int64_t* stride);
+/* Data-gradient operands of many Conv1d layers in one launch: for every task dst[ci][kk][co] = src[co][k-1-kk][ci], src = the GEMM-major
+ * forward weight [Cout][K][Cin] (what ctts_conv_weight_repack mode 4 does for one layer; 32 x 32 tiles through LDS, both sides
+ * coalesced).  `tasks` is a HOST array.  The weights are constant during a step: trainer.TrainStep calls this once before the forward. */
+typedef struct ctts_repack_task { const float* src; float* dst; int32_t cout, cin, k; } ctts_repack_task;
+int ctts_conv_dgrad_weights(const ctts_repack_task* tasks, int ntasks, void* stream);
 /* y = rowscale[row] * dropout(x + alpha * table[pos[row]]): positional-embedding add of the fs2 stacks and predictors
  * (`x + self.pos_embed_alpha * self.embed_positions(x)` + F.dropout + non-pad mask, transformer_fs2.py:41-52,113-119, modules.py:1349-1351)
  * as one launch each way; pos from ctts_positions, table [n_pos, C] row-major, alpha a device scalar or NULL (= 1), rowscale / dropout

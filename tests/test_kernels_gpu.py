@@ -1211,3 +1211,35 @@ def test_positional_embedding_add_fwd_bwd(B, T, C, p, use_alpha, use_mask):
     close(xg.grad, go.double() * m64, 1e-6, "posembed dx")
     if use_alpha:
         close(alpha.grad, (go.double() * m64 * pe.double()).sum().view(1), 1e-5 * (B * T * C) ** 0.5, "posembed dalpha")
+
+
+def test_batched_conv_data_gradient_weights_equal_the_per_layer_repack():
+    """ctts_conv_dgrad_weights (one launch for all Conv1d layers, 32 x 32 tiles through LDS) against ctts_conv_weight_repack mode 4 layer
+    by layer - bit-identical copies, ragged channel counts (80), k = 1, more than 32 tasks (two launches) included - and
+    ops.prepare_dgrad_weights feeding _LinearConv.backward the same data gradient as the per-layer path."""
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1024, 256, 9), (256, 1024, 1), (512, 80, 5), (80, 512, 5), (256, 256, 3), (33, 7 * 4, 5)] + [(64, 32, 3)] * 30
+    ws = [torch.rand(co, k, ci, generator=g).to(DEV) for co, ci, k in shapes]
+    outs = K.conv_dgrad_weights([(w.view(w.shape[0], -1), co, ci, k) for w, (co, ci, k) in zip(ws, shapes)])
+    for w, (co, ci, k), o in zip(ws, shapes, outs):
+        ref = torch.empty(ci, k * co, device=DEV)
+        K.conv_weight_repack(w.view(co, k * ci), ref, co, ci, k, 4)
+        assert torch.equal(o, ref), (co, ci, k)
+    # through the autograd function: prepared weights vs per-layer repack
+    B, T, Cin, Cout, ks = 2, 70, 64, 128, 5
+    wp = torch.nn.Parameter(torch.rand(Cout, ks, Cin, generator=g).to(DEV).permute(0, 2, 1))        # GEMM-major like model._Conv
+    x = torch.rand(B, T, Cin, generator=g).to(DEV)
+    go = torch.rand(B, T, Cout, generator=g).to(DEV)
+    grads = []
+    for prepared in (False, True):
+        xi = x.clone().requires_grad_()
+        if prepared:
+            ops.prepare_dgrad_weights([wp])
+            assert wp.data_ptr() in ops._DGRAD_W
+        y = ops.conv1d(xi, wp, None)
+        y.backward(go)
+        assert wp.data_ptr() not in ops._DGRAD_W
+        grads.append(xi.grad.clone())
+        wp.grad = None
+    assert torch.equal(grads[0], grads[1])
+    ops.clear_dgrad_weights()
