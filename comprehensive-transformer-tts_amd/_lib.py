@@ -118,6 +118,8 @@ _SIGNATURES = {
     "ctts_var_loss_bwd": [_vp] * 2 + [C.c_int] + [_vp] * 12 + [C.c_int] * 3 + [_vp, C.c_int, _vp] + [_vp] * 4 + [_vp] * 5 + [_vp],
     "ctts_bin_loss_fwd": [_vp, _vp, _i64, _vp, _vp, _vp],
     "ctts_bin_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "ctts_masked_loss_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp],
+    "ctts_masked_loss_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "ctts_mel_l1_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp, _vp],
     "ctts_mel_l1_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, _vp],
     "ctts_adam_clip_step": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _f32, _f32, _f32, _f32, _f32, _vp, _vp],

@@ -237,6 +237,45 @@ __global__ void bin_loss_bwd_kernel(const float* __restrict__ soft, const float*
   }
 }
 
+// ---- masked mean loss: sum_i w_i * l(p_i, t_i) / sum_i w_i with l = |p-t| (kind 0), (p-t)^2 (1), BCE-with-logits (2).  The terms of the
+// pitch_type "frame" / "ph" and frame-level energy configurations (loss.py:173-178,202-219,234-243) - same two-stage ordered reduction
+__device__ __forceinline__ float masked_term(int kind, float p, float t) {
+  if (kind == 0) return fabsf(p - t);
+  if (kind == 1) return (p - t) * (p - t);
+  return fmaxf(p, 0.f) - p * t + log1pf(expf(-fabsf(p)));
+}
+__global__ __launch_bounds__(256) void masked_loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                                   const float* __restrict__ w, long n, int kind, float* __restrict__ partials) {
+  __shared__ float s4[4];
+  float a = 0.f, h = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float wv = w[i];
+    a += masked_term(kind, pred[i], tgt[i]) * wv;
+    h += wv;
+  }
+  a = block_sum(a, s4); h = block_sum(h, s4);
+  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = a; partials[2 * blockIdx.x + 1] = h; }
+}
+__global__ __launch_bounds__(256) void masked_loss_finalize_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ out) {
+  __shared__ float s4[4];
+  float a = 0.f, h = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) { a += partials[2 * i]; h += partials[2 * i + 1]; }
+  a = block_sum(a, s4); h = block_sum(h, s4);
+  if (threadIdx.x == 0) { out[0] = a / h; out[1] = h; }
+}
+__global__ void masked_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ w,
+                                       const float* __restrict__ out, const float* __restrict__ g, float* __restrict__ dpred, long n, int kind) {
+  const float k = g[0] / out[1];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float p = pred[i], t = tgt[i];
+    float d;
+    if (kind == 0) d = p > t ? 1.f : (p < t ? -1.f : 0.f);
+    else if (kind == 1) d = 2.f * (p - t);
+    else d = 1.f / (1.f + expf(-p)) - t;
+    dpred[i] = k * w[i] * d;
+  }
+}
+
 }  // namespace
 
 extern "C" int ctts_var_loss_fwd(const float* log_d, const void* dur, int dur_is_float, const int64_t* texts, const uint8_t* src_pad,
@@ -302,5 +341,26 @@ extern "C" int ctts_bin_loss_bwd(const float* soft, const float* hard, const flo
   const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(bin_loss_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, soft, hard, out2, g, dsoft, (long)n);
   CTTS_CHECK_LAUNCH("ctts_bin_loss_bwd");
+  return 0;
+}
+
+extern "C" int ctts_masked_loss_fwd(const float* pred, const float* target, const float* weight, int64_t n, int kind, float* partials,
+                                    float* out2, void* stream) {
+  CTTS_REQUIRE(pred && target && weight && partials && out2 && n > 0 && kind >= 0 && kind <= 2, "ctts_masked_loss_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)((n + 255) / 256 > BIN_BLOCKS ? BIN_BLOCKS : (n + 255) / 256);
+  hipLaunchKernelGGL(masked_loss_partial_kernel, dim3(blocks), dim3(256), 0, st, pred, target, weight, (long)n, kind, partials);
+  CTTS_CHECK_LAUNCH("ctts_masked_loss_fwd");
+  hipLaunchKernelGGL(masked_loss_finalize_kernel, dim3(1), dim3(256), 0, st, partials, blocks, out2);
+  CTTS_CHECK_LAUNCH("ctts_masked_loss_fwd(finalize)");
+  return 0;
+}
+
+extern "C" int ctts_masked_loss_bwd(const float* pred, const float* target, const float* weight, const float* out2, const float* g,
+                                    float* dpred, int64_t n, int kind, void* stream) {
+  CTTS_REQUIRE(pred && target && weight && out2 && g && dpred && n > 0 && kind >= 0 && kind <= 2, "ctts_masked_loss_bwd: bad arguments");
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(masked_loss_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, weight, out2, g, dpred, (long)n, kind);
+  CTTS_CHECK_LAUNCH("ctts_masked_loss_bwd");
   return 0;
 }

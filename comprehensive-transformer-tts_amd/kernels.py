@@ -995,6 +995,27 @@ def bin_loss_bwd(soft, hard, out2, g):
     return dsoft
 
 
+MASKED_L1, MASKED_L2, MASKED_BCE = 0, 1, 2
+
+
+def masked_loss_fwd(pred, target, weight, kind):
+    n = pred.numel()
+    partials = torch.empty(1024, dtype=torch.float32, device=pred.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=pred.device)
+    lib = _lib.load()
+    _lib.check(lib.ctts_masked_loss_fwd(_p(_f32c(pred, "pred")), _p(_f32c(target, "target")), _p(_f32c(weight, "weight")), n, int(kind),
+                                        _p(partials), _p(out2), _stream()), "ctts_masked_loss_fwd")
+    return out2
+
+
+def masked_loss_bwd(pred, target, weight, out2, g, kind):
+    dpred = torch.empty_like(pred)
+    lib = _lib.load()
+    _lib.check(lib.ctts_masked_loss_bwd(_p(pred), _p(target), _p(weight), _p(out2), _p(_f32c(g, "g")), _p(dpred), pred.numel(), int(kind),
+                                        _stream()), "ctts_masked_loss_bwd")
+    return dpred
+
+
 # ---- mel front end as a real FFT (csrc/mel.hip) ------------------------------------------------------------------------------
 def mel_prepare(mel_basis, n_fft):
     """-> workspace tensor for `mel_spectrogram_fft` (twiddles, transposed filterbank, per-tile bin ranges)"""

@@ -26,6 +26,8 @@ class CompTransTTSLoss(nn.Module):
         self.binarization_loss_warmup_steps = train_config["duration"]["binarization_loss_warmup_steps"]
         self.loss_config = train_config["loss"]
         self.pitch_config = preprocess_config["preprocessing"]["pitch"]
+        self.pitch_type = self.pitch_config["pitch_type"]
+        self.energy_feature_level = preprocess_config["preprocessing"]["energy"]["feature"]
         self.use_pitch_embed = model_config["variance_embedding"]["use_pitch_embed"]
         self.use_energy_embed = model_config["variance_embedding"]["use_energy_embed"]
         self.var_start_steps = train_config["step"]["var_start_steps"]
@@ -35,6 +37,8 @@ class CompTransTTSLoss(nn.Module):
         lc = self.loss_config
         if lc.get("dur_loss", "mse") != "mse" or lc.get("cwt_loss", "l1") not in ("l1", "l2"):
             raise NotImplementedError("CompTransTTSLoss: dur_loss 'mse' and cwt_loss 'l1' / 'l2' are built (the reference raises for the rest too)")
+        if self.pitch_type != "cwt" and lc.get("pitch_loss", "l1") not in ("l1", "l2"):
+            raise NotImplementedError("CompTransTTSLoss: pitch_loss 'l1' / 'l2' (the reference's 'ssim' branch is NotImplemented there too, loss.py:220-221)")
         # host-side launch constants of the fused variance-loss kernel
         self._lambdas = torch.tensor([lc["lambda_ph_dur"], lc["lambda_word_dur"], lc["lambda_sent_dur"], lc["lambda_f0"], lc["lambda_uv"]],
                                      dtype=torch.float32)
@@ -59,6 +63,24 @@ class CompTransTTSLoss(nn.Module):
         """BinLoss (loss.py:380-386) with a mask product instead of boolean indexing (no host sync) - csrc/loss.hip."""
         from . import ops
         return ops.bin_loss(hard, soft)
+
+    def frame_or_ph_pitch_loss(self, p_pred, pitch_targets, src_masks, mel_masks):
+        """get_pitch_loss / add_f0_loss for pitch_type "ph" (loss.py:173-178) and "frame" (loss.py:202-219): masked means through
+        `ops.masked_loss` (ordered reductions, csrc/loss.hip)."""
+        from . import ops
+        lc = self.loss_config
+        kind = "l1" if lc["pitch_loss"] == "l1" else "l2"
+        pred = p_pred["pitch_pred"]
+        if self.pitch_type == "ph":
+            return {"f0": ops.masked_loss(pred[:, :, 0], pitch_targets["f0"], (~src_masks).float(), kind) * lc["lambda_f0"]}
+        f0, uv = pitch_targets["f0"], pitch_targets["uv"]
+        nonpad = (~mel_masks).float()
+        out = {}
+        if self.pitch_config["use_uv"]:
+            out["uv"] = ops.masked_loss(pred[:, :, 1], uv, nonpad, "bce") * lc["lambda_uv"]
+            nonpad = nonpad * (uv == 0).float()
+        out["f0"] = ops.masked_loss(pred[:, :, 0], f0, nonpad, kind) * lc["lambda_f0"]
+        return out
 
     def forward(self, inputs, predictions, step):
         (texts, _, _, mel_targets, _, _, pitch_targets, energy_targets, duration_targets, _, _) = inputs[3:]
@@ -89,38 +111,53 @@ class CompTransTTSLoss(nn.Module):
             prosody_loss = F.l1_loss(up_tgt, up_vec) + ((pp_tgt - pp_vec).abs() * sel).sum() / (sel.sum() * pp_vec.shape[-1])
         total = mel_loss + postnet_mel_loss + ctc_loss + bin_loss + prosody_loss + zero
         duration_loss = {"pdur": zero, "wdur": zero, "sdur": zero}
-        pitch_loss = {"C": zero, "uv": zero, "f0_mean": zero, "f0_std": zero}
+        # get_init_losses (loss.py:241-264): the keys follow pitch_type
+        if self.pitch_type == "cwt":
+            pitch_loss = {"C": zero, "uv": zero, "f0_mean": zero, "f0_std": zero}
+        elif self.pitch_type == "ph":
+            pitch_loss = {"f0": zero}
+        else:
+            pitch_loss = dict(**({"uv": zero} if self.pitch_config["use_uv"] else {}), f0=zero)
         energy_loss = zero
+        fused_pitch = self.use_pitch_embed and self.pitch_type == "cwt"
+        fused_energy = self.use_energy_embed and self.energy_feature_level == "phoneme_level"
         if step > self.var_start_steps:
             # loss.py:123-243 in one fused launch: terms = (pdur, wdur, sdur, C, uv, f0_mean, f0_std, energy), lambda-weighted
             # variance_embedding.use_pitch_embed / use_energy_embed = False (loss.py:331-334 skips the term, get_init_losses keeps its
             # zero): the fused kernel is fed zero predictions AND zero targets for that branch - the term and its gradients are exactly 0
             B, Tm = mel_masks.shape
             dev = mel_targets.device
-            if self.use_pitch_embed:
+            if fused_pitch:
                 cwt_p, f0m_p, f0s_p = p_pred["cwt"], p_pred["f0_mean"], p_pred["f0_std"]
                 cwt_t, uv_t, f0m_t, f0s_t = pitch_targets["cwt_spec"], pitch_targets["uv"], pitch_targets["f0_mean"], pitch_targets["f0_std"]
             else:
                 cwt_p, cwt_t = torch.zeros(B, Tm, 11, device=dev), torch.zeros(B, Tm, 10, device=dev)
                 uv_t = torch.full((B, Tm), 0.5, device=dev)       # BCE-with-logits of logit 0 against 0.5 has zero gradient; its value is dropped below
                 f0m_p = f0s_p = f0m_t = f0s_t = torch.zeros(B, device=dev)
-            e_p, e_t = (e_pred, energy_targets) if self.use_energy_embed else (torch.zeros_like(log_d), torch.zeros_like(log_d))
+            e_p, e_t = (e_pred, energy_targets) if fused_energy else (torch.zeros_like(log_d), torch.zeros_like(log_d))
             t = ops.variance_losses(log_d, cwt_p, f0m_p, f0s_p, e_p, duration_targets, texts, src_masks,
                                     cwt_t, uv_t, mel_masks, f0m_t, f0s_t, e_t, self._lambdas, self._cwt_l2, self._sil)
             duration_loss = {"pdur": t[0], "wdur": t[1] if self.loss_config["lambda_word_dur"] > 0 else zero,
                              "sdur": t[2] if self.loss_config["lambda_sent_dur"] > 0 else zero}
-            if self.use_pitch_embed:
+            if fused_pitch:
                 pitch_loss = {"C": t[3], "uv": t[4], "f0_mean": t[5], "f0_std": t[6]}
-            if self.use_energy_embed:
+            elif self.use_pitch_embed:
+                pitch_loss = self.frame_or_ph_pitch_loss(p_pred, pitch_targets, src_masks, mel_masks)
+            if fused_energy:
                 energy_loss = t[7]
-            if self.use_pitch_embed and self.use_energy_embed:
+            elif self.use_energy_embed:      # frame level (loss.py:238-242): l1 over the frames of the utterances
+                energy_loss = ops.masked_loss(e_pred, energy_targets, (~mel_masks).float(), "l1")
+            if fused_pitch and fused_energy:
                 total = total + t.sum()
             else:                        # only the terms of the branches that exist (no host tensor here: the step is graph-captured)
                 total = total + t[0] + t[1] + t[2]
-                if self.use_pitch_embed:
+                if fused_pitch:
                     total = total + t[3] + t[4] + t[5] + t[6]
+                elif self.use_pitch_embed:
+                    for v in pitch_loss.values():
+                        total = total + v
                 if self.use_energy_embed:
-                    total = total + t[7]
+                    total = total + energy_loss
         return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, prosody_loss)
 
 

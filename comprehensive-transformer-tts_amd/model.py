@@ -13,8 +13,9 @@ Contract kept from the reference:
 Not a module-tree translation: activations stay [B,T,C]; each reference sub-layer maps to one
 or two fused kernel launches (see ops.py).  Supported here (= every BASELINE.json config): block_type transformer_fs2 and
 conformer (conformer.py); learn_alignment False and True (aligner + device MAS, single- and multi-speaker); prosody_modeling
-"none" and "liu2021" (prosody.py); pitch_type cwt with pitch_norm log and use_uv; phoneme-level energy; ffn_act gelu,
-ffn_padding SAME, use_pitch_embed / use_energy_embed True (the shipped yaml values).  Any other value of these switches raises
+"none" and "liu2021" (prosody.py); pitch_type cwt / frame / ph (pitch_norm log / standard, use_uv); phoneme- and frame-level
+energy; ffn_act gelu / relu / swish ...; ffn_padding SAME / LEFT; use_pitch_embed / use_energy_embed on or off.  Values the reference
+does not build either (prosody du2021 aside, which is outside SURVEY.md section 8; pitch_ar, which the reference cannot run) raise
 NotImplementedError in the constructor - nothing is silently ignored.
 """
 import json
@@ -418,6 +419,32 @@ def phoneme_level_mean(frame_values, dur, src_lens):
     return out * valid
 
 
+def phoneme_level_pitch(f0_frame, mel2ph, mel_lens, n_phones):
+    """get_phoneme_level_pitch (utils/tools.py:47-53, modules.py:873-880): mean of the frame-level f0 over the frames whose mel2ph
+    points at the phoneme (1-based; only the first mel_len frames count), 0-frame phonemes get 0 - as a one-hot contraction in fp64
+    on the device (the reference scatter_adds per utterance on the host)."""
+    B, Tm = f0_frame.shape
+    valid = torch.arange(Tm, device=f0_frame.device)[None, :] < mel_lens[:, None]
+    ids = torch.arange(1, n_phones + 1, device=f0_frame.device)
+    hot = ((mel2ph[:, :Tm, None] == ids[None, None, :]) & valid[:, :, None]).double()          # [B,Tm,Ts]
+    tot = (hot * f0_frame.double()[:, :, None]).sum(1)
+    cnt = hot.sum(1).clamp(min=1)
+    return (tot / cnt).float()
+
+
+def denorm_f0(f0, uv, pitch_cfg, pitch_padding=None):
+    """utils/pitch_tools.py:69-82 without the in-place writes (masks applied with torch.where)."""
+    if pitch_cfg["pitch_norm"] == "standard":
+        f0 = f0 * pitch_cfg["f0_std"] + pitch_cfg["f0_mean"]
+    if pitch_cfg["pitch_norm"] == "log":
+        f0 = 2 ** f0
+    if uv is not None and pitch_cfg["use_uv"]:
+        f0 = torch.where(uv > 0, torch.zeros_like(f0), f0)
+    if pitch_padding is not None:
+        f0 = torch.where(pitch_padding, torch.zeros_like(f0), f0)
+    return f0
+
+
 class VarianceAdaptor(nn.Module):
     """reference: modules.py:726-1114 (supervised, unsupervised (aligner + MAS) and inference branches)."""
 
@@ -430,10 +457,20 @@ class VarianceAdaptor(nn.Module):
             raise NotImplementedError(f"prosody_modeling.model_type '{self.model_type}': only 'none' and 'liu2021' are built "
                                       "(du2021 is outside SURVEY.md section 8)")
         pitch = preprocess_config["preprocessing"]["pitch"]
-        if pitch["pitch_type"] != "cwt" or pitch["pitch_norm"] != "log" or not pitch["use_uv"]:
-            raise NotImplementedError("only pitch_type=cwt / pitch_norm=log / use_uv=True (the shipped configs)")
-        if preprocess_config["preprocessing"]["energy"]["feature"] != "phoneme_level":
-            raise NotImplementedError("only phoneme_level energy (the shipped configs)")
+        self.pitch_type = pitch["pitch_type"]
+        if self.pitch_type not in ("cwt", "frame", "ph"):
+            raise NotImplementedError(f"pitch_type '{self.pitch_type}': the reference builds cwt, frame and ph (modules.py:754-786)")
+        if pitch["pitch_norm"] not in ("log", "standard"):
+            raise NotImplementedError(f"pitch_norm '{pitch['pitch_norm']}': the reference knows log and standard (pitch_tools.py:39-48)")
+        if self.pitch_type == "cwt" and (pitch["pitch_norm"] != "log" or not pitch["use_uv"]):
+            raise NotImplementedError("pitch_type=cwt is built for pitch_norm=log / use_uv=True (the shipped configs)")
+        if pitch.get("pitch_ar", False):
+            raise NotImplementedError("pitch_ar=True: the reference calls PitchPredictor(decoder_inp, f0) (modules.py:922), which its "
+                                      "own PitchPredictor.forward(xs, squeeze) does not accept - nothing to reproduce")
+        self.use_uv = bool(pitch["use_uv"])
+        self.energy_level = preprocess_config["preprocessing"]["energy"]["feature"]       # utils/tools.py:30-44 get_variance_level
+        if self.energy_level not in ("phoneme_level", "frame_level"):
+            raise NotImplementedError(f"energy feature '{self.energy_level}': phoneme_level or frame_level")
         self.pitch_cfg = pitch
         vp = model_config["variance_predictor"]
         ve = model_config["variance_embedding"]
@@ -447,7 +484,8 @@ class VarianceAdaptor(nn.Module):
         hidden = model_config["transformer"]["encoder_hidden"]  # sic: modules.py:739 reads the 'transformer' section
         filt, drop = vp["filter_size"], vp["dropout"]
         # modules.py:788-799: learn_alignment reads the frame-level "unsup" statistics
-        stats_key = "energy_unsup_frame" if self.learn_alignment else "energy_sup_phone"
+        level_tag = "phone" if (not self.learn_alignment and self.energy_level == "phoneme_level") else "frame"
+        stats_key = f"energy_{'unsup' if self.learn_alignment else 'sup'}_{level_tag}"
         with open(os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")) as f:
             emin, emax = json.load(f)[stats_key][:2]
         n_ebins = model_config["variance_embedding"]["energy_n_bins"]
@@ -458,10 +496,14 @@ class VarianceAdaptor(nn.Module):
                 bins = torch.linspace(emin, emax, n_ebins - 1)
             self.energy_bins = nn.Parameter(bins, requires_grad=False)
         self.duration_predictor = DurationPredictor(hidden, vp["dur_predictor_layers"], filt, vp["dur_predictor_kernel"], drop, pad_mode)
-        if self.use_pitch_embed:
+        if self.use_pitch_embed and self.pitch_type == "cwt":
             self.cwt_predictor = _CwtPredictor(hidden, vp["cwt_hidden_size"], filt, vp["predictor_layers"], 11,
                                                vp["predictor_kernel"], drop, pad_mode)
             self.cwt_stats_layers = _StatsMLP(hidden, vp["cwt_hidden_size"])
+        elif self.use_pitch_embed:          # modules.py:777-785: frame -> (f0, uv logit) per frame, ph -> f0 per phoneme
+            self.pitch_predictor = PitchPredictor(hidden, vp["predictor_layers"], filt, 2 if self.pitch_type == "frame" else 1,
+                                                  vp["predictor_kernel"], drop, pad_mode)
+        if self.use_pitch_embed:
             self.pitch_embed = nn.Embedding(model_config["variance_embedding"]["pitch_n_bins"], hidden, padding_idx=0)
         if self.use_energy_embed:
             self.energy_predictor = PitchPredictor(hidden, vp["predictor_layers"], filt, 1, vp["predictor_kernel"], drop, pad_mode)
@@ -525,7 +567,7 @@ class VarianceAdaptor(nn.Module):
             d_rounded = attn_hard_dur
             mel2ph, _, _ = K.lr_index(d_rounded, int(max_len), pad=src_mask, round_mode=1)    # dur_to_mel2ph(...)[:, :max_len]
             pitch_target["mel2ph"] = mel2ph.long()
-            if self.use_energy_embed:        # modules.py:1095-1097
+            if self.use_energy_embed and self.energy_level == "phoneme_level":        # modules.py:1095-1097
                 energy_target = phoneme_level_mean(energy_target, attn_hard_dur, src_len)
             mel2ph = None
         elif duration_target is not None:
@@ -541,7 +583,7 @@ class VarianceAdaptor(nn.Module):
             mel2ph = ops.dur_to_mel2ph(d_rounded, src_mask)
         pitch_prediction = energy_prediction = None          # modules.py:982: stay None when the branch is switched off
         out = x
-        if self.use_pitch_embed:
+        if self.use_pitch_embed and self.pitch_type == "cwt":
             # ---- pitch (cwt)   modules.py:890-948,1071-1091
             cwt = self.cwt_predictor(ops.grad_scale(x, self.predictor_grad)) * p_control
             stats = self.cwt_stats_layers(x_org[:, 0, :].contiguous())
@@ -563,17 +605,61 @@ class VarianceAdaptor(nn.Module):
             pitch_embedding = ops.embedding(pitch_ids, self.pitch_embed.weight, 0)
             pitch_prediction = {"pitch_pred": None, "f0_denorm": f0_denorm, "cwt": cwt, "f0_mean": f0_mean, "f0_std": f0_std}
             out = out + pitch_embedding
+        elif self.use_pitch_embed and self.pitch_type == "frame":
+            # ---- pitch (frame)   modules.py:906-938: [f0, uv logit] per frame from the regulated sequence
+            pitch_pred = self.pitch_predictor(ops.grad_scale(x, self.predictor_grad)) * p_control
+            with torch.no_grad():
+                if pitch_target is not None:
+                    mel2ph = pitch_target["mel2ph"]
+                    f0, uv = pitch_target["f0"], pitch_target["uv"]
+                else:
+                    f0 = pitch_pred[:, :, 0]
+                    uv = (pitch_pred[:, :, 1] > 0) if self.use_uv else None
+                pad = mel2ph[:, : f0.shape[1]] == 0
+                f0_denorm = denorm_f0(f0, uv, self.pitch_cfg, pitch_padding=pad)
+                if pitch_target is not None:
+                    pitch_target["f0"] = torch.where(pad, torch.zeros_like(f0), f0)       # modules.py:934-935 (in place there)
+                else:
+                    pitch_pred[:, :, 0].masked_fill_(pad, 0.0)        # ... where f0 is a VIEW of the prediction (inference output)
+                pitch_ids = f0_to_coarse(f0_denorm)
+            pitch_embedding = ops.embedding(pitch_ids, self.pitch_embed.weight, 0)
+            pitch_prediction = {"pitch_pred": pitch_pred, "f0_denorm": f0_denorm, "cwt": None, "f0_mean": None, "f0_std": None}
+            out = out + pitch_embedding
+        elif self.use_pitch_embed:
+            # ---- pitch (ph)   modules.py:892-905: one f0 per phoneme from the encoder side, gathered to frames through mel2ph
+            pitch_pred = self.pitch_predictor(ops.grad_scale(x_org, self.predictor_grad)) * p_control
+            with torch.no_grad():
+                if pitch_target is not None:
+                    mel2ph = pitch_target["mel2ph"]
+                    # modules.py:1083-1084 replaces the dict's frame-level contour by the phoneme-level one; a TrainStep calls forward
+                    # again with the SAME dict (static graph inputs), so the frame-level tensor is kept under its own key
+                    frame_f0 = pitch_target.setdefault("f0_frame", pitch_target["f0"])
+                    pitch_target["f0"] = phoneme_level_pitch(frame_f0, mel2ph, mel_len, x_org.shape[1])
+                    f0 = pitch_target["f0"]
+                else:
+                    f0 = pitch_pred[:, :, 0]
+                all_pad = x_org.sum().abs() == 0                       # modules.py:895 (a 0-dim flag, never a sync here)
+                f0_denorm = denorm_f0(f0, None, self.pitch_cfg, pitch_padding=all_pad)
+                ph_ids = F.pad(f0_to_coarse(f0_denorm), [1, 0])
+                pitch_ids = torch.gather(ph_ids, 1, mel2ph.long())
+            pitch_embedding = ops.embedding(pitch_ids, self.pitch_embed.weight, 0)
+            pitch_prediction = {"pitch_pred": pitch_pred, "f0_denorm": f0_denorm, "cwt": None, "f0_mean": None, "f0_std": None}
+            out = out + pitch_embedding
         if self.use_energy_embed:
-            # ---- energy (phoneme level)   modules.py:950-960,1095-1099 (no gradient scaling: :951 is a no-op)
-            energy_prediction = self.energy_predictor(x_org, squeeze=True)
+            # ---- energy   modules.py:950-960,1092-1099 (no gradient scaling: :951 is a no-op); frame level reads the regulated sequence
+            frame_e = self.energy_level == "frame_level"
+            energy_prediction = self.energy_predictor(x if frame_e else x_org, squeeze=True)
             if energy_target is not None:
                 e_ids = torch.bucketize(energy_target, self.energy_bins)
             else:
                 energy_prediction = energy_prediction * e_control
                 e_ids = torch.bucketize(energy_prediction.detach(), self.energy_bins)
             energy_embedding = ops.embedding(e_ids, self.energy_embedding.weight, 0)
-            e_frames, _, _ = ops.length_regulate(energy_embedding, d_rounded, max_len)
-            out = out + e_frames
+            if frame_e:
+                out = out + energy_embedding
+            else:
+                e_frames, _, _ = ops.length_regulate(energy_embedding, d_rounded, max_len)
+                out = out + e_frames
         x = out
         return (x, pitch_target, pitch_prediction, energy_target, energy_prediction, log_d, d_rounded, mel_len, mel_mask,
                 attn_out, prosody_info)

@@ -1347,6 +1347,27 @@ def variance_losses(log_d, cwt, f0_mean, f0_std, e_pred, dur, texts, src_pad, cw
                           lambdas_t, cwt_l2, sil_t)
 
 
+class _MaskedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight, kind):
+        pred, target, weight = pred.contiguous(), target.contiguous().float(), weight.contiguous().float()
+        out2 = K.masked_loss_fwd(pred, target, weight, kind)
+        ctx.save_for_backward(pred, target, weight, out2)
+        ctx.kind = kind
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, weight, out2 = ctx.saved_tensors
+        return K.masked_loss_bwd(pred, target, weight, out2, g.reshape(1).contiguous(), ctx.kind), None, None, None
+
+
+def masked_loss(pred, target, weight, kind="l1"):
+    """sum(w * l(pred, target)) / sum(w) with l = l1 / l2 / bce (with logits): the f0 and uv terms of pitch_type "frame" / "ph"
+    (loss.py:173-178,206-219) and the frame-level energy term (loss.py:238-242); ordered two-stage reduction (csrc/loss.hip)"""
+    return _MaskedLoss.apply(pred, target, weight, {"l1": K.MASKED_L1, "l2": K.MASKED_L2, "bce": K.MASKED_BCE}[kind])
+
+
 class _BinLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, soft, hard):

@@ -416,6 +416,13 @@ int ctts_var_loss_bwd(const float* log_d, const void* dur, int dur_is_float, con
                       void* stream);
 int ctts_bin_loss_fwd(const float* soft, const float* hard, int64_t n, float* partials, float* out2, void* stream);
 int ctts_bin_loss_bwd(const float* soft, const float* hard, const float* out2, const float* g, float* dsoft, int64_t n, void* stream);
+/* ctts_masked_loss_*: sum_i w_i l(pred_i, target_i) / sum_i w_i over n elements, l = |p-t| (kind 0), (p-t)^2 (1) or BCE-with-logits (2):
+ *   the f0 / uv terms of pitch_type "frame" and "ph" (loss.py:173-178,206-219) and the frame-level energy term (loss.py:238-242).
+ *   partials [1024], out2 = {loss, sum w}; bwd writes dpred [n] = g * w_i * l'(p_i, t_i) / sum w.  Ordered two-stage reduction. */
+int ctts_masked_loss_fwd(const float* pred, const float* target, const float* weight, int64_t n, int kind, float* partials, float* out2,
+                         void* stream);
+int ctts_masked_loss_bwd(const float* pred, const float* target, const float* weight, const float* out2, const float* g, float* dpred,
+                         int64_t n, int kind, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused gradient clipping + Adam over flat fp32 arenas (train.py:118-125, model/optimizer.py:22-53):

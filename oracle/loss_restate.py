@@ -21,6 +21,8 @@ class RefLoss(nn.Module):
         self.binarization_loss_warmup_steps = train_config["duration"]["binarization_loss_warmup_steps"]
         self.loss_config = train_config["loss"]
         self.pitch_config = preprocess_config["preprocessing"]["pitch"]
+        self.pitch_type = self.pitch_config["pitch_type"]
+        self.energy_feature_level = preprocess_config["preprocessing"]["energy"]["feature"]
         self.use_pitch_embed = model_config["variance_embedding"]["use_pitch_embed"]
         self.use_energy_embed = model_config["variance_embedding"]["use_energy_embed"]
         self.var_start_steps = train_config["step"]["var_start_steps"]
@@ -58,9 +60,22 @@ class RefLoss(nn.Module):
             losses["sdur"] = sl.mean() * self.loss_config["lambda_sent_dur"]
         return losses
 
-    def _pitch_loss(self, p_pred, p_tgt, mel_nonpad):
+    def _pitch_loss(self, p_pred, p_tgt, mel_nonpad, src_nonpad=None):
         lam = self.loss_config["lambda_f0"]
         losses = {}
+        if self.pitch_type != "cwt":
+            fn = F.l1_loss if self.loss_config["pitch_loss"] == "l1" else F.mse_loss          # loss.py:175,217 ('ssim' raises there)
+            pred = p_pred["pitch_pred"]
+            if self.pitch_type == "ph":                                                       # loss.py:173-178
+                losses["f0"] = (fn(pred[:, :, 0], p_tgt["f0"], reduction="none") * src_nonpad).sum() / src_nonpad.sum() * lam
+                return losses
+            nonpad = mel_nonpad                                                               # loss.py:202-219 add_f0_loss
+            if self.pitch_config["use_uv"]:
+                losses["uv"] = ((F.binary_cross_entropy_with_logits(pred[:, :, 1], p_tgt["uv"], reduction="none") * nonpad).sum()
+                                / nonpad.sum() * self.loss_config["lambda_uv"])
+                nonpad = nonpad * (p_tgt["uv"] == 0).float()
+            losses["f0"] = (fn(pred[:, :, 0], p_tgt["f0"], reduction="none") * nonpad).sum() / nonpad.sum() * lam
+            return losses
         cwt_pred = p_pred["cwt"][:, :, :10]
         if self.loss_config["cwt_loss"] == "l1":
             losses["C"] = F.l1_loss(cwt_pred, p_tgt["cwt_spec"]) * lam
@@ -123,14 +138,19 @@ class RefLoss(nn.Module):
             prosody_loss = F.l1_loss(up_tgt, up_vec) + ((pp_tgt - pp_vec).abs() * sel).sum() / (sel.sum() * pp_vec.shape[-1])
         total = mel_loss + postnet_mel_loss + ctc_loss + bin_loss + prosody_loss + zero
         duration_loss = {"pdur": zero, "wdur": zero, "sdur": zero}
-        pitch_loss = {"C": zero, "uv": zero, "f0_mean": zero, "f0_std": zero}
+        if self.pitch_type == "cwt":                  # get_init_losses, loss.py:241-264
+            pitch_loss = {"C": zero, "uv": zero, "f0_mean": zero, "f0_std": zero}
+        elif self.pitch_type == "ph":
+            pitch_loss = {"f0": zero}
+        else:
+            pitch_loss = dict(**({"uv": zero} if self.pitch_config["use_uv"] else {}), f0=zero)
         energy_loss = zero
         if step > self.var_start_steps:
             duration_loss = self._duration_loss(log_d, duration_targets, texts, src_nonpad.float())
             if self.use_pitch_embed:
-                pitch_loss = self._pitch_loss(p_pred, pitch_targets, mel_nonpad.float())
+                pitch_loss = self._pitch_loss(p_pred, pitch_targets, mel_nonpad.float(), src_nonpad.float())
             if self.use_energy_embed:
-                m = src_nonpad.float()
+                m = (src_nonpad if self.energy_feature_level == "phoneme_level" else mel_nonpad).float()      # loss.py:236-241
                 energy_loss = ((e_pred - energy_targets).abs() * m).sum() / m.sum()
             total = total + sum(duration_loss.values()) + sum(pitch_loss.values()) + energy_loss
         return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, prosody_loss)

@@ -301,6 +301,33 @@ def alignment_encoder(sd, mel, text_emb, src_pad, attn_prior, temperature, speak
     return torch.softmax(attn, dim=-1)[:, None], logprob[:, None]
 
 
+def phoneme_level_pitch(n_phones, src_lens, mel2ph, mel_lens, pitch_frame):
+    """utils/tools.py:47-53 + model/modules.py:873-880: per utterance, scatter_add the first mel_len frames of the f0 contour at
+    mel2ph - 1 into src_len slots and divide by the (clamped) frame counts; right-padded to the longest utterance."""
+    B = pitch_frame.shape[0]
+    out = torch.zeros(B, int(src_lens.max()))
+    for b in range(B):
+        s, m = int(src_lens[b]), int(mel_lens[b])
+        idx = mel2ph[b, :m].long() - 1
+        tot = torch.zeros(s).scatter_add(0, idx, pitch_frame[b, :m].float())
+        num = torch.zeros(s).scatter_add(0, idx, torch.ones(m)).clamp_min(1)
+        out[b, :s] = tot / num
+    return out
+
+
+def denorm_f0(f0, uv, pitch_cfg, pitch_padding=None):
+    """utils/pitch_tools.py:69-82"""
+    if pitch_cfg["pitch_norm"] == "standard":
+        f0 = f0 * pitch_cfg["f0_std"] + pitch_cfg["f0_mean"]
+    if pitch_cfg["pitch_norm"] == "log":
+        f0 = 2 ** f0
+    if uv is not None and pitch_cfg["use_uv"]:
+        f0[uv > 0] = 0
+    if pitch_padding is not None:
+        f0[pitch_padding] = 0
+    return f0
+
+
 def phoneme_level_energy(dur, src_lens, energy_frame):
     """utils/tools.py:56-66 + model/modules.py:882-888: per-phoneme mean of the frame-level energy."""
     import numpy as np
@@ -453,7 +480,10 @@ def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pa
     vp = cfg["variance_predictor"]
     va = "variance_adaptor."
     pitch_cfg = pre_cfg["preprocessing"]["pitch"]
-    assert pitch_cfg["pitch_type"] == "cwt" and pitch_cfg["pitch_norm"] == "log" and pitch_cfg["use_uv"]
+    pitch_type = pitch_cfg["pitch_type"]
+    assert pitch_type in ("cwt", "frame", "ph") and pitch_cfg["pitch_norm"] in ("log", "standard") and not pitch_cfg.get("pitch_ar", False)
+    assert pitch_type != "cwt" or (pitch_cfg["pitch_norm"] == "log" and pitch_cfg["use_uv"])
+    frame_energy = pre_cfg["preprocessing"]["energy"]["feature"] == "frame_level"
     x = text.clone()
     if speaker_embedding is not None:
         x = x + speaker_embedding[:, None, :]
@@ -479,7 +509,8 @@ def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pa
         d_rounded = attn_hard_dur
         p_targets = dict(p_targets)
         p_targets["mel2ph"] = dur_to_mel2ph(d_rounded, src_pad)[:, :max_mel_len]
-        e_targets = phoneme_level_energy(attn_hard_dur, src_lens, e_targets)
+        if not frame_energy:
+            e_targets = phoneme_level_energy(attn_hard_dur, src_lens, e_targets)
     elif d_targets is not None:
         x, mel_len = length_regulate(x, d_targets, max_mel_len)
         d_rounded = d_targets
@@ -495,7 +526,42 @@ def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pa
     use_pitch, use_energy = ve.get("use_pitch_embed", True), ve.get("use_energy_embed", True)      # modules.py:735-736,1071,1092-1095
     out = x
     p_pred = e_pred = None
-    if use_pitch:
+    if use_pitch and pitch_type == "frame":
+        # pitch (frame)   modules.py:906-938: [f0, uv logit] per frame from the regulated sequence
+        pitch_pred = pitch_like_predictor(sd, va + "pitch_predictor.", cfg, _grad_scale(x, vp["predictor_grad"]), train_dropout) * p_control
+        if p_targets is not None:
+            p_targets = dict(p_targets)
+            mel2ph = p_targets["mel2ph"]
+            f0, uv = p_targets["f0"].clone(), p_targets["uv"]
+        else:
+            mel2ph = mel2ph_inf
+            f0 = pitch_pred[:, :, 0]
+            uv = (pitch_pred[:, :, 1] > 0) if pitch_cfg["use_uv"] else None
+        pad = mel2ph[:, : f0.shape[1]] == 0
+        f0_denorm = denorm_f0(f0, uv, pitch_cfg, pad)
+        f0[pad] = 0                                            # in place: the target / (inference) channel 0 of the prediction
+        if p_targets is not None:
+            p_targets["f0"] = f0
+        pitch_emb = F.embedding(f0_to_coarse(f0_denorm), sd[va + "pitch_embed.weight"], padding_idx=0)
+        p_pred = {"pitch_pred": pitch_pred, "f0_denorm": f0_denorm, "cwt": None, "f0_mean": None, "f0_std": None}
+        out = out + pitch_emb
+    elif use_pitch and pitch_type == "ph":
+        # pitch (ph)   modules.py:892-905,1083-1084: one f0 per phoneme from the encoder side, gathered to frames through mel2ph
+        pitch_pred = pitch_like_predictor(sd, va + "pitch_predictor.", cfg, _grad_scale(x_org, vp["predictor_grad"]), train_dropout) * p_control
+        if p_targets is not None:
+            p_targets = dict(p_targets)
+            mel2ph = p_targets["mel2ph"]
+            p_targets["f0"] = phoneme_level_pitch(x_org.shape[1], src_lens, mel2ph, mel_len, p_targets["f0"])
+            f0 = p_targets["f0"]
+        else:
+            mel2ph = mel2ph_inf
+            f0 = pitch_pred[:, :, 0]
+        f0_denorm = denorm_f0(f0, None, pitch_cfg, x_org.sum().abs() == 0)
+        ph_ids = F.pad(f0_to_coarse(f0_denorm), [1, 0])
+        pitch_emb = F.embedding(torch.gather(ph_ids, 1, mel2ph.long()), sd[va + "pitch_embed.weight"], padding_idx=0)
+        p_pred = {"pitch_pred": pitch_pred, "f0_denorm": f0_denorm, "cwt": None, "f0_mean": None, "f0_std": None}
+        out = out + pitch_emb
+    elif use_pitch:
         # pitch (cwt)
         dec_inp = _grad_scale(x, vp["predictor_grad"])
         h = dec_inp @ sd[va + "cwt_predictor.0.weight"].t() + sd[va + "cwt_predictor.0.bias"]
@@ -523,7 +589,7 @@ def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pa
         out = out + pitch_emb
     if use_energy:
         # energy (phoneme level; NOTE modules.py:951 discards the grad-scaled tensor -> full gradient)
-        e_pred = pitch_like_predictor(sd, va + "energy_predictor.", cfg, x_org, train_dropout).squeeze(-1)
+        e_pred = pitch_like_predictor(sd, va + "energy_predictor.", cfg, x if frame_energy else x_org, train_dropout).squeeze(-1)
         bins = sd[va + "energy_bins"]
         if e_targets is not None:
             e_idx = torch.bucketize(e_targets, bins)
@@ -531,8 +597,11 @@ def variance_adaptor(sd, cfg, pre_cfg, text, src_lens, src_pad, mel_lens, mel_pa
             e_pred = e_pred * e_control
             e_idx = torch.bucketize(e_pred, bins)
         e_emb = F.embedding(e_idx, sd[va + "energy_embedding.weight"], padding_idx=0)
-        e_emb_frames, _ = length_regulate(e_emb, d_rounded, max_mel_len)
-        out = out + e_emb_frames
+        if frame_energy:                     # modules.py:1092-1094
+            out = out + e_emb
+        else:
+            e_emb_frames, _ = length_regulate(e_emb, d_rounded, max_mel_len)
+            out = out + e_emb_frames
     if taps is not None:
         taps["va_out"] = out
     return out, p_targets, p_pred, e_targets, e_pred, log_d, d_rounded, mel_len, mel_pad

@@ -37,10 +37,13 @@ def pseudo(name, shape):
 
 
 def build(dataset="LJSpeech", block_type="transformer_fs2", learn_alignment=False, prosody="none", vp_overrides=None, tag_suffix="",
-          ve_overrides=None):
+          ve_overrides=None, pitch_overrides=None, energy_overrides=None, loss_overrides=None):
     from model import CompTransTTS
 
     pre, mc, tc = ref_import.load_configs(dataset)
+    pre["preprocessing"]["pitch"].update(pitch_overrides or {})
+    pre["preprocessing"]["energy"].update(energy_overrides or {})
+    tc["loss"].update(loss_overrides or {})
     mc["duration_modeling"]["learn_alignment"] = learn_alignment
     mc["prosody_modeling"]["model_type"] = prosody
     mc["block_type"] = block_type
@@ -66,7 +69,7 @@ def flatten_outputs(out, prefix="out."):
     }
     if p_pred is not None:                   # None with variance_embedding.use_pitch_embed = False (G14)
         d.update({"cwt": _np(p_pred["cwt"]), "f0_denorm": _np(p_pred["f0_denorm"]), "f0_mean": _np(p_pred["f0_mean"]),
-                  "f0_std": _np(p_pred["f0_std"])})
+                  "f0_std": _np(p_pred["f0_std"]), "pitch_pred": _np(p_pred["pitch_pred"])})      # pitch_pred: pitch_type frame / ph (G15)
     if p_t is not None:
         if "f0" in p_t:
             d["pt_f0"] = _np(p_t["f0"])
@@ -134,9 +137,11 @@ def run_case(model, batch, mode, name, with_grads=False, extra_kwargs=None):
                 + (log_d * pseudo("logd", log_d.shape)).sum())
         if e_pred is not None:
             loss = loss + (e_pred * pseudo("e", e_pred.shape)).sum()
-        if p_pred is not None:
+        if p_pred is not None and p_pred["cwt"] is not None:
             loss = loss + ((p_pred["cwt"] * pseudo("cwt", p_pred["cwt"].shape)).sum()
                            + (p_pred["f0_mean"] * 0.7).sum() + (p_pred["f0_std"] * -0.3).sum())
+        if p_pred is not None and p_pred["pitch_pred"] is not None:
+            loss = loss + (p_pred["pitch_pred"] * pseudo("ppred", p_pred["pitch_pred"].shape)).sum()
         if out[10][0] is not None:      # unsupervised: attention outputs enter the loss too
             a_soft, _, _, a_logp = out[10]
             loss = loss + (a_soft * pseudo("asoft", a_soft.shape)).sum() * 10 + (a_logp * pseudo("alogp", a_logp.shape)).sum() * 0.1
@@ -329,6 +334,39 @@ def main_embed_switches():
     golden_loss(out2, b, cfgs2, "g14_nopitch_loss")
 
 
+def main_pitch_energy_switches():
+    """G15: preprocessing.pitch.pitch_type "frame" / "ph" (modules.py:777-785,892-938,1083-1084; loss.py:173-178,202-219), with
+    pitch_norm "standard" + use_uv False + pitch_loss l2 as a second frame case; G16: preprocessing.energy.feature "frame_level"
+    (modules.py:1092-1094; loss.py:238-242; stats key energy_sup_frame)."""
+    torch.manual_seed(0)
+    b = make_batch([24, 17], 6, seed=1515)
+    inf = {k: v for k, v in b.items()}
+    inf.update(mels=None, mel_lens=None, max_mel_len=None, p_targets=None, e_targets=None, d_targets=None)
+    m, cfgs = build("LJSpeech", pitch_overrides=dict(pitch_type="frame"), tag_suffix="_pitchframe")
+    run_case(m, b, "eval", "g15_pitch_frame_eval")
+    out = run_case(m, b, "train", "g15_pitch_frame_train_nodrop", with_grads=True)
+    golden_loss(out, b, cfgs, "g15_pitch_frame_loss")
+    run_case(m, inf, "eval", "g15_pitch_frame_infer", extra_kwargs=dict(p_control=1.1, e_control=0.9, d_control=2.0))
+    m2, cfgs2 = build("LJSpeech", pitch_overrides=dict(pitch_type="frame", pitch_norm="standard", use_uv=False, f0_mean=7.4, f0_std=0.35),
+                      loss_overrides=dict(pitch_loss="l2"), tag_suffix="_pitchframe_nouv")
+    out2 = run_case(m2, b, "train", "g15_pitch_frame_std_nouv_train_nodrop", with_grads=True)
+    golden_loss(out2, b, cfgs2, "g15_pitch_frame_std_nouv_loss")
+    m3, cfgs3 = build("LJSpeech", pitch_overrides=dict(pitch_type="ph"), tag_suffix="_pitchph")
+    run_case(m3, b, "eval", "g15_pitch_ph_eval")
+    out3 = run_case(m3, b, "train", "g15_pitch_ph_train_nodrop", with_grads=True)
+    golden_loss(out3, b, cfgs3, "g15_pitch_ph_loss")
+    run_case(m3, inf, "eval", "g15_pitch_ph_infer", extra_kwargs=dict(p_control=1.1, e_control=0.9, d_control=2.0))
+    # G16: frame-level energy - the targets are per frame
+    g = torch.Generator().manual_seed(1616)
+    be = {k: v for k, v in b.items()}
+    Tm = b["mels"].shape[1]
+    be["e_targets"] = torch.randn(len(b["src_lens"]), Tm, generator=g) * (torch.arange(Tm)[None, :] < b["mel_lens"][:, None])
+    m4, cfgs4 = build("LJSpeech", energy_overrides=dict(feature="frame_level"), tag_suffix="_energyframe")
+    run_case(m4, be, "eval", "g16_energy_frame_eval")
+    out4 = run_case(m4, be, "train", "g16_energy_frame_train_nodrop", with_grads=True)
+    golden_loss(out4, be, cfgs4, "g16_energy_frame_loss")
+
+
 from tests.util import synthetic_samples  # noqa: E402  (shared with tests/test_data_cpu.py)
 
 
@@ -392,6 +430,8 @@ if __name__ == "__main__":
         main_ffn_switches()
     elif len(sys.argv) > 1 and sys.argv[1] == "embed_switches":
         main_embed_switches()
+    elif len(sys.argv) > 1 and sys.argv[1] == "pitch_energy_switches":
+        main_pitch_energy_switches()
     else:
         main()
         main_liu2021()
@@ -399,3 +439,4 @@ if __name__ == "__main__":
         main_vctk_unsup()
         main_ffn_switches()
         main_embed_switches()
+        main_pitch_energy_switches()

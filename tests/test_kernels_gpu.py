@@ -1243,3 +1243,28 @@ def test_batched_conv_data_gradient_weights_equal_the_per_layer_repack():
         wp.grad = None
     assert torch.equal(grads[0], grads[1])
     ops.clear_dgrad_weights()
+
+
+@pytest.mark.parametrize("kind", ["l1", "l2", "bce"])
+def test_masked_loss_matches_torch_and_is_bit_reproducible(kind):
+    """ops.masked_loss (csrc/loss.hip): sum(w * l(p, t)) / sum(w) and its gradient against stock torch in fp64; two runs identical."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(17)
+    n = (16, 1000)
+    p = torch.randn(n, generator=g).to(DEV).requires_grad_(True)
+    t = (torch.rand(n, generator=g) < 0.4).float().to(DEV) if kind == "bce" else torch.randn(n, generator=g).to(DEV)
+    w = (torch.rand(n, generator=g) < 0.7).float().to(DEV)
+    fn = {"l1": lambda a, b: (a - b).abs(), "l2": lambda a, b: (a - b) ** 2,
+          "bce": lambda a, b: F.binary_cross_entropy_with_logits(a, b, reduction="none")}[kind]
+    p64 = p.detach().double().requires_grad_(True)
+    ref = (fn(p64, t.double()) * w.double()).sum() / w.double().sum()
+    ref.backward()
+    outs = []
+    for _ in range(2):
+        p.grad = None
+        v = ops.masked_loss(p, t, w, kind)
+        (v * 3.0).backward()
+        outs.append((v.item(), p.grad.clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    assert abs(outs[0][0] - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    assert (outs[0][1].double() - 3.0 * p64.grad).abs().max().item() <= 1e-9 + 1e-5 * p64.grad.abs().max().item()

@@ -297,3 +297,48 @@ def test_g14_pitch_and_energy_embedding_switches(gname, suffix, ve, training):
     _close(post, g["out.postnet_mel"], 5e-5, name="postnet_mel")
     if e_pred is not None:
         _close(e_pred, g["out.e_pred"], name="e_pred")
+
+
+@pytest.mark.parametrize("case,mode", [("g15_pitch_frame", "eval"), ("g15_pitch_frame", "train_nodrop"), ("g15_pitch_frame", "infer"),
+                                       ("g15_pitch_frame_std_nouv", "train_nodrop"), ("g15_pitch_ph", "eval"),
+                                       ("g15_pitch_ph", "train_nodrop"), ("g15_pitch_ph", "infer"),
+                                       ("g16_energy_frame", "eval"), ("g16_energy_frame", "train_nodrop")])
+def test_g15_g16_pitch_type_and_energy_level_switches(case, mode):
+    """preprocessing.pitch.pitch_type "frame" / "ph" (+ pitch_norm standard, use_uv False) and preprocessing.energy.feature
+    "frame_level" (modules.py:777-785,892-938,1083-1094): forward values and - for the train cases - the loss 9-tuple
+    (loss.py:173-178,202-219,238-242) against the live reference's goldens."""
+    from tests.util import switch_configs
+    from oracle.loss_restate import RefLoss
+    g = load_golden(f"{case}_{mode}")
+    (pre, mc, tc), sd = switch_configs(case)
+    b = batch_from_golden(g)
+    taps, stats = {}, {}
+    kw = dict(p_control=1.1, e_control=0.9, d_control=2.0) if mode == "infer" else {}
+    args = [b["speakers"], b["texts"], b["src_lens"], b["max_src_len"], b["mels"], b["mel_lens"], b["max_mel_len"], b["p_targets"],
+            b["e_targets"], b["d_targets"], None, b["spker_embeds"]]
+    with torch.no_grad():
+        out = R.comp_trans_tts_forward(sd, mc, pre, *args, training=(mode == "train_nodrop"), taps=taps, new_stats=stats, **kw)
+    mel, post, p_pred, e_pred, log_d = out[:5]
+    for name, a, key in (("encoder_out", taps["encoder_out"], "tap.encoder_out"), ("va_out", taps["va_out"], "tap.va_out"),
+                         ("decoder_out", taps["decoder_out"], "tap.decoder_out"), ("mel", mel, "out.mel"), ("log_d", log_d, "out.log_d"),
+                         ("e_pred", e_pred, "out.e_pred"), ("f0_denorm", p_pred["f0_denorm"], "out.f0_denorm")):
+        _close(a, g[key], name=name)
+    _close(post, g["out.postnet_mel"], 5e-5, name="postnet_mel")
+    if case.startswith("g15"):
+        assert "out.cwt" not in g and p_pred["cwt"] is None
+        _close(p_pred["pitch_pred"], g["out.pitch_pred"], name="pitch_pred")
+        assert p_pred["pitch_pred"].shape[-1] == (1 if "ph" in case else 2)
+    if mode != "infer" and "out.pt_f0" in g:
+        _close(out[-2]["f0"], g["out.pt_f0"], name="pitch_target f0 (padding-zeroed / phoneme level)")
+    if mode == "train_nodrop":
+        gl = load_golden(f"{case}_loss")
+        inputs = [None, None] + list(args)
+        inputs[9:11] = out[-2:]
+        losses = RefLoss(pre, mc, tc)(inputs, out[:-2], int(gl["step"]))
+        flat = {"total": losses[0], "mel": losses[1], "postnet_mel": losses[2], "energy": losses[4]}
+        flat.update({"pitch." + k: v for k, v in losses[3].items()})
+        flat.update({"duration." + k: v for k, v in losses[5].items()})
+        assert {k for k in gl if k.startswith("loss.pitch.")} == {"loss.pitch." + k for k in losses[3]}
+        for k, v in flat.items():
+            ref = float(np.asarray(gl["loss." + k]).reshape(-1)[0])
+            assert abs(float(v.reshape(-1)[0]) - ref) <= 2e-4 * max(1.0, abs(ref)), (k, float(v.reshape(-1)[0]), ref)

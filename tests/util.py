@@ -23,7 +23,27 @@ def schema(dataset="LJSpeech", block="transformer_fs2", unsup=False, prosody="no
         return json.load(f)
 
 
-def closed_form_sd(dataset="LJSpeech", block="transformer_fs2", unsup=False, prosody="none", suffix=""):
+# G15 / G16: preprocessing.pitch / preprocessing.energy / train.loss overrides of the goldens make_goldens.main_pitch_energy_switches wrote
+SWITCH_CASES = {
+    "g15_pitch_frame": dict(suffix="_pitchframe", pitch=dict(pitch_type="frame")),
+    "g15_pitch_frame_std_nouv": dict(suffix="_pitchframe_nouv", loss=dict(pitch_loss="l2"),
+                                     pitch=dict(pitch_type="frame", pitch_norm="standard", use_uv=False, f0_mean=7.4, f0_std=0.35)),
+    "g15_pitch_ph": dict(suffix="_pitchph", pitch=dict(pitch_type="ph")),
+    "g16_energy_frame": dict(suffix="_energyframe", energy=dict(feature="frame_level"), energy_key="energy_sup_frame"),
+}
+
+
+def switch_configs(case):
+    """(preprocess, model, train) configs of a SWITCH_CASES entry + its closed-form state dict"""
+    c = SWITCH_CASES[case]
+    pre, mc, tc = get_configs()
+    pre["preprocessing"]["pitch"].update(c.get("pitch", {}))
+    pre["preprocessing"]["energy"].update(c.get("energy", {}))
+    tc["loss"].update(c.get("loss", {}))
+    return (pre, mc, tc), closed_form_sd(suffix=c["suffix"], energy_key=c.get("energy_key"))
+
+
+def closed_form_sd(dataset="LJSpeech", block="transformer_fs2", unsup=False, prosody="none", suffix="", energy_key=None):
     """Closed-form weights for every schema key (energy_bins from stats.json like modules.py:795-818).  `suffix`: schema of a
     configuration variant (G13: "_swish_left", "_relu")."""
     pre, mc, tc = get_configs(dataset)
@@ -31,7 +51,7 @@ def closed_form_sd(dataset="LJSpeech", block="transformer_fs2", unsup=False, pro
     for k, (shape, dtype, is_param) in schema(dataset, block, unsup, prosody, suffix).items():
         if k.endswith("energy_bins"):
             with open(os.path.join(pre["path"]["preprocessed_path"], "stats.json")) as f:
-                emin, emax = json.load(f)["energy_unsup_frame" if unsup else "energy_sup_phone"][:2]
+                emin, emax = json.load(f)[energy_key or ("energy_unsup_frame" if unsup else "energy_sup_phone")][:2]
             sd[k] = torch.linspace(emin, emax, shape[0])
         elif "position_enc" in k or "positional_encoding" in k:
             from oracle.restate import interleaved_sinusoid_table
