@@ -71,3 +71,61 @@ def test_grad_acc_step_clip_pattern_follows_train_py():
             ts.step_no = step
             got.append(ts._clip_now())
         assert got == want, (k, got)
+
+
+def test_phoneme_level_pitch_matches_the_reference_scatter_formulation():
+    """model.phoneme_level_pitch (fp64 one-hot contraction, device-side) against the oracle's per-utterance scatter_add
+    (utils/tools.py:47-53 / modules.py:873-880), including 0-frame phonemes and frames beyond mel_len."""
+    from oracle import restate as R
+    g = torch.Generator().manual_seed(3)
+    src_lens, Ts, Tm = torch.tensor([7, 4, 5]), 7, 30
+    dur = torch.zeros(3, Ts, dtype=torch.long)
+    for b, n in enumerate(src_lens.tolist()):
+        dur[b, :n] = torch.randint(0, 6, (n,), generator=g)
+        dur[b, 0] = max(int(dur[b, 0]), 1)
+    mel_lens = dur.sum(1)
+    mel2ph = torch.zeros(3, Tm, dtype=torch.long)
+    for b in range(3):
+        mel2ph[b, : int(mel_lens[b])] = torch.repeat_interleave(torch.arange(1, Ts + 1), dur[b])
+    f0 = torch.randn(3, Tm, generator=g) + 7.0            # NOT zeroed beyond mel_len: those frames must not count
+    want = R.phoneme_level_pitch(Ts, src_lens, mel2ph, mel_lens, f0)
+    got = M.phoneme_level_pitch(f0, mel2ph, mel_lens, Ts)
+    assert got.shape == want.shape == (3, Ts)
+    assert (got - want).abs().max().item() <= 1e-6
+    assert (got[dur == 0] == 0).all()
+
+
+@pytest.mark.parametrize("norm,use_uv", [("log", True), ("log", False), ("standard", True)])
+def test_denorm_f0_matches_pitch_tools(norm, use_uv):
+    """model.denorm_f0 (torch.where masks) == the oracle's in-place restatement of utils/pitch_tools.py:69-82"""
+    from oracle import restate as R
+    g = torch.Generator().manual_seed(4)
+    cfg = {"pitch_norm": norm, "use_uv": use_uv, "f0_mean": 7.4, "f0_std": 0.35}
+    f0 = torch.randn(2, 9, generator=g)
+    uv = (torch.rand(2, 9, generator=g) < 0.4).float()
+    pad = torch.arange(9)[None, :] >= torch.tensor([9, 6])[:, None]
+    got = M.denorm_f0(f0, uv, cfg, pad)
+    want = R.denorm_f0(f0.clone(), uv, cfg, pad)
+    assert torch.equal(got, want)
+    assert torch.equal(M.denorm_f0(f0, None, cfg, torch.tensor(False)), R.denorm_f0(f0.clone(), None, cfg, torch.tensor(False)))
+
+
+def test_pitch_and_energy_switches_that_the_reference_cannot_run_raise():
+    pre, mc, tc = get_configs()
+    pre["preprocessing"]["pitch"]["pitch_ar"] = True
+    with pytest.raises(NotImplementedError, match="pitch_ar"):
+        ctts_amd.CompTransTTS(pre, mc, tc)
+    pre, mc, tc = get_configs()
+    pre["preprocessing"]["pitch"]["pitch_type"] = "dct"
+    with pytest.raises(NotImplementedError, match="pitch_type"):
+        ctts_amd.CompTransTTS(pre, mc, tc)
+    pre, mc, tc = get_configs()
+    pre["preprocessing"]["energy"]["feature"] = "word_level"
+    with pytest.raises(NotImplementedError, match="energy"):
+        ctts_amd.CompTransTTS(pre, mc, tc)
+    pre, mc, tc = get_configs()
+    pre["preprocessing"]["pitch"]["pitch_type"] = "frame"
+    tc["loss"]["pitch_loss"] = "ssim"
+    from ctts_amd.loss import CompTransTTSLoss
+    with pytest.raises(NotImplementedError, match="pitch_loss"):
+        CompTransTTSLoss(pre, mc, tc)
