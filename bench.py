@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE configs[2..4] lines measured after the headline")
     ap.add_argument("--no-roofline", action="store_true", help="skip the stand-alone timing of the dominant kernel (kernel-trace runs: keeps "
                                                                "the 80 extra launches out of the per-step statistics)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC passes instead of two live "
+                    "rocprofv3 --pmc passes over the dominant kernel (adds ~1 min)")
     ap.add_argument("--batch", default="canonical", choices=["canonical", "c1"])
     ap.add_argument("--block", default="transformer_fs2", choices=["transformer_fs2", "conformer"],
                     help="block_type plugin; the headline metric (BASELINE configs[1]) is transformer_fs2, conformer = configs[2]")
@@ -117,7 +119,55 @@ def spawn_ranks(n):
 
 
 # ----------------------------------------------------------------------------------------------------------- measurement
-def measure_dominant_kernel(dev, batch, iters=50, warm=30):
+def _pmc_per_launch(db_path, counter, kernel_substr="gemm_sk_kernel"):
+    """average over the launches of `kernel_substr` of the counter summed over its hardware instances (rocprofv3 rocpd sqlite result)"""
+    import sqlite3
+    db = sqlite3.connect(db_path)
+    cols = [r[1] for r in db.execute("pragma table_info('counters_collection')")]
+    namecol = "kernel_name" if "kernel_name" in cols else "name"
+    vcol = "value" if "value" in cols else "counter_value"
+    rows = db.execute(f"select dispatch_id, sum({vcol}) from counters_collection where counter_name = ? and {namecol} like ? "
+                      "group by dispatch_id", (counter, f"%{kernel_substr}%")).fetchall()
+    db.close()
+    if not rows:
+        raise RuntimeError(f"no {counter} rows for {kernel_substr} in {db_path}")
+    return sum(v for _, v in rows) / len(rows), len(rows)
+
+
+def measure_traffic_live(timeout=150):
+    """HBM-side bytes per launch of the dominant kernel, measured IN THIS RUN: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+    --kernel-trace only, as the pool allows) over tools/bench_one.py ffn1_step = the same launch `measure_dominant_kernel` times, corrected
+    as MI355X_MICROARCH.md prescribes for gfx950 (unit KiB; FETCH_SIZE tallies 128-B requests at 64 B -> doubled).
+    Returns (bytes, source dict) or raises; the caller falls back to the committed passes."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        raise RuntimeError("rocprofv3 not on PATH")
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("already running under a profiler")
+    kib = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ctts_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "bench_one.py"),
+                   "ffn1_step", "10"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dbs = glob.glob(os.path.join(d, "**", "*results.db"), recursive=True)
+            if not dbs:
+                raise RuntimeError("rocprofv3 wrote no results.db")
+            kib[ctr], n = _pmc_per_launch(dbs[0], ctr)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0
+    return traffic, {"measured": "live in this bench.py run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+                                 "tools/bench_one.py ffn1_step", "launches_averaged": n, "FETCH_SIZE_KiB": kib["FETCH_SIZE"],
+                     "WRITE_SIZE_KiB": kib["WRITE_SIZE"], "correction": "gfx950: FETCH_SIZE doubled (128-B requests tallied at 64 B), unit KiB"}
+
+
+def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
     """HIP-event timing (on the launch stream) of the dominant kernel at its train-step arguments:
     decoder FFN Conv1d(256->1024, k=9) as implicit GEMM, M=B*Tm rows, N=1024, K=2304."""
     from ctts_amd import kernels as K
@@ -152,11 +202,17 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30):
     valid = int(batch["mel_lens"].sum())
     algo_flops = 2.0 * cout * ks * cin * valid          # 4,718,592 FLOP per valid frame per layer
     padded_flops = 2.0 * cout * ks * cin * M
-    # traffic is NOT measured by this run: it is the committed result of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
-    # same launch (tools/collect_profiles.sh); traffic_source says which passes (file, date, commit)
+    # traffic: measured live by two rocprofv3 --pmc passes over this same launch when rocprofv3 is available (it
+    # used to be a committed constant); otherwise the committed result of the same passes (tools/collect_r04.sh) - traffic_source says which
     traffic, traffic_src = None, None
+    if live_traffic:
+        try:
+            traffic, traffic_src = measure_traffic_live()
+        except Exception as e:      # noqa: BLE001 - any profiler problem: fall back to the committed passes and say so
+            traffic_src = None
+            print(f"[bench] live HBM-traffic passes skipped ({type(e).__name__}: {e}); using the committed PMC passes", file=sys.stderr)
     tj = os.path.join(ROOT, "profiles", "pmc_traffic_dominant_kernel.json")
-    if os.path.exists(tj):
+    if traffic is None and os.path.exists(tj):
         with open(tj) as f:
             tjs = json.load(f)
         traffic = tjs.get("traffic_bytes_per_launch")
@@ -466,7 +522,8 @@ def main():
     if rank == 0:
         headline = (a.batch == "canonical" and a.block == "transformer_fs2" and a.prosody == "none" and not a.learn_alignment
                     and a.dataset == "LJSpeech")
-        roof = measure_dominant_kernel(dev, make_batch(None, seed=1234)) if (headline and not a.no_roofline) else None
+        roof = (measure_dominant_kernel(dev, make_batch(None, seed=1234), live_traffic=(not a.no_live_traffic and world == 1))
+                if (headline and not a.no_roofline) else None)
         # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
         step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
         secondary = measure_secondary(dev) if (headline and world == 1 and not a.no_secondary) else None

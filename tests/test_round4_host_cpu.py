@@ -129,3 +129,36 @@ def test_pitch_and_energy_switches_that_the_reference_cannot_run_raise():
     from ctts_amd.loss import CompTransTTSLoss
     with pytest.raises(NotImplementedError, match="pitch_loss"):
         CompTransTTSLoss(pre, mc, tc)
+
+
+def test_bench_pmc_parser_and_live_traffic_guards(tmp_path, monkeypatch):
+    """bench.py's live roofline.traffic: per-launch average of a counter summed over its hardware instances from a rocpd result, and the
+    guards that make it fall back to the committed passes (no rocprofv3 / already under a profiler)."""
+    import importlib.util
+    import os
+    import sqlite3
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dbp = str(tmp_path / "x_results.db")
+    db = sqlite3.connect(dbp)
+    db.execute("create table counters_collection (dispatch_id int, kernel_name text, counter_name text, value real)")
+    rows = []
+    for disp in (1, 2):                     # two launches of the kernel, 8 instances each
+        rows += [(disp, "void (anonymous namespace)::gemm_sk_kernel<true, true>(x)", "FETCH_SIZE", 100.0 * disp)] * 8
+    rows += [(3, "other_kernel", "FETCH_SIZE", 7.0), (1, "gemm_sk_kernel<..>", "WRITE_SIZE", 5.0)]
+    db.executemany("insert into counters_collection values (?,?,?,?)", rows)
+    db.commit()
+    db.close()
+    v, n = bench._pmc_per_launch(dbp, "FETCH_SIZE")
+    assert n == 2 and v == (800.0 + 1600.0) / 2
+    with pytest.raises(RuntimeError, match="no SQ_WAVES rows"):
+        bench._pmc_per_launch(dbp, "SQ_WAVES")
+    monkeypatch.setenv("ROCPROFILER_REGISTER_FORCE_LOAD", "1")
+    monkeypatch.setattr("shutil.which", lambda name: "/opt/rocm/bin/rocprofv3")
+    with pytest.raises(RuntimeError, match="under a profiler"):
+        bench.measure_traffic_live()
+    monkeypatch.delenv("ROCPROFILER_REGISTER_FORCE_LOAD")
+    monkeypatch.setattr("shutil.which", lambda name: None)
+    with pytest.raises(RuntimeError, match="not on PATH"):
+        bench.measure_traffic_live()
