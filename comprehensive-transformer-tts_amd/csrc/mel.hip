@@ -17,7 +17,8 @@ namespace {
 constexpr int NFFT = 1024, NC = 512, NBINS = 513;
 constexpr int TILE_F = 16;                 // frames per workgroup tile (4 waves x 4 frames)
 constexpr int MS_MAX = 517;                // magnitude-tile row stride when every bin may carry filter weight (odd: conflict-free column reads)
-constexpr int SCR = 544;                   // per-wave FFT scratch: 512 complex + padding (index + index/32)
+constexpr int SCR = 584;                   // per-wave FFT scratch: 512 complex + padding (pad32: index + index/32 + 8 * (index/64))
+constexpr int LDS_HDR = 1540 + 112;        // twiddle tables in LDS: W512 | W1024 | the 7 x 8 twiddles of FFT pass 1, one row per r
 // workspace layout (floats): [0, 1024) W512 (cos, sin) | [1024, 1024+516) W1024 k = 0..256 (cos, sin) | melT [516][96] | int32 kranges[12]
 constexpr int WS_W512 = 0, WS_W1024 = 1024, WS_MELT = 1024 + 516, WS_KR = WS_MELT + 516 * 96, WS_FLOATS = WS_KR + 16;
 
@@ -38,7 +39,11 @@ __device__ __forceinline__ void fft8(float2_ (&v)[8]) {
   fft4(v[0], v[1], v[2], v[3]); fft4(v[4], v[5], v[6], v[7]);
 }
 __device__ __forceinline__ int brev3(int r) { return ((r & 1) << 2) | (r & 2) | (r >> 2); }
-__device__ __forceinline__ int pad32(int i) { return i + (i >> 5); }
+// scratch slot of complex element i.  Every exchange pattern of the three passes must spread a 16-lane group over all 64 banks
+// (8-byte accesses): consecutive i (pass reads, pass-2 writes), i = 8 * lane + r (pass-0 writes: + i/32 shifts every 4th lane by a
+// bank pair) and i = 64 * (lane / 8) + (lane & 7) + 8 r (pass-1 writes: + 8 * (i/64) moves the second 8-lane run 20 banks away from
+// the first; with i + i/32 alone the two runs overlapped in 12 of 16 banks - 2-way conflicts on all 8 writes of every lane).
+__device__ __forceinline__ int pad32(int i) { return i + (i >> 5) + ((i >> 6) << 3); }
 
 __device__ __forceinline__ float sample_reflect(const float* __restrict__ yb, int N, int p) {
   // index into the reflect-padded waveform (F.pad(..., mode="reflect") by n_fft/2 on both sides, stft.py:66-71)
@@ -64,10 +69,14 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
                            // NaN pattern sorts above 1.0): raises *range_flag when the waveform leaves [-1, 1] (the reference's asserts)
   float* tw512 = lds;                                   // 1024
   float* tw1024 = lds + 1024;                           // 516
-  float* magt = lds + 1540;                             // TILE_F x MS
+  float* tw1 = lds + 1540;                              // 56 complex: W512^(8 * jm * r) at [(r - 1) * 8 + jm]
+  float* magt = lds + LDS_HDR;                          // TILE_F x MS
   float* scr = magt + TILE_F * MS;                      // 4 waves x SCR complex (re | im interleaved)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < 1540; e += 256) lds[e] = ws[e];
+  // pass 1 needs only 8 distinct twiddles per r (jm = lane & 7); read from the W512 table they sit 64 r bytes apart - up to 8 lanes of
+  // a group on one bank.  A row of 8 consecutive entries per r is conflict-free.
+  if (tid < 56) { const int t = (tid & 7) * 8 * ((tid >> 3) + 1); tw1[2 * tid] = ws[2 * t]; tw1[2 * tid + 1] = ws[2 * t + 1]; }
   // only bins < MS-1 are kept in the tile (the filterbank is zero above fmax); columns >= 513 are K padding of the MFMA and stay zero
   for (int e = tid; e < TILE_F * 4; e += 256) { const int c = NBINS + (e & 3); if (c < MS) magt[(e >> 2) * MS + c] = 0.f; }
   const int* kr = reinterpret_cast<const int*>(ws + WS_KR);
@@ -79,7 +88,8 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
   const int tiles_per_b = (F + TILE_F - 1) / TILE_F;
   const long n_tiles = (long)B * tiles_per_b;
   __syncthreads();
-  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  int it = 0;
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++it) {
     const int b = (int)(tile / tiles_per_b), f0 = (int)(tile - (long)b * tiles_per_b) * TILE_F;
     const float* yb = y + (long)b * N;
     // ragged batches (preprocessing): utterance b has lens[b] samples; reflection happens at ITS end and it has Fb = 1 + lens[b]/hop
@@ -91,16 +101,25 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
       const int fl = wave * 4 + ff, f = f0 + fl, fc = min(f, Fb - 1);
       float2_ v[8];
       const int base = fc * hop;
-      // no reflection needed and the 8-byte pair loads are aligned
+      // no reflection needed and the 8-byte pair loads are aligned: a property of the FRAME, so the two paths are a scalar branch (the
+      // select-per-sample form cost ~100 VALU instructions per frame)
       const bool interior = base >= NFFT / 2 && base + NFFT - NFFT / 2 <= Nb && ((((long)b * N + base) | (reinterpret_cast<uintptr_t>(y) >> 2)) & 1) == 0;
+      if (__builtin_amdgcn_readfirstlane((int)interior)) {
+        const float2* p2 = reinterpret_cast<const float2*>(yb + (base - NFFT / 2)) + lane;      // 512-byte steps: immediate offsets
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int n = 2 * (lane + 64 * r);
-        float a, c;
-        if (interior) { const float2 t = *reinterpret_cast<const float2*>(yb + base - NFFT / 2 + n) ; a = t.x; c = t.y; }
-        else { a = sample_reflect(yb, Nb, base + n); c = sample_reflect(yb, Nb, base + n + 1); }
-        amax = max(amax, max(__float_as_uint(a) & 0x7FFFFFFFu, __float_as_uint(c) & 0x7FFFFFFFu));
-        v[r] = {a * win[2 * r], c * win[2 * r + 1]};
+        for (int r = 0; r < 8; ++r) {
+          const float2 t = p2[64 * r];
+          amax = max(amax, max(__float_as_uint(t.x) & 0x7FFFFFFFu, __float_as_uint(t.y) & 0x7FFFFFFFu));
+          v[r] = {t.x * win[2 * r], t.y * win[2 * r + 1]};
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int n = 2 * (lane + 64 * r);
+          const float a = sample_reflect(yb, Nb, base + n), c = sample_reflect(yb, Nb, base + n + 1);
+          amax = max(amax, max(__float_as_uint(a) & 0x7FFFFFFFu, __float_as_uint(c) & 0x7FFFFFFFu));
+          v[r] = {a * win[2 * r], c * win[2 * r + 1]};
+        }
       }
       // pass 0 (Ns = 1): no twiddles
       fft8(v);
@@ -110,14 +129,14 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
       // pass 1 (Ns = 8) and pass 2 (Ns = 64)
 #pragma unroll
       for (int pass = 1; pass < 3; ++pass) {
-        const int Ns = pass == 1 ? 8 : 64, tmul = pass == 1 ? 8 : 1;
+        const int Ns = pass == 1 ? 8 : 64;
         const int jm = lane & (Ns - 1);
 #pragma unroll
         for (int r = 0; r < 8; ++r) { const int o = pad32(lane + 64 * r); v[r] = {S[2 * o], S[2 * o + 1]}; }
 #pragma unroll
-        for (int r = 1; r < 8; ++r) {
-          const int t = jm * tmul * r;                    // W512^(jm * r * 64 / Ns)
-          v[r] = cmul(v[r], float2_{tw512[2 * t], tw512[2 * t + 1]});
+        for (int r = 1; r < 8; ++r) {                     // W512^(jm * r * 64 / Ns)
+          const float* tw = pass == 1 ? tw1 + 2 * ((r - 1) * 8 + jm) : tw512 + 2 * (jm * r);
+          v[r] = cmul(v[r], float2_{tw[0], tw[1]});
         }
         fft8(v);
         CTTS_WAVE_SYNC();                                 // every lane of THIS wave has read its inputs
@@ -139,8 +158,9 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
         const float er = 0.5f * (a + c), ei = 0.5f * (bb - dd), orr = 0.5f * (bb + dd), oi = -0.5f * (a - c);
         const float wr = tw1024[2 * k], wi = tw1024[2 * k + 1];
         const float tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
-        const float m1 = sqrtf((er + tr) * (er + tr) + (ei + ti) * (ei + ti));
-        const float m2 = sqrtf((er - tr) * (er - tr) + (ei - ti) * (ei - ti));
+        // v_sqrt_f32 (1 ulp): the correctly rounded sqrtf expansion is ~15 VALU instructions, eight times per lane and frame
+        const float m1 = __builtin_amdgcn_sqrtf((er + tr) * (er + tr) + (ei + ti) * (ei + ti));
+        const float m2 = __builtin_amdgcn_sqrtf((er - tr) * (er - tr) + (ei - ti) * (ei - ti));
         if (k < MS) mrow[k] = m1;
         e2 += m1 * m1;
         if (gmag) gmag[k] = m1;
@@ -154,15 +174,46 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
     // ------------------------------------------------------------------ mel phase: [16 frames x K] x [K x 16 filters] per MFMA tile
     const int n_tiles16 = (n_mel + 15) / 16;
     float* T = scr;                                       // [n_mel_pad][17] staging for the transposed store
-    for (int nt = wave; nt < n_tiles16; nt += 4) {
+    // The 16-filter tiles differ 7x in K range (7 ... 46 steps of 4 bins for the 80-filter / 8 kHz bank): a fixed wave -> tile map
+    // loads one SIMD of the CU with half of the phase while the others idle, for every co-resident workgroup alike; the map ROTATES with
+    // the workgroup's tile counter instead, so that over four tiles every SIMD gets every share.
+    const int role = (wave + it) & 3;
+    for (int nt = role; nt < n_tiles16; nt += 4) {
       const int klo = kr[2 * nt], khi = kr[2 * nt + 1];  // multiples of 4
-      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
       const int fr = lane & 15, kq = lane >> 4;
-      for (int k0 = klo; k0 < khi; k0 += 4) {
-        const float av = magt[fr * MS + k0 + kq];                   // A[frame][k]
-        const float bv = melT[(long)(k0 + kq) * 96 + nt * 16 + fr]; // B[k][filter]   (fr doubles as the filter column index)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      // A[frame][k] from the magnitude tile (LDS), B[k][filter] from the transposed filterbank (global, L2-resident; fr doubles as the
+      // filter column).  One load per MFMA in program order made every step wait a full L2 round trip (~300 cycles for a 32-cycle MFMA):
+      // groups of MU steps with all their loads in flight and two independent accumulation chains; the last, partial group is predicated
+      // to weight 0 on a clamped (finite) magnitude.
+      constexpr int MU = 8;
+      const float* ap = magt + fr * MS + kq;
+      const float* bp = melT + (long)kq * 96 + nt * 16 + fr;
+      int k0 = klo;
+      for (; k0 + 4 * MU <= khi; k0 += 4 * MU) {
+        float bv[MU], av[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) bv[u] = bp[(long)(k0 + 4 * u) * 96];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) av[u] = ap[k0 + 4 * u];
+#pragma unroll
+        for (int u = 0; u < MU; u += 2) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc2, 0, 0, 0);
+        }
       }
+      if (k0 < khi) {
+        float bv[MU], av[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) { const int kk = min(k0 + 4 * u, khi - 4); bv[u] = k0 + 4 * u < khi ? bp[(long)kk * 96] : 0.f; av[u] = ap[kk]; }
+#pragma unroll
+        for (int u = 0; u < MU; u += 2) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc2, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
       // D: col = lane & 15 (filter), row = (lane >> 4) * 4 + reg (frame)
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[(nt * 16 + (lane & 15)) * 17 + (lane >> 4) * 4 + r] = logf(fmaxf(acc[r], clip));
@@ -234,12 +285,24 @@ extern "C" int ctts_mel_spectrogram(const float* y, const int32_t* lens, const f
   // (fmax 8 kHz of 11 kHz: 372 bins -> 48 KB of LDS per workgroup, 3 workgroups per CU instead of 2)
   CTTS_REQUIRE(kmax >= 0 && kmax <= NBINS, "ctts_mel_spectrogram: kmax out of range");
   const int MS = kmax > 0 ? (((kmax + 3) & ~3) | 1) : MS_MAX;
-  const size_t lds_bytes = sizeof(float) * (size_t)(1540 + TILE_F * MS + 4 * 2 * SCR);
+  const size_t lds_bytes = sizeof(float) * (size_t)(LDS_HDR + TILE_F * MS + 4 * 2 * SCR);
   // raise the kernel's dynamic-LDS limit to the LARGEST footprint (kmax = 0) on every call: the attribute is per device and per
   // process-wide function handle, a one-shot static flag would pin the first call's (possibly smaller) size and the first device
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * (size_t)(1540 + TILE_F * MS_MAX + 4 * 2 * SCR)));
-  const int grid = (int)(tiles < 4096 ? tiles : 4096);
+                            (int)(sizeof(float) * (size_t)(LDS_HDR + TILE_F * MS_MAX + 4 * 2 * SCR)));
+  // persistent grid: the workgroups that fit the chip at once walk the tiles (twiddles / window / filter ranges are loaded once per
+  // workgroup); env CTTS_MEL_GRID overrides (tools)
+  static int resident = 0;
+  if (!resident) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(mel_kernel), 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+    const char* ge = getenv("CTTS_MEL_GRID");
+    resident = ge ? atoi(ge) : per_cu * prop.multiProcessorCount;
+    if (resident < 1) resident = 768;
+  }
+  const int grid = (int)(tiles < resident ? tiles : resident);
   hipLaunchKernelGGL(mel_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, y, lens, window, workspace, mel, energy, mag, (long)ld_mag,
                      B, N, F, hop, n_mel, clip, MS, range_flag);
   CTTS_CHECK_LAUNCH("ctts_mel_spectrogram");
