@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 artefacts in one GPU-box call:  bash tools/collect_r04.sh  -> gpurun_out/r04_*  (copy the ones to keep into profiles/)
+# Round-4 artefacts in one GPU-box call:  bash tools/collect_r04.sh  -> gpurun_out/r04_*  (copy the ones to keep into profiles/)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out; R=r04
 mkdir -p $OUT
@@ -40,6 +40,10 @@ for P in "$P1" "$P2"; do
   rm -rf /tmp/pmc; timeout 200 rocprofv3 --kernel-trace --pmc $P -d /tmp/pmc -- python $ROOT/tools/bench_one.py ffn1_step 30 > /tmp/pmc.log 2>&1
   python $ROOT/tools/rocpd_pmc_summary.py $(find /tmp/pmc -name "*results.db" | head -1) 2>&1 < /dev/null | grep -E "^\| kernel|gemm_" | cut -c1-400 >> $OUT/${R}_pmc_sq_gemm.md
 done
+# stock-torch launches that remain in one eager step, by call site
+timeout 200 python $ROOT/tools/find_torch_ops.py > $OUT/${R}_torch_ops_fs2.txt 2>&1
+timeout 200 python $ROOT/tools/find_torch_ops.py --block conformer > $OUT/${R}_torch_ops_conformer.txt 2>&1
+timeout 300 python $ROOT/tools/find_torch_ops.py --c5 > $OUT/${R}_torch_ops_c5.txt 2>&1
 # micro-benchmarks
 timeout 200 python $ROOT/tools/profile_gemm_shapes.py > $OUT/${R}_gemm_shapes_in_step_fs2.txt 2>&1
 timeout 200 python $ROOT/tools/profile_gemm_shapes.py --block conformer > $OUT/${R}_gemm_shapes_in_step_conformer.txt 2>&1
