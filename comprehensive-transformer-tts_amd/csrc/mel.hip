@@ -65,8 +65,10 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
                                                    long ld_mag, int B, int N, int F, int hop, int n_mel, float clip, int MS,
                                                    unsigned* __restrict__ range_flag) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  unsigned amax = 0u;      // largest |sample| this thread loaded, as float bits with the sign cleared (orders like the magnitudes, and every
-                           // NaN pattern sorts above 1.0): raises *range_flag when the waveform leaves [-1, 1] (the reference's asserts)
+  // largest |sample| this thread loaded (v_max3_f32 with |.| modifiers: one instruction per pair; fmax drops NaNs, which instead turn the
+  // frame's energy into NaN and are caught there): raises *range_flag when the waveform leaves [-1, 1] or holds a NaN (the reference's asserts)
+  float amax = 0.f;
+  bool saw_nan = false;
   float* tw512 = lds;                                   // 1024
   float* tw1024 = lds + 1024;                           // 516
   float* tw1 = lds + 1540;                              // 56 complex: W512^(8 * jm * r) at [(r - 1) * 8 + jm]
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
 #pragma unroll
   for (int r = 0; r < 8; ++r) { win[2 * r] = window[2 * (lane + 64 * r)]; win[2 * r + 1] = window[2 * (lane + 64 * r) + 1]; }
   float* S = scr + wave * (2 * SCR);
+  const bool keep_low = MS > 256;                        // every bin below 256 has a column in the magnitude tile (always, for real filterbanks)
   const int tiles_per_b = (F + TILE_F - 1) / TILE_F;
   const long n_tiles = (long)B * tiles_per_b;
   __syncthreads();
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const float2 t = p2[64 * r];
-          amax = max(amax, max(__float_as_uint(t.x) & 0x7FFFFFFFu, __float_as_uint(t.y) & 0x7FFFFFFFu));
+          amax = fmaxf(amax, fmaxf(fabsf(t.x), fabsf(t.y)));
           v[r] = {t.x * win[2 * r], t.y * win[2 * r + 1]};
         }
       } else {
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
         for (int r = 0; r < 8; ++r) {
           const int n = 2 * (lane + 64 * r);
           const float a = sample_reflect(yb, Nb, base + n), c = sample_reflect(yb, Nb, base + n + 1);
-          amax = max(amax, max(__float_as_uint(a) & 0x7FFFFFFFu, __float_as_uint(c) & 0x7FFFFFFFu));
+          amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(c)));
           v[r] = {a * win[2 * r], c * win[2 * r + 1]};
         }
       }
@@ -149,11 +152,13 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
       float e2 = 0.f;
       float* mrow = magt + fl * MS;
       float* gmag = (mag_out && f < F) ? mag_out + ((long)b * F + f) * ld_mag : nullptr;
+      // bins k = lane + 64 m and their mirrors 512 - k.  k < 256 < MS is always kept; a mirror at or above MS goes to an unused slot of
+      // the wave's scratch (pad32 never produces slot 32) instead of under an exec mask: no saveexec / branch pairs in this loop
+      float* dump = S + 64;
 #pragma unroll
-      for (int m = 0; m < 5; ++m) {
-        const int k = m < 4 ? lane + 64 * m : 256;
-        if (m == 4 && lane != 0) break;
-        const int o1 = pad32(k & 511), o2 = pad32((NC - k) & 511);
+      for (int m = 0; m < 4; ++m) {
+        const int k = lane + 64 * m, km = NC - k;
+        const int o1 = pad32(k), o2 = pad32(km & 511);
         const float a = S[2 * o1], bb = S[2 * o1 + 1], c = S[2 * o2], dd = S[2 * o2 + 1];
         const float er = 0.5f * (a + c), ei = 0.5f * (bb - dd), orr = 0.5f * (bb + dd), oi = -0.5f * (a - c);
         const float wr = tw1024[2 * k], wi = tw1024[2 * k + 1];
@@ -161,12 +166,19 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
         // v_sqrt_f32 (1 ulp): the correctly rounded sqrtf expansion is ~15 VALU instructions, eight times per lane and frame
         const float m1 = __builtin_amdgcn_sqrtf((er + tr) * (er + tr) + (ei + ti) * (ei + ti));
         const float m2 = __builtin_amdgcn_sqrtf((er - tr) * (er - tr) + (ei - ti) * (ei - ti));
-        if (k < MS) mrow[k] = m1;
-        e2 += m1 * m1;
-        if (gmag) gmag[k] = m1;
-        if (k != 256) { if (NC - k < MS) mrow[NC - k] = m2; e2 += m2 * m2; if (gmag) gmag[NC - k] = m2; }
+        if (keep_low) mrow[k] = m1; else if (k < MS) mrow[k] = m1;
+        *(km < MS ? mrow + km : dump) = m2;
+        e2 += m1 * m1 + m2 * m2;
+        if (gmag) { gmag[k] = m1; gmag[km] = m2; }
+      }
+      {   // bin 256 pairs with itself: E = Re Z[256], O = Im Z[256], W1024^256 = -i  ->  |X[256]| = |Z[256]| (every lane reads the same slot)
+        const int o = pad32(256);
+        const float a = S[2 * o], bb = S[2 * o + 1];
+        const float m1 = __builtin_amdgcn_sqrtf(a * a + bb * bb);
+        if (lane == 0) { if (256 < MS) mrow[256] = m1; if (gmag) gmag[256] = m1; e2 += m1 * m1; }
       }
       e2 = ctts_wave_sum(e2);
+      saw_nan |= !(e2 == e2);
       if (lane == 0 && f < F) energy[(long)b * F + f] = sqrtf(e2);
       CTTS_WAVE_SYNC();                                   // this wave's scratch is reused by its next frame
     }
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ y, c
   }
   // out-of-range or NaN input.  No traffic at all for valid input; the flag may live in pinned host memory (plain store: any offending
   // value will do, the host only tests for non-zero)
-  if (range_flag && amax > 0x3F800000u) *reinterpret_cast<volatile unsigned*>(range_flag) = amax;
+  if (range_flag && (amax > 1.0f || saw_nan)) *reinterpret_cast<volatile unsigned*>(range_flag) = saw_nan ? 0x7FC00000u : __float_as_uint(amax);
 }
 
 // workspace set-up (once per filterbank): twiddles in double precision, the transposed / zero-padded mel basis and, per tile of 16
