@@ -134,7 +134,7 @@ def _pmc_per_launch(db_path, counter, kernel_substr="gemm_sk_kernel"):
     return sum(v for _, v in rows) / len(rows), len(rows)
 
 
-def measure_traffic_live(timeout=150):
+def measure_traffic_live(timeout=90):
     """HBM-side bytes per launch of the dominant kernel, measured IN THIS RUN: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
     --kernel-trace only, as the pool allows) over tools/bench_one.py ffn1_step = the same launch `measure_dominant_kernel` times, corrected
     as MI355X_MICROARCH.md prescribes for gfx950 (unit KiB; FETCH_SIZE tallies 128-B requests at 64 B -> doubled).
