@@ -726,6 +726,161 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
   gemm_epilogue_auto<MT, NT>(d, acc, Cb, z, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
+// ---- fp32 GEMM on the BF16 matrix pipe (NT layout: both operands K-contiguous, conv view on A allowed) --------------------------
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32 on gfx950.  Every fp32 operand is split EXACTLY into three
+// bf16 pieces (x = hi + mid + lo, 8 mantissa bits each, by truncation) once, on its way from the staging registers into LDS, and a
+// product is the six cross terms  hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi  accumulated in fp32; the dropped terms are
+// <= 2^-24 relative, i.e. the products are fp32-class (measured: max error against float64 1.36e-5 where an fp32 FMA chain has 1.63e-5,
+// tools/ubench/bf16x_split_gemm.hip; tests/test_kernels_gpu.py compares this kernel with float64 and with the fp32-MFMA kernels).
+// Everything else is the tile kernel above: buffer loads with the im2col view, register staging, ONE LDS stage and two barriers per
+// K-block (two workgroups per CU alternate), the same epilogues, the same zero-fill of wholly padded row tiles.  LDS: per operand three
+// planes of [128 rows][32 bf16] with 80-byte rows (16-byte fragment reads of 8 consecutive rows hit 8 distinct bank quads) = 61,440 B.
+constexpr int X6_PROW = 80, X6_PLANE = 128 * X6_PROW;
+typedef __bf16 x6_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void x6_split_store(const float4 v, unsigned char* base) {      // 4 consecutive-K floats -> 8 bytes per plane
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  float r1[4], r2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);                     // exact
+    r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);
+  }
+  uint2 hi, mid, lo;       // upper halves of two floats -> one register = the truncations above
+  hi.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+  hi.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
+  mid.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+  mid.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+  lo.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+  lo.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+  *reinterpret_cast<uint2*>(base) = hi;
+  *reinterpret_cast<uint2*>(base + X6_PLANE) = mid;
+  *reinterpret_cast<uint2*>(base + 2 * X6_PLANE) = lo;
+}
+
+__device__ __forceinline__ floatx16 x6_mma(const ctts_u32x4 a, const ctts_u32x4 b, const floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(x6_bf16x8, a), __builtin_bit_cast(x6_bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const ctts_gemm_desc d) {
+  static_assert(BK == 32, "the bf16 planes hold 32-deep K-blocks");
+  constexpr int BM = 128, BN = 128, MT = 2, NT = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[6 * X6_PLANE];       // A hi | mid | lo, B hi | mid | lo
+  const int Mv = d.M, Nv = d.N, Kv = d.K;
+  const int tiles_n = d.N / BN, nwg = gridDim.x;
+  int wg, tm;
+  if (d.tile_map == reinterpret_cast<const int32_t*>(1)) {
+    wg = blockIdx.x; tm = wg / tiles_n;
+  } else {          // XCD-contiguous remap + scrambled m order, as the tile kernel without a device-built schedule
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int tiles_m = nwg / tiles_n;
+    tm = wg / tiles_n;
+    const int P = (tiles_m % 37) ? 37 : ((tiles_m % 41) ? 41 : 43);
+    tm = (int)(((long)tm * P) % tiles_m);
+  }
+  const int row0 = tm * BM, col0 = (wg % tiles_n) * BN;
+  float* Cb = d.C;
+  if (d.row_lens) {                       // a tile that lies wholly in the padding of one utterance: defined as zero, no operand touched
+    const int last = min(row0 + BM, Mv) - 1;
+    const int b0 = row0 / d.row_T, b1 = last / d.row_T;
+    if (b0 == b1 && (row0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo) {
+      const int nrows = last - row0 + 1;
+      for (int e = threadIdx.x; e < nrows * BN; e += 256) {
+        const int r = e / BN, c = e - r * BN;
+        Cb[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
+        if (d.Z && !d.epi_bwd) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
+      }
+      return;
+    }
+  }
+  // the zero rule has 64-row granularity in the other kernels (and in the tile schedules built for them): when only the UPPER 64 rows of
+  // this tile lie wholly in padding, the two waves that own them write zeros instead of their epilogue
+  bool pad_hi = false;
+  if (d.row_lens && row0 + 64 < Mv) {
+    const int first = row0 + 64, last = min(row0 + BM, Mv) - 1;
+    const int b0 = first / d.row_T;
+    pad_hi = b0 == last / d.row_T && (first - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo;
+  }
+  const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, 0x7FFFFFFE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, 0x7FFFFFFE, 0x00020000);
+  ConvView cv{d.conv_T, d.conv_pad, d.conv_cin};
+  ConvView nocv{1, 0, 1};
+  BLoaderKC<BM, CONV, false> la;
+  BLoaderKC<BN, false, false> lb;
+  la.init(d.lda, row0, Mv, CONV ? cv : nocv, threadIdx.x);
+  lb.init(d.ldb, col0, Nv, nocv, threadIdx.x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 ra[4], rb[4];
+  // staging: float4 i of this thread is row (tid + 256 i) / 8 = tid / 8 + 32 i, K offset (tid % 8) * 4 (BLoaderKC's chunking)
+  unsigned char* st_a = smem + (threadIdx.x >> 3) * X6_PROW + (threadIdx.x & 7) * 8;
+  unsigned char* st_b = st_a + 3 * X6_PLANE;
+  // fragment of a 32-row MFMA tile: row l31, the 8 consecutive K values from h * 8 of a 16-deep step
+  const unsigned char* fr_a = smem + (wm0 + l31) * X6_PROW + h * 16;
+  const unsigned char* fr_b = smem + 3 * X6_PLANE + (wn0 + l31) * X6_PROW + h * 16;
+  la.load(ra_src, 0, Kv, ra);
+  lb.load(rb_src, 0, Kv, rb);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { x6_split_store(ra[i], st_a + 32 * i * X6_PROW); x6_split_store(rb[i], st_b + 32 * i * X6_PROW); }
+  __syncthreads();
+  for (int k0 = 0; k0 < Kv; k0 += BK) {
+    {                                      // unconditional (the last block is fetched again): keeps the staging registers in registers
+      const int kn = k0 + BK < Kv ? k0 + BK : k0;
+      la.load(ra_src, kn, Kv, ra);
+      lb.load(rb_src, kn, Kv, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      ctts_u32x4 fa[MT][3], fb[NT][3];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fa[i][p] = *reinterpret_cast<const ctts_u32x4*>(fr_a + p * X6_PLANE + 32 * i * X6_PROW + ks * 32);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fb[j][p] = *reinterpret_cast<const ctts_u32x4*>(fr_b + p * X6_PLANE + 32 * j * X6_PROW + ks * 32);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {      // smallest terms first
+          floatx16 c = acc[i][j];
+          c = x6_mma(fa[i][2], fb[j][0], c);
+          c = x6_mma(fa[i][0], fb[j][2], c);
+          c = x6_mma(fa[i][1], fb[j][1], c);
+          c = x6_mma(fa[i][1], fb[j][0], c);
+          c = x6_mma(fa[i][0], fb[j][1], c);
+          c = x6_mma(fa[i][0], fb[j][0], c);
+          acc[i][j] = c;
+        }
+    }
+    __syncthreads();                       // every wave has read the tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x6_split_store(ra[i], st_a + 32 * i * X6_PROW); x6_split_store(rb[i], st_b + 32 * i * X6_PROW); }
+    __syncthreads();
+  }
+  if (pad_hi && wm0 == 64) {
+    const int nrows = min(row0 + BM, Mv) - (row0 + 64);
+    for (int e = lane; e < nrows * 64; e += 64) {
+      const int r = e >> 6, c = e & 63;
+      Cb[(long)(row0 + 64 + r) * d.ldc + col0 + wn0 + c] = 0.f;
+      if (d.Z && !d.epi_bwd) d.Z[(long)(row0 + 64 + r) * d.ldz + col0 + wn0 + c] = 0.f;
+    }
+    return;
+  }
+  gemm_epilogue_auto<MT, NT>(d, acc, Cb, 0, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+}
+
 // Under-filled launches (few output tiles, long reduction: the 2,048-row phoneme-level layers give 128 tiles of 64 x 64 on 256 CUs, each
 // a chain of K / 32 staged K-blocks on one workgroup per CU): 32 x 64 tiles - twice the workgroups - and the reduction split in two INSIDE
 // the workgroup.  Waves 0,1 (32 columns each) take the even 32-deep K-blocks, waves 2,3 the odd ones: one load / barrier round per 64
@@ -1028,6 +1183,25 @@ namespace {
 struct GemmSplitPlan { int deferred_ok; int count; long stride; };
 }
 // plan != nullptr: no launch - only answer how a split-K launch of this descriptor would lay out its partial matrices
+// fp32-on-bf16-pipe kernel (gemm_x6_kernel): large unbatched NT launches whose N is a multiple of the 128-column tile.  CTTS_X6=0 turns it off.
+static bool gemm_x6_takes(const ctts_gemm_desc& d) {
+  static const int on = getenv("CTTS_X6") ? atoi(getenv("CTTS_X6")) : 1;
+  static const long min_tiles = getenv("CTTS_X6_MIN_TILES") ? atol(getenv("CTTS_X6_MIN_TILES")) : 384;
+  if (!on || !d.a_kc || !d.b_kc || d.nb0 * d.nb1 != 1 || d.split_k > 1 || d.E || d.lens || d.conv_on_b) return false;
+  if (d.K < 256 || d.K % BK || d.N % 128 || d.M < 1024) return false;
+  if (d.conv_T > 0 && d.conv_cin % 4) return false;
+  if ((long)((d.M + 127) / 128) * (d.N / 128) < min_tiles) return false;
+  return vec_ok(d) && buf_ok(d);
+}
+
+static int gemm_x6_launch(const ctts_gemm_desc& d, hipStream_t st) {
+  const int tiles = ((d.M + 127) / 128) * (d.N / 128);
+  if (d.conv_T > 0) hipLaunchKernelGGL(gemm_x6_kernel<true>, dim3(tiles), dim3(256), 0, st, d);
+  else hipLaunchKernelGGL(gemm_x6_kernel<false>, dim3(tiles), dim3(256), 0, st, d);
+  CTTS_CHECK_LAUNCH("ctts_gemm(x6)");
+  return 0;
+}
+
 static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan) {
   CTTS_REQUIRE(dp != nullptr, "ctts_gemm: null descriptor");
   ctts_gemm_desc d = *dp;
@@ -1052,6 +1226,7 @@ static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan
   } else {
     const int ws = ctts_gemm_ws_try(d, st);      // weight-stationary kernel (gemm_ws.hip) for K = 256 linears with many rows
     if (ws != 0) return ws > 0 ? 0 : ws;
+    if (gemm_x6_takes(d)) return gemm_x6_launch(d, st);      // fp32 products on the bf16 matrix pipe (six-term split)
     const int sk = ctts_gemm_sk_try(d, st);      // persistent stream-K kernel (gemm_sk.hip) when the descriptor is eligible
     if (sk != 0) return sk > 0 ? 0 : sk;
   }

@@ -1,5 +1,7 @@
 """GPU: every HIP kernel (through the C ABI) against an independent fp64/fp32 torch-CPU
 computation of the same op on seeded inputs.  Integer kernels are compared bit-exactly."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -596,7 +598,7 @@ def test_dominant_stream_k_kernel_vs_fp64_at_the_bench_shape():
     args = (x, w, out, M, N, Kd, Cin, Kd, N, True, True)
     kw = dict(conv=(T, pad, Cin), alpha=alpha, bias=bias, Z=Z, ldz=N, act=K.ACT_GELU, p_drop=p, seed=seed, drop_offset=off,
               row_lens=lens, row_T=T, row_halo=0, tile_map=K.row_tile_map(lens, T, 0, M))
-    assert K.gemm_takes_persistent(*args, **kw), "expected on the persistent stream-K kernel"
+    assert K.gemm_takes_persistent(*args, **kw) or os.environ.get("CTTS_X6", "0") != "0", "expected on the persistent stream-K kernel"
     K.gemm(*args, **kw)
     torch.cuda.synchronize()
     assert _sk_error_word() == 0
