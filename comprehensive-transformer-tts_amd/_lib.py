@@ -67,6 +67,8 @@ _SIGNATURES = {
     "ctts_gemm_takes_persistent": [C.POINTER(GemmDesc)],
     "ctts_gemm_ws_enable": [C.c_int],
     "ctts_gemm_takes_weight_stationary": [C.POINTER(GemmDesc)],
+    "ctts_gemm_takes_bf16_split": [C.POINTER(GemmDesc)],
+    "ctts_gemm_bf16_split_enable": [_i32],
     "ctts_rowdot_heads": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_mel_prepare": [_vp, C.c_int, C.c_int, _vp, _vp],
     "ctts_mel_spectrogram": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp],

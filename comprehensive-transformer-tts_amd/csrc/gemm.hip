@@ -839,31 +839,31 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const ctts_gemm_desc d)
       la.load(ra_src, kn, Kv, ra);
       lb.load(rb_src, kn, Kv, rb);
     }
+    // all fragments of the K-block first (one exposed LDS round trip per block instead of one per 16-deep step), then the 48 MFMAs
+    ctts_u32x4 fa[2][MT][3], fb[2][NT][3];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      ctts_u32x4 fa[MT][3], fb[NT][3];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) fa[i][p] = *reinterpret_cast<const ctts_u32x4*>(fr_a + p * X6_PLANE + 32 * i * X6_PROW + ks * 32);
+        for (int p = 0; p < 3; ++p) fa[ks][i][p] = *reinterpret_cast<const ctts_u32x4*>(fr_a + p * X6_PLANE + 32 * i * X6_PROW + ks * 32);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) fb[j][p] = *reinterpret_cast<const ctts_u32x4*>(fr_b + p * X6_PLANE + 32 * j * X6_PROW + ks * 32);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {      // smallest terms first
-          floatx16 c = acc[i][j];
-          c = x6_mma(fa[i][2], fb[j][0], c);
-          c = x6_mma(fa[i][0], fb[j][2], c);
-          c = x6_mma(fa[i][1], fb[j][1], c);
-          c = x6_mma(fa[i][1], fb[j][0], c);
-          c = x6_mma(fa[i][0], fb[j][1], c);
-          c = x6_mma(fa[i][0], fb[j][0], c);
-          acc[i][j] = c;
-        }
+        for (int p = 0; p < 3; ++p) fb[ks][j][p] = *reinterpret_cast<const ctts_u32x4*>(fr_b + p * X6_PLANE + 32 * j * X6_PROW + ks * 32);
     }
+    // term-major order: consecutive MFMAs go to DIFFERENT accumulators (a chain of six on one accumulator waits for each result);
+    // smallest terms first
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = x6_mma(fa[ks][i][PA[t]], fb[ks][j][PB[t]], acc[i][j]);
+      }
     __syncthreads();                       // every wave has read the tile
 #pragma unroll
     for (int i = 0; i < 4; ++i) { x6_split_store(ra[i], st_a + 32 * i * X6_PROW); x6_split_store(rb[i], st_b + 32 * i * X6_PROW); }
@@ -1184,8 +1184,10 @@ struct GemmSplitPlan { int deferred_ok; int count; long stride; };
 }
 // plan != nullptr: no launch - only answer how a split-K launch of this descriptor would lay out its partial matrices
 // fp32-on-bf16-pipe kernel (gemm_x6_kernel): large unbatched NT launches whose N is a multiple of the 128-column tile.  CTTS_X6=0 turns it off.
+static int g_x6_on = -1;           // -1: not read yet (env CTTS_X6, default on); ctts_gemm_bf16_split_enable overrides
 static bool gemm_x6_takes(const ctts_gemm_desc& d) {
-  static const int on = getenv("CTTS_X6") ? atoi(getenv("CTTS_X6")) : 1;
+  if (g_x6_on < 0) g_x6_on = getenv("CTTS_X6") ? (atoi(getenv("CTTS_X6")) != 0) : 1;
+  const int on = g_x6_on;
   static const long min_tiles = getenv("CTTS_X6_MIN_TILES") ? atol(getenv("CTTS_X6_MIN_TILES")) : 384;
   if (!on || !d.a_kc || !d.b_kc || d.nb0 * d.nb1 != 1 || d.split_k > 1 || d.E || d.lens || d.conv_on_b) return false;
   if (d.K < 256 || d.K % BK || d.N % 128 || d.M < 1024) return false;
@@ -1200,6 +1202,22 @@ static int gemm_x6_launch(const ctts_gemm_desc& d, hipStream_t st) {
   else hipLaunchKernelGGL(gemm_x6_kernel<false>, dim3(tiles), dim3(256), 0, st, d);
   CTTS_CHECK_LAUNCH("ctts_gemm(x6)");
   return 0;
+}
+
+extern "C" int ctts_gemm_bf16_split_enable(int on) {
+  if (g_x6_on < 0) g_x6_on = getenv("CTTS_X6") ? (atoi(getenv("CTTS_X6")) != 0) : 1;
+  const int prev = g_x6_on;
+  g_x6_on = on != 0;
+  return prev;
+}
+
+extern "C" int ctts_gemm_takes_bf16_split(const ctts_gemm_desc* dp) {
+  if (!dp) return 0;
+  ctts_gemm_desc d = *dp;
+  if (d.nb0 < 1) d.nb0 = 1;
+  if (d.nb1 < 1) d.nb1 = 1;
+  if (ctts_gemm_takes_weight_stationary(&d)) return 0;       // ctts_gemm asks the weight-stationary kernel first
+  return gemm_x6_takes(d) ? 1 : 0;
 }
 
 static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan) {

@@ -286,6 +286,17 @@ def gemm_takes_persistent(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=Tr
     return bool(_lib.load().ctts_gemm_takes_persistent(C.byref(d)))
 
 
+def gemm_takes_bf16_split(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):
+    """True when ctts_gemm would run these arguments on the fp32-on-bf16-pipe kernel (six-term operand split; no launch)."""
+    d = _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc, b_kc, **kw)
+    return bool(_lib.load().ctts_gemm_takes_bf16_split(C.byref(d)))
+
+
+def gemm_bf16_split_enable(on):
+    """Process-wide switch of that kernel (tests / A/B timing); returns the previous setting."""
+    return bool(_lib.load().ctts_gemm_bf16_split_enable(int(bool(on))))
+
+
 def gemm_takes_weight_stationary(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):
     """True when ctts_gemm would run these arguments on the weight-stationary K = 256 kernel (no launch)."""
     d = _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc, b_kc, **kw)

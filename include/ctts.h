@@ -142,6 +142,14 @@ int ctts_gemm_takes_persistent(const ctts_gemm_desc* d);
 int ctts_gemm_ws_enable(int on);
 /* 1 when ctts_gemm would run this descriptor on the weight-stationary kernel (no launch). */
 int ctts_gemm_takes_weight_stationary(const ctts_gemm_desc* d);
+/* fp32 GEMM on the BF16 matrix pipe (csrc/gemm.hip gemm_x6_kernel; default on, env CTTS_X6=0 turns it off): large unbatched NT launches
+ * (both operands K-contiguous, conv view on A allowed, N a multiple of 128, split_k <= 1) form every fp32 product from six
+ * v_mfma_f32_32x32x16_bf16 terms of the EXACT three-way bf16 split of both operands (x = hi + mid + lo by truncation), accumulated in
+ * fp32 - fp32-class results (error against float64 not above an fp32 FMA chain's) at up to 16/6 of the fp32-MFMA rate.
+ * ctts_gemm_bf16_split_enable returns the previous setting (process-wide, not thread-safe: parity tests and A/B timing);
+ * ctts_gemm_takes_bf16_split: 1 when ctts_gemm would run this descriptor on that kernel (no launch). */
+int ctts_gemm_bf16_split_enable(int on);
+int ctts_gemm_takes_bf16_split(const ctts_gemm_desc* d);
 
 /* out[b,h,t] = sum_d a[b,t,h*dh+d] * b[b,t,h*dh+d]   (a, b [B,T,H*dh] channel-last; the D vector of the fused softmax backward). */
 int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, int H, int dh, void* stream);

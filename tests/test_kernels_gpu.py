@@ -598,7 +598,7 @@ def test_dominant_stream_k_kernel_vs_fp64_at_the_bench_shape():
     args = (x, w, out, M, N, Kd, Cin, Kd, N, True, True)
     kw = dict(conv=(T, pad, Cin), alpha=alpha, bias=bias, Z=Z, ldz=N, act=K.ACT_GELU, p_drop=p, seed=seed, drop_offset=off,
               row_lens=lens, row_T=T, row_halo=0, tile_map=K.row_tile_map(lens, T, 0, M))
-    assert K.gemm_takes_persistent(*args, **kw) or os.environ.get("CTTS_X6", "0") != "0", "expected on the persistent stream-K kernel"
+    assert K.gemm_takes_bf16_split(*args, **kw) or K.gemm_takes_persistent(*args, **kw), "expected on the bf16-split or the stream-K kernel"
     K.gemm(*args, **kw)
     torch.cuda.synchronize()
     assert _sk_error_word() == 0
@@ -1270,3 +1270,79 @@ def test_masked_loss_matches_torch_and_is_bit_reproducible(kind):
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
     assert abs(outs[0][0] - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
     assert (outs[0][1].double() - 3.0 * p64.grad).abs().max().item() <= 1e-9 + 1e-5 * p64.grad.abs().max().item()
+
+
+def _nt_gemm(A, B, M, N, Kd, **kw):
+    out = torch.full((M, N), float("nan"), device=DEV)
+    K.gemm(A, B, out, M, N, Kd, Kd, Kd, N, True, True, **kw)
+    return out
+
+
+def test_bf16_split_gemm_is_exact_where_fp32_is_and_fp32_class_elsewhere():
+    """csrc/gemm.hip gemm_x6_kernel: fp32 products from six bf16 MFMA terms of the exact hi / mid / lo split of both operands.
+    (1) integer operands whose products and sums are exactly representable in fp32 - one operand with 18 significant bits (needs all
+    three pieces), the other sparse in {-1, 0, 1}, in both roles (the lo x hi and the hi x lo terms) - must come out EXACTLY; (2) on random
+    data the error against float64 is not above the fp32-MFMA kernels' on the same launch (same-process A/B through
+    ctts_gemm_bf16_split_enable); (3) two runs are bit-identical."""
+    M, N, Kd = 8192, 768, 512
+    g = torch.Generator().manual_seed(5)
+
+    def big(rows):
+        return torch.randint(-(1 << 17), (1 << 17) + 1, (rows, Kd), generator=g).float()
+
+    def sparse(rows):
+        return (torch.randint(-1, 2, (rows, Kd), generator=g) * (torch.rand(rows, Kd, generator=g) < 1 / 32)).float()
+    for A, B in ((big(M), sparse(N)), (sparse(M), big(N))):
+        assert K.gemm_takes_bf16_split(A.to(DEV), B.to(DEV), torch.empty(M, N, device=DEV), M, N, Kd, Kd, Kd, N, True, True)
+        ref = A.double() @ B.double().t()
+        assert float(ref.abs().max()) < 2 ** 24                    # every partial sum is an integer below 2^24: exact in fp32
+        got = _nt_gemm(A.to(DEV), B.to(DEV), M, N, Kd)
+        assert torch.equal(got.double().cpu(), ref), float((got.double().cpu() - ref).abs().max())
+    A = torch.randn(M, Kd, generator=g).to(DEV)
+    B = (torch.randn(N, Kd, generator=g) * 0.1).to(DEV)
+    ref = A.double() @ B.double().t()
+    x6 = _nt_gemm(A, B, M, N, Kd)
+    assert torch.equal(x6, _nt_gemm(A, B, M, N, Kd))
+    prev = K.gemm_bf16_split_enable(False)
+    try:
+        assert not K.gemm_takes_bf16_split(A, B, x6, M, N, Kd, Kd, Kd, N, True, True)
+        f32 = _nt_gemm(A, B, M, N, Kd)
+    finally:
+        K.gemm_bf16_split_enable(prev)
+    e6, e32 = float((x6.double() - ref).abs().max()), float((f32.double() - ref).abs().max())
+    print(f"max |err| vs fp64: bf16-split {e6:.3e}, fp32 MFMA {e32:.3e}")
+    assert e6 <= 1.25 * e32 + 1e-7, (e6, e32)
+
+
+@pytest.mark.parametrize("act,drop", [(0, 0.0), (2, 0.2)])
+def test_bf16_split_gemm_conv_view_ragged_rows_and_epilogues_equal_the_fp32_kernels(act, drop):
+    """The same launch (im2col view on A, ragged utterances with the 64-row zero rule, bias / GELU + pre-activation store / dropout /
+    residual / row scale) on the bf16-split kernel and on the fp32-MFMA kernels: equal to accumulation-order noise, identical zeros."""
+    B_, T, Cin, N, ks = 16, 512, 128, 768, 5
+    M, Kd = B_ * T, ks * Cin
+    lens = torch.tensor([512, 200, 129, 64, 330, 1, 448, 449, 384, 385, 511, 65, 63, 128, 300, 256], dtype=torch.int32, device=DEV)
+    x, w, bias = rnd(B_, T, Cin, seed=301).to(DEV), rnd(N, Kd, seed=302, scale=0.05).to(DEV), rnd(N, seed=303).to(DEV)
+    R = rnd(B_, T, N, seed=304).to(DEV)
+    rs = (torch.arange(T, device=DEV)[None, :] < lens[:, None]).float().reshape(-1).contiguous()
+    seed = torch.full((1,), 7, dtype=torch.int64, device=DEV)
+    outs = {}
+    for on in (True, False):
+        prev = K.gemm_bf16_split_enable(on)
+        try:
+            out = torch.full((B_, T, N), float("nan"), device=DEV)
+            Z = torch.full((B_, T, N), float("nan"), device=DEV) if act else None
+            args = (x, w, out, M, N, Kd, Cin, Kd, N, True, True)
+            kw = dict(conv=(T, ks // 2, Cin), alpha=0.5, bias=bias, act=act, p_drop=drop, seed=seed, drop_offset=3, R=R, ldr=N, rowscale=rs,
+                      row_lens=lens, row_T=T, row_halo=0)
+            if act:
+                kw.update(Z=Z, ldz=N)
+            assert K.gemm_takes_bf16_split(*args, **kw) == on
+            K.gemm(*args, **kw)
+            outs[on] = (out, Z)
+        finally:
+            K.gemm_bf16_split_enable(prev)
+    (o6, z6), (o32, z32) = outs[True], outs[False]
+    assert torch.isfinite(o6).all() and (o6 == 0).eq(o32 == 0).all()
+    assert float((o6 - o32).abs().max()) <= 2e-5
+    if act:
+        assert float((z6 - z32).abs().max()) <= 2e-5 and (z6 == 0).eq(z32 == 0).all()
