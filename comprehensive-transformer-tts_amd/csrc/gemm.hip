@@ -734,8 +734,11 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
 // tools/ubench/bf16x_split_gemm.hip; tests/test_kernels_gpu.py compares this kernel with float64 and with the fp32-MFMA kernels).
 // Everything else is the tile kernel above: buffer loads with the im2col view, register staging, ONE LDS stage and two barriers per
 // K-block (two workgroups per CU alternate), the same epilogues, the same zero-fill of wholly padded row tiles.  LDS: per operand three
-// planes of [128 rows][32 bf16] with 80-byte rows (16-byte fragment reads of 8 consecutive rows hit 8 distinct bank quads) = 61,440 B.
-constexpr int X6_PROW = 80, X6_PLANE = 128 * X6_PROW;
+// planes of [128 rows][32 bf16] = 64-byte rows with XOR-swizzled 16-byte chunks (conflict-free both ways) = 49,152 B: three per CU.
+constexpr int X6_PROW = 64, X6_PLANE = 128 * X6_PROW;      // 64-byte rows, 16-byte chunks XOR-swizzled by (row >> 2) & 3 (see x6_chunk)
+// physical 16-byte chunk of logical chunk c (0..3) in `row`: staging writes (8 lanes per row, 4 aligned rows per 256-byte beat) and
+// fragment reads (16 consecutive rows, one chunk) both touch every bank exactly once per beat; no padding: 48 KB per workgroup, three per CU
+__device__ __forceinline__ int x6_chunk(int row, int c) { return c ^ ((row >> 2) & 3); }
 typedef __bf16 x6_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void x6_split_store(const float4 v, unsigned char* base) {      // 4 consecutive-K floats -> 8 bytes per plane
@@ -823,11 +826,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const ctts_gemm_desc d)
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float4 ra[4], rb[4];
   // staging: float4 i of this thread is row (tid + 256 i) / 8 = tid / 8 + 32 i, K offset (tid % 8) * 4 (BLoaderKC's chunking)
-  unsigned char* st_a = smem + (threadIdx.x >> 3) * X6_PROW + (threadIdx.x & 7) * 8;
+  // (rows 32 i apart share (row >> 2) & 3, so one swizzled offset serves all four staging rows / both MFMA row tiles)
+  const int srow = threadIdx.x >> 3, sc8 = threadIdx.x & 7;
+  unsigned char* st_a = smem + srow * X6_PROW + x6_chunk(srow, sc8 >> 1) * 16 + (sc8 & 1) * 8;
   unsigned char* st_b = st_a + 3 * X6_PLANE;
-  // fragment of a 32-row MFMA tile: row l31, the 8 consecutive K values from h * 8 of a 16-deep step
-  const unsigned char* fr_a = smem + (wm0 + l31) * X6_PROW + h * 16;
-  const unsigned char* fr_b = smem + 3 * X6_PLANE + (wn0 + l31) * X6_PROW + h * 16;
+  // fragment of a 32-row MFMA tile: row l31, the 8 consecutive K values from h * 8 of the 16-deep step ks = logical chunk ks * 2 + h
+  const unsigned char* fr_a = smem + (wm0 + l31) * X6_PROW;
+  const unsigned char* fr_b = smem + 3 * X6_PLANE + (wn0 + l31) * X6_PROW;
+  const int fc0 = x6_chunk(l31, h) * 16, fc1 = x6_chunk(l31, 2 + h) * 16;      // byte offsets of the fragment chunk for ks = 0, 1
   la.load(ra_src, 0, Kv, ra);
   lb.load(rb_src, 0, Kv, rb);
 #pragma unroll
@@ -846,11 +852,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const ctts_gemm_desc d)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) fa[ks][i][p] = *reinterpret_cast<const ctts_u32x4*>(fr_a + p * X6_PLANE + 32 * i * X6_PROW + ks * 32);
+        for (int p = 0; p < 3; ++p) fa[ks][i][p] = *reinterpret_cast<const ctts_u32x4*>(fr_a + p * X6_PLANE + 32 * i * X6_PROW + (ks ? fc1 : fc0));
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) fb[ks][j][p] = *reinterpret_cast<const ctts_u32x4*>(fr_b + p * X6_PLANE + 32 * j * X6_PROW + ks * 32);
+        for (int p = 0; p < 3; ++p) fb[ks][j][p] = *reinterpret_cast<const ctts_u32x4*>(fr_b + p * X6_PLANE + 32 * j * X6_PROW + (ks ? fc1 : fc0));
     }
     // term-major order: consecutive MFMAs go to DIFFERENT accumulators (a chain of six on one accumulator waits for each result);
     // smallest terms first
