@@ -887,6 +887,146 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const ctts_gemm_desc d)
   gemm_epilogue_auto<MT, NT>(d, acc, Cb, 0, row0, col0, wm0, wn0, l31, h, Mv, Nv);
 }
 
+// ---- the same arithmetic for WEIGHT GRADIENTS (TN layout: C[m][n] = sum_k A[k][m] B[k][n], both operands reduction-major, optional
+// im2col view on B).  A bf16 MFMA fragment is 8 consecutive k of one row, which in memory lie a whole row apart: every thread owns ONE
+// column (m or n) of the tile and reads 8 consecutive k of it with 8 dword loads (a wave still reads 256 contiguous bytes per k), splits
+// the 8 values and stores 16 bytes per plane - the same LDS image as the NT kernel, so fragments, MFMA sequence and epilogue are shared.
+// K-blocks that lie wholly in the padding of one utterance are skipped (their dZ rows are zero by construction); grid.y = split_k with
+// ctts_gemm's ordered partial matrices.
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_x6tn_kernel(const ctts_gemm_desc d) {
+  static_assert(BK == 32, "the bf16 planes hold 32-deep K-blocks");
+  constexpr int BM = 128, BN = 128, MT = 2, NT = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[6 * X6_PLANE];
+  const int Mv = d.M, Nv = d.N, Kv = d.K;
+  const int tiles_n = d.N / BN, nwg = gridDim.x, split = blockIdx.y;
+  int wg, tm;
+  {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    tm = wg / tiles_n;
+  }
+  const int row0 = tm * BM, col0 = (wg % tiles_n) * BN;
+  float* Cb = d.C;
+  if (d.split_k > 1) Cb += (long)split * d.M * d.ldc;        // partial matrix P_split (ctts_gemm rewrote the descriptor)
+  int k_begin = 0, k_end = Kv;
+  if (d.split_k > 1) {
+    const int chunk = ((Kv + d.split_k - 1) / d.split_k + BK - 1) / BK * BK;
+    k_begin = split * chunk;
+    k_end = min(Kv, k_begin + chunk);
+    if (k_begin >= k_end) return;
+  }
+  auto kblock_active = [&](int k0) -> bool {
+    if (!d.row_lens) return true;
+    const int lastk = min(k0 + BK, k_end) - 1;
+    const int b0 = k0 / d.row_T;
+    return !(b0 == lastk / d.row_T && (k0 - b0 * d.row_T) >= d.row_lens[b0] + d.row_halo);
+  };
+  auto next_active = [&](int k0) -> int { while (k0 < k_end && !kblock_active(k0)) k0 += BK; return k0; };
+  const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, 0x7FFFFFFE, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, 0x7FFFFFFE, 0x00020000);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  // staging: thread -> column `scol` of both tiles, k octets og and og + 2 of the 32-deep block
+  const int scol = threadIdx.x & 127, og = threadIdx.x >> 7;
+  const unsigned a_col = (unsigned)(row0 + scol) * 4u, b_col = (unsigned)(col0 + scol) * 4u;
+  const unsigned lda4 = (unsigned)(d.lda * 4), ldb4 = (unsigned)(d.ldb * 4);
+  const int tapb = CONV ? (col0 + scol) / d.conv_cin - d.conv_pad : 0;      // im2col column = (tap, channel): the row shift of this column
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float va[2][8], vb[2][8];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int kk0 = k0 + (og + 2 * o) * 8;
+      const int t0 = CONV ? kk0 % d.conv_T + tapb : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = kk0 + j;
+        const bool ok = k < k_end;
+        const unsigned offa = ok ? (unsigned)k * lda4 + a_col : CTTS_OOB;
+        bool okb = ok;
+        if (CONV) okb = okb && ((unsigned)(t0 + j) < (unsigned)d.conv_T);
+        const unsigned offb = okb ? (unsigned)(CONV ? k - d.conv_pad : k) * ldb4 + b_col : CTTS_OOB;
+        va[o][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_src, offa, 0, 0));
+        vb[o][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_src, offb, 0, 0));
+      }
+    }
+  };
+  auto split_store8 = [&](const float (&x)[8], unsigned char* base) {       // 8 consecutive k of one LDS row -> 16 bytes per plane
+    float r1[8], r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);
+      r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);
+    }
+    ctts_u32x4 hi, mid, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hi[q] = __builtin_amdgcn_perm(__float_as_uint(x[2 * q + 1]), __float_as_uint(x[2 * q]), 0x07060302u);
+      mid[q] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * q + 1]), __float_as_uint(r1[2 * q]), 0x07060302u);
+      lo[q] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * q + 1]), __float_as_uint(r2[2 * q]), 0x07060302u);
+    }
+    *reinterpret_cast<ctts_u32x4*>(base) = hi;
+    *reinterpret_cast<ctts_u32x4*>(base + X6_PLANE) = mid;
+    *reinterpret_cast<ctts_u32x4*>(base + 2 * X6_PLANE) = lo;
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      unsigned char* pa = smem + scol * X6_PROW + x6_chunk(scol, og + 2 * o) * 16;
+      split_store8(va[o], pa);
+      split_store8(vb[o], pa + 3 * X6_PLANE);
+    }
+  };
+  const unsigned char* fr_a = smem + (wm0 + l31) * X6_PROW;
+  const unsigned char* fr_b = smem + 3 * X6_PLANE + (wn0 + l31) * X6_PROW;
+  const int fc0 = x6_chunk(l31, h) * 16, fc1 = x6_chunk(l31, 2 + h) * 16;
+  int k_cur = next_active(k_begin);
+  if (k_cur < k_end) {
+    gload(k_cur);
+    lstore();
+  }
+  __syncthreads();
+  while (k_cur < k_end) {
+    const int k_nxt = next_active(k_cur + BK);
+    gload(k_nxt < k_end ? k_nxt : k_cur);                      // unconditional: keeps the staging registers out of scratch
+    ctts_u32x4 fa[2][MT][3], fb[2][NT][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fa[ks][i][p] = *reinterpret_cast<const ctts_u32x4*>(fr_a + p * X6_PLANE + 32 * i * X6_PROW + (ks ? fc1 : fc0));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fb[ks][j][p] = *reinterpret_cast<const ctts_u32x4*>(fr_b + p * X6_PLANE + 32 * j * X6_PROW + (ks ? fc1 : fc0));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = x6_mma(fa[ks][i][PA[t]], fb[ks][j][PB[t]], acc[i][j]);
+      }
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    k_cur = k_nxt;
+  }
+  gemm_epilogue_auto<MT, NT>(d, acc, Cb, 0, row0, col0, wm0, wn0, l31, h, Mv, Nv);
+}
+
 // Under-filled launches (few output tiles, long reduction: the 2,048-row phoneme-level layers give 128 tiles of 64 x 64 on 256 CUs, each
 // a chain of K / 32 staged K-blocks on one workgroup per CU): 32 x 64 tiles - twice the workgroups - and the reduction split in two INSIDE
 // the workgroup.  Waves 0,1 (32 columns each) take the even 32-deep K-blocks, waves 2,3 the odd ones: one load / barrier round per 64
@@ -1198,8 +1338,28 @@ static bool gemm_x6_takes(const ctts_gemm_desc& d) {
   if (!on || !d.a_kc || !d.b_kc || d.nb0 * d.nb1 != 1 || d.split_k > 1 || d.E || d.lens || d.conv_on_b) return false;
   if (d.K < 256 || d.K % BK || d.N % 128 || d.M < 1024) return false;
   if (d.conv_T > 0 && d.conv_cin % 4) return false;
-  if ((long)((d.M + 127) / 128) * (d.N / 128) < min_tiles) return false;
+  if (on != 2 && (long)((d.M + 127) / 128) * (d.N / 128) < min_tiles) return false;      // 2 = forced (tests): no size threshold
   return vec_ok(d) && buf_ok(d);
+}
+
+// the TN (weight-gradient) form: unbatched, both operands reduction-major, tile-aligned output, long reduction; CTTS_X6_TN=0 turns it off
+static bool gemm_x6tn_takes(const ctts_gemm_desc& d) {
+  if (g_x6_on < 0) g_x6_on = getenv("CTTS_X6") ? (atoi(getenv("CTTS_X6")) != 0) : 1;
+  static const int tn = getenv("CTTS_X6_TN") ? atoi(getenv("CTTS_X6_TN")) : 1;
+  static const long min_wg = getenv("CTTS_X6_TN_MIN_WG") ? atol(getenv("CTTS_X6_TN_MIN_WG")) : 384;
+  if (!g_x6_on || !tn || d.a_kc || d.b_kc || d.nb0 * d.nb1 != 1 || d.E || d.lens || d.epi_bwd) return false;
+  if (d.M % 128 || d.N % 128 || d.K % BK || d.K < 2048) return false;
+  if (d.conv_T > 0 && (!d.conv_on_b || d.conv_T % BK || d.conv_cin % 4)) return false;
+  if (g_x6_on != 2 && (long)(d.M / 128) * (d.N / 128) * (d.split_k > 1 ? d.split_k : 1) < min_wg) return false;
+  return vec_ok(d) && buf_ok(d);
+}
+
+static int gemm_x6tn_launch(const ctts_gemm_desc& d, hipStream_t st) {
+  const dim3 grid((d.M / 128) * (d.N / 128), d.split_k > 1 ? d.split_k : 1, 1);
+  if (d.conv_T > 0) hipLaunchKernelGGL(gemm_x6tn_kernel<true>, grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL(gemm_x6tn_kernel<false>, grid, dim3(256), 0, st, d);
+  CTTS_CHECK_LAUNCH("ctts_gemm(x6tn)");
+  return 0;
 }
 
 static int gemm_x6_launch(const ctts_gemm_desc& d, hipStream_t st) {
@@ -1213,7 +1373,7 @@ static int gemm_x6_launch(const ctts_gemm_desc& d, hipStream_t st) {
 extern "C" int ctts_gemm_bf16_split_enable(int on) {
   if (g_x6_on < 0) g_x6_on = getenv("CTTS_X6") ? (atoi(getenv("CTTS_X6")) != 0) : 1;
   const int prev = g_x6_on;
-  g_x6_on = on != 0;
+  g_x6_on = on == 2 ? 2 : (on != 0);          // 2: also below the size thresholds (tests of small launches)
   return prev;
 }
 
@@ -1223,7 +1383,7 @@ extern "C" int ctts_gemm_takes_bf16_split(const ctts_gemm_desc* dp) {
   if (d.nb0 < 1) d.nb0 = 1;
   if (d.nb1 < 1) d.nb1 = 1;
   if (ctts_gemm_takes_weight_stationary(&d)) return 0;       // ctts_gemm asks the weight-stationary kernel first
-  return gemm_x6_takes(d) ? 1 : 0;
+  return (gemm_x6_takes(d) || gemm_x6tn_takes(d)) ? 1 : 0;
 }
 
 static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan) {
@@ -1244,15 +1404,18 @@ static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan
   CTTS_REQUIRE(!d.E || (d.rowsub && d.split_k <= 1 && !d.bias && !d.act && d.p_drop == 0.f && !d.R && !d.rowscale && !d.Z),
                "ctts_gemm: the E/rowsub epilogue excludes bias, activation, dropout, residual, rowscale and split-K");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool x6tn = gemm_x6tn_takes(d);            // weight gradient on the bf16-split kernel: a tile-kernel launch with ordered split-K partials
   if (plan) {
     plan->deferred_ok = 0;
-    if (d.split_k <= 1 || ctts_gemm_takes_weight_stationary(&d) || ctts_gemm_takes_persistent(&d)) return 0;
+    if (d.split_k <= 1 || ctts_gemm_takes_weight_stationary(&d) || (!x6tn && ctts_gemm_takes_persistent(&d))) return 0;
   } else {
     const int ws = ctts_gemm_ws_try(d, st);      // weight-stationary kernel (gemm_ws.hip) for K = 256 linears with many rows
     if (ws != 0) return ws > 0 ? 0 : ws;
     if (gemm_x6_takes(d)) return gemm_x6_launch(d, st);      // fp32 products on the bf16 matrix pipe (six-term split)
-    const int sk = ctts_gemm_sk_try(d, st);      // persistent stream-K kernel (gemm_sk.hip) when the descriptor is eligible
-    if (sk != 0) return sk > 0 ? 0 : sk;
+    if (!x6tn) {
+      const int sk = ctts_gemm_sk_try(d, st);    // persistent stream-K kernel (gemm_sk.hip) when the descriptor is eligible
+      if (sk != 0) return sk > 0 ? 0 : sk;
+    }
   }
   const long tiles128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.split_k > 1 ? d.split_k : 1) * d.nb0 * d.nb1;
   static const int force_tile = getenv("CTTS_FORCE_TILE") ? atoi(getenv("CTTS_FORCE_TILE")) : 0;   // tuning knob
@@ -1283,9 +1446,10 @@ static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan
   const bool buf_unaligned = !aligned && chunks_ok(d) && d.conv_T <= 0 && !(d.lens && (d.lim_m || d.lim_n || d.lim_k));
 #endif
   // ---- which kernel family / tile takes the launch (decided first: the ordered split-K sum needs the tile shape)
-  enum { K_SCALAR64, K_BUF128, K_BUF_K2, K_BUF_NARROW, K_BUF64, K_VEC128, K_VEC64 } kind;
+  enum { K_SCALAR64, K_BUF128, K_BUF_K2, K_BUF_NARROW, K_BUF64, K_VEC128, K_VEC64, K_X6TN } kind;
   int BMs = 64, BNs = 64;
-  if (!aligned && !(buf_unaligned && buf_ok(d))) kind = K_SCALAR64;
+  if (x6tn) { kind = K_X6TN; BMs = BNs = 128; }
+  else if (!aligned && !(buf_unaligned && buf_ok(d))) kind = K_SCALAR64;
 #ifndef CTTS_NO_BUF
   else if (buf_ok(d)) {
     // 64x64 tiles (64 VGPRs: 8 waves/SIMD) match the 128x128 kernel on every measured shape (109 / 119 / 108 / 107 TFLOP/s on FFN conv fwd,
@@ -1359,6 +1523,7 @@ static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan
     case K_BUF64: rc = dispatch_buf<64, 64>(d, st); break;
 #endif
     case K_VEC128: rc = dispatch_layout<128, 128, true>(d, st); break;
+    case K_X6TN: rc = gemm_x6tn_launch(d, st); break;
     default: rc = dispatch_layout<64, 64, true>(d, st); break;
   }
   if (rc != 0 || !split || d_user.split_out) return rc;

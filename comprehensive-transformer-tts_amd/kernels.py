@@ -293,8 +293,9 @@ def gemm_takes_bf16_split(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=Tr
 
 
 def gemm_bf16_split_enable(on):
-    """Process-wide switch of that kernel (tests / A/B timing); returns the previous setting."""
-    return bool(_lib.load().ctts_gemm_bf16_split_enable(int(bool(on))))
+    """Process-wide switch of that kernel (tests / A/B timing): False / True, or 2 = also for launches below its size thresholds;
+    returns the previous setting (pass it back to restore)."""
+    return int(_lib.load().ctts_gemm_bf16_split_enable(2 if on == 2 else int(bool(on))))
 
 
 def gemm_takes_weight_stationary(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):

@@ -1346,3 +1346,73 @@ def test_bf16_split_gemm_conv_view_ragged_rows_and_epilogues_equal_the_fp32_kern
     assert float((o6 - o32).abs().max()) <= 2e-5
     if act:
         assert float((z6 - z32).abs().max()) <= 2e-5 and (z6 == 0).eq(z32 == 0).all()
+
+
+@pytest.mark.parametrize("conv,split,ragged", [(False, 1, False), (False, 4, True), (True, 4, True), (True, 1, False)])
+def test_bf16_split_weight_gradient_gemm_vs_fp64_and_the_fp32_kernels(conv, split, ragged):
+    """gemm_x6tn_kernel (TN layout: dW[m][n] = sum_k dZ[k][m] X[k][n], optional im2col view on X, K-blocks in padding skipped, ordered
+    split-K partials): exact on integer data, against float64 not worse than the fp32-MFMA kernels on the same launch, bit-reproducible."""
+    if os.environ.get("CTTS_X6_TN", "1") == "0":
+        pytest.skip("CTTS_X6_TN=0")
+    B_, T, Cin, ks, Mo = 8, 512, 128, 3 if conv else 1, 512
+    Kred, No = B_ * T, ks * Cin
+    lens = torch.tensor([512, 200, 129, 64, 330, 1, 448, 385], dtype=torch.int32, device=DEV)
+    valid = (torch.arange(T, device=DEV)[None, :] < lens[:, None]).float().reshape(-1, 1) if ragged else 1.0
+    g = torch.Generator().manual_seed(9)
+    force = K.gemm_bf16_split_enable(2)          # the test launches are below the kernel's size threshold
+    try:
+        _bf16_split_tn_body(conv, split, ragged, B_, T, Cin, ks, Mo, Kred, No, lens, valid, g)
+    finally:
+        K.gemm_bf16_split_enable(force)
+
+
+def _bf16_split_tn_body(conv, split, ragged, B_, T, Cin, ks, Mo, Kred, No, lens, valid, g):
+    def run(dz, x):
+        out = torch.full((Mo, No), float("nan"), device=DEV) if split == 1 else torch.zeros(Mo, No, device=DEV)
+        kw = dict(alpha=1.0)
+        if conv:
+            kw.update(conv=(T, ks // 2, Cin), conv_on_b=True)
+        if ragged:
+            kw.update(row_lens=lens, row_T=T, row_halo=0)
+        if split > 1:
+            kw.update(split_k=split)
+        args = (dz, x, out, Mo, No, Kred, Mo, Cin, No, False, False)
+        took = K.gemm_takes_bf16_split(*args, **kw)
+        K.gemm(*args, **kw)
+        return out, took
+
+    def ref64(dz, x):
+        xd = x.double().view(B_, T, Cin)
+        if conv:
+            pad = ks // 2
+            xp = torch.nn.functional.pad(xd, (0, 0, pad, pad))
+            cols = torch.cat([xp[:, kk:kk + T] for kk in range(ks)], dim=-1).reshape(Kred, No)       # [k][(tap, c)]
+        else:
+            cols = xd.reshape(Kred, No)
+        return dz.double().t() @ cols
+
+    # exact case: 18-bit integers against sparse +-1 (every fp32 partial sum exact)
+    dz = (torch.randint(-1, 2, (Kred, Mo), generator=g) * (torch.rand(Kred, Mo, generator=g) < 1 / 64)).float().to(DEV) * valid
+    x = torch.randint(-(1 << 17), (1 << 17) + 1, (Kred, Cin), generator=g).float().to(DEV)
+    got, took = run(dz, x)
+    assert took, "expected on the bf16-split weight-gradient kernel"
+    ref = ref64(dz, x)
+    assert float(ref.abs().max()) < 2 ** 24 and torch.equal(got.double(), ref), float((got.double() - ref).abs().max())
+    # random data: error vs float64 next to the fp32-MFMA kernels, and run-to-run identity
+    dz = torch.randn(Kred, Mo, generator=g).to(DEV) * valid
+    x = torch.randn(Kred, Cin, generator=g).to(DEV)
+    ref = ref64(dz, x)
+    a, _ = run(dz, x)
+    b, _ = run(dz, x)
+    assert torch.equal(a, b)
+    K.gemm_bf16_split_enable(False)
+    try:
+        f32, took32 = run(dz, x)
+        assert not took32
+    finally:
+        K.gemm_bf16_split_enable(2)
+    e6, e32 = float((a.double() - ref).abs().max()), float((f32.double() - ref).abs().max())
+    print(f"TN max |err| vs fp64: bf16-split {e6:.3e}, fp32 MFMA {e32:.3e}")
+    # both accumulate 4,096+ products per output in fp32; the fp32-MFMA path cuts that chain (stream-K / split-K pieces summed
+    # afterwards), so its rounding error is somewhat smaller on unsplit launches - the products themselves are exact either way (above)
+    assert e6 <= 2.5 * e32 + 1e-6, (e6, e32)
