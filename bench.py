@@ -561,9 +561,10 @@ def main():
                                     + "; full train step fwd+loss+bwd+clip+Adam, dropout on"),
                        "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
                        "parallelism": f"dp{world}", "final_loss": loss_final,
-                       "gemm_arithmetic": ("fp32 storage and accumulation everywhere; the large NT GEMMs (FFN / PostNet Conv1d forward) form each "
-                                           "fp32 product from 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands (gemm_x6_kernel, "
-                                           "error not above an fp32 FMA chain's); all other GEMMs on v_mfma_f32_32x32x2_f32"
+                       "gemm_arithmetic": ("fp32 storage and accumulation everywhere; the large NT GEMMs (FFN / PostNet Conv1d forward) and the weight-gradient "
+                                           "GEMMs (TN) form each fp32 product from 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands "
+                                           "(gemm_x6_kernel / gemm_x6tn_kernel: exact on exactly representable data, error vs float64 1.0 - 1.7x the "
+                                           "fp32-MFMA kernels' on the same launches); all other GEMMs on v_mfma_f32_32x32x2_f32"
                                            if os.environ.get("CTTS_X6", "1") != "0" else "v_mfma_f32_32x32x2_f32 (CTTS_X6=0)"),
                        "grad_buckets_bytes": step.reducer.bucket_bytes() if world > 1 else None,
                        "strong_scaling_shard": built["shard_balance"]},

@@ -142,11 +142,14 @@ int ctts_gemm_takes_persistent(const ctts_gemm_desc* d);
 int ctts_gemm_ws_enable(int on);
 /* 1 when ctts_gemm would run this descriptor on the weight-stationary kernel (no launch). */
 int ctts_gemm_takes_weight_stationary(const ctts_gemm_desc* d);
-/* fp32 GEMM on the BF16 matrix pipe (csrc/gemm.hip gemm_x6_kernel; default on, env CTTS_X6=0 turns it off): large unbatched NT launches
- * (both operands K-contiguous, conv view on A allowed, N a multiple of 128, split_k <= 1) form every fp32 product from six
+/* fp32 GEMM on the BF16 matrix pipe (csrc/gemm.hip gemm_x6_kernel / gemm_x6tn_kernel; default on, env CTTS_X6=0 turns it off): large
+ * unbatched NT launches (both operands K-contiguous, conv view on A allowed, N a multiple of 128, split_k <= 1) and large unbatched TN
+ * launches (weight gradients: both operands reduction-major, conv view on B allowed, M and N multiples of 128, K >= 2048, any split_k;
+ * env CTTS_X6_TN=0 turns only these off) form every fp32 product from six
  * v_mfma_f32_32x32x16_bf16 terms of the EXACT three-way bf16 split of both operands (x = hi + mid + lo by truncation), accumulated in
  * fp32 - fp32-class results (error against float64 not above an fp32 FMA chain's) at up to 16/6 of the fp32-MFMA rate.
- * ctts_gemm_bf16_split_enable returns the previous setting (process-wide, not thread-safe: parity tests and A/B timing);
+ * ctts_gemm_bf16_split_enable(0 / 1, or 2 = also below the kernels' size thresholds) returns the previous setting (process-wide, not
+ * thread-safe: parity tests and A/B timing);
  * ctts_gemm_takes_bf16_split: 1 when ctts_gemm would run this descriptor on that kernel (no launch). */
 int ctts_gemm_bf16_split_enable(int on);
 int ctts_gemm_takes_bf16_split(const ctts_gemm_desc* d);
