@@ -405,6 +405,10 @@ SECONDARY = [   # BASELINE configs[2..4] measured in the same invocation (N = 1 
      dict(dataset="VCTK", block="transformer_fs2", prosody="none", learn_alignment=False), 157.4e6),
     ("configs[4] LJSpeech transformer_fs2 + liu2021 prosody + learn_alignment batch=16",
      dict(dataset="LJSpeech", block="transformer_fs2", prosody="liu2021", learn_alignment=True), 157.4e6),
+    # the HEADLINE configuration once more with every GEMM on v_mfma_f32_32x32x2_f32 (ctts_gemm_bf16_split_enable(0)): the same-run,
+    # same-box figure of the step without the bf16-split kernels
+    ("configs[1] LJSpeech transformer_fs2 batch=16 with fp32 MFMAs only (bf16-split GEMM kernels switched off)",
+     dict(dataset="LJSpeech", block="transformer_fs2", prosody="none", learn_alignment=False, fp32_mfma_only=True), 157.4e6),
 ]
 
 
@@ -412,7 +416,11 @@ def measure_secondary(dev, steps=10, warmup=3):
     """same step definition and timing as the headline (inputs resident, hipGraph replay), fewer steps; FLOP per valid frame from SURVEY 8(d)"""
     out = []
     for name, cfg, flop_per_frame in SECONDARY:
+        prev_split = None
         try:
+            if cfg.get("fp32_mfma_only"):
+                from ctts_amd import kernels as _K
+                prev_split = _K.gemm_bf16_split_enable(False)          # the graphs captured below hold fp32-MFMA launches only
             b = build_step(dev, 0, 1, cfg["dataset"], cfg["block"], cfg["prosody"], cfg["learn_alignment"], "canonical", "weak")
             st = b["step"]
             for _ in range(warmup):
@@ -432,6 +440,10 @@ def measure_secondary(dev, steps=10, warmup=3):
             del b, st
         except Exception as e:                                # noqa: BLE001
             out.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+        finally:
+            if prev_split is not None:
+                from ctts_amd import kernels as _K
+                _K.gemm_bf16_split_enable(prev_split)
         torch.cuda.empty_cache()
     return out
 
