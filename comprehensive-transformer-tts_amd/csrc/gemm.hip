@@ -734,10 +734,12 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
 // tools/ubench/bf16x_split_gemm.hip; tests/test_kernels_gpu.py compares this kernel with float64 and with the fp32-MFMA kernels).
 // Everything else is the tile kernel above: buffer loads with the im2col view, register staging, ONE LDS stage and two barriers per
 // K-block (two workgroups per CU alternate), the same epilogues, the same zero-fill of wholly padded row tiles.  LDS: per operand three
-// planes of [128 rows][32 bf16] = 64-byte rows with XOR-swizzled 16-byte chunks (conflict-free both ways) = 49,152 B: three per CU.
+// planes of [128 rows][32 bf16] = 64-byte rows with XOR-swizzled 16-byte chunks (conflict-free both ways) = 49,152 B per
+// workgroup (LDS would take three per CU; the kernel's 188 VGPRs keep it at two waves per SIMD = two workgroups, which measured faster
+// than three at 168 VGPRs with a spill).  The shader clock under this kernel is 1.8 - 1.9 GHz (2.39 under the fp32-MFMA kernels): DESIGN.md.
 constexpr int X6_PROW = 64, X6_PLANE = 128 * X6_PROW;      // 64-byte rows, 16-byte chunks XOR-swizzled by (row >> 2) & 3 (see x6_chunk)
 // physical 16-byte chunk of logical chunk c (0..3) in `row`: staging writes (8 lanes per row, 4 aligned rows per 256-byte beat) and
-// fragment reads (16 consecutive rows, one chunk) both touch every bank exactly once per beat; no padding: 48 KB per workgroup, three per CU
+// fragment reads (16 consecutive rows, one chunk) both touch every bank exactly once per beat; no padding
 __device__ __forceinline__ int x6_chunk(int row, int c) { return c ^ ((row >> 2) & 3); }
 typedef __bf16 x6_bf16x8 __attribute__((ext_vector_type(8)));
 
