@@ -227,7 +227,8 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
         # the fp32-MFMA peak (what the launch would be bounded by on v_mfma_f32_32x32x2_f32) is reported next to it.
         peak = BF16_MFMA_PEAK_TFLOPS / X6_TERMS
         extra = {"arithmetic": "fp32 in / out / accumulate; each product = 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands "
-                               "(dropped terms <= 2^-24 relative: error vs float64 not above an fp32 FMA chain's, tests/test_kernels_gpu.py)",
+                               "(dropped terms <= 2^-21 of a product worst case, < 2^-24 typically; exact on exactly representable data; error vs float64 of the "
+                               "same class as the fp32-MFMA kernels' on the same launches: tests/test_kernels_gpu.py, tests/test_bf16_split_cpu.py)",
                  "peak_definition": "2500 TFLOP/s dense bf16 MFMA / 6 terms", "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                  "executed_bf16_tflops": ach * X6_TERMS,
                  "kernel": "ctts_gemm conv fwd on gemm_x6_kernel (decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments incl. padded-row skipping)"}

@@ -730,7 +730,8 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
 // v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32 on gfx950.  Every fp32 operand is split EXACTLY into three
 // bf16 pieces (x = hi + mid + lo, 8 mantissa bits each, by truncation) once, on its way from the staging registers into LDS, and a
 // product is the six cross terms  hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi  accumulated in fp32; the dropped terms are
-// <= 2^-24 relative, i.e. the products are fp32-class (measured: max error against float64 1.36e-5 where an fp32 FMA chain has 1.63e-5,
+// <= 2^-21 of the product in the worst case (truncation: |mid| <= 2^-7 |hi|, |lo| <= 2^-15 |hi|) and below 2^-24 typically
+// (tests/test_bf16_split_cpu.py), i.e. the products are fp32-class (measured: max error against float64 1.36e-5 where an fp32 FMA chain has 1.63e-5,
 // tools/ubench/bf16x_split_gemm.hip; tests/test_kernels_gpu.py compares this kernel with float64 and with the fp32-MFMA kernels).
 // Everything else is the tile kernel above: buffer loads with the im2col view, register staging, ONE LDS stage and two barriers per
 // K-block (two workgroups per CU alternate), the same epilogues, the same zero-fill of wholly padded row tiles.  LDS: per operand three
