@@ -227,8 +227,8 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
         # the fp32-MFMA peak (what the launch would be bounded by on v_mfma_f32_32x32x2_f32) is reported next to it.
         peak = BF16_MFMA_PEAK_TFLOPS / X6_TERMS
         extra = {"arithmetic": "fp32 in / out / accumulate; each product = 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands "
-                               "(dropped terms <= 2^-21 of a product worst case, < 2^-24 typically; exact on exactly representable data; error vs float64 of the "
-                               "same class as the fp32-MFMA kernels' on the same launches: tests/test_kernels_gpu.py, tests/test_bf16_split_cpu.py)",
+                               "(round-to-nearest pieces: dropped terms <= 2^-24 of a product = one fp32 rounding, 2^-29 in the median; exact on exactly "
+                               "representable data; error vs float64 as the fp32-MFMA kernels' on the same launches: tests/test_kernels_gpu.py, tests/test_bf16_split_cpu.py)",
                  "peak_definition": "2500 TFLOP/s dense bf16 MFMA / 6 terms", "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                  "executed_bf16_tflops": ach * X6_TERMS,
                  "kernel": "ctts_gemm conv fwd on gemm_x6_kernel (decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments incl. padded-row skipping)"}
@@ -576,8 +576,8 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": loss_final,
                        "gemm_arithmetic": ("fp32 storage and accumulation everywhere; the large NT GEMMs (FFN / PostNet Conv1d forward) and the weight-gradient "
                                            "GEMMs (TN) form each fp32 product from 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands "
-                                           "(gemm_x6_kernel / gemm_x6tn_kernel: exact on exactly representable data, error vs float64 1.0 - 1.7x the "
-                                           "fp32-MFMA kernels' on the same launches); all other GEMMs on v_mfma_f32_32x32x2_f32"
+                                           "(gemm_x6_kernel / gemm_x6tn_kernel: exact on exactly representable data, dropped cross terms <= one fp32 "
+                                           "rounding per product); all other GEMMs on v_mfma_f32_32x32x2_f32"
                                            if os.environ.get("CTTS_X6", "1") != "0" else "v_mfma_f32_32x32x2_f32 (CTTS_X6=0)"),
                        "grad_buckets_bytes": step.reducer.bucket_bytes() if world > 1 else None,
                        "strong_scaling_shard": built["shard_balance"]},

@@ -728,10 +728,11 @@ __global__ __launch_bounds__(256, CTTS_GEMM_WAVES) void gemm_buf_kernel(const ct
 
 // ---- fp32 GEMM on the BF16 matrix pipe (NT layout: both operands K-contiguous, conv view on A allowed) --------------------------
 // v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32 on gfx950.  Every fp32 operand is split EXACTLY into three
-// bf16 pieces (x = hi + mid + lo, 8 mantissa bits each, by truncation) once, on its way from the staging registers into LDS, and a
+// bf16 pieces (x = hi + mid + lo, 8 significand bits each, each the round-to-nearest of what is left) once, on its way from the staging registers into LDS, and a
 // product is the six cross terms  hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi  accumulated in fp32; the dropped terms are
-// <= 2^-21 of the product in the worst case (truncation: |mid| <= 2^-7 |hi|, |lo| <= 2^-15 |hi|) and below 2^-24 typically
-// (tests/test_bf16_split_cpu.py), i.e. the products are fp32-class (measured: max error against float64 1.36e-5 where an fp32 FMA chain has 1.63e-5,
+// <= 2^-24 of the product in the worst case - ONE fp32 rounding - and 2^-29 in the median (|mid| <= 2^-8 |hi|, |lo| <= 2^-16 |hi|;
+// tests/test_bf16_split_cpu.py; with truncated pieces the worst case was 2^-21),
+// i.e. the products are fp32-class (measured: max error against float64 1.36e-5 where an fp32 FMA chain has 1.63e-5,
 // tools/ubench/bf16x_split_gemm.hip; tests/test_kernels_gpu.py compares this kernel with float64 and with the fp32-MFMA kernels).
 // Everything else is the tile kernel above: buffer loads with the im2col view, register staging, ONE LDS stage and two barriers per
 // K-block (two workgroups per CU alternate), the same epilogues, the same zero-fill of wholly padded row tiles.  LDS: per operand three
@@ -744,21 +745,23 @@ constexpr int X6_PROW = 64, X6_PLANE = 128 * X6_PROW;      // 64-byte rows, 16-b
 __device__ __forceinline__ int x6_chunk(int row, int c) { return c ^ ((row >> 2) & 3); }
 typedef __bf16 x6_bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef __bf16 x6_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float x6_floatx2 __attribute__((ext_vector_type(2)));
+// two floats -> their bf16 roundings (to nearest even: v_cvt_pk_bf16_f32), packed low | high, and the exact remainders in place
+__device__ __forceinline__ unsigned x6_round_pair(float& a, float& b) {
+  const x6_floatx2 v = {a, b};
+  const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_bf16x2));
+  a -= __uint_as_float(p << 16);                       // exact: a number minus its rounding to fewer bits
+  b -= __uint_as_float(p & 0xFFFF0000u);
+  return p;
+}
+
 __device__ __forceinline__ void x6_split_store(const float4 v, unsigned char* base) {      // 4 consecutive-K floats -> 8 bytes per plane
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  float r1[4], r2[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);                     // exact
-    r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);
-  }
-  uint2 hi, mid, lo;       // upper halves of two floats -> one register = the truncations above
-  hi.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
-  hi.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
-  mid.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
-  mid.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
-  lo.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
-  lo.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+  float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+  uint2 hi, mid, lo;
+  hi.x = x6_round_pair(x0, x1);  hi.y = x6_round_pair(x2, x3);          // x = hi + r1
+  mid.x = x6_round_pair(x0, x1); mid.y = x6_round_pair(x2, x3);         // r1 = mid + r2
+  lo.x = x6_round_pair(x0, x1);  lo.y = x6_round_pair(x2, x3);          // r2 = lo exactly (<= 8 significant bits are left)
   *reinterpret_cast<uint2*>(base) = hi;
   *reinterpret_cast<uint2*>(base + X6_PLANE) = mid;
   *reinterpret_cast<uint2*>(base + 2 * X6_PLANE) = lo;
@@ -962,20 +965,17 @@ __global__ __launch_bounds__(256, 2) void gemm_x6tn_kernel(const ctts_gemm_desc 
       }
     }
   };
-  auto split_store8 = [&](const float (&x)[8], unsigned char* base) {       // 8 consecutive k of one LDS row -> 16 bytes per plane
-    float r1[8], r2[8];
+  auto split_store8 = [&](const float (&xin)[8], unsigned char* base) {     // 8 consecutive k of one LDS row -> 16 bytes per plane
+    float x[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xFFFF0000u);
-      r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xFFFF0000u);
-    }
+    for (int i = 0; i < 8; ++i) x[i] = xin[i];
     ctts_u32x4 hi, mid, lo;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      hi[q] = __builtin_amdgcn_perm(__float_as_uint(x[2 * q + 1]), __float_as_uint(x[2 * q]), 0x07060302u);
-      mid[q] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * q + 1]), __float_as_uint(r1[2 * q]), 0x07060302u);
-      lo[q] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * q + 1]), __float_as_uint(r2[2 * q]), 0x07060302u);
-    }
+    for (int q = 0; q < 4; ++q) hi[q] = x6_round_pair(x[2 * q], x[2 * q + 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mid[q] = x6_round_pair(x[2 * q], x[2 * q + 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lo[q] = x6_round_pair(x[2 * q], x[2 * q + 1]);
     *reinterpret_cast<ctts_u32x4*>(base) = hi;
     *reinterpret_cast<ctts_u32x4*>(base + X6_PLANE) = mid;
     *reinterpret_cast<ctts_u32x4*>(base + 2 * X6_PLANE) = lo;

@@ -146,9 +146,9 @@ int ctts_gemm_takes_weight_stationary(const ctts_gemm_desc* d);
  * unbatched NT launches (both operands K-contiguous, conv view on A allowed, N a multiple of 128, split_k <= 1) and large unbatched TN
  * launches (weight gradients: both operands reduction-major, conv view on B allowed, M and N multiples of 128, K >= 2048, any split_k;
  * env CTTS_X6_TN=0 turns only these off) form every fp32 product from six
- * v_mfma_f32_32x32x16_bf16 terms of the EXACT three-way bf16 split of both operands (x = hi + mid + lo by truncation), accumulated in
- * fp32 - fp32-class results (exact wherever fp32 is exact; the three dropped cross terms are <= 2^-21 of a product, typically < 2^-24; error
- * against float64 within 1.0 - 1.7x of the fp32-MFMA kernels' on the same launches) at up to 16/6 of the fp32-MFMA rate.
+ * v_mfma_f32_32x32x16_bf16 terms of the EXACT three-way bf16 split of both operands (x = hi + mid + lo, each piece the round-to-nearest of what is left),
+ * accumulated in fp32 - fp32-class results (exact wherever fp32 is exact; the three dropped cross terms are <= 2^-24 of a product - one fp32
+ * rounding - and 2^-29 in the median; error against float64 as the fp32-MFMA kernels' on the same launches) at up to 16/6 of the fp32-MFMA rate.
  * ctts_gemm_bf16_split_enable(0 / 1, or 2 = also below the kernels' size thresholds) returns the previous setting (process-wide, not
  * thread-safe: parity tests and A/B timing);
  * ctts_gemm_takes_bf16_split: 1 when ctts_gemm would run this descriptor on that kernel (no launch). */

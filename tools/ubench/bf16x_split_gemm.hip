@@ -1,5 +1,6 @@
 // Micro-benchmark: an fp32 GEMM computed on the BF16 matrix pipe by splitting every fp32 operand into bf16 pieces in registers
-// (x = hi + mid + lo, 8 mantissa bits each, exact by truncation) and accumulating the cross products in fp32:
+// (x = hi + mid + lo, 8 significand bits each; THIS micro-benchmark truncates, the library kernels round to nearest - same instruction
+// count, dropped terms <= 2^-24 instead of 2^-21 of a product: tests/test_bf16_split_cpu.py) and accumulating the cross products in fp32:
 //   TERMS = 6: hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi   (dropped terms <= 2^-21 of a product worst case, < 2^-24 typically: fp32-class results)
 //   TERMS = 3: hi*hi + hi*mid + mid*hi                              (2^-16 relative per product)
 // v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32 on gfx950, so 6 of them per fp32-equivalent product are a
