@@ -41,12 +41,20 @@ class GemmDesc(C.Structure):
         ("epi_bwd", _i32),
         ("split_out", _vp), ("split_out_floats", _i64),
         ("split_overwrite", _i32),
+        ("bf16_split", _i32),
+        ("A_planes", _vp), ("a_plane_stride", _i64),
+        ("B_planes", _vp), ("b_plane_stride", _i64),
     ]
 
 
 class PsumTask(C.Structure):
     """ctts_psum_task of include/ctts.h"""
     _fields_ = [("src", _vp), ("dst", _vp), ("n", _i64), ("stride", _i64), ("count", _i32), ("alpha", _f32)]
+
+
+class SplitTask(C.Structure):
+    """ctts_split_task of include/ctts.h"""
+    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i64), ("cols", _i64), ("ld", _i64), ("plane_stride", _i64)]
 
 
 class RepackTask(C.Structure):
@@ -68,7 +76,8 @@ _SIGNATURES = {
     "ctts_gemm_ws_enable": [C.c_int],
     "ctts_gemm_takes_weight_stationary": [C.POINTER(GemmDesc)],
     "ctts_gemm_takes_bf16_split": [C.POINTER(GemmDesc)],
-    "ctts_gemm_bf16_split_enable": [_i32],
+    "ctts_gemm_takes_planes": [C.POINTER(GemmDesc)],
+    "ctts_split_planes": [C.POINTER(SplitTask), C.c_int, _vp],
     "ctts_rowdot_heads": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_mel_prepare": [_vp, C.c_int, C.c_int, _vp, _vp],
     "ctts_mel_spectrogram": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp],

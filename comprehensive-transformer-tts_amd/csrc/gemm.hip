@@ -1332,13 +1332,12 @@ namespace {
 struct GemmSplitPlan { int deferred_ok; int count; long stride; };
 }
 // plan != nullptr: no launch - only answer how a split-K launch of this descriptor would lay out its partial matrices
-// fp32-on-bf16-pipe kernel (gemm_x6_kernel): large unbatched NT launches whose N is a multiple of the 128-column tile.  CTTS_X6=0 turns it off.
-static int g_x6_on = -1;           // -1: not read yet (env CTTS_X6, default on); ctts_gemm_bf16_split_enable overrides
+// fp32-on-bf16-pipe kernel (gemm_x6_kernel): large unbatched NT launches whose N is a multiple of the 128-column tile.  The arithmetic is
+// the CALLER's choice, per descriptor (ctts_gemm_desc.bf16_split: 0 = fp32 MFMA only, 1 = allowed, 2 = allowed below the size thresholds).
 static bool gemm_x6_takes(const ctts_gemm_desc& d) {
-  if (g_x6_on < 0) g_x6_on = getenv("CTTS_X6") ? (atoi(getenv("CTTS_X6")) != 0) : 1;
-  const int on = g_x6_on;
+  const int on = d.bf16_split;
   static const long min_tiles = getenv("CTTS_X6_MIN_TILES") ? atol(getenv("CTTS_X6_MIN_TILES")) : 384;
-  if (!on || !d.a_kc || !d.b_kc || d.nb0 * d.nb1 != 1 || d.split_k > 1 || d.E || d.lens || d.conv_on_b) return false;
+  if (on < 1 || !d.a_kc || !d.b_kc || d.nb0 * d.nb1 != 1 || d.split_k > 1 || d.E || d.lens || d.conv_on_b) return false;
   if (d.K < 256 || d.K % BK || d.N % 128 || d.M < 1024) return false;
   if (d.conv_T > 0 && d.conv_cin % 4) return false;
   if (on != 2 && (long)((d.M + 127) / 128) * (d.N / 128) < min_tiles) return false;      // 2 = forced (tests): no size threshold
@@ -1347,13 +1346,12 @@ static bool gemm_x6_takes(const ctts_gemm_desc& d) {
 
 // the TN (weight-gradient) form: unbatched, both operands reduction-major, tile-aligned output, long reduction; CTTS_X6_TN=0 turns it off
 static bool gemm_x6tn_takes(const ctts_gemm_desc& d) {
-  if (g_x6_on < 0) g_x6_on = getenv("CTTS_X6") ? (atoi(getenv("CTTS_X6")) != 0) : 1;
   static const int tn = getenv("CTTS_X6_TN") ? atoi(getenv("CTTS_X6_TN")) : 1;
   static const long min_wg = getenv("CTTS_X6_TN_MIN_WG") ? atol(getenv("CTTS_X6_TN_MIN_WG")) : 384;
-  if (!g_x6_on || !tn || d.a_kc || d.b_kc || d.nb0 * d.nb1 != 1 || d.E || d.lens || d.epi_bwd) return false;
+  if (d.bf16_split < 1 || !tn || d.a_kc || d.b_kc || d.nb0 * d.nb1 != 1 || d.E || d.lens || d.epi_bwd) return false;
   if (d.M % 128 || d.N % 128 || d.K % BK || d.K < 2048) return false;
   if (d.conv_T > 0 && (!d.conv_on_b || d.conv_T % BK || d.conv_cin % 4)) return false;
-  if (g_x6_on != 2 && (long)(d.M / 128) * (d.N / 128) * (d.split_k > 1 ? d.split_k : 1) < min_wg) return false;
+  if (d.bf16_split != 2 && (long)(d.M / 128) * (d.N / 128) * (d.split_k > 1 ? d.split_k : 1) < min_wg) return false;
   return vec_ok(d) && buf_ok(d);
 }
 
@@ -1373,19 +1371,13 @@ static int gemm_x6_launch(const ctts_gemm_desc& d, hipStream_t st) {
   return 0;
 }
 
-extern "C" int ctts_gemm_bf16_split_enable(int on) {
-  if (g_x6_on < 0) g_x6_on = getenv("CTTS_X6") ? (atoi(getenv("CTTS_X6")) != 0) : 1;
-  const int prev = g_x6_on;
-  g_x6_on = on == 2 ? 2 : (on != 0);          // 2: also below the size thresholds (tests of small launches)
-  return prev;
-}
-
 extern "C" int ctts_gemm_takes_bf16_split(const ctts_gemm_desc* dp) {
   if (!dp) return 0;
   ctts_gemm_desc d = *dp;
   if (d.nb0 < 1) d.nb0 = 1;
   if (d.nb1 < 1) d.nb1 = 1;
-  if (ctts_gemm_takes_weight_stationary(&d)) return 0;       // ctts_gemm asks the weight-stationary kernel first
+  if (ctts_gemm_takes_planes(&d)) return 0;                  // ctts_gemm asks the plane kernel first,
+  if (ctts_gemm_takes_weight_stationary(&d)) return 0;       // then the weight-stationary kernel
   return (gemm_x6_takes(d) || gemm_x6tn_takes(d)) ? 1 : 0;
 }
 
@@ -1412,6 +1404,8 @@ static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan
     plan->deferred_ok = 0;
     if (d.split_k <= 1 || ctts_gemm_takes_weight_stationary(&d) || (!x6tn && ctts_gemm_takes_persistent(&d))) return 0;
   } else {
+    const int pl = ctts_gemm_pl_try(d, st);      // pre-split bf16 planes given and eligible: persistent plane kernel (gemm_pl.hip)
+    if (pl != 0) return pl > 0 ? 0 : pl;
     const int ws = ctts_gemm_ws_try(d, st);      // weight-stationary kernel (gemm_ws.hip) for K = 256 linears with many rows
     if (ws != 0) return ws > 0 ? 0 : ws;
     if (gemm_x6_takes(d)) return gemm_x6_launch(d, st);      // fp32 products on the bf16 matrix pipe (six-term split)

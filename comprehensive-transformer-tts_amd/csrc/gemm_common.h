@@ -295,3 +295,6 @@ int ctts_gemm_sk_try(const ctts_gemm_desc& d, hipStream_t st);
 // gemm_ws.hip: weight-stationary kernel for K = 256 (the weight slice of a workgroup lives in registers, A tiles stream through LDS).
 // Same return convention.
 int ctts_gemm_ws_try(const ctts_gemm_desc& d, hipStream_t st);
+
+// gemm_pl.hip: persistent stream-K kernel on pre-split bf16 planes (ctts_gemm_desc.A_planes / B_planes).  Same return convention.
+int ctts_gemm_pl_try(const ctts_gemm_desc& d, hipStream_t st);

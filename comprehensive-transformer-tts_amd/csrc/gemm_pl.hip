@@ -1,0 +1,609 @@
+// fp32 GEMM on the BF16 matrix pipe from PRE-SPLIT operands: persistent stream-K kernel whose main loop is LDS-DMA + ds_read + MFMA only.
+//
+// Round 4's gemm_x6_kernel (gemm.hip) splits every fp32 operand into its three bf16 pieces while it stages a tile into LDS: every
+// workgroup that stages an element splits it again (an activation tile 8 times - once per n-tile -, a weight tile once per m-tile), the
+// split's VALU work sits between the matrix pipe's K-blocks of an in-order wave, and the staging registers exist only for the split.
+// Here the split has LEFT the GEMM: the operands arrive as three bf16 planes per matrix (ctts_split_planes, or a producer's epilogue),
+//   * a K-block (32 deep) of a tile is 64 bytes per row and plane; `buffer_load_dwordx4 ... lds` moves 16 rows x 64 bytes per instruction
+//     straight into LDS (the image of gemm_x6_kernel: 64-byte plane rows whose 16-byte chunks are XOR-swizzled by (row >> 2) & 3 - applied
+//     to the SOURCE address, the DMA writes lane-linear - so that the ds_read_b128 fragment reads are conflict free);
+//   * workgroup = 8 waves (2 x 4), tile 128 x 256 (a wave owns 64 x 64 = 2 x 2 MFMA tiles, 48 v_mfma_f32_32x32x16_bf16 per K-block: the six
+//     cross terms hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi, smallest first, fp32 accumulate - the arithmetic of gemm_x6_kernel);
+//     one workgroup per CU, two waves per SIMD; 2 LDS stages of 72 KB;
+//   * ONE barrier per K-block, placed in the MIDDLE of the block's MFMAs: the fragments of the second half (k-step 1) are read before the
+//     first half's MFMAs are issued; at the barrier every wave has finished reading this stage (so the DMA of block i+2 may overwrite it)
+//     and block i+1 has landed (so its first-half fragments are read while the second half's MFMAs run).  Neither the DMA latency nor
+//     the LDS read latency is exposed - only the barrier skew;
+//   * persistent grid with the even (tile, K-block) partition and the fixed-order slab hand-off of gemm_sk.hip (sk_plan.h): deterministic;
+//   * conv view on A (implicit im2col, K walked channel-block-major so that consecutive K-blocks re-read the same lines shifted by a row);
+//   * ragged (b, t) rows: the schedule of the ACTIVE 128-row tiles is built by every workgroup itself from row_lens (prefix sums in LDS;
+//     row_T % 128 == 0), wholly padded tiles are zero-filled, and - the zero rule has 64-row granularity in the other kernels - the waves
+//     that own a wholly padded upper half of an active tile write zeros instead of their epilogue.
+// Eligibility: pl_try below.  Everything else stays on gemm.hip / gemm_sk.hip / gemm_ws.hip.
+#include "ctts_common.h"
+#include "gemm_common.h"
+#include "sk_plan.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef unsigned int pl_u32x4 __attribute__((ext_vector_type(4)));
+typedef int pl_i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pl_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pl_floatx2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) unsigned int pl_gu32;
+
+constexpr unsigned PL_OOB = 0x80000000u;
+constexpr int PL_BM = 128, PL_BN = 256;
+constexpr int PL_ROW = 64;                                    // bytes per plane row of a 32-deep K-block
+constexpr int PL_A_PLANE = PL_BM * PL_ROW, PL_B_PLANE = PL_BN * PL_ROW;
+constexpr int PL_STAGE = 3 * (PL_A_PLANE + PL_B_PLANE);       // 73,728 bytes
+constexpr int PL_SLAB = PL_BM * PL_BN;                        // floats per workgroup slab
+constexpr int PL_MAX_UTT = 256;
+constexpr int PL_MAX_WG = 2048;                               // flags[0 .. 2047], error word at [2048]: the layout of gemm_sk.hip
+constexpr int PL_SLAB_FLOATS_MAX = 2048 * 4096;
+
+struct PlArgs {
+  int tiles_m, tiles_n;      // static tile grid (128 x 256 tiles); tiles_m counts ALL m-tiles (the active count comes from row_lens)
+  int nkb;                   // K-blocks per tile
+  int gw;                    // n-tiles per schedule group
+  int whole_tiles;           // 1: never split a tile
+  int ntap;                  // conv view: taps (K / cin); K is walked (channel block, tap)
+  int nutt, tpu;             // ragged rows: utterances and 128-row tiles per utterance (nutt = 0: dense)
+  int debug;                 // CTTS_PL_DEBUG (tools): 1 = no DMA after the prologue, 4 = no epilogue, 8 = no MFMA
+  unsigned* ws;
+};
+
+__device__ __forceinline__ pl_i32x4 pl_make_rsrc(const void* base) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  pl_i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  r.z = 0x7FFFFFFE;
+  r.w = 0x00020000;
+  return r;
+}
+
+// One LDS-DMA instruction (64 lanes x 16 bytes -> LDS [lds_addr + lane * 16)); inline asm for the reason given in gemm_sk.hip: hipcc's
+// waitcnt pass must not know about it (it would drain the DMA in front of every fragment read).  m0 is used by nothing else here.
+__device__ __forceinline__ void pl_dma16(pl_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff))
+               : "memory");
+}
+
+__device__ __forceinline__ floatx16 pl_mma(const pl_u32x4 a, const pl_u32x4 b, const floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pl_bf16x8, a), __builtin_bit_cast(pl_bf16x8, b), c, 0, 0, 0);
+}
+
+// The epilogues this kernel carries (pl_epilogue_ok is the host-side twin: descriptors with any other combination are not taken).  Only
+// lean variants: the generic epilogue and the full dispatch of gemm_epilogue_auto (14 variants) cost this kernel 12 - 27 spilled VGPRs
+// with reloads INSIDE the K loop.
+//   forward:  bias, then act 0 / 1 / 2 / 4 (+ pre-activation store), dropout with act 2 / 4;   bias + dropout + residual + rowscale ("bdrs")
+//   backward: the producer-epilogue backward of GELU / swish + dropout ("a2zdB", "a4zdB")
+__host__ __device__ __forceinline__ int pl_epilogue_kind(const ctts_gemm_desc& d) {
+  const bool drop = d.p_drop > 0.f, res = d.R != nullptr, rs = d.rowscale != nullptr;
+  if (d.E || !gemm_fits32(d.C, d.M, d.ldc, d.N) || !gemm_fits32(d.Z, d.M, d.ldz, d.N) || !gemm_fits32(d.R, d.M, d.ldr, d.N)) return -1;
+  if (d.epi_bwd) {
+    if (d.Z && !rs && drop && d.act == 2) return 8;
+    if (d.Z && !rs && drop && d.act == 4) return 9;
+    return -1;
+  }
+  if (res || rs) return (d.act == 0 && !d.Z && res && rs && drop) ? 7 : -1;
+  if (d.act == 0) return (!d.Z && !drop) ? 0 : -1;
+  if (d.act == 1) return drop ? -1 : 1;
+  if (d.act == 2) return drop ? 3 : 2;
+  if (d.act == 4) return drop ? 5 : 4;
+  return -1;
+}
+__device__ __forceinline__ void pl_epilogue(const ctts_gemm_desc& d, const floatx16 (&acc)[2][2], int row0, int col0, int wm0, int wn0,
+                                            int l31, int h, int Mv, int Nv) {
+#define PL_LEAN(ACT, DROP, BWD, AUX, RS) gemm_epilogue_lean<2, 2, ACT, DROP, BWD, AUX, RS>(d, acc, d.C, 0, row0, col0, wm0, wn0, l31, h, Mv, Nv)
+  switch (pl_epilogue_kind(d)) {
+    case 0: PL_LEAN(0, false, false, false, false); break;
+    case 1: PL_LEAN(1, false, false, false, false); break;
+    case 2: PL_LEAN(2, false, false, false, false); break;
+    case 3: PL_LEAN(2, true, false, false, false); break;
+    case 4: PL_LEAN(4, false, false, false, false); break;
+    case 5: PL_LEAN(4, true, false, false, false); break;
+    case 7: PL_LEAN(0, true, false, true, true); break;
+    case 8: PL_LEAN(2, true, true, true, false); break;
+    case 9: PL_LEAN(4, true, true, true, false); break;
+    default: break;
+  }
+#undef PL_LEAN
+}
+
+struct PlFrag { pl_u32x4 a[2][3], b[2][3]; };      // one 16-deep k-step: [MFMA row / column tile][plane]
+
+template <bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d, const PlArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PL_STAGE];
+  __shared__ int s_pref[PL_MAX_UTT + 1];          // active 128-row tiles of the utterances before b
+  __shared__ int s_lenh[PL_MAX_UTT];              // row_lens[b] + row_halo
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wave >> 2) * 64, wn0 = (wave & 3) * 64;
+  const int nutt = p.nutt, tpu = p.tpu;
+
+  // ---- schedule of the active m-tiles (ragged rows)
+  int n_mt = p.tiles_m;
+  if (nutt > 0) {
+    for (int t = tid; t <= nutt; t += 512) {
+      int s = 0;
+      for (int b = 0; b < t; ++b) {
+        const int L = d.row_lens[b] + d.row_halo;
+        s += L <= 0 ? 0 : min(tpu, (L + PL_BM - 1) / PL_BM);
+      }
+      s_pref[t] = s;
+      if (t < nutt) s_lenh[t] = d.row_lens[t] + d.row_halo;
+    }
+    __syncthreads();
+    n_mt = s_pref[nutt];
+    // wholly padded tiles are defined as zero: stores only, spread over the grid
+    const int n_zero = (nutt * tpu - n_mt) * p.tiles_n;
+    const bool v4 = ((d.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.C) & 15) == 0) &&
+                    (!d.Z || d.epi_bwd || (((d.ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.Z) & 15) == 0)));
+    for (int zt = blockIdx.x; zt < n_zero; zt += gridDim.x) {
+      const int mi = zt / p.tiles_n, nt = zt - mi * p.tiles_n;
+      int lo = 0, hi = nutt;                      // inactive prefix ip(b) = b * tpu - s_pref[b]: ip(lo) <= mi < ip(hi)
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (mid * tpu - s_pref[mid] <= mi) lo = mid; else hi = mid; }
+      const int j = (s_pref[lo + 1] - s_pref[lo]) + (mi - (lo * tpu - s_pref[lo]));
+      const int row0 = lo * d.row_T + j * PL_BM, col0 = nt * PL_BN;
+      const int ncols = min(PL_BN, d.N - col0);
+      if (v4 && (ncols & 3) == 0) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < PL_BM * (PL_BN / 4); e += 512) {
+          const int r = e / (PL_BN / 4), c = (e - r * (PL_BN / 4)) * 4;
+          if (c < ncols) {
+            *reinterpret_cast<float4*>(d.C + (long)(row0 + r) * d.ldc + col0 + c) = z4;
+            if (d.Z && !d.epi_bwd) *reinterpret_cast<float4*>(d.Z + (long)(row0 + r) * d.ldz + col0 + c) = z4;
+          }
+        }
+      } else {
+        for (int e = tid; e < PL_BM * PL_BN; e += 512) {
+          const int r = e / PL_BN, c = e - r * PL_BN;
+          if (c < ncols) {
+            d.C[(long)(row0 + r) * d.ldc + col0 + c] = 0.f;
+            if (d.Z && !d.epi_bwd) d.Z[(long)(row0 + r) * d.ldz + col0 + c] = 0.f;
+          }
+        }
+      }
+    }
+  }
+
+  const int nkb = p.nkb;
+  SkGeom g{n_mt * p.tiles_n, nkb, (int)(gridDim.x >> 3), p.whole_tiles};
+  if (g.n_tiles <= 0 || nkb <= 0) return;
+  const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3;
+  const SkRange rg = sk_range(g, xcd, wj);
+  if (rg.hi <= rg.lo) return;
+
+  const int cin = d.conv_cin > 0 ? d.conv_cin : 32;
+  const int T = d.conv_T > 0 ? d.conv_T : 1;
+  const pl_i32x4 ra_src = pl_make_rsrc(d.A_planes - (CONV ? (long)d.conv_pad * d.lda : 0));
+  const pl_i32x4 rb_src = pl_make_rsrc(d.B_planes);
+  const unsigned pa_bytes = (unsigned)(d.a_plane_stride * 2), pb_bytes = (unsigned)(d.b_plane_stride * 2);
+  const unsigned lda2 = (unsigned)(d.lda * 2), ldb2 = (unsigned)(d.ldb * 2);
+  const unsigned smem_addr = (unsigned)reinterpret_cast<uintptr_t>(smem);
+  unsigned* flags = p.ws;
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.ws) + CTTS_WS_SLABS);
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, 0, 0x7FFFFFFE, 0x00020000);
+
+  // ---- (schedule slot, n-tile) -> rows / columns; pad_hi: the upper 64 rows of the tile lie wholly in one utterance's padding
+  auto decode = [&](const SkPiece& pc, int& row0, int& col0, bool& pad_hi) {
+    int mslot, nt;
+    sk_tile_decode(rg.T0 + pc.t, n_mt, p.gw, mslot, nt);
+    pad_hi = false;
+    if (nutt > 0) {
+      int lo = 0, hi = nutt;                      // s_pref[lo] <= mslot < s_pref[hi]
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pref[mid] <= mslot) lo = mid; else hi = mid; }
+      const int j = mslot - s_pref[lo];
+      row0 = lo * d.row_T + j * PL_BM;
+      pad_hi = j * PL_BM + 64 >= s_lenh[lo];
+    } else {
+      row0 = mslot * PL_BM;
+    }
+    row0 = __builtin_amdgcn_readfirstlane(row0);
+    col0 = __builtin_amdgcn_readfirstlane(nt * PL_BN);
+  };
+
+  // ---- loader: wave w moves rows 16 w .. 16 w + 15 of the three A planes and rows 32 w .. 32 w + 31 of the three B planes of a K-block
+  //      (9 DMA instructions); lane L -> row L >> 2 of its 16-row group, physical chunk L & 3 = logical chunk (L & 3) ^ ((L >> 4) & 3)
+  const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  unsigned voffA = PL_OOB, voffB[2] = {PL_OOB, PL_OOB};
+  int trowA = 0;
+  int lu = rg.hi;
+  SkPiece lp;
+  bool have_l = sk_next_piece(lu, rg.lo, nkb, lp);
+  int lkb = lp.kb_lo, ltap = 0, lcb = 0;
+  auto loader_set_piece = [&]() {
+    int row0, col0; bool ph;
+    decode(lp, row0, col0, ph);
+    const int rA = row0 + 16 * wave + lrow;
+    voffA = rA < d.M ? (unsigned)rA * lda2 + (unsigned)(lchunk * 16) : PL_OOB;
+    if (CONV) trowA = rA % T;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = col0 + 32 * wave + 16 * j + lrow;
+      voffB[j] = n < d.N ? (unsigned)n * ldb2 + (unsigned)(lchunk * 16) : PL_OOB;
+    }
+    lkb = lp.kb_lo;
+    if (CONV) { lcb = lkb / p.ntap; ltap = lkb - lcb * p.ntap; }
+  };
+  auto loader_issue = [&](int stage) {
+    unsigned soffA, soffB, vA = voffA;
+    if (CONV) {
+      soffA = (unsigned)ltap * lda2 + (unsigned)(lcb * 64);
+      soffB = (unsigned)(ltap * cin + lcb * 32) * 2u;
+      vA = ((unsigned)(trowA + ltap - d.conv_pad) < (unsigned)T) ? vA : PL_OOB;
+    } else {
+      soffA = soffB = (unsigned)lkb * 64u;
+    }
+    const unsigned sA = smem_addr + (unsigned)(stage * PL_STAGE + wave * 1024);
+    const unsigned sB = smem_addr + (unsigned)(stage * PL_STAGE + 3 * PL_A_PLANE + wave * 2048);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pl_dma16(ra_src, sA + q * PL_A_PLANE, vA, soffA + q * pa_bytes);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      pl_dma16(rb_src, sB + q * PL_B_PLANE, voffB[0], soffB + q * pb_bytes);
+      pl_dma16(rb_src, sB + q * PL_B_PLANE + 1024, voffB[1], soffB + q * pb_bytes);
+    }
+  };
+  auto loader_advance = [&]() {
+    ++lkb;
+    if (lkb == lp.kb_hi) {
+      have_l = sk_next_piece(lu, rg.lo, nkb, lp);
+      if (have_l) loader_set_piece();
+    } else if (CONV) {
+      ++ltap;
+      if (ltap == p.ntap) { ltap = 0; ++lcb; }
+    }
+  };
+
+  // ---- fragments: row l31 of a 32-row MFMA tile, the 8 consecutive k from h * 8 of the 16-deep k-step ks = logical chunk 2 ks + h
+  const int fsw = (l31 >> 2) & 3;
+  const int fcb[2] = {((0 + h) ^ fsw) * 16, ((2 + h) ^ fsw) * 16};
+  const unsigned char* fr_a = smem + (wm0 + l31) * PL_ROW;
+  const unsigned char* fr_b = smem + 3 * PL_A_PLANE + (wn0 + l31) * PL_ROW;
+  auto read_frag = [&](int stage, int ks, PlFrag& f) {
+    const unsigned char* pa = fr_a + stage * PL_STAGE + fcb[ks];
+    const unsigned char* pb = fr_b + stage * PL_STAGE + fcb[ks];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f.a[i][q] = *reinterpret_cast<const pl_u32x4*>(pa + q * PL_A_PLANE + i * 32 * PL_ROW);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f.b[j][q] = *reinterpret_cast<const pl_u32x4*>(pb + q * PL_B_PLANE + j * 32 * PL_ROW);
+  };
+  floatx16 acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  // terms [t0, t1) of the six-term product of one k-step; term-major: consecutive MFMAs hit different accumulators; smallest terms first
+  auto mma_terms = [&](const PlFrag& f, int t0, int t1) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      if (t < t0 || t >= t1) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = pl_mma(f.a[i][PA[t]], f.b[j][PB[t]], acc[i][j]);
+    }
+  };
+
+  // ---- prologue: blocks 0 and 1 in flight, first-half fragments of block 0 in registers
+  loader_set_piece();
+  loader_issue(0);
+  loader_advance();
+  if (have_l) {
+    loader_issue(1);
+    loader_advance();
+  }
+  int cu = rg.hi;
+  SkPiece cp;
+  sk_next_piece(cu, rg.lo, nkb, cp);
+  int ckb = cp.kb_lo;
+  int remaining = rg.hi - rg.lo;              // K-blocks this workgroup still has to compute (the current one included)
+  zero_acc();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  PlFrag f0, f1;
+  read_frag(0, 0, f0);
+  int stage = 0;
+  __builtin_amdgcn_s_waitcnt(0);
+  while (true) {
+    // first half: the fragments of k-step 0 are in registers (read during the previous block); k-step 1 is read under its MFMAs
+    const bool do_mma = !(p.debug & 8);
+    if (do_mma) mma_terms(f0, 0, 1);
+    read_frag(stage, 1, f1);
+    if (do_mma) mma_terms(f0, 1, 6);
+    __builtin_amdgcn_sched_barrier(0);
+    // every wave is done reading this stage, and (mine of) block i + 1 has landed: after the barrier the whole block has
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // second half, with the loader's work (DMA issue of block i + 2 into this stage, cursor arithmetic) and the fragment reads of block
+    // i + 1 placed BETWEEN groups of MFMAs in program order: the branches keep hipcc from regrouping them, the matrix pipe never waits
+    // for the ~100 scalar / lane-read instructions of the loader
+    if (do_mma) mma_terms(f1, 0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (have_l && !(p.debug & 1)) loader_issue(stage);
+    if (do_mma) mma_terms(f1, 2, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (have_l) loader_advance();
+    // first half of block i + 1 - unless this block ends the piece: the fragments would have to stay live across the epilogue (48 more
+    // registers there); they are read after it instead, once per piece
+    if (ckb + 1 < cp.kb_hi) read_frag(stage ^ 1, 0, f0);
+    if (do_mma) mma_terms(f1, 4, 6);
+    --remaining;
+    ++ckb;
+    stage ^= 1;
+    if (ckb < cp.kb_hi) continue;
+
+    // ---------------- the piece is complete
+    // Everything below runs once per piece and must not cost the K loop registers.  (1) Its lane / wave constants are laundered through an
+    // empty asm so that loop-invariant code motion cannot hoist the epilogues' lane offsets in front of the K loop.  (2) The descriptor
+    // fields only the epilogue needs (C, Z, bias, strides, dropout, ...) are read HERE from the kernel-argument segment (`d` is the first
+    // kernel argument: offset 0) through a laundered pointer: s_load at the point of use instead of ~60 SGPRs that stay live across the
+    // K loop - hipcc preloads a by-value struct argument and then spills it to VGPR lanes (560 SGPR spills, 27 VGPR spills and scratch
+    // reloads in front of every DMA issue in the first build of this kernel).
+    int e_l31 = l31, e_h = h, e_wm0 = wm0, e_wn0 = wn0;
+    unsigned long long kargs = (unsigned long long)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+v"(e_l31), "+v"(e_h), "+s"(e_wm0), "+s"(e_wn0), "+s"(kargs));
+    const ctts_gemm_desc& dc = *(const ctts_gemm_desc*)(const __attribute__((address_space(4))) ctts_gemm_desc*)kargs;
+    const int Mv = dc.M, Nv = dc.N;
+    int row0, col0; bool pad_hi;
+    decode(cp, row0, col0, pad_hi);
+    if (cp.kb_hi < nkb) {
+      // contribution: slab (write-through stores) + flag
+      const unsigned base = (unsigned)blockIdx.x * (PL_SLAB * 4) + (unsigned)(wave * (PL_SLAB / 8) + lane * 4) * 4u;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            pl_u32x4 v;
+            v.x = __float_as_uint(acc[i][j][4 * q + 0]); v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+            v.z = __float_as_uint(acc[i][j][4 * q + 2]); v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_src, base + (unsigned)(((i * 2 + j) * 4 + q) * 1024), 0, 16);      // aux 16 = sc1
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store((pl_gu32*)(flags + blockIdx.x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (cp.kb_lo > 0) {
+        // owner of a cut tile: add the slabs of the workgroups below, nearest first, until the tile's unit 0 is covered
+        const int tile_lo = cp.t * nkb;
+        const int Ux = (rg.T1 - rg.T0) * nkb;
+        int upper = rg.lo;
+        for (int jj = wj - 1; jj >= 0 && upper > tile_lo; --jj) {
+          const int blo = sk_bound(g, Ux, jj);
+          if (blo >= upper) continue;
+          upper = blo;
+          const int src = jj * 8 + xcd;
+          if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load((pl_gu32*)(flags + src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins > (1u << 24)) {
+                __hip_atomic_store((pl_gu32*)(flags + PL_MAX_WG), 1u + (unsigned)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+            __hip_atomic_store((pl_gu32*)(flags + src), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          const unsigned base = (unsigned)src * (PL_SLAB * 4) + (unsigned)(wave * (PL_SLAB / 8) + lane * 4) * 4u;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const pl_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_src, base + (unsigned)(((i * 2 + j) * 4 + q) * 1024), 0, 0);
+                acc[i][j][4 * q + 0] += __uint_as_float(v.x); acc[i][j][4 * q + 1] += __uint_as_float(v.y);
+                acc[i][j][4 * q + 2] += __uint_as_float(v.z); acc[i][j][4 * q + 3] += __uint_as_float(v.w);
+              }
+        }
+      }
+      if (pad_hi && e_wm0 == 64) {
+        for (int e = lane; e < 64 * 64; e += 64) {
+          const int r = e >> 6, c = e & 63;
+          const int n = col0 + e_wn0 + c;
+          if (n < Nv) {
+            dc.C[(long)(row0 + 64 + r) * dc.ldc + n] = 0.f;
+            if (dc.Z && !dc.epi_bwd) dc.Z[(long)(row0 + 64 + r) * dc.ldz + n] = 0.f;
+          }
+        }
+      } else if (!(p.debug & 4)) {
+        pl_epilogue(dc, acc, row0, col0, e_wm0, e_wn0, e_l31, e_h, Mv, Nv);
+      }
+    }
+    // a wait hipcc can see (gemm_sk.hip): its scoreboard is empty when control returns to the K loop
+    __builtin_amdgcn_s_waitcnt(0);
+    if (!sk_next_piece(cu, rg.lo, nkb, cp)) break;
+    ckb = cp.kb_lo;
+    zero_acc();
+    read_frag(stage, 0, f0);            // the next piece's first block landed before the last barrier
+  }
+}
+
+int pl_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// ---------------------------------------------------------------- exact three-way bf16 split of fp32 matrices (many per launch)
+constexpr int SPL_BATCH = 24;
+struct SplitBatch {
+  const float* src[SPL_BATCH];
+  uint16_t* dst[SPL_BATCH];
+  long rows[SPL_BATCH], cols8[SPL_BATCH], ld[SPL_BATCH], pstride[SPL_BATCH];
+  int first_block[SPL_BATCH + 1];
+  int ntasks;
+};
+constexpr int SPL_PER_BLOCK = 256 * 4;           // 8-element groups per workgroup
+
+// one float -> (hi bits, mid bits, lo bits) with the domain rules of include/ctts.h
+__device__ __forceinline__ void spl_one(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const pl_floatx2 v0 = {x, 0.f};
+  unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, pl_bf16x2)) & 0xFFFFu;
+  const bool x_fin = fabsf(x) < __builtin_inff();
+  if ((hb & 0x7F80u) == 0x7F80u) {               // hi is +-inf / NaN
+    if (x_fin) hb = (hb & 0x8000u) | 0x7F7Fu;    // a finite x that would round to infinity: the largest bf16 (the remainder stays exact)
+    else { hi = hb; mid = 0u; lo = 0u; return; }
+  }
+  const float r1 = x - __uint_as_float(hb << 16);
+  const pl_floatx2 v1 = {r1, 0.f};
+  const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, pl_bf16x2)) & 0xFFFFu;
+  const float r2 = r1 - __uint_as_float(mb << 16);
+  const pl_floatx2 v2 = {r2, 0.f};
+  const unsigned lb = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, pl_bf16x2)) & 0xFFFFu;
+  hi = hb; mid = mb; lo = lb;
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch b) {
+  int t = 0;
+  while (t + 1 < b.ntasks && (int)blockIdx.x >= b.first_block[t + 1]) ++t;
+  const float* __restrict__ src = b.src[t];
+  uint16_t* __restrict__ dst = b.dst[t];
+  const long c8 = b.cols8[t], ld = b.ld[t], ps = b.pstride[t], n8 = b.rows[t] * c8;
+  const long g0 = (long)((int)blockIdx.x - b.first_block[t]) * SPL_PER_BLOCK;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long gidx = g0 + u * 256 + threadIdx.x;
+    if (gidx >= n8) continue;
+    const long r = gidx / c8, c = (gidx - r * c8) * 8;
+    const float4 x0 = *reinterpret_cast<const float4*>(src + r * ld + c), x1 = *reinterpret_cast<const float4*>(src + r * ld + c + 4);
+    const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) spl_one(xs[e], hi[e], mid[e], lo[e]);
+    pl_u32x4 ph, pm, pq;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ph[e] = hi[2 * e] | (hi[2 * e + 1] << 16);
+      pm[e] = mid[2 * e] | (mid[2 * e + 1] << 16);
+      pq[e] = lo[2 * e] | (lo[2 * e + 1] << 16);
+    }
+    uint16_t* o = dst + r * ld + c;
+    *reinterpret_cast<pl_u32x4*>(o) = ph;
+    *reinterpret_cast<pl_u32x4*>(o + ps) = pm;
+    *reinterpret_cast<pl_u32x4*>(o + 2 * ps) = pq;
+  }
+}
+
+}  // namespace
+
+extern "C" int ctts_split_planes(const ctts_split_task* tasks, int ntasks, void* stream) {
+  CTTS_REQUIRE(ntasks >= 0 && (tasks || ntasks == 0), "ctts_split_planes: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < ntasks; t0 += SPL_BATCH) {
+    SplitBatch b;
+    b.ntasks = 0;
+    long blocks = 0;
+    for (int t = t0; t < ntasks && t < t0 + SPL_BATCH; ++t) {
+      const ctts_split_task& q = tasks[t];
+      CTTS_REQUIRE(q.src && q.dst && q.rows >= 0 && q.cols >= 0 && q.cols % 8 == 0 && q.ld >= q.cols && q.ld % 8 == 0 && q.plane_stride % 8 == 0 &&
+                       q.plane_stride >= (q.rows > 0 ? (q.rows - 1) * q.ld + q.cols : 0) &&
+                       (reinterpret_cast<uintptr_t>(q.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.dst) & 15) == 0,
+                   "ctts_split_planes: task %d needs 16-byte aligned pointers, cols %% 8 == 0, ld %% 8 == 0 and planes that do not overlap", t);
+      if (q.rows == 0 || q.cols == 0) continue;
+      const int i = b.ntasks++;
+      b.src[i] = q.src; b.dst[i] = q.dst; b.rows[i] = q.rows; b.cols8[i] = q.cols / 8; b.ld[i] = q.ld; b.pstride[i] = q.plane_stride;
+      b.first_block[i] = (int)blocks;
+      blocks += (q.rows * (q.cols / 8) + SPL_PER_BLOCK - 1) / SPL_PER_BLOCK;
+      CTTS_REQUIRE(blocks < (1L << 30), "ctts_split_planes: too many elements in one call");
+    }
+    if (b.ntasks == 0) continue;
+    b.first_block[b.ntasks] = (int)blocks;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    CTTS_CHECK_LAUNCH("ctts_split_planes");
+  }
+  return 0;
+}
+
+// launch == false: only answer whether the plane kernel WOULD take this descriptor (ctts_gemm_takes_planes)
+static int pl_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
+  static const int enabled = pl_env("CTTS_PL", 1);
+  static const int min_units = pl_env("CTTS_PL_MIN_UNITS", 4096);     // (tile, K-block) units; below this the launch is latency bound either way
+  static const int split_from = pl_env("CTTS_PL_SPLIT_NKB", 24);
+  static const int max_split = pl_env("CTTS_PL_MAX_SPLIT", 2);
+  static const int wg_units = pl_env("CTTS_PL_WG_UNITS", 16);
+  static const int force_w = pl_env("CTTS_PL_W", 0);
+  static const int debug = pl_env("CTTS_PL_DEBUG", 0);
+  if (!enabled || d.bf16_split < 1 || !d.A_planes || !d.B_planes) return 0;
+  if (!d.sk_ws || d.sk_ws_bytes < (int64_t)CTTS_WS_BYTES) return 0;
+  if (!d.a_kc || !d.b_kc || d.nb0 * d.nb1 != 1 || d.lens || d.E) return 0;
+  if (d.split_k > 1 && !d.split_overwrite) return 0;                 // "C += alpha A B" is not built here
+  if (d.K % 32 != 0 || d.K < 64 || d.N % 128 != 0 || d.N < 256 || d.M < 128) return 0;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!al16(d.A_planes) || !al16(d.B_planes) || ((d.lda | d.ldb | d.a_plane_stride | d.b_plane_stride) & 7)) return 0;
+  const bool conv = d.conv_T > 0;
+  if (conv && (d.conv_on_b || d.conv_cin % 32 != 0 || d.K % d.conv_cin != 0 || d.conv_T < 16)) return 0;
+  // 32-bit buffer offsets over the three planes (plus a tile of rows beyond M and the conv shift)
+  const long a_ext = 2 * d.a_plane_stride + (long)(d.M + 256) * d.lda + d.K;
+  const long b_ext = 2 * d.b_plane_stride + (long)(d.N + 256) * d.ldb + d.K;
+  if (a_ext * 2 >= 0x7FFF0000L || b_ext * 2 >= 0x7FFF0000L) return 0;
+  if (pl_epilogue_kind(d) < 0) return 0;          // only the lean epilogues the kernel carries
+  PlArgs p;
+  p.nutt = p.tpu = 0;
+  p.tiles_m = (d.M + PL_BM - 1) / PL_BM;
+  long act_tiles_m = p.tiles_m;
+  if (d.row_lens) {
+    if (d.row_T <= 0 || d.row_T % PL_BM != 0 || d.M % d.row_T != 0 || d.M / d.row_T > PL_MAX_UTT) return 0;
+    p.nutt = d.M / d.row_T;
+    p.tpu = d.row_T / PL_BM;
+  }
+  p.tiles_n = (d.N + PL_BN - 1) / PL_BN;
+  p.nkb = d.K / 32;
+  p.ntap = conv ? d.K / d.conv_cin : 1;
+  p.whole_tiles = p.nkb < split_from ? 1 : 0;
+  p.gw = (p.tiles_n % 4 == 0) ? p.tiles_n / 4 : p.tiles_n;
+  p.debug = debug;
+  p.ws = reinterpret_cast<unsigned*>(d.sk_ws);
+  // grid from the STATIC tile count (the active count lives on the device): with ragged rows ~3/4 of the m-tiles are active - a grid that
+  // is a little too large only makes the pieces shorter
+  const long tiles = act_tiles_m * p.tiles_n;
+  const long units = tiles * p.nkb;
+  if (d.bf16_split < 2 && units < min_units) return 0;
+  const int cuts = p.whole_tiles ? 1 : ((p.nkb >= 256 && max_split < 4) ? 4 : max_split);
+  long W = force_w > 0 ? force_w : 32;
+  const long Wu = units / (8L * wg_units);
+  if (W > Wu) W = Wu;
+  const long Wt = d.row_lens ? (tiles * cuts * 3 / 4) / 8 : (tiles * cuts) / 8;      // ragged: expect >= 3/4 of the tiles to be active
+  if (W > Wt) W = Wt;
+  if (W < 1) {
+    if (d.bf16_split < 2) return 0;
+    W = 1;
+  }
+  const int grid = (int)W * 8;
+  if (grid > PL_MAX_WG || (long)grid * PL_SLAB > PL_SLAB_FLOATS_MAX) return 0;
+  if (!launch) return 1;
+  if (conv) hipLaunchKernelGGL(gemm_pl_kernel<true>, dim3(grid), dim3(512), 0, st, d, p);
+  else hipLaunchKernelGGL(gemm_pl_kernel<false>, dim3(grid), dim3(512), 0, st, d, p);
+  CTTS_CHECK_LAUNCH("ctts_gemm(planes)");
+  return 1;
+}
+
+int ctts_gemm_pl_try(const ctts_gemm_desc& d, hipStream_t st) { return pl_try(d, st, true); }
+
+extern "C" int ctts_gemm_takes_planes(const ctts_gemm_desc* d) {
+  if (!d) return 0;
+  ctts_gemm_desc c = *d;
+  if (c.nb0 < 1) c.nb0 = 1;
+  if (c.nb1 < 1) c.nb1 = 1;
+  return pl_try(c, nullptr, false) > 0 ? 1 : 0;
+}

@@ -70,6 +70,10 @@ class DropCtx:
 import os as _os
 
 SK_ENABLED = _os.environ.get("CTTS_SK", "1") != "0"      # persistent stream-K GEMM (csrc/gemm_sk.hip) for large unbatched launches
+BF16_SPLIT = 0 if _os.environ.get("CTTS_X6", "1") == "0" else 1          # default ctts_gemm_desc.bf16_split of this module's descriptors
+PLANES_ENABLED = _os.environ.get("CTTS_PL", "1") != "0"                  # pre-split operand planes + the persistent plane kernel (csrc/gemm_pl.hip)
+PLANES_MIN_UNITS = int(_os.environ.get("CTTS_PL_MIN_UNITS", "4096"))
+PLANES_MIN_TILES = int(_os.environ.get("CTTS_PL_MIN_TILES", "64"))
 _SK_WS = {}          # (device index, stream handle) -> zero-filled workspace (include/ctts.h ctts_workspace_bytes)
 
 
@@ -221,8 +225,13 @@ def _sink_for(dst):
 def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0, b_off=0, c_off=0, nb0=1, nb1=1,
                sA=(0, 0), sB=(0, 0), sC=(0, 0), lens=None, lim=(0, 0, 0), conv=None, conv_on_b=False, split_k=1, alpha=1.0,
                bias=None, Z=None, ldz=0, act=ACT_NONE, p_drop=0.0, seed=None, drop_offset=0, R=None, ldr=0, rowscale=None,
-               row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None, use_sk=None, epi_bwd=False, split_overwrite=False):
+               row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None, use_sk=None, epi_bwd=False, split_overwrite=False,
+               bf16_split=None, a_planes=None, b_planes=None):
     d = GemmDesc()
+    d.bf16_split = int(BF16_SPLIT if bf16_split is None else bf16_split)
+    if a_planes is not None and b_planes is not None:
+        d.A_planes, d.a_plane_stride = a_planes.data_ptr(), a_planes.stride(0)
+        d.B_planes, d.b_plane_stride = b_planes.data_ptr(), b_planes.stride(0)
     d.A, d.B, d.C = _p(A, a_off), _p(B, b_off), _p(Cout, c_off)
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.lda, d.ldb, d.ldc = int(lda), int(ldb), int(ldc)
@@ -252,7 +261,7 @@ def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0
     d.E, d.rowsub = _p(E), _p(rowsub)
     d.epi_bwd = int(bool(epi_bwd))
     d.split_overwrite = int(bool(split_overwrite))
-    if int(split_k) > 1 or ((SK_ENABLED if use_sk is None else use_sk) and nb0 * nb1 == 1 and M * N * K >= (1 << 24)):
+    if int(split_k) > 1 or a_planes is not None or ((SK_ENABLED if use_sk is None else use_sk) and nb0 * nb1 == 1 and M * N * K >= (1 << 24)):
         # split-K sums its pieces in a fixed order through the workspace (required); large unbatched GEMMs may run on the persistent
         # stream-K kernel (the library decides: ctts_gemm_sk_try)
         ws = gemm_workspace(A.device)
@@ -293,9 +302,50 @@ def gemm_takes_bf16_split(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=Tr
 
 
 def gemm_bf16_split_enable(on):
-    """Process-wide switch of that kernel (tests / A/B timing): False / True, or 2 = also for launches below its size thresholds;
-    returns the previous setting (pass it back to restore)."""
-    return int(_lib.load().ctts_gemm_bf16_split_enable(2 if on == 2 else int(bool(on))))
+    """Default arithmetic of the descriptors this module builds (ctts_gemm_desc.bf16_split; env CTTS_X6=0 starts with it off): False =
+    fp32 MFMA only, True = the large launches may run on the bf16 matrix pipe with the exact six-term operand split, 2 = also launches
+    below the kernels' size thresholds (tests).  Returns the previous setting (pass it back to restore).  The library itself holds no
+    such state any more: the choice travels in every descriptor, so a captured graph keeps the arithmetic it was captured with and two
+    models can differ (`bf16_split=` on a single call overrides the default)."""
+    global BF16_SPLIT
+    prev, BF16_SPLIT = BF16_SPLIT, (2 if on == 2 else int(bool(on)))
+    return prev
+
+
+def gemm_takes_planes(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):
+    """True when ctts_gemm would run these arguments (a_planes / b_planes given) on the persistent plane kernel (no launch)."""
+    d = _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc, b_kc, **kw)
+    return bool(_lib.load().ctts_gemm_takes_planes(C.byref(d)))
+
+
+def plane_shape_ok(M, N, K, conv_cin=None):
+    """Host-side pre-filter of the plane kernel's shape rules (csrc/gemm_pl.hip pl_try) - callers use it to decide whether splitting
+    an operand is worth a launch; the library's answer (gemm_takes_planes) stays authoritative."""
+    if not PLANES_ENABLED or BF16_SPLIT < 1 or not SK_ENABLED:
+        return False
+    if K % 32 or K < 64 or N % 128 or N < 256 or M < 128:
+        return False
+    if conv_cin is not None and (conv_cin % 32 or K % conv_cin):
+        return False
+    tiles = -(-M // 128) * -(-N // 256)
+    return BF16_SPLIT == 2 or (tiles * (K // 32) >= PLANES_MIN_UNITS and tiles >= PLANES_MIN_TILES)
+
+
+def split_planes(mats):
+    """Exact three-way bf16 split of fp32 matrices in one launch per 24 (include/ctts.h ctts_split_planes): `mats` = list of dense 2-D
+    float32 tensors [rows, cols] (cols % 8 == 0) -> list of bf16 tensors [3, rows, cols] (planes hi | mid | lo)."""
+    if not mats:
+        return []
+    outs = []
+    arr = (_lib.SplitTask * len(mats))()
+    for t, m in zip(arr, mats):
+        _f32c(m, "split_planes operand")
+        rows, cols = m.shape
+        o = torch.empty(3, rows, cols, dtype=torch.bfloat16, device=m.device)
+        outs.append(o)
+        t.src, t.dst, t.rows, t.cols, t.ld, t.plane_stride = _p(m), o.data_ptr(), int(rows), int(cols), int(cols), int(rows * cols)
+    _lib.check(_lib.load().ctts_split_planes(arr, len(arr), _stream()), "ctts_split_planes")
+    return outs
 
 
 def gemm_takes_weight_stationary(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):

@@ -282,9 +282,11 @@ class _LinearConv(torch.autograd.Function):
             wf, conv, Kdim = w.contiguous(), None, Cin
         if residual is not None:
             residual = residual.contiguous()
-        K.gemm(x, wf, out, M, N, Kdim, Cin, Kdim, N, True, True, conv=conv, alpha=alpha, bias=b, Z=Z, ldz=N, act=act,
-               p_drop=p_drop, seed=seed, drop_offset=drop_offset, R=residual, ldr=N, rowscale=rowscale,
-               row_lens=row_lens, row_T=row_T, row_halo=0, tile_map=pr.tile_map(0, M) if pr is not None else None)
+        gk = dict(conv=conv, alpha=alpha, bias=b, Z=Z, ldz=N, act=act, p_drop=p_drop, seed=seed, drop_offset=drop_offset, R=residual, ldr=N,
+                  rowscale=rowscale, row_lens=row_lens, row_T=row_T, row_halo=0)
+        planes = _operand_planes("fwd", w, x.view(M, Cin), wf, M, N, Kdim, Cin, Kdim, N, out, gk) if ksize else {}
+        K.gemm(x, wf, out, M, N, Kdim, Cin, Kdim, N, True, True, tile_map=pr.tile_map(0, M) if (pr is not None and not planes) else None,
+               **gk, **planes)
         ctx.save_for_backward(x, w, Z, rowscale, seed, row_lens, b)
         ctx.cfg = (act, alpha, p_drop, drop_offset, ksize, b is not None, residual is not None, row_T)
         ctx.pr = pr
@@ -340,8 +342,8 @@ class _LinearConv(torch.autograd.Function):
             pad = ctx.pad_left                   # forward / weight-gradient view
             pad_d = ksize - 1 - pad              # data gradient: correlation with the flipped taps (equal to `pad` for SAME with odd k)
             if ctx.needs_input_grad[0]:
-                wd = _DGRAD_W.pop(w.data_ptr(), None)          # prepared for the whole model at the start of the step (prepare_dgrad_weights)
-                if wd is None or tuple(wd.shape) != (Cin, ksize * N):
+                wd = _DGRAD_W.take(w, (Cin, ksize * N))          # prepared for the whole model at the start of the step (prepare_dgrad_weights)
+                if wd is None:
                     wd = torch.empty(Cin, ksize * N, dtype=torch.float32, device=x.device)
                     wmaj = _gemm_major(w)
                     if wmaj is not None:
@@ -352,11 +354,16 @@ class _LinearConv(torch.autograd.Function):
                 # all 256 CUs x 8 resident workgroups (atomic accumulation into a zero-filled dX)
                 tiles = -(-M // 64) * -(-Cin // 64)
                 sk = min(4, max(2, -(-2304 // tiles))) if (_DGRAD_SPLIT_K and tiles < 1536 and ksize * N >= 4096) else 1
-                dg = dict(conv=(T, pad_d, N), alpha=alpha, row_halo=pad_d, tile_map=pr.tile_map(pad_d, M) if pr is not None else None, **rl)
-                if sk > 1 and K.gemm_takes_persistent(dZ, wd, x, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=1, **dg):
-                    sk = 1          # the persistent stream-K kernel balances the reduction itself: no split, no zero fill, no atomics
                 dX = torch.empty_like(x)             # split: the ordered reduce launch writes every element (zeros in padded tiles)
-                K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=sk, split_overwrite=True, **dg)
+                dg0 = dict(conv=(T, pad_d, N), alpha=alpha, row_halo=pad_d, **rl)
+                planes = _operand_planes("dgrad", w, dZ.view(M, N), wd, M, Cin, ksize * N, N, ksize * N, Cin, dX, dict(split_overwrite=True, **dg0))
+                if planes:          # pre-split operands on the persistent plane kernel: balances the reduction itself, writes every element
+                    K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=1, split_overwrite=True, **dg0, **planes)
+                else:
+                    dg = dict(tile_map=pr.tile_map(pad_d, M) if pr is not None else None, **dg0)
+                    if sk > 1 and K.gemm_takes_persistent(dZ, wd, x, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=1, **dg):
+                        sk = 1          # the persistent stream-K kernel balances the reduction itself: no split, no zero fill, no atomics
+                    K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=sk, split_overwrite=True, **dg)
             if ctx.needs_input_grad[1]:
                 Kd = ksize * Cin
                 fused = _fusable(w)
@@ -408,26 +415,89 @@ class _LinearConv(torch.autograd.Function):
 
 
 # data-gradient operands of the Conv1d weights, keyed by the weight's device address; filled by prepare_dgrad_weights at the start of a
-# train step (ONE launch for all layers instead of one repack inside every layer's backward), consumed by _LinearConv.backward
-_DGRAD_W = {}
+# train step (ONE launch for all layers instead of one repack inside every layer's backward), consumed by _LinearConv.backward.
+# Entries carry the weight's autograd version: an in-place update through torch after the preparation invalidates them.
+
+
+class _DgradCache(dict):
+    """data_ptr -> (wd, version of the weight it was made from); pop() hands out only entries that still match the weight"""
+
+    def take(self, w, shape):
+        ent = dict.pop(self, w.data_ptr(), None)
+        if ent is None or ent[1] != w._version or tuple(ent[0].shape) != tuple(shape):
+            return None
+        return ent[0]
+
+
+_DGRAD_W = _DgradCache()
+
+# Pre-split bf16 planes (include/ctts.h ctts_split_planes) of the weight-side GEMM operands: the forward matrix [Cout, k*Cin] ("fwd") and
+# the data-gradient matrix [Cin, k*Cout] ("dgrad") of the Conv1d layers whose launches the persistent plane kernel takes.  A layer
+# announces itself the first time its launch qualifies (`want`); from then on prepare_dgrad_weights splits all announced weights in ONE
+# launch at the start of the step.  Without a prepared entry (first step, plain forward outside trainer.TrainStep) the weight is split
+# on the spot - a 5 - 8 us launch per layer.
+_PLANES = {"fwd": {}, "dgrad": {}, "want_fwd": set(), "want_dgrad": set()}
+
+
+def _operand_planes(kind, w, a_mat, b_mat, M, N, Kdim, lda, ldb, ldc, out, gk):
+    """{} or dict(a_planes=, b_planes=) for K.gemm: the three-way bf16 split of the activation-side matrix `a_mat` [M, lda] (made here:
+    one streaming launch) and of the weight-side matrix `b_mat` [N, Kdim] (from the step's cache) - when the library would run this
+    launch on the plane kernel (asked with placeholder planes: no device work)."""
+    conv = gk.get("conv")
+    if not K.plane_shape_ok(M, N, Kdim, conv[2] if conv is not None else None):
+        return {}
+    if not (a_mat.is_contiguous() and b_mat.is_contiguous() and a_mat.shape[1] % 8 == 0 and b_mat.shape[1] % 8 == 0):
+        return {}
+    if not K.gemm_takes_planes(a_mat, b_mat, out, M, N, Kdim, lda, ldb, ldc, True, True, a_planes=_FakePlanes(a_mat), b_planes=_FakePlanes(b_mat), **gk):
+        return {}
+    ent = _PLANES[kind].get(w.data_ptr())
+    if ent is not None and ent[1] == w._version and tuple(ent[0].shape[1:]) == tuple(b_mat.shape):
+        bp = ent[0]
+    else:
+        _PLANES["want_" + kind].add(w.data_ptr())
+        bp = K.split_planes([b_mat])[0]
+    return dict(a_planes=K.split_planes([a_mat])[0], b_planes=bp)
+
+
+class _FakePlanes:
+    """stand-in with the addressing of a plane set (for the library's eligibility query only: nothing is read)"""
+
+    def __init__(self, mat):
+        self._m = mat
+
+    def data_ptr(self):
+        return self._m.data_ptr()
+
+    def stride(self, i):
+        return self._m.numel()
 
 
 def prepare_dgrad_weights(params):
     """`params`: Conv1d weights in the GEMM-major layout of model._Conv (others are ignored).  Valid until the weights change - call it
-    once per step, after the optimizer update and before the backward pass (trainer.TrainStep does, in front of the forward)."""
-    _DGRAD_W.clear()
+    once per step, after the optimizer update and before the backward pass (trainer.TrainStep does, in front of the forward).  Builds
+    the data-gradient matrices of all layers (one launch) and the bf16 planes of the weights the plane kernel consumes (one launch)."""
+    clear_dgrad_weights()
     todo = []
     for w in params:
         wm = _gemm_major(w) if w.dim() == 3 else None
         if wm is not None and w.requires_grad:
             N, Cin, k = w.shape
             todo.append((w, (wm.detach(), N, Cin, k)))
-    for (w, _), wd in zip(todo, K.conv_dgrad_weights([t for _, t in todo])):
-        _DGRAD_W[w.data_ptr()] = wd
+    mats, slots = [], []
+    for (w, (wm, _, _, _)), wd in zip(todo, K.conv_dgrad_weights([t for _, t in todo])):
+        _DGRAD_W[w.data_ptr()] = (wd, w._version)
+        if w.data_ptr() in _PLANES["want_fwd"]:
+            mats.append(wm.contiguous()); slots.append(("fwd", w))
+        if w.data_ptr() in _PLANES["want_dgrad"]:
+            mats.append(wd); slots.append(("dgrad", w))
+    for (kind, w), pl in zip(slots, K.split_planes(mats)):
+        _PLANES[kind][w.data_ptr()] = (pl, w._version)
 
 
 def clear_dgrad_weights():
     _DGRAD_W.clear()
+    _PLANES["fwd"].clear()
+    _PLANES["dgrad"].clear()
 
 
 class PadRows:

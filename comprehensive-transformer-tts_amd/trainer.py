@@ -91,27 +91,32 @@ class TrainStep:
         collects the deferred ordered sums into the arena (split-K weight gradients, bias / LayerNorm column sums) and finishes them
         with one launch per 24 sums at the END of the stage - before the stage's bucket is all-reduced / the optimizer reads it."""
         from . import kernels as _K
-        if self._conv_weights:
-            ops.prepare_dgrad_weights(self._conv_weights)         # one launch: the transposed / flipped taps every conv's data gradient needs
-        rec = ops.CutRecorder(self.cut_names)
-        with rec:
-            loss = self._forward_loss()
-        self.flat_grad.zero_()
-        if self.grad_acc_step > 1:
-            loss = loss * (1.0 / self.grad_acc_step)          # train.py:112
-        sink = _K.PartialSink()
-        gen = rec.backward_stages(loss)
-        while True:
-            prev = _K.set_partial_sink(sink)
-            try:
-                s = next(gen)
-                sink.flush()
-            except StopIteration:
-                ops.clear_dgrad_weights()
-                return
-            finally:
-                _K.set_partial_sink(prev)
-            yield s
+        try:
+            if self._conv_weights:
+                # one launch: the transposed / flipped taps every conv's data gradient needs; one more: the bf16 planes of the weights
+                # the plane kernel consumes.  Valid for THIS step only - the finally below drops them also when the step raises
+                # (a stale entry would silently give a later backward last step's weights: ADVICE r04)
+                ops.prepare_dgrad_weights(self._conv_weights)
+            rec = ops.CutRecorder(self.cut_names)
+            with rec:
+                loss = self._forward_loss()
+            self.flat_grad.zero_()
+            if self.grad_acc_step > 1:
+                loss = loss * (1.0 / self.grad_acc_step)          # train.py:112
+            sink = _K.PartialSink()
+            gen = rec.backward_stages(loss)
+            while True:
+                prev = _K.set_partial_sink(sink)
+                try:
+                    s = next(gen)
+                    sink.flush()
+                except StopIteration:
+                    return
+                finally:
+                    _K.set_partial_sink(prev)
+                yield s
+        finally:
+            ops.clear_dgrad_weights()
 
     def _clip_now(self):
         return self.step_no % self.grad_acc_step == 0        # train.py:118 (always true for grad_acc_step = 1)

@@ -97,6 +97,21 @@ typedef struct ctts_gemm_desc {
    * convolution data gradient saved).  With split_k > 1 (library-side sum only) this also turns C += alpha * A B into C = alpha * A B;
    * with split_k <= 1 it only adds the zeros outside the limits of a batched, length-limited launch. */
   int32_t split_overwrite;
+  /* Arithmetic of the large launches (a DESCRIPTOR field since round 5; it used to be the process-wide ctts_gemm_bf16_split_enable
+   * switch, which a captured graph ignored and two models in one process could not set differently):
+   *   0 = fp32 MFMA only (v_mfma_f32_32x32x2_f32: every product an exact fp32 product) - what a zero-initialised descriptor gets;
+   *   1 = launches that qualify by shape and size may run on the BF16 matrix pipe with the six-term operand split described at
+   *       ctts_gemm_takes_bf16_split below (fp32-class results);
+   *   2 = as 1 without the size thresholds (parity tests of small launches). */
+  int32_t bf16_split;
+  /* Optional PRE-SPLIT operands (ctts_split_planes): A_planes / B_planes hold the exact three-way bf16 split of the SAME fp32 matrices
+   * A / B point to - plane p of element (row, k) at planes[p * plane_stride + row * ld + k] (bf16 bit patterns, same ld as the fp32
+   * operand, plane strides in elements, 16-byte aligned, ld % 8 == 0).  With both given (bf16_split >= 1, a_kc = b_kc = 1, unbatched,
+   * sk_ws given) the persistent plane kernel (csrc/gemm_pl.hip) moves the planes to LDS by DMA and its main loop is ds_read + MFMA
+   * only: no split arithmetic in the GEMM, every operand element split ONCE per tensor instead of once per tile that stages it.  A / B
+   * must stay valid: descriptors the plane kernel does not take (ctts_gemm_takes_planes) run on the other kernels from A / B. */
+  const uint16_t* A_planes; int64_t a_plane_stride;
+  const uint16_t* B_planes; int64_t b_plane_stride;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
@@ -142,18 +157,35 @@ int ctts_gemm_takes_persistent(const ctts_gemm_desc* d);
 int ctts_gemm_ws_enable(int on);
 /* 1 when ctts_gemm would run this descriptor on the weight-stationary kernel (no launch). */
 int ctts_gemm_takes_weight_stationary(const ctts_gemm_desc* d);
-/* fp32 GEMM on the BF16 matrix pipe (csrc/gemm.hip gemm_x6_kernel / gemm_x6tn_kernel; default on, env CTTS_X6=0 turns it off): large
- * unbatched NT launches (both operands K-contiguous, conv view on A allowed, N a multiple of 128, split_k <= 1) and large unbatched TN
- * launches (weight gradients: both operands reduction-major, conv view on B allowed, M and N multiples of 128, K >= 2048, any split_k;
- * env CTTS_X6_TN=0 turns only these off) form every fp32 product from six
- * v_mfma_f32_32x32x16_bf16 terms of the EXACT three-way bf16 split of both operands (x = hi + mid + lo, each piece the round-to-nearest of what is left),
- * accumulated in fp32 - fp32-class results (exact wherever fp32 is exact; the three dropped cross terms are <= 2^-24 of a product - one fp32
- * rounding - and 2^-29 in the median; error against float64 as the fp32-MFMA kernels' on the same launches) at up to 16/6 of the fp32-MFMA rate.
- * ctts_gemm_bf16_split_enable(0 / 1, or 2 = also below the kernels' size thresholds) returns the previous setting (process-wide, not
- * thread-safe: parity tests and A/B timing);
- * ctts_gemm_takes_bf16_split: 1 when ctts_gemm would run this descriptor on that kernel (no launch). */
-int ctts_gemm_bf16_split_enable(int on);
+/* fp32 GEMM on the BF16 matrix pipe (ctts_gemm_desc.bf16_split >= 1; csrc/gemm.hip gemm_x6_kernel / gemm_x6tn_kernel, csrc/gemm_pl.hip
+ * gemm_pl_kernel): large unbatched NT launches (both operands K-contiguous, conv view on A allowed, N a multiple of 128, split_k <= 1)
+ * and large unbatched TN launches (weight gradients: both operands reduction-major, conv view on B allowed, M and N multiples of 128,
+ * K >= 2048, any split_k) form every fp32 product from six v_mfma_f32_32x32x16_bf16 terms of the EXACT three-way bf16 split of both
+ * operands (x = hi + mid + lo, each piece the round-to-nearest-even of what is left: hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi),
+ * accumulated in fp32 - fp32-class results (exact wherever the fp32 result is exact; the three dropped cross terms are <= 2^-24 of a
+ * product - one fp32 rounding - and 2^-29 in the median; error against float64 as the fp32-MFMA kernels' on the same launches) at up
+ * to 16/6 of the fp32-MFMA rate.
+ * DOMAIN (tests/test_kernels_gpu.py::test_bf16_split_domain_*):
+ *   - finite operands with 2^-100 <= |x| < 3.396e38 (or x = 0): as stated above;
+ *   - |x| < 2^-100: the lo (then mid) piece leaves the normal range of bf16 and is flushed by the matrix pipe: the product keeps >= 16
+ *     (then >= 8) significant bits - an absolute error below 2^-116 |y| per product, far under the fp32 rounding of any sum that also
+ *     holds a normal-sized term;
+ *   - 3.396e38 <= |x| <= FLT_MAX (the top 0.2 % of the fp32 range, where hi would round to infinity): the pre-split path
+ *     (ctts_split_planes) clamps hi to the largest bf16 and stays exact; the kernels that split inside the GEMM (x6 / x6tn) treat
+ *     such an operand like an infinity;
+ *   - an infinite or NaN operand makes every output element it contributes to NON-FINITE (NaN where fp32 arithmetic would give
+ *     +-inf: inf * 0-piece = NaN), elements it does not contribute to are unaffected - the finite / non-finite pattern of the result
+ *     equals the fp32-MFMA kernels', which is what overflow diagnostics (isfinite checks, GradScaler) look at.
+ * ctts_gemm_takes_bf16_split: 1 when ctts_gemm would run this descriptor on the in-kernel-split kernels (x6 / x6tn; no launch);
+ * ctts_gemm_takes_planes: 1 when it would run it on the plane kernel. */
 int ctts_gemm_takes_bf16_split(const ctts_gemm_desc* d);
+int ctts_gemm_takes_planes(const ctts_gemm_desc* d);
+/* Exact three-way bf16 split of fp32 matrices, many per launch: for every task and element (r, c), c < cols (cols % 8 == 0, src and dst
+ * 16-byte aligned, ld % 8 == 0): x = src[r * ld + c] -> dst[p * plane_stride + r * ld + c] = bf16 bits of piece p (0 hi, 1 mid, 2 lo),
+ * hi = RNE_bf16(x) (clamped to +-bf16 max when a finite x would round to infinity), mid = RNE_bf16(x - hi), lo = x - hi - mid (exact);
+ * for x = +-inf / NaN: hi = x, mid = lo = 0.  `tasks` is a HOST array.  HBM-bound: 4 bytes read + 6 written per element. */
+typedef struct ctts_split_task { const float* src; uint16_t* dst; int64_t rows, cols, ld, plane_stride; } ctts_split_task;
+int ctts_split_planes(const ctts_split_task* tasks, int ntasks, void* stream);
 
 /* out[b,h,t] = sum_d a[b,t,h*dh+d] * b[b,t,h*dh+d]   (a, b [B,T,H*dh] channel-last; the D vector of the fused softmax backward). */
 int ctts_rowdot_heads(const float* a, const float* b, float* out, int B, int T, int H, int dh, void* stream);

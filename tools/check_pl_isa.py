@@ -1,0 +1,59 @@
+"""ISA check of the plane kernel's main loop (csrc/gemm_pl.hip), in the spirit of tools/check_sk_isa.py: the K loop of every instantiation
+must hold 48 MFMAs, 24 ds_read_b128, 9 LDS-DMA instructions, exactly one s_barrier, NO scratch access and no compiler-inserted
+`s_waitcnt vmcnt` besides the loop's own.  Usage: python tools/check_pl_isa.py [path/to/gemm_pl.s]  (compiles csrc/gemm_pl.hip when no
+path is given).  Prints one line per instantiation, exit code 1 on a violation."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "..", "comprehensive-transformer-tts_amd", "csrc", "gemm_pl.hip")
+
+
+def compile_isa():
+    out = os.path.join(tempfile.mkdtemp(prefix="plisa"), "gemm_pl.s")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", SRC, "-o", out],
+                   check=True, stderr=subprocess.DEVNULL)
+    return out
+
+
+def loops(body):
+    """(start, end) line ranges of the innermost backward branches"""
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    res = []
+    for i, l in enumerate(body):
+        m = re.search(r"s_cbranch\w*\s+(\.LBB\d+_\d+)", l) or re.search(r"s_branch\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            res.append((labels[m.group(1)], i))
+    return res
+
+
+def check(path):
+    lines = open(path).read().split("\n")
+    ok = True
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*gemm_pl_kernel.*:", l)]
+    for st in starts:
+        name = lines[st].split(":")[0]
+        end = next(i for i in range(st, len(lines)) if ".Lfunc_end" in lines[i])
+        body = lines[st:end]
+        mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+        cand = [(a, b) for a, b in loops(body) if a <= mf[0] and b >= mf[-1]]
+        a, b = min(cand, key=lambda ab: ab[1] - ab[0])
+        # the K loop proper = from the loop head to the `continue` branch after the last MFMA
+        cont = next(i for i in range(mf[-1], b + 1) if re.search(r"s_cbranch", body[i]))
+        seg = body[a:cont + 1]
+        cnt = lambda pat: sum(1 for l in seg if re.match(r"\s+" + pat, l))
+        n = dict(mfma=cnt("v_mfma"), ds_read_b128=cnt("ds_read_b128"), dma=sum(1 for l in seg if "buffer_load_dwordx4" in l and " lds" in l),
+                 barrier=cnt("s_barrier"), scratch=cnt("scratch_"), vm_wait=sum(1 for l in seg if re.match(r"\s+s_waitcnt.*vmcnt", l)),
+                 instr=sum(1 for l in seg if re.match(r"\s+[sv]_|\s+ds_|\s+buffer_|\s+global_|\s+scratch_", l)))
+        good = n["mfma"] == 48 and n["ds_read_b128"] == 24 and n["dma"] == 9 and n["barrier"] == 1 and n["scratch"] == 0 and n["vm_wait"] <= 1
+        ok &= good
+        print(("ok  " if good else "BAD ") + name[-40:], n)
+    return ok
+
+
+if __name__ == "__main__":
+    sys.exit(0 if check(sys.argv[1] if len(sys.argv) > 1 else compile_isa()) else 1)
