@@ -42,8 +42,8 @@ class GemmDesc(C.Structure):
         ("split_out", _vp), ("split_out_floats", _i64),
         ("split_overwrite", _i32),
         ("bf16_split", _i32),
-        ("A_planes", _vp), ("a_plane_stride", _i64),
-        ("B_planes", _vp), ("b_plane_stride", _i64),
+        ("A_planes", _vp),
+        ("B_planes", _vp),
     ]
 
 
@@ -54,7 +54,7 @@ class PsumTask(C.Structure):
 
 class SplitTask(C.Structure):
     """ctts_split_task of include/ctts.h"""
-    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i64), ("cols", _i64), ("ld", _i64), ("plane_stride", _i64)]
+    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i64), ("cols", _i64), ("ld", _i64)]
 
 
 class RepackTask(C.Structure):

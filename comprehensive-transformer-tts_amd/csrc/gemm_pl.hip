@@ -4,6 +4,11 @@
 // workgroup that stages an element splits it again (an activation tile 8 times - once per n-tile -, a weight tile once per m-tile), the
 // split's VALU work sits between the matrix pipe's K-blocks of an in-order wave, and the staging registers exist only for the split.
 // Here the split has LEFT the GEMM: the operands arrive as three bf16 planes per matrix (ctts_split_planes, or a producer's epilogue),
+//   * HBM layout of a plane set (ctts_split_planes): [rows][K / 32][3 pieces][32] bf16 - the hi | mid | lo pieces of one 32-deep K-block
+//     of one row are 192 CONTIGUOUS bytes, consecutive K-blocks follow each other: the three 64-byte plane rows a K-block needs share
+//     1.5 cache lines (two fetches) instead of three half-used lines ([3][rows][K] planes, the first version: the vector L1 moves whole
+//     128-byte lines at 64 B/clk, so half-used lines halved the rate at which a tile arrives - the DMA alone took 1.4 us per K-block
+//     next to 1.65 us of MFMAs, and with one block of prefetch the two did not overlap: 363 us for the dense FFN conv, 2.46 us per block);
 //   * a K-block (32 deep) of a tile is 64 bytes per row and plane; `buffer_load_dwordx4 ... lds` moves 16 rows x 64 bytes per instruction
 //     straight into LDS (the image of gemm_x6_kernel: 64-byte plane rows whose 16-byte chunks are XOR-swizzled by (row >> 2) & 3 - applied
 //     to the SOURCE address, the DMA writes lane-linear - so that the ds_read_b128 fragment reads are conflict free);
@@ -24,6 +29,7 @@
 #include "gemm_common.h"
 #include "sk_plan.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -33,6 +39,14 @@ typedef __bf16 pl_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 pl_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float pl_floatx2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned int pl_gu32;
+
+// CTTS_PL_DEBUG bits (tools builds only: -DCTTS_PL_TOOLS; the product build compiles them out - their scalar branches and the clock
+// stamps cost the conv instantiation three spilled VGPRs with reloads inside the K loop)
+#ifdef CTTS_PL_TOOLS
+#define PL_DBG(bit) (p.debug & (bit))
+#else
+#define PL_DBG(bit) 0
+#endif
 
 constexpr unsigned PL_OOB = 0x80000000u;
 constexpr int PL_BM = 128, PL_BN = 256;
@@ -51,7 +65,7 @@ struct PlArgs {
   int whole_tiles;           // 1: never split a tile
   int ntap;                  // conv view: taps (K / cin); K is walked (channel block, tap)
   int nutt, tpu;             // ragged rows: utterances and 128-row tiles per utterance (nutt = 0: dense)
-  int debug;                 // CTTS_PL_DEBUG (tools): 1 = no DMA after the prologue, 4 = no epilogue, 8 = no MFMA
+  int debug;                 // CTTS_PL_DEBUG (tools): 1 = no DMA after the prologue, 4 = no epilogue, 8 = no MFMA, 32 = no rotated order in the upper wave group, 16 = record shader cycles / wall ticks of workgroup 8 in the workspace header
   unsigned* ws;
 };
 
@@ -128,6 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wave >> 2) * 64, wn0 = (wave & 3) * 64;
   const int nutt = p.nutt, tpu = p.tpu;
+  const unsigned long long dbg_c0 = PL_DBG(16) ? clock64() : 0ull, dbg_w0 = PL_DBG(16) ? wall_clock64() : 0ull;
 
   // ---- schedule of the active m-tiles (ragged rows)
   int n_mt = p.tiles_m;
@@ -184,10 +199,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
 
   const int cin = d.conv_cin > 0 ? d.conv_cin : 32;
   const int T = d.conv_T > 0 ? d.conv_T : 1;
-  const pl_i32x4 ra_src = pl_make_rsrc(d.A_planes - (CONV ? (long)d.conv_pad * d.lda : 0));
+  // plane set: row stride 3 * ld bf16 = 6 * ld bytes; K-block kb of a row at + kb * 192 bytes, piece q at + q * 64 bytes
+  const pl_i32x4 ra_src = pl_make_rsrc(d.A_planes - (CONV ? (long)d.conv_pad * d.lda * 3 : 0));
   const pl_i32x4 rb_src = pl_make_rsrc(d.B_planes);
-  const unsigned pa_bytes = (unsigned)(d.a_plane_stride * 2), pb_bytes = (unsigned)(d.b_plane_stride * 2);
-  const unsigned lda2 = (unsigned)(d.lda * 2), ldb2 = (unsigned)(d.ldb * 2);
+  const unsigned lda2 = (unsigned)(d.lda * 6), ldb2 = (unsigned)(d.ldb * 6);
   const unsigned smem_addr = (unsigned)reinterpret_cast<uintptr_t>(smem);
   unsigned* flags = p.ws;
   float* slabs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(p.ws) + CTTS_WS_SLABS);
@@ -237,21 +252,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
   auto loader_issue = [&](int stage) {
     unsigned soffA, soffB, vA = voffA;
     if (CONV) {
-      soffA = (unsigned)ltap * lda2 + (unsigned)(lcb * 64);
-      soffB = (unsigned)(ltap * cin + lcb * 32) * 2u;
+      soffA = (unsigned)ltap * lda2 + (unsigned)(lcb * 192);
+      soffB = (unsigned)(ltap * (cin >> 5) + lcb) * 192u;
       vA = ((unsigned)(trowA + ltap - d.conv_pad) < (unsigned)T) ? vA : PL_OOB;
     } else {
-      soffA = soffB = (unsigned)lkb * 64u;
+      soffA = soffB = (unsigned)lkb * 192u;
     }
     const unsigned sA = smem_addr + (unsigned)(stage * PL_STAGE + wave * 1024);
     const unsigned sB = smem_addr + (unsigned)(stage * PL_STAGE + 3 * PL_A_PLANE + wave * 2048);
+    // the three pieces of a row group back to back: they share cache lines
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pl_dma16(ra_src, sA + q * PL_A_PLANE, vA, soffA + q * pa_bytes);
+    for (int q = 0; q < 3; ++q) pl_dma16(ra_src, sA + q * PL_A_PLANE, vA, soffA + q * 64);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      pl_dma16(rb_src, sB + q * PL_B_PLANE, voffB[0], soffB + q * pb_bytes);
-      pl_dma16(rb_src, sB + q * PL_B_PLANE + 1024, voffB[1], soffB + q * pb_bytes);
-    }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) pl_dma16(rb_src, sB + q * PL_B_PLANE + j * 1024, voffB[j], soffB + q * 64);
   };
   auto loader_advance = [&]() {
     ++lkb;
@@ -318,32 +333,57 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
   int remaining = rg.hi - rg.lo;              // K-blocks this workgroup still has to compute (the current one included)
   zero_acc();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // The K loop exists twice - once per wave group, chosen ONCE by a wave-uniform branch: the same work in two instruction orders (see the
+  // comment in the loop).  Both copies execute the same sequence of barriers.
+  auto run = [&](auto skew_c) {
+  constexpr bool SKEW = decltype(skew_c)::value;
   PlFrag f0, f1;
   read_frag(0, 0, f0);
   int stage = 0;
   __builtin_amdgcn_s_waitcnt(0);
   while (true) {
+    // The two waves of a SIMD (w and w + 4) meet the same barrier, so their non-MFMA sections (fragment reads, DMA issue, cursor
+    // arithmetic: ~450 issue cycles per block and wave) would coincide and the matrix pipe would idle through them.  The upper wave
+    // group therefore runs the same work in a ROTATED order: its reads / DMA issue sit 8 MFMAs (one wave's 256 pipe cycles) later,
+    // under the lower group's MFMAs and vice versa.  (p.debug & 32 switches the rotation off: A/B timing.)
+    const bool do_mma = PL_DBG(8) == 0;
     // first half: the fragments of k-step 0 are in registers (read during the previous block); k-step 1 is read under its MFMAs
-    const bool do_mma = !(p.debug & 8);
-    if (do_mma) mma_terms(f0, 0, 1);
-    read_frag(stage, 1, f1);
-    if (do_mma) mma_terms(f0, 1, 6);
+    if constexpr (!SKEW) {
+      if (do_mma) mma_terms(f0, 0, 1);
+      read_frag(stage, 1, f1);
+      if (do_mma) mma_terms(f0, 1, 6);
+    } else {
+      if (do_mma) mma_terms(f0, 0, 3);
+      read_frag(stage, 1, f1);
+      if (do_mma) mma_terms(f0, 3, 6);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // every wave is done reading this stage, and (mine of) block i + 1 has landed: after the barrier the whole block has
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // second half, with the loader's work (DMA issue of block i + 2 into this stage, cursor arithmetic) and the fragment reads of block
-    // i + 1 placed BETWEEN groups of MFMAs in program order: the branches keep hipcc from regrouping them, the matrix pipe never waits
-    // for the ~100 scalar / lane-read instructions of the loader
-    if (do_mma) mma_terms(f1, 0, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (have_l && !(p.debug & 1)) loader_issue(stage);
-    if (do_mma) mma_terms(f1, 2, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    if (have_l) loader_advance();
-    // first half of block i + 1 - unless this block ends the piece: the fragments would have to stay live across the epilogue (48 more
-    // registers there); they are read after it instead, once per piece
-    if (ckb + 1 < cp.kb_hi) read_frag(stage ^ 1, 0, f0);
-    if (do_mma) mma_terms(f1, 4, 6);
+    // second half, with the loader's work (DMA issue of block i + 2 into this stage, cursor arithmetic) and the first-half fragment reads
+    // of block i + 1 (it has landed) placed BETWEEN groups of MFMAs in program order: the branches keep hipcc from regrouping them, the
+    // matrix pipe never waits for the ~100 scalar / lane-read instructions of the loader.  The fragments of block i + 1 are NOT read
+    // when this block ends the piece: they would have to stay live across the epilogue (48 more registers there); they are read after it
+    const bool more = ckb + 1 < cp.kb_hi;
+    if constexpr (!SKEW) {
+      if (more) read_frag(stage ^ 1, 0, f0);
+      if (do_mma) mma_terms(f1, 0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (have_l && !PL_DBG(1)) loader_issue(stage);
+      if (do_mma) mma_terms(f1, 2, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (have_l) loader_advance();
+      if (do_mma) mma_terms(f1, 4, 6);
+    } else {
+      if (do_mma) mma_terms(f1, 0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) read_frag(stage ^ 1, 0, f0);
+      if (do_mma) mma_terms(f1, 2, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (have_l && !PL_DBG(1)) loader_issue(stage);
+      if (have_l) loader_advance();
+      if (do_mma) mma_terms(f1, 4, 6);
+    }
     --remaining;
     ++ckb;
     stage ^= 1;
@@ -427,9 +467,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
             if (dc.Z && !dc.epi_bwd) dc.Z[(long)(row0 + 64 + r) * dc.ldz + n] = 0.f;
           }
         }
-      } else if (!(p.debug & 4)) {
+      } else if (!PL_DBG(4)) {
         pl_epilogue(dc, acc, row0, col0, e_wm0, e_wn0, e_l31, e_h, Mv, Nv);
       }
+    }
+    if (PL_DBG(16) && blockIdx.x == 8 && tid == 0) {         // tools: shader cycles and 100 MHz wall ticks of one workgroup's life so far
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws + PL_MAX_WG + 2);
+      o[0] = clock64() - dbg_c0;
+      o[1] = wall_clock64() - dbg_w0;
     }
     // a wait hipcc can see (gemm_sk.hip): its scoreboard is empty when control returns to the K loop
     __builtin_amdgcn_s_waitcnt(0);
@@ -438,6 +483,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
     zero_acc();
     read_frag(stage, 0, f0);            // the next piece's first block landed before the last barrier
   }
+  };
+  if (wave >= 4 && !PL_DBG(32)) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 int pl_env(const char* name, int dflt) {
@@ -450,7 +498,7 @@ constexpr int SPL_BATCH = 24;
 struct SplitBatch {
   const float* src[SPL_BATCH];
   uint16_t* dst[SPL_BATCH];
-  long rows[SPL_BATCH], cols8[SPL_BATCH], ld[SPL_BATCH], pstride[SPL_BATCH];
+  long rows[SPL_BATCH], cols8[SPL_BATCH], ld[SPL_BATCH];
   int first_block[SPL_BATCH + 1];
   int ntasks;
 };
@@ -474,12 +522,13 @@ __device__ __forceinline__ void spl_one(float x, unsigned& hi, unsigned& mid, un
   hi = hb; mid = mb; lo = lb;
 }
 
+// dst [rows][ld / 32][3][32] bf16: thread = 8 consecutive k of one row -> three 16-byte stores 64 bytes apart inside the K-block's 192 bytes
 __global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch b) {
   int t = 0;
   while (t + 1 < b.ntasks && (int)blockIdx.x >= b.first_block[t + 1]) ++t;
   const float* __restrict__ src = b.src[t];
   uint16_t* __restrict__ dst = b.dst[t];
-  const long c8 = b.cols8[t], ld = b.ld[t], ps = b.pstride[t], n8 = b.rows[t] * c8;
+  const long c8 = b.cols8[t], ld = b.ld[t], n8 = b.rows[t] * c8;
   const long g0 = (long)((int)blockIdx.x - b.first_block[t]) * SPL_PER_BLOCK;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -498,10 +547,10 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch b) {
       pm[e] = mid[2 * e] | (mid[2 * e + 1] << 16);
       pq[e] = lo[2 * e] | (lo[2 * e + 1] << 16);
     }
-    uint16_t* o = dst + r * ld + c;
+    uint16_t* o = dst + r * ld * 3 + (c >> 5) * 96 + (c & 31);
     *reinterpret_cast<pl_u32x4*>(o) = ph;
-    *reinterpret_cast<pl_u32x4*>(o + ps) = pm;
-    *reinterpret_cast<pl_u32x4*>(o + 2 * ps) = pq;
+    *reinterpret_cast<pl_u32x4*>(o + 32) = pm;
+    *reinterpret_cast<pl_u32x4*>(o + 64) = pq;
   }
 }
 
@@ -516,13 +565,12 @@ extern "C" int ctts_split_planes(const ctts_split_task* tasks, int ntasks, void*
     long blocks = 0;
     for (int t = t0; t < ntasks && t < t0 + SPL_BATCH; ++t) {
       const ctts_split_task& q = tasks[t];
-      CTTS_REQUIRE(q.src && q.dst && q.rows >= 0 && q.cols >= 0 && q.cols % 8 == 0 && q.ld >= q.cols && q.ld % 8 == 0 && q.plane_stride % 8 == 0 &&
-                       q.plane_stride >= (q.rows > 0 ? (q.rows - 1) * q.ld + q.cols : 0) &&
+      CTTS_REQUIRE(q.src && q.dst && q.rows >= 0 && q.cols >= 0 && q.cols % 32 == 0 && q.ld >= q.cols && q.ld % 32 == 0 &&
                        (reinterpret_cast<uintptr_t>(q.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(q.dst) & 15) == 0,
-                   "ctts_split_planes: task %d needs 16-byte aligned pointers, cols %% 8 == 0, ld %% 8 == 0 and planes that do not overlap", t);
+                   "ctts_split_planes: task %d needs 16-byte aligned pointers, cols %% 32 == 0 and ld %% 32 == 0", t);
       if (q.rows == 0 || q.cols == 0) continue;
       const int i = b.ntasks++;
-      b.src[i] = q.src; b.dst[i] = q.dst; b.rows[i] = q.rows; b.cols8[i] = q.cols / 8; b.ld[i] = q.ld; b.pstride[i] = q.plane_stride;
+      b.src[i] = q.src; b.dst[i] = q.dst; b.rows[i] = q.rows; b.cols8[i] = q.cols / 8; b.ld[i] = q.ld;
       b.first_block[i] = (int)blocks;
       blocks += (q.rows * (q.cols / 8) + SPL_PER_BLOCK - 1) / SPL_PER_BLOCK;
       CTTS_REQUIRE(blocks < (1L << 30), "ctts_split_planes: too many elements in one call");
@@ -550,12 +598,12 @@ static int pl_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
   if (d.split_k > 1 && !d.split_overwrite) return 0;                 // "C += alpha A B" is not built here
   if (d.K % 32 != 0 || d.K < 64 || d.N % 128 != 0 || d.N < 256 || d.M < 128) return 0;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  if (!al16(d.A_planes) || !al16(d.B_planes) || ((d.lda | d.ldb | d.a_plane_stride | d.b_plane_stride) & 7)) return 0;
+  if (!al16(d.A_planes) || !al16(d.B_planes) || ((d.lda | d.ldb) & 31)) return 0;
   const bool conv = d.conv_T > 0;
   if (conv && (d.conv_on_b || d.conv_cin % 32 != 0 || d.K % d.conv_cin != 0 || d.conv_T < 16)) return 0;
   // 32-bit buffer offsets over the three planes (plus a tile of rows beyond M and the conv shift)
-  const long a_ext = 2 * d.a_plane_stride + (long)(d.M + 256) * d.lda + d.K;
-  const long b_ext = 2 * d.b_plane_stride + (long)(d.N + 256) * d.ldb + d.K;
+  const long a_ext = (long)(d.M + 256) * d.lda * 3 + 3L * d.K;
+  const long b_ext = (long)(d.N + 256) * d.ldb * 3 + 3L * d.K;
   if (a_ext * 2 >= 0x7FFF0000L || b_ext * 2 >= 0x7FFF0000L) return 0;
   if (pl_epilogue_kind(d) < 0) return 0;          // only the lean epilogues the kernel carries
   PlArgs p;

@@ -230,8 +230,7 @@ def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0
     d = GemmDesc()
     d.bf16_split = int(BF16_SPLIT if bf16_split is None else bf16_split)
     if a_planes is not None and b_planes is not None:
-        d.A_planes, d.a_plane_stride = a_planes.data_ptr(), a_planes.stride(0)
-        d.B_planes, d.b_plane_stride = b_planes.data_ptr(), b_planes.stride(0)
+        d.A_planes, d.B_planes = a_planes.data_ptr(), b_planes.data_ptr()
     d.A, d.B, d.C = _p(A, a_off), _p(B, b_off), _p(Cout, c_off)
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.lda, d.ldb, d.ldc = int(lda), int(ldb), int(ldc)
@@ -333,7 +332,8 @@ def plane_shape_ok(M, N, K, conv_cin=None):
 
 def split_planes(mats):
     """Exact three-way bf16 split of fp32 matrices in one launch per 24 (include/ctts.h ctts_split_planes): `mats` = list of dense 2-D
-    float32 tensors [rows, cols] (cols % 8 == 0) -> list of bf16 tensors [3, rows, cols] (planes hi | mid | lo)."""
+    float32 tensors [rows, cols] (cols % 32 == 0) -> list of bf16 tensors [rows, cols / 32, 3, 32]: pieces hi | mid | lo of every 32-deep
+    K-block of a row side by side (the layout the plane kernel's DMA reads; `planes_piece` gives a piece back as [rows, cols])."""
     if not mats:
         return []
     outs = []
@@ -341,11 +341,18 @@ def split_planes(mats):
     for t, m in zip(arr, mats):
         _f32c(m, "split_planes operand")
         rows, cols = m.shape
-        o = torch.empty(3, rows, cols, dtype=torch.bfloat16, device=m.device)
+        if cols % 32:
+            raise _lib.CttsError(f"split_planes: cols = {cols} is not a multiple of 32")
+        o = torch.empty(rows, cols // 32, 3, 32, dtype=torch.bfloat16, device=m.device)
         outs.append(o)
-        t.src, t.dst, t.rows, t.cols, t.ld, t.plane_stride = _p(m), o.data_ptr(), int(rows), int(cols), int(cols), int(rows * cols)
+        t.src, t.dst, t.rows, t.cols, t.ld = _p(m), o.data_ptr(), int(rows), int(cols), int(cols)
     _lib.check(_lib.load().ctts_split_planes(arr, len(arr), _stream()), "ctts_split_planes")
     return outs
+
+
+def planes_piece(pl, q):
+    """piece q (0 hi, 1 mid, 2 lo) of a plane set as a [rows, cols] bf16 tensor"""
+    return pl[:, :, q, :].reshape(pl.shape[0], -1)
 
 
 def gemm_takes_weight_stationary(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):

@@ -105,13 +105,15 @@ typedef struct ctts_gemm_desc {
    *   2 = as 1 without the size thresholds (parity tests of small launches). */
   int32_t bf16_split;
   /* Optional PRE-SPLIT operands (ctts_split_planes): A_planes / B_planes hold the exact three-way bf16 split of the SAME fp32 matrices
-   * A / B point to - plane p of element (row, k) at planes[p * plane_stride + row * ld + k] (bf16 bit patterns, same ld as the fp32
-   * operand, plane strides in elements, 16-byte aligned, ld % 8 == 0).  With both given (bf16_split >= 1, a_kc = b_kc = 1, unbatched,
-   * sk_ws given) the persistent plane kernel (csrc/gemm_pl.hip) moves the planes to LDS by DMA and its main loop is ds_read + MFMA
-   * only: no split arithmetic in the GEMM, every operand element split ONCE per tensor instead of once per tile that stages it.  A / B
-   * must stay valid: descriptors the plane kernel does not take (ctts_gemm_takes_planes) run on the other kernels from A / B. */
-  const uint16_t* A_planes; int64_t a_plane_stride;
-  const uint16_t* B_planes; int64_t b_plane_stride;
+   * A / B point to, in the K-block-interleaved layout [rows][ld / 32][3][32] (bf16 bit patterns): piece q (0 hi, 1 mid, 2 lo) of element
+   * (row, k) at planes[row * 3 * ld + (k / 32) * 96 + q * 32 + k % 32] - the three pieces of one 32-deep K-block of a row are 192
+   * contiguous bytes; same ld as the fp32 operand, ld % 32 == 0, 16-byte aligned.  With both given (bf16_split >= 1, a_kc = b_kc = 1,
+   * unbatched, sk_ws given) the persistent plane kernel (csrc/gemm_pl.hip) moves the pieces to LDS by DMA and its main loop is
+   * ds_read + MFMA only: no split arithmetic in the GEMM, every operand element split ONCE per tensor instead of once per tile that
+   * stages it.  A / B must stay valid: descriptors the plane kernel does not take (ctts_gemm_takes_planes) run on the other kernels
+   * from A / B. */
+  const uint16_t* A_planes;
+  const uint16_t* B_planes;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
@@ -180,11 +182,12 @@ int ctts_gemm_takes_weight_stationary(const ctts_gemm_desc* d);
  * ctts_gemm_takes_planes: 1 when it would run it on the plane kernel. */
 int ctts_gemm_takes_bf16_split(const ctts_gemm_desc* d);
 int ctts_gemm_takes_planes(const ctts_gemm_desc* d);
-/* Exact three-way bf16 split of fp32 matrices, many per launch: for every task and element (r, c), c < cols (cols % 8 == 0, src and dst
- * 16-byte aligned, ld % 8 == 0): x = src[r * ld + c] -> dst[p * plane_stride + r * ld + c] = bf16 bits of piece p (0 hi, 1 mid, 2 lo),
- * hi = RNE_bf16(x) (clamped to +-bf16 max when a finite x would round to infinity), mid = RNE_bf16(x - hi), lo = x - hi - mid (exact);
- * for x = +-inf / NaN: hi = x, mid = lo = 0.  `tasks` is a HOST array.  HBM-bound: 4 bytes read + 6 written per element. */
-typedef struct ctts_split_task { const float* src; uint16_t* dst; int64_t rows, cols, ld, plane_stride; } ctts_split_task;
+/* Exact three-way bf16 split of fp32 matrices, many per launch: for every task and element (r, c), c < cols (cols % 32 == 0, ld % 32 == 0,
+ * src and dst 16-byte aligned): x = src[r * ld + c] -> dst[r * 3 * ld + (c / 32) * 96 + q * 32 + c % 32] = bf16 bits of piece q (the
+ * layout of ctts_gemm_desc.A_planes), hi = RNE_bf16(x) (clamped to +-bf16 max when a finite x would round to infinity),
+ * mid = RNE_bf16(x - hi), lo = x - hi - mid (exact); for x = +-inf / NaN: hi = x, mid = lo = 0.  dst holds rows * 3 * ld bf16.
+ * `tasks` is a HOST array.  HBM-bound: 4 bytes read + 6 written per element. */
+typedef struct ctts_split_task { const float* src; uint16_t* dst; int64_t rows, cols, ld; } ctts_split_task;
 int ctts_split_planes(const ctts_split_task* tasks, int ntasks, void* stream);
 
 /* out[b,h,t] = sum_d a[b,t,h*dh+d] * b[b,t,h*dh+d]   (a, b [B,T,H*dh] channel-last; the D vector of the fused softmax backward). */

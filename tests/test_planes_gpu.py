@@ -22,32 +22,33 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 def planes_to_f64(pl):
-    """[3, rows, cols] bf16 -> the three pieces as float64"""
-    return [p.float().double().cpu() for p in pl]
+    """plane set [rows, cols / 32, 3, 32] bf16 -> the three pieces as float64 [rows, cols]"""
+    return [K.planes_piece(pl, q).float().double().cpu() for q in range(3)]
 
 
 # ---------------------------------------------------------------------------------------------------------------- the split itself
 def test_split_planes_is_the_exact_round_to_nearest_split():
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(300, 264, generator=g) * torch.exp(torch.randn(300, 264, generator=g) * 6)
+    x = torch.randn(300, 288, generator=g) * torch.exp(torch.randn(300, 288, generator=g) * 6)
     x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 2.0 ** -100, 2.0 ** -120])
     pl = K.split_planes([x.to(DEV)])[0]
-    assert pl.dtype == torch.bfloat16 and tuple(pl.shape) == (3, 300, 264)
+    assert pl.dtype == torch.bfloat16 and tuple(pl.shape) == (300, 9, 3, 32)
     hi, mid, lo = planes_to_f64(pl)
     xd = x.double()
     assert torch.equal(hi + mid + lo, xd)                                            # exact: nothing is dropped by the split
-    assert torch.equal(pl[0].cpu(), x.bfloat16())                                    # hi = RNE(x)
+    assert torch.equal(K.planes_piece(pl, 0).cpu(), x.bfloat16())                                    # hi = RNE(x)
     r1 = (xd - hi).float()
-    assert torch.equal(pl[1].cpu(), r1.bfloat16())                                   # mid = RNE(x - hi)
+    assert torch.equal(K.planes_piece(pl, 1).cpu(), r1.bfloat16())                                   # mid = RNE(x - hi)
     assert float((mid.abs() - hi.abs() * 2.0 ** -8).max()) <= 0 and float((lo.abs() - hi.abs() * 2.0 ** -16).max()) <= 0
 
 
 def test_split_planes_domain_huge_finite_values_infinities_and_nans():
     big = torch.tensor([3.3961e38, 3.4e38, 3.4028234e38, -3.4028234e38, 3.3895e38, float("inf"), -float("inf"), float("nan")])
-    x = torch.zeros(8, 8)
-    x[0] = big
+    x = torch.zeros(8, 32)
+    x[0, :8] = big
     pl = K.split_planes([x.to(DEV)])[0]
     hi, mid, lo = planes_to_f64(pl)
+    hi, mid, lo, x = hi[:, :8], mid[:, :8], lo[:, :8], x[:, :8]
     fin = torch.isfinite(x[0])
     # finite values that would round to infinity: hi clamped to the largest bf16, the remainder stays exact
     assert torch.isfinite(hi[0][fin]).all() and torch.equal((hi + mid + lo)[0][fin], x[0].double()[fin])
@@ -58,12 +59,12 @@ def test_split_planes_domain_huge_finite_values_infinities_and_nans():
 
 
 def test_split_planes_many_tasks_per_launch_and_bad_arguments():
-    mats = [rnd(37 + i, 8 * (1 + i % 5), seed=i).to(DEV) for i in range(30)]           # > 24: two launches
+    mats = [rnd(37 + i, 32 * (1 + i % 5), seed=i).to(DEV) for i in range(30)]           # > 24: two launches
     for m, pl in zip(mats, K.split_planes(mats)):
         hi, mid, lo = planes_to_f64(pl)
         assert torch.equal(hi + mid + lo, m.double().cpu())
     with pytest.raises(Exception):
-        K.split_planes([rnd(4, 12).to(DEV)])                                        # cols % 8 != 0
+        K.split_planes([rnd(4, 24).to(DEV)])                                        # cols % 32 != 0
 
 
 # ---------------------------------------------------------------------------------------------------------------- the plane GEMM

@@ -41,6 +41,15 @@ def err_word():
     return max(int(ws.view(torch.int32)[2048].item()) for ws in K._SK_WS.values())
 
 
+def pl_clock():
+    """GHz of the shader clock during the last plane-kernel launch (CTTS_PL_DEBUG & 16)"""
+    if not (int(os.environ.get("CTTS_PL_DEBUG", "0")) & 16):
+        return ""
+    ws = K.gemm_workspace(torch.device(dev))
+    c = ws.view(torch.int64)[(2048 + 2) // 2:(2048 + 2) // 2 + 2].tolist()
+    return f" clk {c[0] / max(c[1], 1) * 0.1:.3f} GHz ({c[0]} cycles)" if c[1] else ""
+
+
 def run(name, A, Bm, out_shape, M, N, Kd, lda, flops, kw, tmap=None):
     if only and only not in name:
         return
@@ -69,10 +78,11 @@ def run(name, A, Bm, out_shape, M, N, Kd, lda, flops, kw, tmap=None):
     d_x6 = float((outs["pl"] - outs["x6"]).abs().max())
     d_32 = float((outs["pl"] - outs["f32"]).abs().max())
     t = {m: timeit(f) for m, f in fns.items()}
+    clk = pl_clock()
     t_sa = timeit(lambda: K.split_planes([A2]))
     t_sb = timeit(lambda: K.split_planes([Bm]))
     print(f"{name:26s} " + " | ".join(f"{m} {t[m]*1e6:7.1f} us {flops/t[m]/1e12:6.1f} TF" for m in ("f32", "x6", "pl")) +
-          f" | split A {t_sa*1e6:5.1f} us B {t_sb*1e6:5.1f} us | pl-x6 {d_x6:.2e} pl-f32 {d_32:.2e} (|out| {float(outs['f32'].abs().max()):.2f}) err {err_word()}",
+          f" | split A {t_sa*1e6:5.1f} us B {t_sb*1e6:5.1f} us | pl-x6 {d_x6:.2e} pl-f32 {d_32:.2e} (|out| {float(outs['f32'].abs().max()):.2f}) err {err_word()}{clk}",
           flush=True)
 
 

@@ -40,18 +40,21 @@ def check(path):
         end = next(i for i in range(st, len(lines)) if ".Lfunc_end" in lines[i])
         body = lines[st:end]
         mf = [i for i, l in enumerate(body) if "v_mfma" in l]
-        cand = [(a, b) for a, b in loops(body) if a <= mf[0] and b >= mf[-1]]
-        a, b = min(cand, key=lambda ab: ab[1] - ab[0])
-        # the K loop proper = from the loop head to the `continue` branch after the last MFMA
-        cont = next(i for i in range(mf[-1], b + 1) if re.search(r"s_cbranch", body[i]))
-        seg = body[a:cont + 1]
-        cnt = lambda pat: sum(1 for l in seg if re.match(r"\s+" + pat, l))
-        n = dict(mfma=cnt("v_mfma"), ds_read_b128=cnt("ds_read_b128"), dma=sum(1 for l in seg if "buffer_load_dwordx4" in l and " lds" in l),
-                 barrier=cnt("s_barrier"), scratch=cnt("scratch_"), vm_wait=sum(1 for l in seg if re.match(r"\s+s_waitcnt.*vmcnt", l)),
-                 instr=sum(1 for l in seg if re.match(r"\s+[sv]_|\s+ds_|\s+buffer_|\s+global_|\s+scratch_", l)))
-        good = n["mfma"] == 48 and n["ds_read_b128"] == 24 and n["dma"] == 9 and n["barrier"] == 1 and n["scratch"] == 0 and n["vm_wait"] <= 1
-        ok &= good
-        print(("ok  " if good else "BAD ") + name[-40:], n)
+        # the K loop exists once per wave group (two instruction orders): runs of 48 MFMAs
+        groups = [mf[k:k + 48] for k in range(0, len(mf), 48)]
+        for gi, grp in enumerate(groups):
+            cand = [(a, b) for a, b in loops(body) if a <= grp[0] and b >= grp[-1]]
+            a, b = min(cand, key=lambda ab: ab[1] - ab[0])
+            # the K loop proper = from the loop head to the `continue` branch after the last MFMA
+            cont = next(i for i in range(grp[-1], b + 1) if re.search(r"s_cbranch", body[i]))
+            seg = body[a:cont + 1]
+            cnt = lambda pat: sum(1 for l in seg if re.match(r"\s+" + pat, l))
+            n = dict(mfma=cnt("v_mfma"), ds_read_b128=cnt("ds_read_b128"), dma=sum(1 for l in seg if "buffer_load_dwordx4" in l and " lds" in l),
+                     barrier=cnt("s_barrier"), scratch=cnt("scratch_"), vm_wait=sum(1 for l in seg if re.match(r"\s+s_waitcnt.*vmcnt", l)),
+                     instr=sum(1 for l in seg if re.match(r"\s+[sv]_|\s+ds_|\s+buffer_|\s+global_|\s+scratch_", l)))
+            good = n["mfma"] == 48 and n["ds_read_b128"] == 24 and n["dma"] == 9 and n["barrier"] == 1 and n["scratch"] == 0 and n["vm_wait"] <= 1
+            ok &= good
+            print(("ok  " if good else "BAD ") + name[-40:] + f" loop {gi}", n)
     return ok
 
 
