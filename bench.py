@@ -169,10 +169,28 @@ def measure_traffic_live(timeout=90):
                      "WRITE_SIZE_KiB": kib["WRITE_SIZE"], "correction": "gfx950: FETCH_SIZE doubled (128-B requests tallied at 64 B), unit KiB"}
 
 
+def _time_launches(launch, iters, warm):
+    """average duration of `launch` by HIP events on the launch stream (torch's current stream = the stream ctts_gemm launches on)"""
+    for _ in range(warm):
+        launch()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        launch()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
 def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
-    """HIP-event timing (on the launch stream) of the dominant kernel at its train-step arguments:
-    decoder FFN Conv1d(256->1024, k=9) as implicit GEMM, M=B*Tm rows, N=1024, K=2304."""
+    """HIP-event timing (on the launch stream) of the three GEMMs of the decoder FFN Conv1d(256->1024, k=9) at their train-step
+    arguments (M = B*Tm rows of which `valid` are not padding, N = 1024, K = 2304): forward (implicit GEMM on the activation),
+    data gradient (N = 256, K = 9216) and weight gradient (TN, reduction over the rows).  `roofline` prices the FORWARD launch: it runs on
+    gemm_pl_kernel, the kernel with the largest per-step total (24 launches of the fs2 step: profiles/r05_fs2_graph_replay_kernels.md);
+    the other two are listed next to it (`ffn_conv`)."""
     from ctts_amd import kernels as K
+    from ctts_amd import ops as O
 
     B, T = batch["mels"].shape[0], batch["mels"].shape[1]
     M, cin, cout, ks = B * T, 256, 1024, 9
@@ -183,29 +201,46 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
     Z = torch.empty(B, T, cout, device=dev)
     seed = torch.zeros(1, dtype=torch.int64, device=dev)
     lens = batch["mel_lens"].to(torch.int32).to(dev)          # padded-row skipping exactly as the decoder passes it (model.py FFTBlocks.run)
+    valid = int(batch["mel_lens"].sum())
+    bf16 = K.BF16_SPLIT >= 1
+    split_us = None
+    fwd_kw = dict(conv=(T, ks // 2, cin), alpha=ks ** -0.5, bias=bias, Z=Z, ldz=cout, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1,
+                  row_lens=lens, row_T=T, row_halo=0)
+    planes = {}
+    if bf16 and K.plane_shape_ok(M, cout, ks * cin, cin):
+        ap, bp = K.split_planes([x.view(M, cin), wf])
+        if K.gemm_takes_planes(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, a_planes=ap, b_planes=bp, **fwd_kw):
+            planes = dict(a_planes=ap, b_planes=bp)
+            split_us = _time_launches(lambda: K.split_planes([x.view(M, cin)]), 20, 5) * 1e6      # the activation's split launch (the weight's is per step)
+    tmap = None if planes else K.row_tile_map(lens, T, 0, M)   # device-built m-tile schedule, as ops.PadRows hands it to every layer
 
-    tmap = K.row_tile_map(lens, T, 0, M)                      # device-built m-tile schedule, as ops.PadRows hands it to every layer
-
-    def launch():
-        K.gemm(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, conv=(T, ks // 2, cin), alpha=ks ** -0.5, bias=bias,
-               Z=Z, ldz=cout, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1, row_lens=lens, row_T=T, row_halo=0, tile_map=tmap)
+    def fwd():
+        K.gemm(x, wf, out, M, cout, ks * cin, cin, ks * cin, cout, True, True, tile_map=tmap, **fwd_kw, **planes)
     # `warm` launches first: after the host-side pause between the timed loops and this measurement the first ~30 launches run 15 %
     # slower (594 vs 511 us, tools/dbg_dom.py) while the clocks come back up; inside the train step the GPU never idles
-    for _ in range(warm):
-        launch()
-    st = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        launch()
-    e1.record(st)
-    e1.synchronize()
-    dt = e0.elapsed_time(e1) * 1e-3 / iters
-    valid = int(batch["mel_lens"].sum())
+    dt = _time_launches(fwd, iters, warm)
     algo_flops = 2.0 * cout * ks * cin * valid          # 4,718,592 FLOP per valid frame per layer
     padded_flops = 2.0 * cout * ks * cin * M
+    # ---- data gradient and weight gradient of the same layer, as ops._LinearConv.backward launches them
+    dz = torch.randn(B, T, cout, device=dev) * (torch.arange(T, device=dev)[None, :, None] < lens[:, None, None])
+    wd = torch.randn(cin, ks * cout, device=dev) * 0.02
+    dx = torch.empty(B, T, cin, device=dev)
+    dg_kw = dict(conv=(T, ks // 2, cout), alpha=ks ** -0.5, row_lens=lens, row_T=T, row_halo=ks // 2, split_overwrite=True)
+    dplanes = {}
+    if bf16 and K.plane_shape_ok(M, cin, ks * cout, cout):
+        ap2, bp2 = K.split_planes([dz.view(M, cout), wd])
+        if K.gemm_takes_planes(dz, wd, dx, M, cin, ks * cout, cout, ks * cout, cin, True, True, a_planes=ap2, b_planes=bp2, **dg_kw):
+            dplanes = dict(a_planes=ap2, b_planes=bp2)
+    tmap_d = None if dplanes else K.row_tile_map(lens, T, ks // 2, M)
+    dt_d = _time_launches(lambda: K.gemm(dz, wd, dx, M, cin, ks * cout, cout, ks * cout, cin, True, True, tile_map=tmap_d, **dg_kw, **dplanes),
+                          iters // 2, warm // 2)
+    dw = torch.zeros(cout, ks * cin, device=dev)
+    kmap = K.row_tile_map(lens, T, 0, M)
+    sk = max(2, O._split_k_for(cout, ks * cin, M))
+    dt_w = _time_launches(lambda: K.gemm(dz, x, dw, cout, ks * cin, M, cout, cin, ks * cin, False, False, conv=(T, ks // 2, cin), conv_on_b=True,
+                                         split_k=sk, alpha=ks ** -0.5, tile_map=kmap, row_lens=lens, row_T=T), iters // 2, warm // 2)
     # traffic: measured live by two rocprofv3 --pmc passes over this same launch when rocprofv3 is available (it
-    # used to be a committed constant); otherwise the committed result of the same passes (tools/collect_r04.sh) - traffic_source says which
+    # used to be a committed constant); otherwise the committed result of the same passes (tools/collect_r05.sh) - traffic_source says which
     traffic, traffic_src = None, None
     if live_traffic:
         try:
@@ -221,22 +256,35 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
         traffic_src = {"file": "profiles/pmc_traffic_dominant_kernel.json", "collected": tjs.get("collected"), "commit": tjs.get("commit"),
                        "kernel": tjs.get("kernel")}
     ach = algo_flops / dt / 1e12
-    if os.environ.get("CTTS_X6", "1") != "0":
-        # the launch runs on gemm_x6_kernel: fp32 products as six bf16 MFMA terms (exact 3-way operand split, fp32 accumulate).  The pipe
-        # that bounds it is the BF16 matrix pipe, so the algorithmic fp32 FLOPs are priced against bf16 dense peak / 6; the fraction of
+    if bf16:
+        # the launches run on the BF16 matrix pipe: fp32 products as six bf16 MFMA terms (exact 3-way operand split, fp32 accumulate).  The
+        # pipe that bounds them is the bf16 pipe, so the algorithmic fp32 FLOPs are priced against bf16 dense peak / 6; the fraction of
         # the fp32-MFMA peak (what the launch would be bounded by on v_mfma_f32_32x32x2_f32) is reported next to it.
         peak = BF16_MFMA_PEAK_TFLOPS / X6_TERMS
+        kname = ("ctts_gemm conv fwd on gemm_pl_kernel (pre-split bf16 operand planes, persistent stream-K, LDS-DMA; " if planes else
+                 "ctts_gemm conv fwd on gemm_x6_kernel (operands split inside the GEMM; ")
         extra = {"arithmetic": "fp32 in / out / accumulate; each product = 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands "
                                "(round-to-nearest pieces: dropped terms <= 2^-24 of a product = one fp32 rounding, 2^-29 in the median; exact on exactly "
-                               "representable data; error vs float64 as the fp32-MFMA kernels' on the same launches: tests/test_kernels_gpu.py, tests/test_bf16_split_cpu.py)",
+                               "representable data; error vs float64 as the fp32-MFMA kernels' on the same launches: tests/test_planes_gpu.py, "
+                               "tests/test_kernels_gpu.py, tests/test_bf16_split_cpu.py)",
                  "peak_definition": "2500 TFLOP/s dense bf16 MFMA / 6 terms", "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                  "executed_bf16_tflops": ach * X6_TERMS,
-                 "kernel": "ctts_gemm conv fwd on gemm_x6_kernel (decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments incl. padded-row skipping)"}
+                 "kernel": kname + "decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments incl. padded-row skipping)",
+                 "activation_split_launch_us": split_us}
     else:
         peak = FP32_MFMA_PEAK_TFLOPS
         extra = {"kernel": "ctts_gemm conv fwd (decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments incl. padded-row skipping)"}
+
+    def entry(t, kernel):
+        a = algo_flops / t / 1e12
+        return {"launch_us": t * 1e6, "achieved": a, "frac": a / peak, "frac_of_fp32_mfma_peak": a / FP32_MFMA_PEAK_TFLOPS, "kernel": kernel}
     out = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-           "traffic_source": traffic_src, "launch_us": dt * 1e6, "padded_tflops": padded_flops / dt / 1e12}
+           "traffic_source": traffic_src, "launch_us": dt * 1e6, "padded_tflops": padded_flops / dt / 1e12,
+           "algorithmic_bytes": 4.0 * (M * cin + cout * ks * cin + 2 * valid * cout),
+           "ffn_conv": {"fwd": entry(dt, "gemm_pl_kernel" if planes else ("gemm_x6_kernel" if bf16 else "gemm_sk_kernel")),
+                        "dgrad": entry(dt_d, "gemm_pl_kernel" if dplanes else "gemm_sk_kernel (fp32 MFMA)"),
+                        "wgrad": entry(dt_w, ("gemm_x6tn_kernel" if bf16 else "fp32 tile kernels") + f" + ordered split-K sum (split_k = {sk})"),
+                        "flops_each": algo_flops, "launches_per_step_each": 6}}
     out.update(extra)
     return out
 
@@ -301,10 +349,12 @@ def cpu_baseline(mode="full"):
     from ctts_amd.synthetic import C1_SRC_LENS
     phys = _physical_cores()
     runs = []
-    # (config, lengths, threads, timed steps, warm-up steps); the run that becomes the headline (C2 at 8 threads, the faster thread count on
-    # every host measured) gets a warm-up step and the median of 2 timed steps - the first step pays allocator / thread-pool start-up
-    plan = [("C2", None, 8, 2, 1)] if mode == "primary" else \
-           [("C1", C1_SRC_LENS, 8, 2, 1), ("C2", None, phys, 1, 0), ("C2", None, 8, 2, 1)]
+    # (config, lengths, threads, timed steps, warm-up steps); every run gets a warm-up step (the first step pays allocator / thread-pool
+    # start-up) and reports the MEDIAN of 3 timed steps: ~22 s for C2, ~5 s for C1
+    # (median of the timed steps; the n = physical-cores leg of round 4 - one cold step at 128 threads, slower than 8 threads
+    #  on every host: oversubscribing the small ops hurts - is dropped)
+    plan = [("C2", None, 8, 3, 1)] if mode == "primary" else \
+           [("C1", C1_SRC_LENS, 8, 3, 1), ("C2", None, 8, 3, 1)]
     for name, lens, nt, n_timed, warm in plan:
         sec, valid = _cpu_train_steps(lens, nt, n_timed, warm)
         runs.append({"config": name, "threads": nt, "valid_frames": valid, "s_per_step": sec, "frames_per_s": valid / sec,
@@ -398,6 +448,98 @@ def build_step(dev, rank, world, dataset, block, prosody, learn_alignment, batch
             step.graphs = step.g_opt = step.g_all = None
     return {"step": step, "mode": mode, "batch_cpu": batch_cpu, "collated": collated, "packed": packed,
             "valid_frames": valid_frames, "padded_frames": padded_frames, "shard_balance": balance}
+
+
+def _bf16_on():
+    from ctts_amd import kernels as _K
+    return _K.BF16_SPLIT >= 1
+
+
+FWD_FLOP_PER_FRAME = {"transformer_fs2": 629.1e9 / 11992, "conformer": 454.4e9 / 11968}      # SURVEY 8(d) forward FLOP of the canonical batch
+
+
+def measure_forward(dev, steps=10, warmup=3):
+    """Forward-only lines (SURVEY 8(d) "also report forward-only"; the inference call is synthesize.py:95-101): for fs2 and conformer
+    (a) the teacher-forced eval() forward of the canonical batch under torch.no_grad() - the fused flash-style attention pair and every
+    no-grad GEMM path - replayed from a hipGraph, and (b) the FREE-RUNNING inference branch (durations from the duration predictor, length
+    regulator, pitch / energy from their predictors: the branch holds a host-visible length, so it runs eagerly).  Random-init weights
+    predict ~0 frames per phoneme; for (b) the duration predictor's output bias is set to log(1 + 8) so that it predicts ~8 frames per
+    phoneme like the synthetic targets (stated in the line).  Returns secondary entries."""
+    import math
+    import ctts_amd
+    from ctts_amd.configs import get_configs
+    from ctts_amd.synthetic import make_batch, as_model_args
+    out = []
+    for block in ("transformer_fs2", "conformer"):
+        try:
+            pre, mc, tc = get_configs("LJSpeech")
+            mc["block_type"] = block
+            torch.manual_seed(1234)
+            model = ctts_amd.CompTransTTS(pre, mc, tc).to(dev).eval()
+            batch = make_batch(None, seed=1234, max_mel_cap=1000 if block == "conformer" else None)
+            args = [a.to(dev) if torch.is_tensor(a) else a for a in as_model_args(batch)]
+            args[7] = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in args[7].items()}
+            valid = int(batch["mel_lens"].sum())
+            fl = FWD_FLOP_PER_FRAME[block]
+
+            def tf():
+                a = list(args); a[7] = dict(a[7])
+                with torch.no_grad():
+                    return model(*a)
+            for _ in range(warmup):
+                tf()
+            torch.cuda.synchronize()
+            mode, run = "eager", tf
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    tf()
+                torch.cuda.current_stream().wait_stream(side)
+                mode, run = "hipgraph(forward)", g.replay
+            except Exception as e:                                # noqa: BLE001
+                print(f"[bench] forward-only {block}: capture failed ({type(e).__name__}: {e}); eager", file=sys.stderr)
+                torch.cuda.synchronize()
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / steps
+            out.append({"config": f"forward only, {block}: teacher-forced eval() forward of the canonical batch (B=16), torch.no_grad()",
+                        "value": valid / el, "unit": "mel-frames/s", "ms_per_step": el * 1e3, "steps": steps, "warmup": warmup,
+                        "valid_frames": valid, "launch_mode": mode, "dtype": "f32",
+                        "forward_frac_of_fp32_mfma_peak": valid / el * fl / 1e12 / FP32_MFMA_PEAK_TFLOPS})
+            # (b) free-running inference
+            with torch.no_grad():
+                model.variance_adaptor.duration_predictor.linear.bias.fill_(math.log(9.0))
+            free_args = args[:4]
+
+            def fr():
+                with torch.no_grad():
+                    return model(*free_args)
+            for _ in range(warmup):
+                o = fr()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                o = fr()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / steps
+            frames = int(o[9].sum())                          # mel_lens of the synthesised batch
+            out.append({"config": f"forward only, {block}: free-running inference (synthesize.py:95-101 call: no targets), B=16, duration-predictor "
+                                  "bias = log 9 (~8 frames per phoneme, random-init weights otherwise)",
+                        "value": frames / el, "unit": "mel-frames/s", "ms_per_step": el * 1e3, "steps": steps, "warmup": warmup,
+                        "valid_frames": frames, "launch_mode": "eager (data-dependent output length)", "dtype": "f32",
+                        "forward_frac_of_fp32_mfma_peak": frames / el * fl / 1e12 / FP32_MFMA_PEAK_TFLOPS})
+            del model
+        except Exception as e:                                    # noqa: BLE001
+            out.append({"config": f"forward only, {block}", "error": f"{type(e).__name__}: {e}"})
+        torch.cuda.empty_cache()
+    return out
 
 
 SECONDARY = [   # BASELINE configs[2..4] measured in the same invocation (N = 1 only), so that every claimed configuration is driver-run
@@ -548,6 +690,13 @@ def main():
                 "path": "collate-layout tuple -> PackedBatch (one pinned buffer) -> one async H2D on a copy stream (prefetch depth 2) -> "
                         "one D2D copy into the graph's static inputs"}
 
+    # world > 1: a few extra steps with per-bucket timing events (outside the timed region) so that a SCALE run explains itself
+    comm = None
+    if world > 1 and step.g_all is None and step.reducer.active:
+        step.reducer.start_timing()
+        for _ in range(min(5, a.steps)):
+            step()
+        comm = step.reducer.stop_timing()
     if rank == 0:
         headline = (a.batch == "canonical" and a.block == "transformer_fs2" and a.prosody == "none" and not a.learn_alignment
                     and a.dataset == "LJSpeech")
@@ -555,7 +704,7 @@ def main():
                 if (headline and not a.no_roofline) else None)
         # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
         step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
-        secondary = measure_secondary(dev) if (headline and world == 1 and not a.no_secondary) else None
+        secondary = (measure_secondary(dev) + measure_forward(dev)) if (headline and world == 1 and not a.no_secondary) else None
         cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.cpu_baseline)      # reported baseline: rank 0 at N = 1 only
         nb = len(batch_cpu["src_lens"])
         what = ("supervised durations, multi-speaker (per-GPU slice of BASELINE configs[3] = 64 utterances over 8 GPUs)"
@@ -574,12 +723,13 @@ def main():
                                     + "; full train step fwd+loss+bwd+clip+Adam, dropout on"),
                        "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
                        "parallelism": f"dp{world}", "final_loss": loss_final,
-                       "gemm_arithmetic": ("fp32 storage and accumulation everywhere; the large NT GEMMs (FFN / PostNet Conv1d forward) and the weight-gradient "
-                                           "GEMMs (TN) form each fp32 product from 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands "
-                                           "(gemm_x6_kernel / gemm_x6tn_kernel: exact on exactly representable data, dropped cross terms <= one fp32 "
-                                           "rounding per product); all other GEMMs on v_mfma_f32_32x32x2_f32"
-                                           if os.environ.get("CTTS_X6", "1") != "0" else "v_mfma_f32_32x32x2_f32 (CTTS_X6=0)"),
+                       "gemm_arithmetic": ("fp32 storage and accumulation everywhere; the large NT GEMMs (FFN / PostNet Conv1d forward and data gradient: "
+                                           "gemm_pl_kernel on pre-split operand planes) and the weight-gradient GEMMs (TN: gemm_x6tn_kernel) form each fp32 "
+                                           "product from 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands (exact on exactly representable "
+                                           "data, dropped cross terms <= one fp32 rounding per product); all other GEMMs on v_mfma_f32_32x32x2_f32"
+                                           if _bf16_on() else "v_mfma_f32_32x32x2_f32 (CTTS_X6=0)"),
                        "grad_buckets_bytes": step.reducer.bucket_bytes() if world > 1 else None,
+                       "communication": comm,
                        "strong_scaling_shard": built["shard_balance"]},
             "roofline": roof, "step_model_tflops_per_gpu": step_tflops,
             "step_frac_of_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,

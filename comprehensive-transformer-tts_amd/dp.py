@@ -184,13 +184,54 @@ class BucketedReducer:
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(ev)
-            self._reduce(s)
+            if self._timing is not None:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.comm)
+                self._reduce(s)
+                t1.record(self.comm)
+                self._timing["buckets"].append((s, t0, t1))
+            else:
+                self._reduce(s)
 
     def finish(self):
         assert self.launched == len(self.ranges), f"BucketedReducer: {self.launched} of {len(self.ranges)} stages were launched"
         self.launched = 0
         if self.comm is not None:
+            if self._timing is not None:
+                # exposed communication = how long the compute stream stalls here for the side stream (everything before this point ran
+                # under the backward stages): two events around the wait on the compute stream
+                cur = torch.cuda.current_stream()
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(cur)
+                cur.wait_stream(self.comm)
+                t1.record(cur)
+                self._timing["exposed"].append((t0, t1))
+                return
             torch.cuda.current_stream().wait_stream(self.comm)
+
+    # ---- per-bucket timing (bench.py --gpus N: the first real SCALE run should explain itself)
+    _timing = None
+
+    def start_timing(self):
+        """from now on every launch() / finish() is bracketed by timing events (eager collectives between stage replays only: the
+        whole-step graph of graph_collectives has no host-side launch points)"""
+        self._timing = {"buckets": [], "exposed": []}
+
+    def stop_timing(self):
+        """-> {"allreduce_ms_per_bucket": [...], "exposed_ms_per_step": x, "steps": n} averaged over the steps since start_timing();
+        synchronises the device"""
+        t, self._timing = self._timing, None
+        if not t or not t["exposed"]:
+            return None
+        torch.cuda.synchronize()
+        n = len(t["exposed"])
+        per = [0.0] * len(self.ranges)
+        for s, a, b in t["buckets"]:
+            per[s] += a.elapsed_time(b)
+        return {"allreduce_ms_per_bucket": [v / n for v in per], "bucket_bytes": self.bucket_bytes(),
+                "exposed_ms_per_step": sum(a.elapsed_time(b) for a, b in t["exposed"]) / n, "steps": n,
+                "note": "all-reduce time of a bucket is measured on the reducer's side stream (it overlaps the next backward stage); "
+                        "exposed = stall of the compute stream at the join in front of the optimizer"}
 
 
 class FlatAdam:

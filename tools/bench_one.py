@@ -16,9 +16,15 @@ elif which == "ffn1_step":      # the dominant kernel exactly as the train step 
     x = torch.randn(B, T, 256, device=dev); wf = torch.randn(1024, 2304, device=dev) * 0.02; C = torch.empty(B, T, 1024, device=dev)
     Z = torch.empty_like(C); bias = torch.zeros(1024, device=dev); seed = torch.zeros(1, dtype=torch.int64, device=dev)
     lens = torch.tensor([8 * v for v in CANONICAL_SRC_LENS], dtype=torch.int32, device=dev)
-    tmap = K.row_tile_map(lens, T, 0, M)
-    fn = lambda: K.gemm(x, wf, C, M, 1024, 2304, 256, 2304, 1024, True, True, conv=(T, 4, 256), alpha=9 ** -0.5, bias=bias, Z=Z, ldz=1024,
-                        act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1, row_lens=lens, row_T=T, row_halo=0, tile_map=tmap)
+    kw = dict(conv=(T, 4, 256), alpha=9 ** -0.5, bias=bias, Z=Z, ldz=1024, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1,
+              row_lens=lens, row_T=T, row_halo=0)
+    planes = {}
+    if K.BF16_SPLIT >= 1 and K.plane_shape_ok(M, 1024, 2304, 256):
+        ap, bp = K.split_planes([x.view(M, 256), wf])
+        if K.gemm_takes_planes(x, wf, C, M, 1024, 2304, 256, 2304, 1024, True, True, a_planes=ap, b_planes=bp, **kw):
+            planes = dict(a_planes=ap, b_planes=bp)
+    tmap = None if planes else K.row_tile_map(lens, T, 0, M)
+    fn = lambda: K.gemm(x, wf, C, M, 1024, 2304, 256, 2304, 1024, True, True, tile_map=tmap, **kw, **planes)
     fl = 2 * int(lens.sum()) * 1024 * 2304
 elif which == "dgrad":
     dz = torch.randn(M, 1024, device=dev); wd = torch.randn(256, 9216, device=dev); C = torch.empty(B, T, 256, device=dev)
