@@ -96,6 +96,7 @@ _SIGNATURES = {
     "ctts_embedding_fwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp],
     "ctts_embedding_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "ctts_positions": [_vp, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp],
+    "ctts_cwt_pitch": [_vp, _i64, C.c_int, _vp, _vp, _f32, _vp, C.c_int, _f32, _f32, _f32, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp, _vp],
     "ctts_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _u32, _vp, C.c_int, _vp, _vp, _vp, _vp],
     "ctts_colstats": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],

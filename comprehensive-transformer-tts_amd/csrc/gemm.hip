@@ -1350,7 +1350,8 @@ static bool gemm_x6tn_takes(const ctts_gemm_desc& d) {
   static const long min_wg = getenv("CTTS_X6_TN_MIN_WG") ? atol(getenv("CTTS_X6_TN_MIN_WG")) : 384;
   if (d.bf16_split < 1 || !tn || d.a_kc || d.b_kc || d.nb0 * d.nb1 != 1 || d.E || d.lens || d.epi_bwd) return false;
   if (d.M % 128 || d.N % 128 || d.K % BK || d.K < 2048) return false;
-  if (d.conv_T > 0 && (!d.conv_on_b || d.conv_T % BK || d.conv_cin % 4)) return false;
+  // (a thread stages 8 consecutive reduction rows starting at a multiple of 8: they stay inside one utterance when conv_T % 8 == 0)
+  if (d.conv_T > 0 && (!d.conv_on_b || d.conv_T % 8 || d.conv_cin % 4)) return false;
   if (d.bf16_split != 2 && (long)(d.M / 128) * (d.N / 128) * (d.split_k > 1 ? d.split_k : 1) < min_wg) return false;
   return vec_ok(d) && buf_ok(d);
 }

@@ -440,6 +440,25 @@ def positions(src, stride=1):
     return pos
 
 
+def cwt_pitch(spec, f0_mean, f0_std, std_scale, eps, mel_min, mel_max, f0_bin, uv=None, uv_chan=-1, nscale=10, width=None):
+    """include/ctts.h ctts_cwt_pitch: spec [B,T,C>=nscale] -> (f0 [B,width] float (log2 domain), f0_denorm [B,width] float, ids [B,width] int64)"""
+    spec = _f32c(spec, "cwt_pitch spec")
+    B, T, ld = spec.shape
+    width = T if width is None else int(width)
+    f0 = torch.empty(B, width, dtype=torch.float32, device=spec.device)
+    den = torch.empty_like(f0)
+    ids = torch.empty(B, width, dtype=torch.int64, device=spec.device)
+    if uv is not None:
+        uv = _f32c(uv if uv.dtype == torch.float32 else uv.float(), "cwt_pitch uv")
+        if tuple(uv.shape) != (B, width):
+            raise _lib.CttsError(f"cwt_pitch: uv has shape {tuple(uv.shape)}, expected {(B, width)}")
+    f0_mean, f0_std = _f32c(f0_mean.contiguous(), "f0_mean"), _f32c(f0_std.contiguous(), "f0_std")      # named: the copies must outlive the launch
+    _lib.check(_lib.load().ctts_cwt_pitch(_p(spec), ld, int(nscale), _p(f0_mean), _p(f0_std), float(std_scale),
+                                          _p(uv), int(uv_chan), float(eps), float(mel_min), float(mel_max), int(f0_bin), _p(f0), _p(den), _p(ids),
+                                          B, T, width, _stream()), "ctts_cwt_pitch")
+    return f0, den, ids
+
+
 def layernorm_fwd(x, gamma, beta, eps, p_drop=0.0, seed=None, drop_offset=0, rowscale=None):
     Cc = x.shape[-1]
     rows = x.numel() // Cc
@@ -595,8 +614,11 @@ def colsum(x2d, ld=None, scale=1.0, acc_into=None):
         _lib.check(lib.ctts_colsum(_p(x2d), None, rows, Cc, ld if ld is not None else Cc, 1.0, 1, None, _p(parts), _stream()), "ctts_colsum")
         sink.add(parts, nparts, Cc, Cc, out, scale)
         return out
-    _lib.check(lib.ctts_colsum(_p(x2d), _p(out), rows, Cc, ld if ld is not None else Cc, float(scale), int(acc_into is not None),
-                               _ws(x2d), None, _stream()), "ctts_colsum")
+    ldv = ld if ld is not None else Cc
+    CH = 65536                                   # the kernel's column-block limit (1024 blocks of 64): wider matrices go in column chunks
+    for c0 in range(0, Cc, CH):
+        _lib.check(lib.ctts_colsum(_p(x2d, c0), _p(out, c0), rows, min(CH, Cc - c0), ldv, float(scale), int(acc_into is not None),
+                                   _ws(x2d), None, _stream()), "ctts_colsum")
     return out
 
 

@@ -53,10 +53,22 @@ class CompTransTTSLoss(nn.Module):
         if not attn_logprob.is_cuda:
             raise _lib.CttsError("CompTransTTSLoss runs on the HIP device only (ForwardSum kernels, csrc/align.hip); got host tensors")
         from . import ops
-        # the alpha/beta recursions of all utterances in one launch each, no host round trip
-        per = ops.forward_sum_nll(attn_logprob[:, 0], in_lens, out_lens, blank_logprob)
-        per = torch.where(torch.isinf(per), torch.zeros_like(per), per)                # zero_infinity=True
-        return (per / in_lens.clamp(min=1).to(per.dtype)).sum() / B
+        def term():
+            # the alpha/beta recursions of all utterances in one launch each, no host round trip
+            per = ops.forward_sum_nll(attn_logprob[:, 0], in_lens, out_lens, blank_logprob)
+            per = torch.where(torch.isinf(per), torch.zeros_like(per), per)                # zero_infinity=True
+            return ops.sum_all(per / in_lens.clamp(min=1).to(per.dtype), 1.0 / B)          # ordered sum (no torch reduction on the captured path)
+        ev = ops.take_ready(attn_logprob)
+        if ev is None:
+            return term()
+        # 16 workgroups of latency chain: beside the decoder on a side stream forked where the aligner produced the log-probabilities
+        cur, side = torch.cuda.current_stream(), ops.side_stream(attn_logprob.device)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            out = term()
+        cur.wait_stream(side)
+        out.record_stream(cur)
+        return out
 
     @staticmethod
     def bin_loss(hard, soft):
@@ -108,8 +120,15 @@ class CompTransTTSLoss(nn.Module):
             # it averages |pp_tgt - pp_vec| over the PADDED phoneme positions (0/0 = NaN for a batch without padding).
             up_tgt, pp_tgt, up_vec, pp_vec, _ = prosody_info
             sel = src_masks.unsqueeze(-1).to(pp_vec.dtype)
-            prosody_loss = F.l1_loss(up_tgt, up_vec) + ((pp_tgt - pp_vec).abs() * sel).sum() / (sel.sum() * pp_vec.shape[-1])
-        total = mel_loss + postnet_mel_loss + ctc_loss + bin_loss + prosody_loss + zero
+            # both means through the ordered masked-loss kernel pair (csrc/loss.hip) on the difference: gradients reach target AND prediction
+            # like F.l1_loss's; sum(w |d|) / sum(w) with w = sel over all channels = ... / (sel.sum() * channels)
+            d_up, d_pp = up_tgt - up_vec, pp_tgt - pp_vec
+            prosody_loss = (ops.masked_loss(d_up, torch.zeros_like(d_up), torch.ones_like(d_up), "l1")
+                            + ops.masked_loss(d_pp, torch.zeros_like(d_pp), sel.expand_as(d_pp).contiguous(), "l1"))
+        # every term enters the sum with shape [1] (the reference's prosody_loss = zeros(1) makes the total [1]): adding 0-dim terms to a [1]
+        # tensor would make autograd sum_to_size every gradient - two torch reduce launches per step on the captured path
+        r1 = lambda v: v.reshape(1)                                                                      # noqa: E731
+        total = r1(mel_loss) + r1(postnet_mel_loss) + r1(ctc_loss) + r1(bin_loss) + r1(prosody_loss) + zero
         duration_loss = {"pdur": zero, "wdur": zero, "sdur": zero}
         # get_init_losses (loss.py:241-264): the keys follow pitch_type
         if self.pitch_type == "cwt":
@@ -148,16 +167,16 @@ class CompTransTTSLoss(nn.Module):
             elif self.use_energy_embed:      # frame level (loss.py:238-242): l1 over the frames of the utterances
                 energy_loss = ops.masked_loss(e_pred, energy_targets, (~mel_masks).float(), "l1")
             if fused_pitch and fused_energy:
-                total = total + t.sum()
+                total = total + ops.sum_all(t)
             else:                        # only the terms of the branches that exist (no host tensor here: the step is graph-captured)
-                total = total + t[0] + t[1] + t[2]
+                total = total + r1(t[0]) + r1(t[1]) + r1(t[2])
                 if fused_pitch:
-                    total = total + t[3] + t[4] + t[5] + t[6]
+                    total = total + r1(t[3]) + r1(t[4]) + r1(t[5]) + r1(t[6])
                 elif self.use_pitch_embed:
                     for v in pitch_loss.values():
-                        total = total + v
+                        total = total + r1(v)
                 if self.use_energy_embed:
-                    total = total + energy_loss
+                    total = total + r1(energy_loss)
         return (total, mel_loss, postnet_mel_loss, pitch_loss, energy_loss, duration_loss, ctc_loss, bin_loss, prosody_loss)
 
 

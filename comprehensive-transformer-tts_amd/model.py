@@ -140,7 +140,10 @@ def mask_aux(pad_mask, lens=None):
     if aux is None:
         valid = ~pad_mask
         nonpad = valid.to(torch.float32).reshape(-1).contiguous()
-        li = (lens if lens is not None else valid.sum(1)).to(torch.int32).contiguous()
+        if lens is None:         # row sums of the mask through the ordered column-sum kernel (no torch reduction on a captured path)
+            B_, T_ = pad_mask.shape
+            lens = K.colsum(nonpad.view(B_, T_).t().contiguous())
+        li = lens.to(torch.int32).contiguous()
         aux = (nonpad, li)
         try:
             pad_mask._ctts_aux = aux
@@ -388,8 +391,8 @@ class AlignmentEncoder(nn.Module):
     def forward(self, mel, text_emb, src_pad, attn_prior, speaker_embedding=None):
         """mel [B,Tm,80], text_emb [B,Ts,256], src_pad [B,Ts] bool, attn_prior [B,Tm,Ts] -> (soft, logprob) [B,1,Tm,Ts]"""
         if speaker_embedding is not None:     # the projected speaker vector is added to every key / query position (:1188-1194)
-            text_emb = text_emb + ops.linear(speaker_embedding, self.key_spk_proj.linear.weight).unsqueeze(1)
-            mel = mel + ops.linear(speaker_embedding, self.query_spk_proj.linear.weight).unsqueeze(1)
+            text_emb = ops.add_over_time(text_emb, ops.linear(speaker_embedding, self.key_spk_proj.linear.weight))
+            mel = ops.add_over_time(mel, ops.linear(speaker_embedding, self.query_spk_proj.linear.weight))
         kp, qp = self.key_proj, self.query_proj
         k0, k2 = getattr(kp, "0").conv, getattr(kp, "2").conv
         q0, q2, q4 = getattr(qp, "0").conv, getattr(qp, "2").conv, getattr(qp, "4").conv
@@ -401,6 +404,7 @@ class AlignmentEncoder(nn.Module):
         attn = ops.neg_sqdist(q, k, self.temperature)                                   # [B,Tm,Ts]
         attn = torch.log_softmax(attn, dim=-1) + torch.log(attn_prior + 1e-8)
         logprob = attn
+        ops.mark_ready(logprob)               # the CTC forward-sum loss may start from here, beside the decoder (ops.mark_ready)
         soft = torch.softmax(attn.masked_fill(src_pad[:, None, :], float("-inf")), dim=-1)
         return soft.unsqueeze(1), logprob.unsqueeze(1)
 
@@ -424,11 +428,18 @@ def phoneme_level_pitch(f0_frame, mel2ph, mel_lens, n_phones):
     points at the phoneme (1-based; only the first mel_len frames count), 0-frame phonemes get 0 - as a one-hot contraction in fp64
     on the device (the reference scatter_adds per utterance on the host)."""
     B, Tm = f0_frame.shape
-    valid = torch.arange(Tm, device=f0_frame.device)[None, :] < mel_lens[:, None]
-    ids = torch.arange(1, n_phones + 1, device=f0_frame.device)
-    hot = ((mel2ph[:, :Tm, None] == ids[None, None, :]) & valid[:, :, None]).double()          # [B,Tm,Ts]
-    tot = (hot * f0_frame.double()[:, :, None]).sum(1)
-    cnt = hot.sum(1).clamp(min=1)
+    dev = f0_frame.device
+    valid = torch.arange(Tm, device=dev)[None, :] < mel_lens[:, None]
+    # mel2ph is non-decreasing over an utterance's frames (the length regulator's contiguous runs): the frames of phoneme p are
+    # [first index with mel2ph >= p, first index with mel2ph > p) - two binary searches per phoneme and a prefix-sum difference in fp64
+    # instead of a [B, Tm, Ts] one-hot contraction (whose .sum(1) was a stock-torch reduction on the captured path)
+    keys = torch.where(valid, mel2ph[:, :Tm].long(), torch.full_like(mel2ph[:, :Tm].long(), n_phones + 1)).contiguous()
+    ids = torch.arange(1, n_phones + 1, device=dev)[None, :].expand(B, n_phones).contiguous()
+    lo = torch.searchsorted(keys, ids, right=False)
+    hi = torch.searchsorted(keys, ids, right=True)
+    cs = torch.cat([f0_frame.new_zeros(B, 1, dtype=torch.float64), f0_frame.double().cumsum(1)], 1)
+    tot = cs.gather(1, hi) - cs.gather(1, lo)
+    cnt = (hi - lo).clamp(min=1).double()
     return (tot / cnt).float()
 
 
@@ -537,7 +548,7 @@ class VarianceAdaptor(nn.Module):
             pp_emb, pp_attn = pe.head(x, src_len.to(torch.int32), src_nonpad, mel_len.to(torch.int32), mem_p)
         up_vec = self.utterance_prosody_predictor(x)
         u = up_emb if self.training else up_vec
-        x = x + ops.linear(u, self.utterance_prosody_prj.weight, self.utterance_prosody_prj.bias)      # [N,1,H] broadcast over Ts
+        x = ops.add_over_time(x, ops.linear(u, self.utterance_prosody_prj.weight, self.utterance_prosody_prj.bias))      # [N,1,H] broadcast over Ts
         pp_vec = self.phoneme_prosody_predictor(x)
         pp = pp_emb if self.training else pp_vec
         x = ops.linear(pp, self.phoneme_prosody_prj.weight, self.phoneme_prosody_prj.bias, residual=x)
@@ -548,7 +559,7 @@ class VarianceAdaptor(nn.Module):
                 p_control=1.0, e_control=1.0, d_control=1.0, step=None):
         x = text
         if speaker_embedding is not None:
-            x = x + speaker_embedding.unsqueeze(1)
+            x = ops.add_over_time(x, speaker_embedding)
         prosody_info = None
         if self.model_type == "liu2021":
             x, prosody_info = self._liu2021(x, src_len, src_mask, mel, mel_len, mel_mask)
@@ -590,18 +601,26 @@ class VarianceAdaptor(nn.Module):
             f0_mean, f0_std = stats[:, 0], stats[:, 1]
             eps = self.pitch_cfg["pitch_norm_eps"]
             with torch.no_grad():
+                # inverse CWT -> normalisation -> f0 -> 2 ** f0 with the uv mask -> f0_to_coarse: ONE launch (csrc/pitch.hip) instead of
+                # ~25 stock-torch ones incl. the multi-block mean / std reductions (cwt2f0_norm / f0_to_coarse above are the same
+                # arithmetic op by op: the CPU tests and tests/test_kernels_gpu.py compare the kernel with them)
+                pk = dict(eps=eps, mel_min=F0_MEL_MIN, mel_max=F0_MEL_MAX, f0_bin=F0_BIN)
                 if pitch_target is not None:
                     mel2ph = pitch_target["mel2ph"]
-                    pitch_target["f0"] = cwt2f0_norm(pitch_target["cwt_spec"], pitch_target["f0_mean"], pitch_target["f0_std"],
-                                                     mel2ph.shape[1], eps)
+                    f0, f0_denorm, pitch_ids = K.cwt_pitch(pitch_target["cwt_spec"], pitch_target["f0_mean"], pitch_target["f0_std"], 1.0,
+                                                           uv=pitch_target["uv"], width=mel2ph.shape[1], **pk)
+                    pitch_target["f0"] = f0
                     pitch_target.update({"f0_cwt": pitch_target["f0"]})
-                    f0, uv = pitch_target["f0"], pitch_target["uv"]
                 else:
-                    f0 = cwt2f0_norm(cwt[:, :, :10], f0_mean, f0_std * self.cwt_std_scale, mel2ph.shape[1], eps)
-                    uv = cwt[:, :, -1] > 0
-                f0_denorm = 2 ** f0
-                f0_denorm = torch.where(uv > 0, torch.zeros_like(f0_denorm), f0_denorm)
-                pitch_ids = f0_to_coarse(f0_denorm)
+                    w = mel2ph.shape[1]
+                    if w == cwt.shape[1]:
+                        f0, f0_denorm, pitch_ids = K.cwt_pitch(cwt, f0_mean, f0_std, self.cwt_std_scale, uv_chan=cwt.shape[-1] - 1,
+                                                               nscale=cwt.shape[-1] - 1, **pk)
+                    else:                    # the reference repeats the last f0 column up to mel2ph's width; uv is then indexed at that width too
+                        uvf = (cwt[:, :, -1] > 0).float()
+                        uvf = torch.cat([uvf] + [uvf[:, -1:]] * (w - uvf.shape[1]), 1).contiguous()
+                        f0, f0_denorm, pitch_ids = K.cwt_pitch(cwt, f0_mean, f0_std, self.cwt_std_scale, uv=uvf,
+                                                               nscale=cwt.shape[-1] - 1, width=w, **pk)
             pitch_embedding = ops.embedding(pitch_ids, self.pitch_embed.weight, 0)
             pitch_prediction = {"pitch_pred": None, "f0_denorm": f0_denorm, "cwt": cwt, "f0_mean": f0_mean, "f0_std": f0_std}
             out = out + pitch_embedding
@@ -638,7 +657,9 @@ class VarianceAdaptor(nn.Module):
                     f0 = pitch_target["f0"]
                 else:
                     f0 = pitch_pred[:, :, 0]
-                all_pad = x_org.sum().abs() == 0                       # modules.py:895 (a 0-dim flag, never a sync here)
+                # modules.py:895 `encoder_out.sum().abs() == 0` (a flag, never a sync here) through the ordered sum kernel: torch's
+                # multi-block reduction over 0.5 M elements is the kind of launch that mis-replays under hipGraph
+                all_pad = ops.sum_all(x_org).abs().reshape(()) == 0
                 f0_denorm = denorm_f0(f0, None, self.pitch_cfg, pitch_padding=all_pad)
                 ph_ids = F.pad(f0_to_coarse(f0_denorm), [1, 0])
                 pitch_ids = torch.gather(ph_ids, 1, mel2ph.long())

@@ -1053,7 +1053,7 @@ class _RelPosAttention(torch.autograd.Function):
         K.gemm(dPS, pos, dqv, T, dh, T, T, C, C, True, False, nb0=B, nb1=H, sA=sS, sB=(0, dh), sC=(T * C, dh))
         dpos_b = torch.empty(B, T, C, dtype=torch.float32, device=qu.device)
         K.gemm(dPS, qv, dpos_b, T, dh, T, T, C, C, False, False, nb0=B, nb1=H, sA=sS, sB=(T * C, dh), sC=(T * C, dh))
-        dpos = dpos_b.sum(0)
+        dpos = K.colsum(dpos_b.view(dpos_b.shape[0], -1)).view(dpos_b.shape[1:])          # ordered sum over the batch (no torch reduction)
         return dqu, dqv, dkv, dpos, None, None, None, None, None
 
 
@@ -1076,7 +1076,7 @@ class _FusedRelPosAttention(torch.autograd.Function):
         qu, qv, kv, pos, out, lse, seed = ctx.saved_tensors
         H, scale, p_drop, drop_offset = ctx.cfg
         dqu, dqv, dkv, dpos_b = K.relmha_bwd(qu, qv, kv, pos, out, dO.contiguous(), lse, H, scale, p_drop, seed, drop_offset)
-        return dqu, dqv, dkv, dpos_b.sum(0), None, None, None, None, None
+        return dqu, dqv, dkv, K.colsum(dpos_b.view(dpos_b.shape[0], -1)).view(dpos_b.shape[1:]), None, None, None, None, None
 
 
 class _RelAttnSplit(torch.autograd.Function):
@@ -1168,13 +1168,23 @@ class _NegSqDist(torch.autograd.Function):
         q, k = ctx.saved_tensors
         g = g.contiguous()
         t2 = -2.0 * ctx.temp
-        # d/dq = -2 temp (q * rowsum(g) - g k);   d/dk = -2 temp (k * colsum(g) - g^T q)
-        dq = t2 * (q * g.sum(2, keepdim=True) - bmm_nn(g, k))
-        gtq = torch.empty_like(k)
+        # d/dq = -2 temp (q * rowsum(g) - g k);   d/dk = -2 temp (k * colsum(g) - g^T q).  The two sums of g ride in the GEMMs that read g
+        # anyway: a ones column appended to k / q (padded to a multiple of four columns) makes the last used output column rowsum(g) /
+        # colsum(g) - no stock-torch reduction over the [B, Tq, Tk] gradient on the captured path
         B, Tq, Tk = g.shape
         Cc = q.shape[2]
-        K.gemm(g, q, gtq, Tk, Cc, Tq, Tk, Cc, Cc, False, False, nb0=B, nb1=1, sA=(Tq * Tk, 0), sB=(Tq * Cc, 0), sC=(Tk * Cc, 0))
-        dk = t2 * (k * g.sum(1).unsqueeze(-1) - gtq)
+        C1 = (Cc + 1 + 3) // 4 * 4
+
+        def with_ones(x):
+            out = x.new_zeros(x.shape[0], x.shape[1], C1)
+            out[:, :, :Cc] = x
+            out[:, :, Cc] = 1.0
+            return out
+        gk = bmm_nn(g, with_ones(k))                                  # [B, Tq, C1]: g k | rowsum(g)
+        dq = t2 * (q * gk[:, :, Cc:Cc + 1] - gk[:, :, :Cc])
+        gtq = torch.empty(B, Tk, C1, dtype=torch.float32, device=g.device)
+        K.gemm(g, with_ones(q), gtq, Tk, C1, Tq, Tk, C1, C1, False, False, nb0=B, nb1=1, sA=(Tq * Tk, 0), sB=(Tq * C1, 0), sC=(Tk * C1, 0))
+        dk = t2 * (k * gtq[:, :, Cc:Cc + 1] - gtq[:, :, :Cc])
         return dq, dk, None
 
 
@@ -1412,6 +1422,86 @@ def variance_losses(log_d, cwt, f0_mean, f0_std, e_pred, dur, texts, src_pad, cw
     """-> tensor [8] = (pdur, wdur, sdur, C, uv, f0_mean, f0_std, energy), lambda-weighted (model/loss.py:123-243)"""
     return _VarLoss.apply(log_d, cwt, f0_mean, f0_std, e_pred, dur, texts, src_pad, cwt_spec, uv, mel_pad, f0_mean_t, f0_std_t, e_tgt,
                           lambdas_t, cwt_l2, sil_t)
+
+
+# ---- low-occupancy work beside the main stream -----------------------------------------------------------------------------------------
+# A few kernels of the unsupervised-duration configuration are latency chains on 16 workgroups (one per utterance: the CTC forward-sum
+# recursion 0.55 ms forward + 0.39 ms backward on 256 CUs' worth of chip) whose result nothing needs until the total loss is formed.
+# `mark_ready(t)` records an event right after `t` was produced; the consumer forks a side stream from THAT event (not from the main
+# stream's tail: the decoder is already enqueued by then), so the chain runs beside the decoder - as a graph dependency under hipGraph
+# capture, by the host running ahead in eager mode - and autograd runs its backward on the same side stream, beside the PostNet / decoder
+# backward.  CTTS_SIDE_LOSS=0 switches it off (A/B).
+_READY = {}
+_SIDE = {}
+SIDE_LOSS = _os.environ.get("CTTS_SIDE_LOSS", "1") != "0"
+
+
+def mark_ready(t):
+    if SIDE_LOSS and t.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record()
+        _READY.clear()                       # one pending marker at a time (a stale entry would pin an event of an earlier step)
+        _READY[t.data_ptr()] = ev
+
+
+def take_ready(t):
+    return _READY.pop(t.data_ptr(), None) if t.is_cuda else None
+
+
+def side_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(idx)
+    if st is None:
+        st = _SIDE[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
+class _AddOverTime(torch.autograd.Function):
+    """x [B,T,C] + v [B,1,C] broadcast over T (speaker / utterance-prosody embeddings added to every position: modules.py:1008,1027,
+    CompTransTTS.py:101).  Forward is the plain broadcast add; the backward's sum over T - a stock-torch reduction when autograd does
+    it - is one batched [1,T] x [T,C] product on ctts_gemm (fixed summation order)."""
+
+    @staticmethod
+    def forward(ctx, x, v):
+        ctx.T = x.shape[1]
+        return x + v
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, T, Cc = g.shape
+        dv = None
+        if ctx.needs_input_grad[1]:
+            ones = torch.ones(B, 1, T, dtype=torch.float32, device=g.device)
+            dv = torch.empty(B, 1, Cc, dtype=torch.float32, device=g.device)
+            K.gemm(ones, g, dv, 1, Cc, T, T, Cc, Cc, True, False, nb0=B, nb1=1, sA=(T, 0), sB=(T * Cc, 0), sC=(Cc, 0))
+        return (g if ctx.needs_input_grad[0] else None), dv
+
+
+def add_over_time(x, v):
+    """x [B,T,C] + v [B,1,C] (v may also be [B,C])"""
+    if v.dim() == 2:
+        v = v.unsqueeze(1)
+    return _AddOverTime.apply(x, v)
+
+
+class _SumAll(torch.autograd.Function):
+    """scale * sum of all elements -> shape [1], through the ordered column-sum kernel (csrc/elementwise.hip): the handful of scalar
+    reductions of the loss glue (sum of the eight variance terms, mean over utterances of the CTC term, the `ph` variant's all-padding
+    flag) without torch's reduce_kernel - none of which may sit on a captured path"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.shape, ctx.scale = x.shape, float(scale)
+        return K.colsum(x.contiguous().view(-1, 1), scale=float(scale))
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.reshape(1) * ctx.scale).expand(ctx.shape), None
+
+
+def sum_all(x, scale=1.0):
+    return _SumAll.apply(x, scale)
 
 
 class _MaskedLoss(torch.autograd.Function):

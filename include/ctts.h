@@ -231,6 +231,17 @@ int ctts_lr_index(const void* dur, int dur_is_float, int round_mode, const uint8
 int ctts_lr_gather_fwd(const float* x, const int32_t* mel2ph, float* out, int B, int Ts, int Tm, int C, void* stream);
 int ctts_lr_gather_bwd(const float* dy, const int32_t* cum, float* dx, int B, int Ts, int Tm, int C, void* stream);
 
+/* Target-side pitch chain of the cwt pitch branch in ONE launch (csrc/pitch.hip; utils/pitch_tools.py:27-36 f0_to_coarse, :258-294 inverse_cwt_torch /
+ * cwt2f0 / cwt2f0_norm with pitch_norm "log", and the denormalisation of modules.py:1071-1091): per utterance b
+ *   rec[t] = sum_{j < nscale} spec[b,t,j] * (j + 3.5)^-2.5;  rec = (rec - mean_t rec) / std_t rec  (unbiased, over all T columns);
+ *   f0[b,t] = log2(exp(rec * f0_std[b] * std_scale + f0_mean[b]) + eps)  (columns T .. width-1 repeat column T-1);
+ *   f0_denorm = unvoiced ? 0 : 2^f0;   ids = f0_to_coarse(f0_denorm) in [1, f0_bin - 1]  (mel_min / mel_max = 1127 ln(1 + f / 700) at 50 / 1100 Hz).
+ * spec [B,T,ld_spec]; unvoiced = uv[b,t] > 0 (uv float [B,width]) or, with uv NULL, spec[b,t,uv_chan] > 0 (the predictor's uv logit).
+ * Outputs f0, f0_denorm [B,width] float, ids [B,width] int64.  Deterministic (ordered two-pass sums in double), no atomics, no memset. */
+int ctts_cwt_pitch(const float* spec, int64_t ld_spec, int nscale, const float* f0_mean, const float* f0_std, float std_scale,
+                   const float* uv, int uv_chan, float eps, float mel_min, float mel_max, int f0_bin, float* f0, float* f0_denorm,
+                   int64_t* ids, int B, int T, int width, void* stream);
+
 /* make_positions (utils/tools.py:640-652): pos = cumsum(x != 0) * (x != 0) along T.
  * src is float32 (stride `stride` elements between time steps, e.g. channel 0 of [B,T,C]) or int64 tokens. */
 int ctts_positions(const void* src, int src_is_float, int64_t stride, int B, int T, int32_t* pos, void* stream);

@@ -1348,13 +1348,14 @@ def test_bf16_split_gemm_conv_view_ragged_rows_and_epilogues_equal_the_fp32_kern
         assert float((z6 - z32).abs().max()) <= 2e-5 and (z6 == 0).eq(z32 == 0).all()
 
 
-@pytest.mark.parametrize("conv,split,ragged", [(False, 1, False), (False, 4, True), (True, 4, True), (True, 1, False)])
-def test_bf16_split_weight_gradient_gemm_vs_fp64_and_the_fp32_kernels(conv, split, ragged):
+@pytest.mark.parametrize("conv,split,ragged,T", [(False, 1, False, 512), (False, 4, True, 512), (True, 4, True, 512), (True, 1, False, 512),
+                                                 (True, 4, False, 1000)])       # T = 1000: the conformer's decoder length (not a multiple of 32)
+def test_bf16_split_weight_gradient_gemm_vs_fp64_and_the_fp32_kernels(conv, split, ragged, T):
     """gemm_x6tn_kernel (TN layout: dW[m][n] = sum_k dZ[k][m] X[k][n], optional im2col view on X, K-blocks in padding skipped, ordered
     split-K partials): exact on integer data, against float64 not worse than the fp32-MFMA kernels on the same launch, bit-reproducible."""
     if os.environ.get("CTTS_X6_TN", "1") == "0":
         pytest.skip("CTTS_X6_TN=0")
-    B_, T, Cin, ks, Mo = 8, 512, 128, 3 if conv else 1, 512
+    B_, Cin, ks, Mo = 8, 128, 3 if conv else 1, 512
     Kred, No = B_ * T, ks * Cin
     lens = torch.tensor([512, 200, 129, 64, 330, 1, 448, 385], dtype=torch.int32, device=DEV)
     valid = (torch.arange(T, device=DEV)[None, :] < lens[:, None]).float().reshape(-1, 1) if ragged else 1.0

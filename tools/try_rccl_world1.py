@@ -75,8 +75,15 @@ def main():
         except Exception as e:                             # noqa: BLE001
             print(f"{mode:20s} FAILED: {type(e).__name__}: {str(e)[:300]}")
             ok = False
-    dist.destroy_process_group()
-    sys.exit(0 if ok else 1)
+    sys.stdout.flush()
+    try:
+        dist.destroy_process_group()
+    except Exception as e:                                 # noqa: BLE001
+        print(f"destroy_process_group: {type(e).__name__}: {e}")
+    sys.stdout.flush()
+    # leave without the interpreter's teardown: RCCL's finalisers abort once in a while on this stack AFTER everything was compared and
+    # printed (one of six runs of the round-5 suite returned non-zero with all three modes identical) - the verdict is `ok`, not the exit path
+    os._exit(0 if ok else 1)
 
 
 if __name__ == "__main__":
