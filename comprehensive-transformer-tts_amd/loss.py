@@ -46,7 +46,7 @@ class CompTransTTSLoss(nn.Module):
         self._cwt_l2 = int(lc.get("cwt_loss", "l1") == "l2")
 
     @staticmethod
-    def forward_sum_loss(attn_logprob, in_lens, out_lens, blank_logprob=-1.0):
+    def forward_sum_loss(attn_logprob, in_lens, out_lens, blank_logprob=-1.0, static_lens=None):
         """ForwardSumLoss (loss.py:350-377): mean over utterances of the CTC negative log-likelihood of the text sequence (per token),
         the log-softmax taken over [blank, first key_len tokens] - all utterances in one launch on the device."""
         B = attn_logprob.shape[0]
@@ -61,14 +61,15 @@ class CompTransTTSLoss(nn.Module):
         ev = ops.take_ready(attn_logprob)
         if ev is None:
             return term()
-        # 16 workgroups of latency chain: beside the decoder on a side stream forked where the aligner produced the log-probabilities
-        cur, side = torch.cuda.current_stream(), ops.side_stream(attn_logprob.device)
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            out = term()
-        cur.wait_stream(side)
-        out.record_stream(cur)
-        return out
+        # 16 workgroups of latency chain, forward AND backward recursion: beside the decoder on a side stream forked where the aligner
+        # produced the log-probabilities (ops._ForwardSumLossSide).  The branch only sees what existed at the fork: the lengths must be the
+        # batch's own src_lens / mel_lens (step inputs), not the model's returned mel_lens - in training the same numbers (the MAS durations
+        # of an utterance sum to its mel length), but a tensor the length regulator produces AFTER the fork (under hipGraph replay the
+        # branch read it before it was written: nll = inf for every utterance)
+        if static_lens is None:
+            torch.cuda.current_stream().wait_stream(ev)
+            return term()
+        return ops.forward_sum_loss_beside(attn_logprob[:, 0], static_lens[0], static_lens[1], blank_logprob, ev)
 
     @staticmethod
     def bin_loss(hard, soft):
@@ -95,7 +96,7 @@ class CompTransTTSLoss(nn.Module):
         return out
 
     def forward(self, inputs, predictions, step):
-        (texts, _, _, mel_targets, _, _, pitch_targets, energy_targets, duration_targets, _, _) = inputs[3:]
+        (texts, in_src_lens, _, mel_targets, in_mel_lens, _, pitch_targets, energy_targets, duration_targets, _, _) = inputs[3:]
         (mel_pred, post_pred, p_pred, e_pred, log_d, _, src_masks, mel_masks, src_lens, mel_lens, attn_outs, prosody_info) = predictions
         mel_targets = mel_targets[:, : mel_masks.shape[1], :]
         if not mel_pred.is_cuda:
@@ -108,7 +109,8 @@ class CompTransTTSLoss(nn.Module):
         if self.learn_alignment:
             attn_soft, attn_hard, attn_hard_dur, attn_logprob = attn_outs
             duration_targets = attn_hard_dur
-            ctc_loss = self.forward_sum_loss(attn_logprob, src_lens, mel_lens)
+            ctc_loss = self.forward_sum_loss(attn_logprob, src_lens, mel_lens,
+                                             static_lens=(in_src_lens, in_mel_lens) if (torch.is_tensor(in_src_lens) and torch.is_tensor(in_mel_lens)) else None)
             if step < self.binarization_loss_enable_steps:
                 w = 0.0
             else:

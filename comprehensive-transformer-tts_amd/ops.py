@@ -1344,6 +1344,42 @@ class _ForwardSum(torch.autograd.Function):
         return K.forward_sum_bwd(a, in32, out32, ctx.blank, lse, alpha, nll, g.contiguous()), None, None, None
 
 
+class _ForwardSumLossSide(torch.autograd.Function):
+    """mean over utterances of nll_b / K_b (infinite terms zeroed: ForwardSumLoss, loss.py:350-377) with BOTH recursions - the alpha pass
+    and the beta pass that yields d loss / d attn_logprob - run inside the FORWARD on the side stream `side`, forked (ops.mark_ready)
+    where the aligner produced the log-probabilities: two latency chains of 16 workgroups (0.55 + 0.39 ms) beside the decoder instead
+    of in front of the loss and at the head of the backward.  The backward is one multiply on the caller's stream (the loss is linear
+    in the upstream gradient), so autograd never crosses streams."""
+
+    @staticmethod
+    def forward(ctx, attn_logprob, in_lens, out_lens, blank, side):
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(side):
+            a = attn_logprob.contiguous()
+            B = a.shape[0]
+            in32, out32 = in_lens.to(torch.int32).contiguous(), out_lens.to(torch.int32).contiguous()
+            nll, lse, alpha = K.forward_sum_fwd(a, in32, out32, blank)
+            finite = ~torch.isinf(nll)                                                  # zero_infinity=True
+            kf = in_lens.clamp(min=1).to(torch.float32)
+            w = finite.to(torch.float32) / (kf * B)
+            loss = K.colsum((torch.where(finite, nll, torch.zeros_like(nll)) / kf).view(-1, 1), scale=1.0 / B)    # ordered sum -> [1]
+            grad_unit = K.forward_sum_bwd(a, in32, out32, blank, lse, alpha, nll, w.contiguous())     # d loss / d attn_logprob
+        cur.wait_stream(side)
+        for t in (loss, grad_unit, a):
+            t.record_stream(cur)
+        ctx.save_for_backward(grad_unit)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad_unit,) = ctx.saved_tensors
+        return grad_unit * g.reshape(()), None, None, None, None
+
+
+def forward_sum_loss_beside(attn_logprob, in_lens, out_lens, blank_logprob, ready):
+    return _ForwardSumLossSide.apply(attn_logprob, in_lens, out_lens, float(blank_logprob), ready)
+
+
 def forward_sum_nll(attn_logprob, in_lens, out_lens, blank_logprob=-1.0):
     """attn_logprob [B,Tm,Ts] (device) -> nll [B]: -log p(1..K_b | frames) with a blank of log-prob `blank_logprob` prepended
     to every frame's logits and the log-softmax taken over [blank, first K_b tokens]."""
@@ -1426,26 +1462,31 @@ def variance_losses(log_d, cwt, f0_mean, f0_std, e_pred, dur, texts, src_pad, cw
 
 # ---- low-occupancy work beside the main stream -----------------------------------------------------------------------------------------
 # A few kernels of the unsupervised-duration configuration are latency chains on 16 workgroups (one per utterance: the CTC forward-sum
-# recursion 0.55 ms forward + 0.39 ms backward on 256 CUs' worth of chip) whose result nothing needs until the total loss is formed.
-# `mark_ready(t)` records an event right after `t` was produced; the consumer forks a side stream from THAT event (not from the main
-# stream's tail: the decoder is already enqueued by then), so the chain runs beside the decoder - as a graph dependency under hipGraph
-# capture, by the host running ahead in eager mode - and autograd runs its backward on the same side stream, beside the PostNet / decoder
-# backward.  CTTS_SIDE_LOSS=0 switches it off (A/B).
+# recursions, 0.55 ms forward + 0.39 ms backward on 256 CUs' worth of chip) whose result nothing needs until the total loss is formed.
+# `mark_ready(t)` FORKS a side stream at the point where `t` was produced (record + wait back to back: an event recorded earlier and
+# waited for later lost its dependency under hipGraph capture on this stack - the replayed CTC term read half-written log-probabilities),
+# the consumer (`take_ready`) launches its chain on that stream - beside the decoder, as a graph branch under capture, by the host running
+# ahead in eager mode - and joins before the total loss is formed.  Only while a caller that is known to consume the marker has switched it
+# on (`side_loss_scope`, trainer.TrainStep): a fork nobody joins would invalidate a capture.  CTTS_SIDE_LOSS=0 switches it off (A/B).
 _READY = {}
 _SIDE = {}
 SIDE_LOSS = _os.environ.get("CTTS_SIDE_LOSS", "1") != "0"
+_SIDE_ACTIVE = [False]
 
 
-def mark_ready(t):
-    if SIDE_LOSS and t.is_cuda:
-        ev = torch.cuda.Event()
-        ev.record()
-        _READY.clear()                       # one pending marker at a time (a stale entry would pin an event of an earlier step)
-        _READY[t.data_ptr()] = ev
+class side_loss_scope:
+    """with side_loss_scope(): model forward + loss.  Leaves no unjoined fork behind."""
 
+    def __enter__(self):
+        self.prev, _SIDE_ACTIVE[0] = _SIDE_ACTIVE[0], SIDE_LOSS
+        return self
 
-def take_ready(t):
-    return _READY.pop(t.data_ptr(), None) if t.is_cuda else None
+    def __exit__(self, *exc):
+        _SIDE_ACTIVE[0] = self.prev
+        for side in _READY.values():             # a marker nobody consumed (e.g. the loss skipped the term): join its fork
+            torch.cuda.current_stream().wait_stream(side)
+        _READY.clear()
+        return False
 
 
 def side_stream(device):
@@ -1454,6 +1495,18 @@ def side_stream(device):
     if st is None:
         st = _SIDE[idx] = torch.cuda.Stream(device=device)
     return st
+
+
+def mark_ready(t):
+    if _SIDE_ACTIVE[0] and t.is_cuda and not _READY:
+        side = side_stream(t.device)
+        side.wait_stream(torch.cuda.current_stream())
+        _READY[t.data_ptr()] = side
+
+
+def take_ready(t):
+    """the side stream forked where `t` was produced, or None"""
+    return _READY.pop(t.data_ptr(), None) if t.is_cuda else None
 
 
 class _AddOverTime(torch.autograd.Function):

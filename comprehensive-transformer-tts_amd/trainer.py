@@ -78,10 +78,11 @@ class TrainStep:
         args = list(self.args)
         if isinstance(args[7], dict):
             args[7] = dict(args[7])                     # the model mutates p_targets like the reference does
-        out = self.model(*args, step=self.step_no)
-        inputs = list(self.loss_inputs)
-        inputs[9:11] = out[-2:]
-        losses = self.loss_fn(inputs, out[:-2], self.step_no)
+        with ops.side_loss_scope():                       # the CTC forward-sum term may run beside the decoder (ops.mark_ready)
+            out = self.model(*args, step=self.step_no)
+            inputs = list(self.loss_inputs)
+            inputs[9:11] = out[-2:]
+            losses = self.loss_fn(inputs, out[:-2], self.step_no)
         self.loss_val = losses[0].detach()
         self.loss_terms = losses                        # the reference's 9-tuple (train.py:127-137 logs it), graph-resident under replay
         return losses[0]
