@@ -152,6 +152,13 @@ __device__ __forceinline__ bool ctts_arrive_last(unsigned* ticket, unsigned coun
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
+    // The ticket is RELAXED on purpose (ADVICE r04 asked for a release here).  What a release would add on gfx950 is `buffer_wbl2 sc1` +
+    // `s_waitcnt vmcnt(0)`: a write-back of the XCD's L2.  The partials above do not live in L2 - they were stored with sc1 (write-through,
+    // agent scope: ctts_st_agent) and every wave has drained them (`s_waitcnt vmcnt(0)`) before the barrier in front of this line, which
+    // is exactly the state a release would establish; the last workgroup pairs it with an acquire fence (L1 invalidate) and sc1 loads.
+    // Measured with __ATOMIC_RELEASE on this fetch_add (round 5, same box, driver-style bench): fs2 19.33 -> 19.67 ms, C5 30.2 -> 30.8 ms,
+    // fp32-only fs2 23.19 -> 23.43 ms - ~1.7 us of L2 write-back per workgroup of ~150 reduction launches per step, for no change in
+    // the bits (tests/test_determinism_gpu.py).  The bounded-spin / error-word hand-off of the GEMMs follows the same scheme.
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = t == count - 1;
     if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

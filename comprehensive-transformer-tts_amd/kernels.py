@@ -184,7 +184,12 @@ class PartialSink:
         self.pending = 0
 
     def add(self, src, count, stride, n, dst, alpha, src_off=0, dst_off=0):
-        self.tasks.append((src.data_ptr() + 4 * int(src_off), dst.data_ptr() + 4 * int(dst_off), int(n), int(stride), int(count), float(alpha)))
+        d0 = dst.data_ptr() + 4 * int(dst_off)
+        # a launch runs its tasks side by side as plain read-modify-write: two pending sums into overlapping destinations (a parameter
+        # used by two call sites of one backward stage, tied weights) must not share a launch - finish the pending ones first
+        if any(d0 < t[1] + 4 * t[2] and t[1] < d0 + 4 * int(n) for t in self.tasks):
+            self.flush()
+        self.tasks.append((src.data_ptr() + 4 * int(src_off), d0, int(n), int(stride), int(count), float(alpha)))
         self.keep.append((src, dst))
         self.pending += 4 * int(count) * int(n)
         if self.FLUSH_BYTES and self.pending >= self.FLUSH_BYTES:

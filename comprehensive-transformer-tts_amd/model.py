@@ -497,10 +497,10 @@ class VarianceAdaptor(nn.Module):
         # modules.py:788-799: learn_alignment reads the frame-level "unsup" statistics
         level_tag = "phone" if (not self.learn_alignment and self.energy_level == "phoneme_level") else "frame"
         stats_key = f"energy_{'unsup' if self.learn_alignment else 'sup'}_{level_tag}"
-        with open(os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")) as f:
-            emin, emax = json.load(f)[stats_key][:2]
         n_ebins = model_config["variance_embedding"]["energy_n_bins"]
-        if self.use_energy_embed:
+        if self.use_energy_embed:          # modules.py:788-799 reads stats.json inside this branch only: a stats file without the key is fine otherwise
+            with open(os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")) as f:
+                emin, emax = json.load(f)[stats_key][:2]
             if model_config["variance_embedding"]["energy_quantization"] == "log":
                 bins = torch.exp(torch.linspace(math.log(emin), math.log(emax), n_ebins - 1))
             else:

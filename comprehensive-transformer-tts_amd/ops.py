@@ -44,9 +44,17 @@ def _grad_of(p):
         return g
     base = p._base
     if (base is None or not base.is_leaf or base.grad is None or base.grad.dtype != torch.float32 or p.numel() != base.numel()
-            or not p.is_contiguous() or not base.is_contiguous() or not base.grad.is_contiguous()):
+            or not p.is_contiguous()):
         return None
-    return base.grad.view(p.shape)
+    if base.is_contiguous() and base.grad.is_contiguous():
+        return base.grad.view(p.shape)
+    # a dense PERMUTED leaf (GEMM-major Conv2d weight: shape [Cout,Cin,3,3], memory [Cout][kh][kw][Cin]) seen through the view that
+    # walks its memory in order: the same walk over the gradient, which the flat arena keeps with the leaf's own strides
+    g = base.grad
+    dense = sum((n - 1) * st for n, st in zip(base.shape, base.stride())) + 1 == base.numel()
+    if dense and g.stride() == base.stride() and p.data_ptr() == base.data_ptr():
+        return torch.as_strided(g, p.shape, p.stride(), g.storage_offset())
+    return None
 
 
 def _fusable(p):

@@ -17,9 +17,13 @@ from .model import _Linear, _Norm, _BatchNorm, _Conv, _ConvNormK
 
 
 class _Conv2dParams(nn.Module):
+    """nn.Conv2d parameters with the reference's shape [Cout, Cin, 3, 3] (state-dict / optimizer compatible) but GEMM-major MEMORY
+    [Cout][kh][kw][Cin] behind permuted strides (model._Conv does the same for Conv1d): the patch-matrix GEMM reads the weight as is
+    and the weight-gradient GEMM accumulates straight into `.grad` - no permuted copy per layer and call, no accumulate-add launch."""
+
     def __init__(self, cin, cout):
         super().__init__()
-        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3))
+        self.weight = nn.Parameter(torch.empty(cout, 3, 3, cin).permute(0, 3, 1, 2))
         self.bias = nn.Parameter(torch.empty(cout))
 
 
