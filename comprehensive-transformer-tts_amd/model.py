@@ -140,9 +140,11 @@ def mask_aux(pad_mask, lens=None):
     if aux is None:
         valid = ~pad_mask
         nonpad = valid.to(torch.float32).reshape(-1).contiguous()
-        if lens is None:         # row sums of the mask through the ordered column-sum kernel (no torch reduction on a captured path)
+        if lens is None and pad_mask.is_cuda:         # row sums of the mask through the ordered column-sum kernel (no torch reduction on a captured path)
             B_, T_ = pad_mask.shape
             lens = K.colsum(nonpad.view(B_, T_).t().contiguous())
+        elif lens is None:                           # host tensors (collate-side helpers, CPU tests)
+            lens = valid.sum(1)
         li = lens.to(torch.int32).contiguous()
         aux = (nonpad, li)
         try:
