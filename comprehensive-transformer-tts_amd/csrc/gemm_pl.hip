@@ -340,13 +340,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
   PlFrag f0, f1;
   read_frag(0, 0, f0);
   int stage = 0;
+  // ragged rows: when the UPPER 64 rows of the current tile lie wholly in padding, the upper wave group's products are discarded (its
+  // waves write zeros instead of an epilogue) - it then issues neither fragment reads nor MFMAs for the piece, only its share of the DMA
+  // and the barriers: ~4 % of the matrix work of a ragged launch, and on a power-limited pipe idle MFMAs are clock for the others
+  bool idle = false;
+  if constexpr (SKEW) { int r0_, c0_; decode(cp, r0_, c0_, idle); }
   __builtin_amdgcn_s_waitcnt(0);
   while (true) {
     // The two waves of a SIMD (w and w + 4) meet the same barrier, so their non-MFMA sections (fragment reads, DMA issue, cursor
     // arithmetic: ~450 issue cycles per block and wave) would coincide and the matrix pipe would idle through them.  The upper wave
     // group therefore runs the same work in a ROTATED order: its reads / DMA issue sit 8 MFMAs (one wave's 256 pipe cycles) later,
     // under the lower group's MFMAs and vice versa.  (p.debug & 32 switches the rotation off: A/B timing.)
-    const bool do_mma = PL_DBG(8) == 0;
+    const bool do_mma = PL_DBG(8) == 0 && !(SKEW && idle);
     // first half: the fragments of k-step 0 are in registers (read during the previous block); k-step 1 is read under its MFMAs
     if constexpr (!SKEW) {
       if (do_mma) mma_terms(f0, 0, 1);
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
       if (do_mma) mma_terms(f0, 1, 6);
     } else {
       if (do_mma) mma_terms(f0, 0, 3);
-      read_frag(stage, 1, f1);
+      if (!idle) read_frag(stage, 1, f1);
       if (do_mma) mma_terms(f0, 3, 6);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
     } else {
       if (do_mma) mma_terms(f1, 0, 2);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) read_frag(stage ^ 1, 0, f0);
+      if (more && !idle) read_frag(stage ^ 1, 0, f0);
       if (do_mma) mma_terms(f1, 2, 4);
       __builtin_amdgcn_sched_barrier(0);
       if (have_l && !PL_DBG(1)) loader_issue(stage);
@@ -481,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
     if (!sk_next_piece(cu, rg.lo, nkb, cp)) break;
     ckb = cp.kb_lo;
     zero_acc();
+    if constexpr (SKEW) { int r0_, c0_; decode(cp, r0_, c0_, idle); }
     read_frag(stage, 0, f0);            // the next piece's first block landed before the last barrier
   }
   };

@@ -205,6 +205,10 @@ class PartialSink:
         self.pending = 0
         try:
             _lib.check(_lib.load().ctts_partial_sums(arr, len(arr), _stream()), "ctts_partial_sums")
+            cur = torch.cuda.current_stream()
+            for src, _ in self.keep:                 # partials a side stream allocated are read by THIS stream's launch: tell the allocator
+                if src.is_cuda:
+                    src.record_stream(cur)
         finally:
             self.keep = []
 

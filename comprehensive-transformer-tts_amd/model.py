@@ -535,19 +535,46 @@ class VarianceAdaptor(nn.Module):
             self.utterance_prosody_prj = _Linear(cfg["bottleneck_size_u"], hidden)
             self.phoneme_prosody_prj = _Linear(cfg["bottleneck_size_p"], hidden)
 
+    def _reference_memories(self, mel, mel_mask):
+        """the part of the liu2021 prosody encoders that reads nothing but the target mel (modules.py:332-397,537-569): both reference
+        encoders (Conv2d stack + BatchNorm, one launch for both 1,000-step GRUs) and the utterance-level head -> (up_emb, mem_p)"""
+        mel_nonpad = mask_aux(mel_mask)[0]
+        ue, pe = self.utterance_prosody_encoder, self.phoneme_prosody_encoder
+        gi_u, whh_u, bhh_u = ue.encoder.features(mel, mel_nonpad)
+        gi_p, whh_p, bhh_p = pe.encoder.features(mel, mel_nonpad)
+        mem_u, mem_p = ops.gru_group([gi_u, gi_p], [whh_u, whh_p], [bhh_u, bhh_p])    # both Tm-step recurrences in one launch
+        return ue.head(mem_u), mem_p
+
+    def start_reference_encoders(self, mel, mel_mask):
+        """called by CompTransTTS.forward BEFORE the text encoder: inside a train step (ops.side_loss_scope) the input-only branch runs
+        on a side stream beside the text encoder; `_liu2021` joins.  Outside such a scope nothing happens here."""
+        self._ref_pending = None
+        if self.model_type != "liu2021" or not self.training or mel is None or mel_mask is None:
+            return
+        side = ops.fork_side(mel)
+        if side is None:
+            return
+        mask_aux(mel_mask)                                    # on the main stream: other consumers share the cached tensors
+        with torch.cuda.stream(side):
+            out = self._reference_memories(mel, mel_mask)
+        self._ref_pending = (side, out)
+
     def _liu2021(self, x, src_len, src_mask, mel, mel_len, mel_mask):
         """Implicit prosody modelling branch (modules.py:1002-1022): encoders only in training, predictors always."""
         up_emb = pp_emb = pp_attn = None
         if self.training:
             assert mel is not None and mel_mask is not None, "liu2021 prosody encoders need the reference mel in training"
-            mel_nonpad = mask_aux(mel_mask)[0]
             src_nonpad = mask_aux(src_mask)[0]
-            ue, pe = self.utterance_prosody_encoder, self.phoneme_prosody_encoder
-            gi_u, whh_u, bhh_u = ue.encoder.features(mel, mel_nonpad)
-            gi_p, whh_p, bhh_p = pe.encoder.features(mel, mel_nonpad)
-            mem_u, mem_p = ops.gru_group([gi_u, gi_p], [whh_u, whh_p], [bhh_u, bhh_p])    # both Tm-step recurrences in one launch
-            up_emb = ue.head(mem_u)
-            pp_emb, pp_attn = pe.head(x, src_len.to(torch.int32), src_nonpad, mel_len.to(torch.int32), mem_p)
+            pend, self._ref_pending = getattr(self, "_ref_pending", None), None
+            if pend is not None:
+                side, (up_emb, mem_p) = pend
+                ops.join_side(side)
+                cur = torch.cuda.current_stream()
+                up_emb.record_stream(cur)
+                mem_p.record_stream(cur)
+            else:
+                up_emb, mem_p = self._reference_memories(mel, mel_mask)
+            pp_emb, pp_attn = self.phoneme_prosody_encoder.head(x, src_len.to(torch.int32), src_nonpad, mel_len.to(torch.int32), mem_p)
         up_vec = self.utterance_prosody_predictor(x)
         u = up_emb if self.training else up_vec
         x = ops.add_over_time(x, ops.linear(u, self.utterance_prosody_prj.weight, self.utterance_prosody_prj.bias))      # [N,1,H] broadcast over Ts
@@ -824,6 +851,8 @@ class CompTransTTS(nn.Module):
         mask_aux(src_masks, src_lens.clamp(max=max_src_len))          # the lengths are known here: no row sums of the masks later
         if mel_masks is not None:
             mask_aux(mel_masks, mel_lens.clamp(max=max_mel_len))
+        if mels is not None and mel_masks is not None:
+            self.variance_adaptor.start_reference_encoders(mels, mel_masks)      # liu2021, inside a train step: beside the text encoder
         enc, text_embeds = self.encoder(texts, src_masks)
         speaker_embeds = None
         if self.speaker_emb is not None:

@@ -1491,9 +1491,10 @@ class side_loss_scope:
 
     def __exit__(self, *exc):
         _SIDE_ACTIVE[0] = self.prev
-        for side in _READY.values():             # a marker nobody consumed (e.g. the loss skipped the term): join its fork
+        for side in list(_READY.values()) + list(_FORKED):      # a fork nobody joined (e.g. the loss skipped the term): join it here
             torch.cuda.current_stream().wait_stream(side)
         _READY.clear()
+        del _FORKED[:]
         return False
 
 
@@ -1503,6 +1504,32 @@ def side_stream(device):
     if st is None:
         st = _SIDE[idx] = torch.cuda.Stream(device=device)
     return st
+
+
+SIDE_PROSODY = _os.environ.get("CTTS_SIDE_PROSODY", "1") != "0"
+_FORKED = []
+
+
+def fork_side(t):
+    """the side stream, forked from the current stream HERE, or None (not inside a side_loss_scope / switched off / host tensors).  The
+    caller runs an input-only branch on it (the liu2021 reference encoders read nothing but the target mel: their Conv2d stacks and
+    1,000-step GRUs run beside the text encoder, and autograd runs their backward beside the encoder's) and joins with join_side()."""
+    if not (_SIDE_ACTIVE[0] and SIDE_PROSODY and t.is_cuda):
+        return None
+    side = side_stream(t.device)
+    side.wait_stream(torch.cuda.current_stream())
+    _FORKED.append(side)
+    return side
+
+
+def join_side(side=None):
+    """the current stream waits for `side` (default: every side stream of this module - trainer.TrainStep calls it in front of the deferred
+    sums of a backward stage, whose partials autograd may have had written on a side stream)"""
+    cur = torch.cuda.current_stream()
+    for st in ([side] if side is not None else list(_SIDE.values())):
+        cur.wait_stream(st)
+        if st in _FORKED:
+            _FORKED.remove(st)
 
 
 def mark_ready(t):

@@ -110,6 +110,7 @@ class TrainStep:
                 prev = _K.set_partial_sink(sink)
                 try:
                     s = next(gen)
+                    ops.join_side()                      # autograd ran the side branches' backward on their streams: their partials are final
                     sink.flush()
                 except StopIteration:
                     return

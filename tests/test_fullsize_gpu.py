@@ -62,7 +62,7 @@ def test_cwt_pitch_single_frame_is_nan_like_torch_std():
 
 
 # ---------------------------------------------------------------------------------------------------------------- captured path
-def _step(block="transformer_fs2", c5=False, pitch_type=None, lens=(60, 41, 33, 17), dataset="LJSpeech", use_graph=False):
+def _step(block="transformer_fs2", c5=False, pitch_type=None, lens=(60, 41, 33, 17), dataset="LJSpeech", use_graph=False, nodrop=False):
     from ctts_amd.loss import CompTransTTSLoss, ScheduledOptim
     from ctts_amd.trainer import TrainStep
     torch.manual_seed(1234)
@@ -75,6 +75,11 @@ def _step(block="transformer_fs2", c5=False, pitch_type=None, lens=(60, 41, 33, 
         pre["preprocessing"]["pitch"]["pitch_type"] = pitch_type
     model = ctts_amd.CompTransTTS(pre, mc, tc).to(DEV)
     model.train()
+    if nodrop:
+        for sub in model.modules():
+            for attr in ("dropout", "p_drop"):
+                if isinstance(getattr(sub, attr, None), float):
+                    setattr(sub, attr, 0.0)
     loss_fn, optim = CompTransTTSLoss(pre, mc, tc).to(DEV), ScheduledOptim(model, tc, mc, 50000, capturable=True)
     cap = 1000 if block == "conformer" else None
     extra = dict(multi_speaker=True) if dataset == "VCTK" else {}
@@ -106,6 +111,43 @@ def test_no_stock_torch_reduction_kernel_in_a_train_step(name, kw):
     assert not bad, f"{name}: stock-torch reductions on the step's path: {bad}"
     ours = sum(1 for n in names if "anonymous namespace" in n or "ctts" in n)
     print(f"{name}: {len(names)} device launches, {len(names) - ours} of them stock torch ({100.0 * (len(names) - ours) / len(names):.1f} %)")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_side_stream_branches_change_nothing_but_the_schedule(use_graph):
+    """liu2021 + learn_alignment (BASELINE configs[4]) with every dropout off (the side branches change the program order in which the
+    dropout call sites draw their offsets, not the arithmetic): the step with the reference encoders beside the text encoder and the CTC
+    recursions beside the decoder (ops.fork_side / mark_ready) reproduces the single-stream step - losses, the whole gradient arena and
+    the parameters after three steps - bit for bit, eagerly and under hipGraph replay."""
+    from ctts_amd import ops
+    res = {}
+    for side in (True, False):
+        prev = (ops.SIDE_LOSS, ops.SIDE_PROSODY)
+        ops.SIDE_LOSS = ops.SIDE_PROSODY = side
+        try:
+            step, _, _ = _step(c5=True, use_graph=use_graph, nodrop=True)
+            if use_graph:
+                step.capture(warmup=2)
+            else:
+                for _ in range(2):
+                    step.optim.update_learning_rate()
+                    step._eager()
+            losses = []
+            for i in range(3):
+                step()
+                losses.append(float(step.loss_val))
+                if i == 0:
+                    torch.cuda.synchronize()
+                    grads = step.flat_grad.clone()
+            torch.cuda.synchronize()
+            res[side] = (losses, grads, step.fadam.flat_param.clone())
+            del step
+        finally:
+            ops.SIDE_LOSS, ops.SIDE_PROSODY = prev
+    a, b = res[True], res[False]
+    assert a[0] == b[0], (a[0], b[0])
+    assert torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())
+    assert torch.equal(a[2], b[2])
 
 
 # ---------------------------------------------------------------------------------------------------------------- full-size configs
