@@ -1525,10 +1525,13 @@ def fork_side(t):
 def join_side(side=None):
     """the current stream waits for `side` (default: every side stream of this module - trainer.TrainStep calls it in front of the deferred
     sums of a backward stage, whose partials autograd may have had written on a side stream)"""
+    streams = [side] if side is not None else list(_SIDE.values())
+    if not streams:
+        return
     cur = torch.cuda.current_stream()
-    for st in ([side] if side is not None else list(_SIDE.values())):
+    for st in streams:
         cur.wait_stream(st)
-        if st in _FORKED:
+        while st in _FORKED:
             _FORKED.remove(st)
 
 
