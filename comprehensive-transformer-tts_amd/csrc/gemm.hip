@@ -1403,10 +1403,12 @@ static int gemm_impl(const ctts_gemm_desc* dp, void* stream, GemmSplitPlan* plan
   const bool x6tn = gemm_x6tn_takes(d);            // weight gradient on the bf16-split kernel: a tile-kernel launch with ordered split-K partials
   if (plan) {
     plan->deferred_ok = 0;
-    if (d.split_k <= 1 || ctts_gemm_takes_weight_stationary(&d) || (!x6tn && ctts_gemm_takes_persistent(&d))) return 0;
+    if (d.split_k <= 1 || ctts_gemm_plw_takes(d) || ctts_gemm_takes_weight_stationary(&d) || (!x6tn && ctts_gemm_takes_persistent(&d))) return 0;
   } else {
     const int pl = ctts_gemm_pl_try(d, st);      // pre-split bf16 planes given and eligible: persistent plane kernel (gemm_pl.hip)
     if (pl != 0) return pl > 0 ? 0 : pl;
+    const int plw = ctts_gemm_plw_try(d, st);    // ... in the weight-gradient layout (gemm_plw.hip): adds into C itself, no partial matrices
+    if (plw != 0) return plw > 0 ? 0 : plw;
     const int ws = ctts_gemm_ws_try(d, st);      // weight-stationary kernel (gemm_ws.hip) for K = 256 linears with many rows
     if (ws != 0) return ws > 0 ? 0 : ws;
     if (gemm_x6_takes(d)) return gemm_x6_launch(d, st);      // fp32 products on the bf16 matrix pipe (six-term split)

@@ -298,3 +298,7 @@ int ctts_gemm_ws_try(const ctts_gemm_desc& d, hipStream_t st);
 
 // gemm_pl.hip: persistent stream-K kernel on pre-split bf16 planes (ctts_gemm_desc.A_planes / B_planes).  Same return convention.
 int ctts_gemm_pl_try(const ctts_gemm_desc& d, hipStream_t st);
+
+// gemm_plw.hip: the weight-gradient (TN) layout on the same plane sets.  _try: same return convention; _takes: 1 / 0 without launching.
+int ctts_gemm_plw_try(const ctts_gemm_desc& d, hipStream_t st);
+int ctts_gemm_plw_takes(const ctts_gemm_desc& d);

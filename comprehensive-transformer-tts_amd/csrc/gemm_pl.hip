@@ -25,38 +25,11 @@
 //     row_T % 128 == 0), wholly padded tiles are zero-filled, and - the zero rule has 64-row granularity in the other kernels - the waves
 //     that own a wholly padded upper half of an active tile write zeros instead of their epilogue.
 // Eligibility: pl_try below.  Everything else stays on gemm.hip / gemm_sk.hip / gemm_ws.hip.
-#include "ctts_common.h"
-#include "gemm_common.h"
-#include "sk_plan.h"
+#include "gemm_pl_common.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
-
-typedef unsigned int pl_u32x4 __attribute__((ext_vector_type(4)));
-typedef int pl_i32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 pl_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 pl_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float pl_floatx2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) unsigned int pl_gu32;
-
-// CTTS_PL_DEBUG bits (tools builds only: -DCTTS_PL_TOOLS; the product build compiles them out - their scalar branches and the clock
-// stamps cost the conv instantiation three spilled VGPRs with reloads inside the K loop)
-#ifdef CTTS_PL_TOOLS
-#define PL_DBG(bit) (p.debug & (bit))
-#else
-#define PL_DBG(bit) 0
-#endif
-
-constexpr unsigned PL_OOB = 0x80000000u;
-constexpr int PL_BM = 128, PL_BN = 256;
-constexpr int PL_ROW = 64;                                    // bytes per plane row of a 32-deep K-block
-constexpr int PL_A_PLANE = PL_BM * PL_ROW, PL_B_PLANE = PL_BN * PL_ROW;
-constexpr int PL_STAGE = 3 * (PL_A_PLANE + PL_B_PLANE);       // 73,728 bytes
-constexpr int PL_SLAB = PL_BM * PL_BN;                        // floats per workgroup slab
-constexpr int PL_MAX_UTT = 256;
-constexpr int PL_MAX_WG = 2048;                               // flags[0 .. 2047], error word at [2048]: the layout of gemm_sk.hip
-constexpr int PL_SLAB_FLOATS_MAX = 2048 * 4096;
 
 struct PlArgs {
   int tiles_m, tiles_n;      // static tile grid (128 x 256 tiles); tiles_m counts ALL m-tiles (the active count comes from row_lens)
@@ -68,28 +41,6 @@ struct PlArgs {
   int debug;                 // CTTS_PL_DEBUG (tools): 1 = no DMA after the prologue, 4 = no epilogue, 8 = no MFMA, 32 = no rotated order in the upper wave group, 16 = record shader cycles / wall ticks of workgroup 8 in the workspace header
   unsigned* ws;
 };
-
-__device__ __forceinline__ pl_i32x4 pl_make_rsrc(const void* base) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-  pl_i32x4 r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-  r.z = 0x7FFFFFFE;
-  r.w = 0x00020000;
-  return r;
-}
-
-// One LDS-DMA instruction (64 lanes x 16 bytes -> LDS [lds_addr + lane * 16)); inline asm for the reason given in gemm_sk.hip: hipcc's
-// waitcnt pass must not know about it (it would drain the DMA in front of every fragment read).  m0 is used by nothing else here.
-__device__ __forceinline__ void pl_dma16(pl_i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff))
-               : "memory");
-}
-
-__device__ __forceinline__ floatx16 pl_mma(const pl_u32x4 a, const pl_u32x4 b, const floatx16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pl_bf16x8, a), __builtin_bit_cast(pl_bf16x8, b), c, 0, 0, 0);
-}
 
 // The epilogues this kernel carries (pl_epilogue_ok is the host-side twin: descriptors with any other combination are not taken).  Only
 // lean variants: the generic epilogue and the full dispatch of gemm_epilogue_auto (14 variants) cost this kernel 12 - 27 spilled VGPRs
@@ -659,5 +610,5 @@ extern "C" int ctts_gemm_takes_planes(const ctts_gemm_desc* d) {
   ctts_gemm_desc c = *d;
   if (c.nb0 < 1) c.nb0 = 1;
   if (c.nb1 < 1) c.nb1 = 1;
-  return pl_try(c, nullptr, false) > 0 ? 1 : 0;
+  return (pl_try(c, nullptr, false) > 0 || ctts_gemm_plw_takes(c)) ? 1 : 0;
 }

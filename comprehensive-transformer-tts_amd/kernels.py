@@ -71,6 +71,7 @@ import os as _os
 
 SK_ENABLED = _os.environ.get("CTTS_SK", "1") != "0"      # persistent stream-K GEMM (csrc/gemm_sk.hip) for large unbatched launches
 BF16_SPLIT = 0 if _os.environ.get("CTTS_X6", "1") == "0" else 1          # default ctts_gemm_desc.bf16_split of this module's descriptors
+PLW_ENABLED = _os.environ.get("CTTS_PLW", "1") != "0"        # weight gradients on the plane kernel (csrc/gemm_plw.hip)
 PLANES_ENABLED = _os.environ.get("CTTS_PL", "1") != "0"                  # pre-split operand planes + the persistent plane kernel (csrc/gemm_pl.hip)
 PLANES_MIN_UNITS = int(_os.environ.get("CTTS_PL_MIN_UNITS", "4096"))
 PLANES_MIN_TILES = int(_os.environ.get("CTTS_PL_MIN_TILES", "64"))
@@ -337,6 +338,19 @@ def plane_shape_ok(M, N, K, conv_cin=None):
         return False
     tiles = -(-M // 128) * -(-N // 256)
     return BF16_SPLIT == 2 or (tiles * (K // 32) >= PLANES_MIN_UNITS and tiles >= PLANES_MIN_TILES)
+
+
+def plane_wgrad_shape_ok(Mo, No, Kred, cin=None):
+    """The same pre-filter for the weight-gradient plane kernel (csrc/gemm_plw.hip plw_try): output [Mo, No] = [cout, k * cin], reduction
+    over Kred (b, t) rows."""
+    if not PLANES_ENABLED or not PLW_ENABLED or BF16_SPLIT < 1 or not SK_ENABLED:
+        return False
+    if Mo % 128 or No % 256 or Kred < 64:
+        return False
+    if cin is not None and (cin % 256 or No % cin):
+        return False
+    tiles = (Mo // 128) * (No // 256)
+    return BF16_SPLIT == 2 or (tiles >= 32 and tiles * (-(-Kred // 32)) >= PLANES_MIN_UNITS)
 
 
 def split_planes(mats):

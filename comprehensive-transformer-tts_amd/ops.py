@@ -295,6 +295,7 @@ class _LinearConv(torch.autograd.Function):
         planes = _operand_planes("fwd", w, x.view(M, Cin), wf, M, N, Kdim, Cin, Kdim, N, out, gk) if ksize else {}
         K.gemm(x, wf, out, M, N, Kdim, Cin, Kdim, N, True, True, tile_map=pr.tile_map(0, M) if (pr is not None and not planes) else None,
                **gk, **planes)
+        ctx.x_planes = planes.get("a_planes")        # the weight-gradient launch reads the same plane set (gemm_plw.hip)
         ctx.save_for_backward(x, w, Z, rowscale, seed, row_lens, b)
         ctx.cfg = (act, alpha, p_drop, drop_offset, ksize, b is not None, residual is not None, row_T)
         ctx.pr = pr
@@ -345,6 +346,7 @@ class _LinearConv(torch.autograd.Function):
             d_res = (gm if rowscale is not None else dY) if has_res else None
             if want_bias and not fuse_bias:
                 dB = dBn
+        dz_planes = None
         if ksize:
             T = x.shape[-2]
             pad = ctx.pad_left                   # forward / weight-gradient view
@@ -366,6 +368,7 @@ class _LinearConv(torch.autograd.Function):
                 dg0 = dict(conv=(T, pad_d, N), alpha=alpha, row_halo=pad_d, **rl)
                 planes = _operand_planes("dgrad", w, dZ.view(M, N), wd, M, Cin, ksize * N, N, ksize * N, Cin, dX, dict(split_overwrite=True, **dg0))
                 if planes:          # pre-split operands on the persistent plane kernel: balances the reduction itself, writes every element
+                    dz_planes = planes["a_planes"]
                     K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=1, split_overwrite=True, **dg0, **planes)
                 else:
                     dg = dict(tile_map=pr.tile_map(pad_d, M) if pr is not None else None, **dg0)
@@ -376,15 +379,17 @@ class _LinearConv(torch.autograd.Function):
                 Kd = ksize * Cin
                 fused = _fusable(w)
                 gmaj = _gemm_major(_grad_of(w)) if fused else None
+                wk = dict(conv=(T, pad, Cin), conv_on_b=True, split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
                 if gmaj is not None:             # GEMM-major parameter: the split-K partials are added straight into param.grad
+                    wp = _wgrad_planes(dZ.view(M, N), x.view(M, Cin), dz_planes, getattr(ctx, "x_planes", None), gmaj, N, Kd, M, Cin, wk)
                     with _wgrad_scope(True, dZ, x, rows=M):
-                        K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, defer=_WGRAD["stream"] is None, **rl)
+                        K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, tile_map=kmap, defer=_WGRAD["stream"] is None, **wk, **wp)
                 else:
                     dwf = torch.empty(N, Kd, dtype=torch.float32, device=x.device)
+                    wk["split_overwrite"] = True
+                    wp = _wgrad_planes(dZ.view(M, N), x.view(M, Cin), dz_planes, getattr(ctx, "x_planes", None), dwf, N, Kd, M, Cin, wk)
                     with _wgrad_scope(fused, dZ, x, dwf, rows=M):
-                        K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, conv=(T, pad, Cin), conv_on_b=True,
-                               split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, tile_map=kmap, split_overwrite=True, **rl)
+                        K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, tile_map=kmap, **wk, **wp)
                         if fused:
                             K.conv_weight_repack(dwf, _grad_of(w), N, Cin, ksize, 3)
                         elif _gemm_major(w) is not None:
@@ -465,6 +470,20 @@ def _operand_planes(kind, w, a_mat, b_mat, M, N, Kdim, lda, ldb, ldc, out, gk):
         _PLANES["want_" + kind].add(w.data_ptr())
         bp = K.split_planes([b_mat])[0]
     return dict(a_planes=K.split_planes([a_mat])[0], b_planes=bp)
+
+
+def _wgrad_planes(dz_mat, x_mat, dz_pl, x_pl, out, Mo, No, Kred, cin, kw):
+    """{} or dict(a_planes=, b_planes=) for the weight-gradient launch `out [Mo, No] (+)= dz_mat^T (*) x_mat`: the ROW-MAJOR plane sets of
+    dZ (made for the data-gradient launch) and of x (made for the forward launch) are what csrc/gemm_plw.hip reads - it transposes in
+    the LDS; a set that is not at hand (first layer: no data gradient; forward on another kernel) is split here."""
+    if not K.plane_wgrad_shape_ok(Mo, No, Kred, cin) or not (dz_mat.is_contiguous() and x_mat.is_contiguous()):
+        return {}
+    a = dz_pl if dz_pl is not None else _FakePlanes(dz_mat)
+    b = x_pl if x_pl is not None else _FakePlanes(x_mat)
+    if not K.gemm_takes_planes(dz_mat, x_mat, out, Mo, No, Kred, Mo, cin, No, False, False, a_planes=a, b_planes=b, **kw):
+        return {}
+    made = iter(K.split_planes([m for m, pl in ((dz_mat, dz_pl), (x_mat, x_pl)) if pl is None]))
+    return dict(a_planes=dz_pl if dz_pl is not None else next(made), b_planes=x_pl if x_pl is not None else next(made))
 
 
 class _FakePlanes:

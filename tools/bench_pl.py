@@ -119,3 +119,52 @@ run("ffn2 fwd step", h, w2, (M, 256), M, 256, 1024, 1024, 2 * nvalid * 256 * 102
     tmap=K.row_tile_map(lens, T, 0, M))
 n = 4096
 run("square 4096", torch.randn(n, n, device=dev), torch.randn(n, n, device=dev) * 0.02, (n, n), n, n, n, n, 2 * n ** 3, dict())
+
+
+# ---- weight gradients (TN, csrc/gemm_plw.hip): the plane sets are the ones the forward / data-gradient launches made, so no split is timed
+def run_tn(name, dZm, Xm, cout, cin, ksize, pad, T, flops, kw):
+    if only and only not in name:
+        return
+    rows, Kd = dZm.shape[0], max(ksize, 1) * cin
+    ap, bp = K.split_planes([dZm, Xm])
+    conv = dict(conv=(T, pad, cin), conv_on_b=True) if ksize else {}
+    outs = {}
+
+    def make(mode):
+        Cm = torch.full((cout, Kd), float("nan"), device=dev)
+        k2 = dict(kw, **conv)
+        if mode == "pl":
+            k2.update(a_planes=ap, b_planes=bp, bf16_split=1)
+            assert K.gemm_takes_planes(dZm, Xm, Cm, cout, Kd, rows, cout, cin, Kd, False, False, **k2), name
+        else:
+            k2.update(bf16_split=1 if mode == "x6" else 0)
+        outs[mode] = Cm
+        return lambda: K.gemm(dZm, Xm, Cm, cout, Kd, rows, cout, cin, Kd, False, False, **k2)
+    fns = {m: make(m) for m in ("f32", "x6", "pl")}
+    for f in fns.values():
+        f()
+    torch.cuda.synchronize()
+    d_x6 = float((outs["pl"] - outs["x6"]).abs().max())
+    d_32 = float((outs["pl"] - outs["f32"]).abs().max())
+    t = {m: timeit(f) for m, f in fns.items()}
+    print(f"{name:26s} " + " | ".join(f"{m} {t[m]*1e6:7.1f} us {flops/t[m]/1e12:6.1f} TF" for m in ("f32", "x6", "pl")) +
+          f" | pl-x6 {d_x6:.2e} pl-f32 {d_32:.2e} (|out| {float(outs['f32'].abs().max()):.2f}) err {err_word()}{pl_clock()}", flush=True)
+
+
+mask = (torch.arange(T, device=dev)[None, :] < lens[:, None]).float().reshape(-1, 1)
+dzw = torch.randn(M, 1024, device=dev) * mask
+xw = torch.randn(M, 256, device=dev)
+rlw = dict(row_lens=lens, row_T=T, row_halo=0)
+run_tn("ffn1 wgrad step", dzw, xw, 1024, 256, 9, 4, T, 2 * nvalid * 1024 * 2304, dict(split_k=4, split_overwrite=True, **rlw))
+run_tn("ffn1 wgrad dense", dzw, xw, 1024, 256, 9, 4, T, 2 * M * 1024 * 2304, dict(split_k=4, split_overwrite=True))
+run_tn("postnet wgrad", torch.randn(M, 512, device=dev), torch.randn(M, 512, device=dev), 512, 512, 5, 2, T, 2 * M * 512 * 2560,
+       dict(split_k=7, split_overwrite=True))
+run_tn("k5 256 wgrad", torch.randn(M, 256, device=dev), torch.randn(M, 256, device=dev), 256, 256, 5, 2, T, 2 * M * 256 * 1280,
+       dict(split_k=26, split_overwrite=True))
+Me = 2048
+lens_e = torch.tensor(list(CANONICAL_SRC_LENS), dtype=torch.int32, device=dev)
+mask_e = (torch.arange(128, device=dev)[None, :] < lens_e[:, None]).float().reshape(-1, 1)
+run_tn("enc ffn1 wgrad", torch.randn(Me, 1024, device=dev) * mask_e, torch.randn(Me, 256, device=dev), 1024, 256, 9, 4, 128,
+       2 * int(lens_e.sum()) * 1024 * 2304, dict(split_k=4, split_overwrite=True, row_lens=lens_e, row_T=128, row_halo=0))
+run_tn("ffn2 wgrad (k=1)", torch.randn(M, 256, device=dev) * mask, torch.randn(M, 1024, device=dev), 256, 1024, 0, 0, 0, 2 * nvalid * 256 * 1024,
+       dict(split_k=32, split_overwrite=True, **rlw))
