@@ -188,7 +188,7 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
     arguments (M = B*Tm rows of which `valid` are not padding, N = 1024, K = 2304): forward (implicit GEMM on the activation),
     data gradient (N = 256, K = 9216) and weight gradient (TN, reduction over the rows).  `roofline` prices the FORWARD launch: it runs on
     gemm_pl_kernel, the kernel with the largest per-step total (24 launches of the fs2 step: profiles/r05_fs2_graph_replay_kernels.md);
-    the other two are listed next to it (`ffn_conv`)."""
+    the other two are listed next to it (`ffn_conv`; the weight gradient runs on gemm_plw_kernel, the same arithmetic on the same planes)."""
     from ctts_amd import kernels as K
     from ctts_amd import ops as O
 
@@ -237,8 +237,16 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
     dw = torch.zeros(cout, ks * cin, device=dev)
     kmap = K.row_tile_map(lens, T, 0, M)
     sk = max(2, O._split_k_for(cout, ks * cin, M))
-    dt_w = _time_launches(lambda: K.gemm(dz, x, dw, cout, ks * cin, M, cout, cin, ks * cin, False, False, conv=(T, ks // 2, cin), conv_on_b=True,
-                                         split_k=sk, alpha=ks ** -0.5, tile_map=kmap, row_lens=lens, row_T=T), iters // 2, warm // 2)
+    wg_kw = dict(conv=(T, ks // 2, cin), conv_on_b=True, split_k=sk, alpha=ks ** -0.5, row_lens=lens, row_T=T)
+    # the step's weight-gradient launch reads the plane sets made for the other two launches (x: forward, dZ: data gradient) and adds
+    # into param.grad itself (csrc/gemm_plw.hip): no split and no reduce launch is part of it
+    wplanes = {}
+    if planes and dplanes and K.plane_wgrad_shape_ok(cout, ks * cin, M, cin):
+        wplanes = dict(a_planes=dplanes["a_planes"], b_planes=planes["a_planes"])
+        if not K.gemm_takes_planes(dz, x, dw, cout, ks * cin, M, cout, cin, ks * cin, False, False, **wg_kw, **wplanes):
+            wplanes = {}
+    dt_w = _time_launches(lambda: K.gemm(dz, x, dw, cout, ks * cin, M, cout, cin, ks * cin, False, False, tile_map=kmap, **wg_kw, **wplanes),
+                          iters // 2, warm // 2)
     # traffic: measured live by two rocprofv3 --pmc passes over this same launch when rocprofv3 is available (it
     # used to be a committed constant); otherwise the committed result of the same passes (tools/collect_r05.sh) - traffic_source says which
     traffic, traffic_src = None, None
@@ -283,7 +291,8 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
            "algorithmic_bytes": 4.0 * (M * cin + cout * ks * cin + 2 * valid * cout),
            "ffn_conv": {"fwd": entry(dt, "gemm_pl_kernel" if planes else ("gemm_x6_kernel" if bf16 else "gemm_sk_kernel")),
                         "dgrad": entry(dt_d, "gemm_pl_kernel" if dplanes else "gemm_sk_kernel (fp32 MFMA)"),
-                        "wgrad": entry(dt_w, ("gemm_x6tn_kernel" if bf16 else "fp32 tile kernels") + f" + ordered split-K sum (split_k = {sk})"),
+                        "wgrad": entry(dt_w, "gemm_plw_kernel (row-major planes of dZ and x, LDS transpose reads; += into the gradient)" if wplanes else
+                                       ("gemm_x6tn_kernel" if bf16 else "fp32 tile kernels") + f" + ordered split-K sum (split_k = {sk})"),
                         "flops_each": algo_flops, "launches_per_step_each": 6}}
     out.update(extra)
     return out

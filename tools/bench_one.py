@@ -26,6 +26,19 @@ elif which == "ffn1_step":      # the dominant kernel exactly as the train step 
     tmap = None if planes else K.row_tile_map(lens, T, 0, M)
     fn = lambda: K.gemm(x, wf, C, M, 1024, 2304, 256, 2304, 1024, True, True, tile_map=tmap, **kw, **planes)
     fl = 2 * int(lens.sum()) * 1024 * 2304
+elif which == "wgrad_step":     # the FFN conv weight gradient as the train step launches it: ragged rows, planes of dZ and x at hand, += into the gradient
+    from ctts_amd.synthetic import CANONICAL_SRC_LENS
+    lens = torch.tensor([8 * v for v in CANONICAL_SRC_LENS], dtype=torch.int32, device=dev)
+    mask = (torch.arange(T, device=dev)[None, :] < lens[:, None]).float().reshape(-1, 1)
+    x = torch.randn(M, 256, device=dev); dz = torch.randn(M, 1024, device=dev) * mask; C = torch.zeros(1024, 2304, device=dev)
+    kw = dict(conv=(T, 4, 256), conv_on_b=True, split_k=4, alpha=9 ** -0.5, row_lens=lens, row_T=T, row_halo=0)
+    planes = {}
+    if K.BF16_SPLIT >= 1 and K.plane_wgrad_shape_ok(1024, 2304, M, 256):
+        ap, bp = K.split_planes([dz, x])
+        if K.gemm_takes_planes(dz, x, C, 1024, 2304, M, 1024, 256, 2304, False, False, a_planes=ap, b_planes=bp, **kw):
+            planes = dict(a_planes=ap, b_planes=bp)
+    fn = lambda: K.gemm(dz, x, C, 1024, 2304, M, 1024, 256, 2304, False, False, **kw, **planes)
+    fl = 2 * int(lens.sum()) * 1024 * 2304
 elif which == "dgrad":
     dz = torch.randn(M, 1024, device=dev); wd = torch.randn(256, 9216, device=dev); C = torch.empty(B, T, 256, device=dev)
     fn = lambda: K.gemm(dz, wd, C, M, 256, 9216, 1024, 9216, 256, True, True, conv=(T, 4, 1024)); fl = 2 * M * 256 * 9216

@@ -134,7 +134,7 @@ def run_tn(name, dZm, Xm, cout, cin, ksize, pad, T, flops, kw):
         Cm = torch.full((cout, Kd), float("nan"), device=dev)
         k2 = dict(kw, **conv)
         if mode == "pl":
-            k2.update(a_planes=ap, b_planes=bp, bf16_split=1)
+            k2.update(a_planes=ap, b_planes=bp, bf16_split=2)      # 2: also the shapes below the kernel's tile-count threshold (shown for the record)
             assert K.gemm_takes_planes(dZm, Xm, Cm, cout, Kd, rows, cout, cin, Kd, False, False, **k2), name
         else:
             k2.update(bf16_split=1 if mode == "x6" else 0)

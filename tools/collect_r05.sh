@@ -32,12 +32,19 @@ for P in "$P1" "$P2" "$P3"; do
   rm -rf /tmp/pmc; timeout 200 rocprofv3 --kernel-trace --pmc $P -d /tmp/pmc -- python $ROOT/tools/bench_one.py ffn1_step 30 > /tmp/pmc.log 2>&1
   python $ROOT/tools/rocpd_pmc_summary.py $(find /tmp/pmc -name "*results.db" | head -1) 2>&1 < /dev/null | grep -E "^\| kernel|gemm_" | cut -c1-400 >> $OUT/${R}_pmc_sq_gemm.md
 done
+# the weight-gradient plane kernel (gemm_plw.hip): same passes over the step's FFN conv weight-gradient launch
+: > $OUT/${R}_pmc_plane_wgrad.md
+for P in "$P1" "$P2" "$P3 SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
+  rm -rf /tmp/pmc; timeout 200 rocprofv3 --kernel-trace --pmc $P -d /tmp/pmc -- python $ROOT/tools/bench_one.py wgrad_step 30 > /tmp/pmc.log 2>&1
+  python $ROOT/tools/rocpd_pmc_summary.py $(find /tmp/pmc -name "*results.db" | head -1) 2>&1 < /dev/null | grep -E "^\| kernel|gemm_" | cut -c1-400 >> $OUT/${R}_pmc_plane_wgrad.md
+done
+echo "(FETCH_SIZE / WRITE_SIZE in KiB per launch; FETCH_SIZE counts 128-B requests at 64 B on gfx950: double it)" >> $OUT/${R}_pmc_plane_wgrad.md
 # stock-torch launches that remain in one eager step, by call site
 timeout 200 python $ROOT/tools/find_torch_ops.py > $OUT/${R}_torch_ops_fs2.txt 2>&1
 timeout 200 python $ROOT/tools/find_torch_ops.py --block conformer > $OUT/${R}_torch_ops_conformer.txt 2>&1
 timeout 300 python $ROOT/tools/find_torch_ops.py --c5 > $OUT/${R}_torch_ops_c5.txt 2>&1
 # micro-benchmarks
-timeout 200 python $ROOT/tools/bench_pl.py 40 > $OUT/${R}_microbench_plane_kernel.txt 2>&1
+timeout 300 python $ROOT/tools/bench_pl.py 40 > $OUT/${R}_microbench_plane_kernel.txt 2>&1
 timeout 200 python $ROOT/tools/profile_gemm_shapes.py > $OUT/${R}_gemm_shapes_in_step_fs2.txt 2>&1
 timeout 200 python $ROOT/tools/profile_gemm_shapes.py --block conformer > $OUT/${R}_gemm_shapes_in_step_conformer.txt 2>&1
 timeout 100 python $ROOT/tools/bench_stft.py > $OUT/${R}_bench_stft.jsonl 2>/dev/null
