@@ -110,8 +110,11 @@ typedef struct ctts_gemm_desc {
    * contiguous bytes; same ld as the fp32 operand, ld % 32 == 0, 16-byte aligned.  With both given (bf16_split >= 1, a_kc = b_kc = 1,
    * unbatched, sk_ws given) the persistent plane kernel (csrc/gemm_pl.hip) moves the pieces to LDS by DMA and its main loop is
    * ds_read + MFMA only: no split arithmetic in the GEMM, every operand element split ONCE per tensor instead of once per tile that
-   * stages it.  A / B must stay valid: descriptors the plane kernel does not take (ctts_gemm_takes_planes) run on the other kernels
-   * from A / B. */
+   * stages it.  The SAME row-major plane sets serve the TN layout (a_kc = b_kc = 0: weight gradients C[m][n] (+)= alpha * sum_k
+   * A[k][m] B[k + tap - pad][c], conv view on B): csrc/gemm_plw.hip DMAs 32-row K-blocks into LDS as they lie and transposes with
+   * ds_read_b64_tr_b16 - pass the planes of dZ (made for the data gradient) as A_planes and of x (made for the forward) as B_planes;
+   * split_k > 1 without split_overwrite adds into C in place (M % 128 == 0, N % 256 == 0, conv_cin % 256 == 0, no epilogue terms).
+   * A / B must stay valid: descriptors the plane kernels do not take (ctts_gemm_takes_planes) run on the other kernels from A / B. */
   const uint16_t* A_planes;
   const uint16_t* B_planes;
 } ctts_gemm_desc;
@@ -179,7 +182,7 @@ int ctts_gemm_takes_weight_stationary(const ctts_gemm_desc* d);
  *     +-inf: inf * 0-piece = NaN), elements it does not contribute to are unaffected - the finite / non-finite pattern of the result
  *     equals the fp32-MFMA kernels', which is what overflow diagnostics (isfinite checks, GradScaler) look at.
  * ctts_gemm_takes_bf16_split: 1 when ctts_gemm would run this descriptor on the in-kernel-split kernels (x6 / x6tn; no launch);
- * ctts_gemm_takes_planes: 1 when it would run it on the plane kernel. */
+ * ctts_gemm_takes_planes: 1 when it would run it on a plane kernel (gemm_pl.hip: NT; gemm_plw.hip: TN). */
 int ctts_gemm_takes_bf16_split(const ctts_gemm_desc* d);
 int ctts_gemm_takes_planes(const ctts_gemm_desc* d);
 /* Exact three-way bf16 split of fp32 matrices, many per launch: for every task and element (r, c), c < cols (cols % 32 == 0, ld % 32 == 0,

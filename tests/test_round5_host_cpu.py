@@ -145,3 +145,29 @@ def test_plane_kernel_loops_hold_only_dma_ds_read_and_mfma():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if "gemm_desc" in l]
     assert len(lines) == 4 and all(l.startswith("ok") for l in lines), r.stdout
+
+
+def test_weight_gradient_plane_kernel_loops_hold_only_dma_transpose_reads_and_mfma():
+    """tools/check_pl_isa.py plw: every K loop of gemm_plw_kernel (csrc/gemm_plw.hip) has 48 MFMAs, 48 ds_read_b64_tr_b16 (two per 8-deep
+    operand), 9 LDS-DMA instructions, one barrier, no scratch access and no compiler-inserted vmcnt wait."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_pl_isa.py"), "plw"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if "gemm_desc" in l]
+    assert len(lines) == 4 and all(l.startswith("ok") for l in lines), r.stdout
+
+
+def test_weight_gradient_plane_prefilter():
+    """kernels.plane_wgrad_shape_ok mirrors plw_try's shape rules (the library's answer stays authoritative on the GPU)"""
+    from ctts_amd import kernels as K
+    prev = K.gemm_bf16_split_enable(True)
+    try:
+        if K.PLANES_ENABLED and K.PLW_ENABLED and K.SK_ENABLED:
+            assert K.plane_wgrad_shape_ok(1024, 2304, 16384, 256)          # decoder FFN conv
+            assert K.plane_wgrad_shape_ok(512, 2560, 16384, 512)           # PostNet conv
+            assert not K.plane_wgrad_shape_ok(256, 1280, 16384, 256)       # 10 output tiles: the split-K kernel's parallel reduce wins
+            assert not K.plane_wgrad_shape_ok(512, 400, 16384, 80)         # cin = 80
+            assert not K.plane_wgrad_shape_ok(1000, 2304, 16384, 256)      # M % 128
+        K.gemm_bf16_split_enable(False)
+        assert not K.plane_wgrad_shape_ok(1024, 2304, 16384, 256)
+    finally:
+        K.gemm_bf16_split_enable(prev)
