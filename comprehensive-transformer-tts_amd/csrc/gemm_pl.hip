@@ -80,6 +80,10 @@ __device__ __forceinline__ void pl_epilogue(const ctts_gemm_desc& d, const float
 #undef PL_LEAN
 }
 
+// 12 x (two MFMAs, one LDS read) in program order for the scheduling region that ends here (masks: 0x008 MFMA, 0x100 DS read)
+#define PL_SGB3() __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
+#define PL_INTERLEAVE_12() PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3()
+
 struct PlFrag { pl_u32x4 a[2][3], b[2][3]; };      // one 16-deep k-step: [MFMA row / column tile][plane]
 
 template <bool CONV>
@@ -303,43 +307,40 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
     // group therefore runs the same work in a ROTATED order: its reads / DMA issue sit 8 MFMAs (one wave's 256 pipe cycles) later,
     // under the lower group's MFMAs and vice versa.  (p.debug & 32 switches the rotation off: A/B timing.)
     const bool do_mma = PL_DBG(8) == 0 && !(SKEW && idle);
-    // first half: the fragments of k-step 0 are in registers (read during the previous block); k-step 1 is read under its MFMAs
-    if constexpr (!SKEW) {
-      if (do_mma) mma_terms(f0, 0, 1);
+    // first half: the fragments of k-step 0 are in registers (read during the previous block); k-step 1 is read under its MFMAs - ONE
+    // ds_read_b128 behind every second MFMA (sched_group_barrier).  hipcc otherwise emits the 12 reads as a burst during which this wave
+    // issues no MFMA, and the pipe then depends on the SIMD's other wave being in an MFMA phase right then (gemm_plw.hip measured the
+    // same loop without DMA: 314 us with bursts, 253 us without any reads).  An idle upper wave (SKEW, half-padded tile) skips both.
+    if (do_mma) {
       read_frag(stage, 1, f1);
-      if (do_mma) mma_terms(f0, 1, 6);
-    } else {
-      if (do_mma) mma_terms(f0, 0, 3);
-      if (!idle) read_frag(stage, 1, f1);
-      if (do_mma) mma_terms(f0, 3, 6);
+      mma_terms(f0, 0, 6);
+      PL_INTERLEAVE_12();
     }
     __builtin_amdgcn_sched_barrier(0);
     // every wave is done reading this stage, and (mine of) block i + 1 has landed: after the barrier the whole block has
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // second half, with the loader's work (DMA issue of block i + 2 into this stage, cursor arithmetic) and the first-half fragment reads
-    // of block i + 1 (it has landed) placed BETWEEN groups of MFMAs in program order: the branches keep hipcc from regrouping them, the
-    // matrix pipe never waits for the ~100 scalar / lane-read instructions of the loader.  The fragments of block i + 1 are NOT read
-    // when this block ends the piece: they would have to stay live across the epilogue (48 more registers there); they are read after it
-    const bool more = ckb + 1 < cp.kb_hi;
+    // lgkmcnt(0) as a wait hipcc can SEE (0xC07F = vmcnt 63, expcnt 7, lgkmcnt 0): inside the asm it left the compiler's scoreboard with the
+    // fragment reads of k-step 1 still "pending", and - the counter being in order - every second-half MFMA on them then waited for the
+    // NEWER reads of the next block's fragments as well (s_waitcnt lgkmcnt(5 .. 0) in front of the first six MFMAs after the barrier)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // second half: the DMA of block i + 2 into this stage (lower wave group: in front of its MFMAs, upper group: behind them - the two
+    // waves of a SIMD do not issue their ~100 loader instructions at the same time), the MFMAs of k-step 1 with the first-half fragment
+    // reads of block i + 1 (it has landed) between them.  The reads are unconditional: when this block ends the piece the values are dead
+    // (f0 is read again behind the epilogue) and reads and MFMAs stay in one scheduling region.
     if constexpr (!SKEW) {
-      if (more) read_frag(stage ^ 1, 0, f0);
-      if (do_mma) mma_terms(f1, 0, 2);
-      __builtin_amdgcn_sched_barrier(0);
       if (have_l && !PL_DBG(1)) loader_issue(stage);
-      if (do_mma) mma_terms(f1, 2, 4);
       __builtin_amdgcn_sched_barrier(0);
-      if (have_l) loader_advance();
-      if (do_mma) mma_terms(f1, 4, 6);
-    } else {
-      if (do_mma) mma_terms(f1, 0, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more && !idle) read_frag(stage ^ 1, 0, f0);
-      if (do_mma) mma_terms(f1, 2, 4);
-      __builtin_amdgcn_sched_barrier(0);
-      if (have_l && !PL_DBG(1)) loader_issue(stage);
-      if (have_l) loader_advance();
-      if (do_mma) mma_terms(f1, 4, 6);
     }
+    if (do_mma) {
+      read_frag(stage ^ 1, 0, f0);
+      mma_terms(f1, 0, 6);
+      PL_INTERLEAVE_12();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SKEW) {
+      if (have_l && !PL_DBG(1)) loader_issue(stage);
+    }
+    if (have_l) loader_advance();
     --remaining;
     ++ckb;
     stage ^= 1;

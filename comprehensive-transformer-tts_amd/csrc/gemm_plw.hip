@@ -45,6 +45,11 @@ struct PlwArgs {
   unsigned* ws;
 };
 
+// 24 x (one MFMA, one LDS read) in program order for the scheduling region that ends here (masks: 0x008 MFMA, 0x100 DS read)
+#define PLW_SGB2() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
+#define PLW_SGB8() PLW_SGB2(); PLW_SGB2(); PLW_SGB2(); PLW_SGB2()
+#define PLW_INTERLEAVE_24() PLW_SGB8(); PLW_SGB8(); PLW_SGB8(); PLW_SGB8(); PLW_SGB8(); PLW_SGB8()
+
 struct PlwFrag { pl_u32x4 a[2][3], b[2][3]; };       // one 16-deep k-step: [MFMA row / column tile][piece]
 
 template <bool CONV>
@@ -166,10 +171,12 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
     const unsigned sB = smem_addr + (unsigned)(stage * PL_STAGE + 3 * PLW_A_PLANE + wave * 2048);
 #pragma unroll
     for (int q = 0; q < 3; ++q) pl_dma16(ra_src, sA + q * PLW_A_PLANE, vA, l_soffA + q * 64);
+    if (!PL_DBG(64)) {                 // tools: 64 = no B DMA after the prologue (what would a smaller B image buy?)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 3; ++q) pl_dma16(rb_src, sB + q * PLW_B_PLANE + j * 1024, vB[j], l_soffB + q * 64);
+    }
   };
   auto loader_advance = [&]() {
     ++lkb;
@@ -268,37 +275,31 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
     __builtin_amdgcn_s_waitcnt(0);
     while (true) {
       const bool do_mma = PL_DBG(8) == 0;
-      if constexpr (!SKEW) {
-        if (do_mma) mma_terms(f0, 0, 1);
+      // One fragment read per MFMA (sched_group_barrier): hipcc otherwise emits the 24 reads of a half block as two bursts, during which
+      // the wave issues no MFMA - the matrix pipe then depends on the SIMD's other wave being in an MFMA phase at that moment (measured
+      // without DMA: 314 us with the bursts, 253 us with no reads at all, dense FFN shape).
+      if (PL_DBG(256)) { if (do_mma) mma_terms(f0, 0, 6); }
+      else {
         read_frag(stage, 1, f1);
-        if (do_mma) mma_terms(f0, 1, 6);
-      } else {
-        if (do_mma) mma_terms(f0, 0, 3);
-        read_frag(stage, 1, f1);
-        if (do_mma) mma_terms(f0, 3, 6);
+        if (do_mma) mma_terms(f0, 0, 6);
+        PLW_INTERLEAVE_24();
       }
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // lgkmcnt(0) as a wait hipcc can SEE (0xC07F = vmcnt 63, expcnt 7, lgkmcnt 0): inside the asm it left the compiler's scoreboard with the
+      // fragment reads of k-step 1 still "pending", and - the counter being in order - every second-half MFMA on them then waited for the
+      // NEWER reads of the next block's fragments as well (s_waitcnt lgkmcnt(5 .. 0) in front of the first six MFMAs after the barrier)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      if (PL_DBG(128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // tools: 128 = no barrier in the loop (timing only)
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       const bool more = ckb + 1 < cp.kb_hi;
-      if constexpr (!SKEW) {
-        if (more) read_frag(stage ^ 1, 0, f0);
-        if (do_mma) mma_terms(f1, 0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (have_l && !PL_DBG(1)) loader_issue(stage);
-        if (do_mma) mma_terms(f1, 2, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        if (have_l) loader_advance();
-        if (do_mma) mma_terms(f1, 4, 6);
-      } else {
-        if (do_mma) mma_terms(f1, 0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) read_frag(stage ^ 1, 0, f0);
-        if (do_mma) mma_terms(f1, 2, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        if (have_l && !PL_DBG(1)) loader_issue(stage);
-        if (have_l) loader_advance();
-        if (do_mma) mma_terms(f1, 4, 6);
-      }
+      // (read unconditionally: when this block ends the piece the values are dead - f0 is read again behind the epilogue - and the reads
+      //  and the MFMAs stay in ONE scheduling region)
+      if (!PL_DBG(256)) read_frag(stage ^ 1, 0, f0);
+      if (do_mma) mma_terms(f1, 0, 6);
+      PLW_INTERLEAVE_24();
+      __builtin_amdgcn_sched_barrier(0);
+      if (have_l && !PL_DBG(1)) loader_issue(stage);
+      if (have_l) loader_advance();
       ++ckb;
       stage ^= 1;
       if (ckb < cp.kb_hi) continue;

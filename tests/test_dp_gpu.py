@@ -214,8 +214,16 @@ def test_rccl_one_rank_group_runs_the_collective_path_on_this_gpu():
     world_size 1, the bucketed all-reduces with ReduceOp.AVG on their side stream: launched eagerly between eager stages, eagerly between
     the replays of the four stage graphs, and captured INSIDE one whole-step hipGraph (trainer.TrainStep graph_collectives).  Each mode
     must reproduce the loss trajectory and the final parameters of the step without collectives bit for bit (tools/try_rccl_world1.py)."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "try_rccl_world1.py")], env=env, capture_output=True, text=True, timeout=600)
-    print(r.stdout[-3000:])
+    # The child process brings up RCCL next to this pytest process (which holds most of its GPU allocations): its start-up - rendezvous
+    # on a local port, communicator creation - failed ONCE in ~10 full-suite runs on the 1-GPU boxes while the same file passed 4 / 4 on its
+    # own.  The claim under test is the bit-identity the child prints, not RCCL's start-up: a failed START is retried once on a fresh
+    # port (both attempts' output is kept in the assertion message); a child that ran and reported a mismatch fails immediately.
+    r = None
+    for attempt in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "try_rccl_world1.py")], env=env, capture_output=True, text=True, timeout=600)
+        print(f"--- attempt {attempt}: rc {r.returncode}\n" + r.stdout[-3000:] + ("\n[stderr]\n" + r.stderr[-2000:] if r.returncode else ""))
+        if r.returncode == 0 or "identical to no-collective run: False" in r.stdout:
+            break
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert "backend=nccl" in r.stdout and r.stdout.count("identical to no-collective run: True") == 3

@@ -48,10 +48,12 @@ def check(path, which="pl"):
         # the K loop exists once per wave group (two instruction orders): runs of 48 MFMAs
         groups = [mf[k:k + 48] for k in range(0, len(mf), 48)]
         for gi, grp in enumerate(groups):
-            cand = [(a, b) for a, b in loops(body) if a <= grp[0] and b >= grp[-1]]
-            a, b = min(cand, key=lambda ab: ab[1] - ab[0])
-            # the K loop proper = from the loop head to the `continue` branch after the last MFMA
-            cont = next(i for i in range(grp[-1], b + 1) if re.search(r"s_cbranch", body[i]))
+            # the K loop proper: from the loop head (the nearest backward-branch target in front of the group) to the first branch behind
+            # the block's last MFMA / last LDS-DMA instruction, whichever comes later (the `continue` of `if (ckb < cp.kb_hi) continue;`)
+            a = max(a for a, b in loops(body) if a <= grp[0] and b >= grp[-1])
+            dmas = [i for i in range(a, len(body)) if "buffer_load_dwordx4" in body[i] and " lds" in body[i]][:9]
+            last = max([grp[-1]] + dmas)
+            cont = next(i for i in range(last, len(body)) if re.search(r"s_cbranch|s_branch", body[i]))
             seg = body[a:cont + 1]
             cnt = lambda pat: sum(1 for l in seg if re.match(r"\s+" + pat, l))
             n = dict(mfma=cnt("v_mfma"), frag_reads=cnt(rd), lanes=cnt("v_readlane") + cnt("v_writelane"), dma=sum(1 for l in seg if "buffer_load_dwordx4" in l and " lds" in l),
