@@ -1340,7 +1340,7 @@ static bool gemm_x6_takes(const ctts_gemm_desc& d) {
   if (on < 1 || !d.a_kc || !d.b_kc || d.nb0 * d.nb1 != 1 || d.split_k > 1 || d.E || d.lens || d.conv_on_b) return false;
   if (d.K < 256 || d.K % BK || d.N % 128 || d.M < 1024) return false;
   if (d.conv_T > 0 && d.conv_cin % 4) return false;
-  if (on != 2 && (long)((d.M + 127) / 128) * (d.N / 128) < min_tiles) return false;      // 2 = forced (tests): no size threshold
+  if (on != 2 && on != 4 && (long)((d.M + 127) / 128) * (d.N / 128) < min_tiles) return false;      // 2 / 4 = forced (tests): no size threshold
   return vec_ok(d) && buf_ok(d);
 }
 
@@ -1352,7 +1352,7 @@ static bool gemm_x6tn_takes(const ctts_gemm_desc& d) {
   if (d.M % 128 || d.N % 128 || d.K % BK || d.K < 2048) return false;
   // (a thread stages 8 consecutive reduction rows starting at a multiple of 8: they stay inside one utterance when conv_T % 8 == 0)
   if (d.conv_T > 0 && (!d.conv_on_b || d.conv_T % 8 || d.conv_cin % 4)) return false;
-  if (d.bf16_split != 2 && (long)(d.M / 128) * (d.N / 128) * (d.split_k > 1 ? d.split_k : 1) < min_wg) return false;
+  if (d.bf16_split != 2 && d.bf16_split != 4 && (long)(d.M / 128) * (d.N / 128) * (d.split_k > 1 ? d.split_k : 1) < min_wg) return false;
   return vec_ok(d) && buf_ok(d);
 }
 

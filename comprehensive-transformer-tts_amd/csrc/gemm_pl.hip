@@ -84,9 +84,15 @@ __device__ __forceinline__ void pl_epilogue(const ctts_gemm_desc& d, const float
 #define PL_SGB3() __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
 #define PL_INTERLEAVE_12() PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3(); PL_SGB3()
 
+#define PL_SGB11() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
+#define PL_INTERLEAVE_4x1() PL_SGB11(); PL_SGB11(); PL_SGB11(); PL_SGB11()
+
 struct PlFrag { pl_u32x4 a[2][3], b[2][3]; };      // one 16-deep k-step: [MFMA row / column tile][plane]
 
-template <bool CONV>
+// TERMS = 6: fp32 products from the six cross terms of the three-way split (bf16_split 1 / 2).  TERMS = 1: the "amp" arithmetic
+// (bf16_split 3 / 4; reference train.py:59,104 `amp.autocast`): operands ROUNDED to bf16 - only the hi pieces are moved and multiplied -
+// fp32 accumulate: one MFMA term, a third of the operand traffic.  Never the default, reported separately.
+template <bool CONV, int TERMS>
 __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d, const PlArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PL_STAGE];
   __shared__ int s_pref[PL_MAX_UTT + 1];          // active 128-row tiles of the utterances before b
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wave >> 2) * 64, wn0 = (wave & 3) * 64;
   const int nutt = p.nutt, tpu = p.tpu;
+  constexpr int NQ = TERMS == 1 ? 1 : 3;          // pieces moved and read
   const unsigned long long dbg_c0 = PL_DBG(16) ? clock64() : 0ull, dbg_w0 = PL_DBG(16) ? wall_clock64() : 0ull;
 
   // ---- schedule of the active m-tiles (ragged rows)
@@ -217,11 +224,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
     const unsigned sB = smem_addr + (unsigned)(stage * PL_STAGE + 3 * PL_A_PLANE + wave * 2048);
     // the three pieces of a row group back to back: they share cache lines
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pl_dma16(ra_src, sA + q * PL_A_PLANE, vA, soffA + q * 64);
+    for (int q = 0; q < NQ; ++q) pl_dma16(ra_src, sA + q * PL_A_PLANE, vA, soffA + q * 64);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) pl_dma16(rb_src, sB + q * PL_B_PLANE + j * 1024, voffB[j], soffB + q * 64);
+      for (int q = 0; q < NQ; ++q) pl_dma16(rb_src, sB + q * PL_B_PLANE + j * 1024, voffB[j], soffB + q * 64);
   };
   auto loader_advance = [&]() {
     ++lkb;
@@ -245,11 +252,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) f.a[i][q] = *reinterpret_cast<const pl_u32x4*>(pa + q * PL_A_PLANE + i * 32 * PL_ROW);
+      for (int q = 0; q < NQ; ++q) f.a[i][q] = *reinterpret_cast<const pl_u32x4*>(pa + q * PL_A_PLANE + i * 32 * PL_ROW);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) f.b[j][q] = *reinterpret_cast<const pl_u32x4*>(pb + q * PL_B_PLANE + j * 32 * PL_ROW);
+      for (int q = 0; q < NQ; ++q) f.b[j][q] = *reinterpret_cast<const pl_u32x4*>(pb + q * PL_B_PLANE + j * 32 * PL_ROW);
   };
   floatx16 acc[2][2];
   auto zero_acc = [&]() {
@@ -262,6 +269,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
   };
   // terms [t0, t1) of the six-term product of one k-step; term-major: consecutive MFMAs hit different accumulators; smallest terms first
   auto mma_terms = [&](const PlFrag& f, int t0, int t1) {
+    if constexpr (TERMS == 1) {          // hi x hi only
+      if (t0 <= 5 && 5 < t1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = pl_mma(f.a[i][0], f.b[j][0], acc[i][j]);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
     if (do_mma) {
       read_frag(stage, 1, f1);
       mma_terms(f0, 0, 6);
-      PL_INTERLEAVE_12();
+      if constexpr (TERMS == 1) { PL_INTERLEAVE_4x1(); } else { PL_INTERLEAVE_12(); }
     }
     __builtin_amdgcn_sched_barrier(0);
     // every wave is done reading this stage, and (mine of) block i + 1 has landed: after the barrier the whole block has
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
     if (do_mma) {
       read_frag(stage ^ 1, 0, f0);
       mma_terms(f1, 0, 6);
-      PL_INTERLEAVE_12();
+      if constexpr (TERMS == 1) { PL_INTERLEAVE_4x1(); } else { PL_INTERLEAVE_12(); }
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SKEW) {
@@ -584,7 +600,8 @@ static int pl_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
   // is a little too large only makes the pieces shorter
   const long tiles = act_tiles_m * p.tiles_n;
   const long units = tiles * p.nkb;
-  if (d.bf16_split < 2 && units < min_units) return 0;
+  const bool forced = d.bf16_split == 2 || d.bf16_split == 4;        // no size thresholds (parity tests of small launches)
+  if (!forced && units < min_units) return 0;
   const int cuts = p.whole_tiles ? 1 : ((p.nkb >= 256 && max_split < 4) ? 4 : max_split);
   long W = force_w > 0 ? force_w : 32;
   const long Wu = units / (8L * wg_units);
@@ -592,14 +609,19 @@ static int pl_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
   const long Wt = d.row_lens ? (tiles * cuts * 3 / 4) / 8 : (tiles * cuts) / 8;      // ragged: expect >= 3/4 of the tiles to be active
   if (W > Wt) W = Wt;
   if (W < 1) {
-    if (d.bf16_split < 2) return 0;
+    if (!forced) return 0;
     W = 1;
   }
   const int grid = (int)W * 8;
   if (grid > PL_MAX_WG || (long)grid * PL_SLAB > PL_SLAB_FLOATS_MAX) return 0;
   if (!launch) return 1;
-  if (conv) hipLaunchKernelGGL(gemm_pl_kernel<true>, dim3(grid), dim3(512), 0, st, d, p);
-  else hipLaunchKernelGGL(gemm_pl_kernel<false>, dim3(grid), dim3(512), 0, st, d, p);
+  if (d.bf16_split >= 3) {
+    if (conv) hipLaunchKernelGGL((gemm_pl_kernel<true, 1>), dim3(grid), dim3(512), 0, st, d, p);
+    else hipLaunchKernelGGL((gemm_pl_kernel<false, 1>), dim3(grid), dim3(512), 0, st, d, p);
+  } else {
+    if (conv) hipLaunchKernelGGL((gemm_pl_kernel<true, 6>), dim3(grid), dim3(512), 0, st, d, p);
+    else hipLaunchKernelGGL((gemm_pl_kernel<false, 6>), dim3(grid), dim3(512), 0, st, d, p);
+  }
   CTTS_CHECK_LAUNCH("ctts_gemm(planes)");
   return 1;
 }

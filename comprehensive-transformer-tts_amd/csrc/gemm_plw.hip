@@ -50,9 +50,13 @@ struct PlwArgs {
 #define PLW_SGB8() PLW_SGB2(); PLW_SGB2(); PLW_SGB2(); PLW_SGB2()
 #define PLW_INTERLEAVE_24() PLW_SGB8(); PLW_SGB8(); PLW_SGB8(); PLW_SGB8(); PLW_SGB8(); PLW_SGB8()
 
+#define PLW_SGB12() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0)
+#define PLW_INTERLEAVE_4x2() PLW_SGB12(); PLW_SGB12(); PLW_SGB12(); PLW_SGB12()
+
 struct PlwFrag { pl_u32x4 a[2][3], b[2][3]; };       // one 16-deep k-step: [MFMA row / column tile][piece]
 
-template <bool CONV>
+// TERMS: 6 = the six cross terms; 1 = the "amp" arithmetic of gemm_pl_kernel (hi pieces only)
+template <bool CONV, int TERMS>
 __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d, const PlwArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PL_STAGE];
   __shared__ int s_pref[PL_MAX_UTT + 1];          // active K-blocks of the utterances before b
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wave >> 2) * 64, wn0 = (wave & 3) * 64;
   const int nutt = p.nutt;
+  constexpr int NQ = TERMS == 1 ? 1 : 3;          // pieces moved and read
 
   int nkb = p.nkb;
   if (nutt > 0) {
@@ -170,12 +175,12 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
     const unsigned sA = smem_addr + (unsigned)(stage * PL_STAGE + wave * 1024);
     const unsigned sB = smem_addr + (unsigned)(stage * PL_STAGE + 3 * PLW_A_PLANE + wave * 2048);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pl_dma16(ra_src, sA + q * PLW_A_PLANE, vA, l_soffA + q * 64);
+    for (int q = 0; q < NQ; ++q) pl_dma16(ra_src, sA + q * PLW_A_PLANE, vA, l_soffA + q * 64);
     if (!PL_DBG(64)) {                 // tools: 64 = no B DMA after the prologue (what would a smaller B image buy?)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) pl_dma16(rb_src, sB + q * PLW_B_PLANE + j * 1024, vB[j], l_soffB + q * 64);
+      for (int q = 0; q < NQ; ++q) pl_dma16(rb_src, sB + q * PLW_B_PLANE + j * 1024, vB[j], l_soffB + q * 64);
     }
   };
   auto loader_advance = [&]() {
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const unsigned char* pa = base + fa_off[i] + q * PLW_A_PLANE + (16 * ks) * (PL_BM * 2);
         const plw_s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plw_lds_s16x4*)(pa));
         const plw_s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plw_lds_s16x4*)(pa + 4 * (PL_BM * 2)));
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const unsigned char* pb = base + fb_off[j] + q * PLW_B_PLANE + (16 * ks) * (PL_BN * 2);
         const plw_s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plw_lds_s16x4*)(pb));
         const plw_s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plw_lds_s16x4*)(pb + 4 * (PL_BN * 2)));
@@ -241,6 +246,15 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
   auto mma_terms = [&](const PlwFrag& f, int t0, int t1) {
+    if constexpr (TERMS == 1) {          // hi x hi only
+      if (t0 <= 5 && 5 < t1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = pl_mma(f.a[i][0], f.b[j][0], acc[i][j]);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
       else {
         read_frag(stage, 1, f1);
         if (do_mma) mma_terms(f0, 0, 6);
-        PLW_INTERLEAVE_24();
+        if constexpr (TERMS == 1) { PLW_INTERLEAVE_4x2(); } else { PLW_INTERLEAVE_24(); }
       }
       __builtin_amdgcn_sched_barrier(0);
       // lgkmcnt(0) as a wait hipcc can SEE (0xC07F = vmcnt 63, expcnt 7, lgkmcnt 0): inside the asm it left the compiler's scoreboard with the
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
       //  and the MFMAs stay in ONE scheduling region)
       if (!PL_DBG(256)) read_frag(stage ^ 1, 0, f0);
       if (do_mma) mma_terms(f1, 0, 6);
-      PLW_INTERLEAVE_24();
+      if constexpr (TERMS == 1) { PLW_INTERLEAVE_4x2(); } else { PLW_INTERLEAVE_24(); }
       __builtin_amdgcn_sched_barrier(0);
       if (have_l && !PL_DBG(1)) loader_issue(stage);
       if (have_l) loader_advance();
@@ -450,7 +464,8 @@ static int plw_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
   p.ws = reinterpret_cast<unsigned*>(d.sk_ws);
   const long tiles = (long)p.tiles_m * p.tiles_n;
   const long units = tiles * p.nkb;
-  if (d.bf16_split < 2 && (units < min_units || tiles < min_tiles)) return 0;
+  const bool forced = d.bf16_split == 2 || d.bf16_split == 4;        // no size thresholds (parity tests of small launches)
+  if (!forced && (units < min_units || tiles < min_tiles)) return 0;
   long W = force_w > 0 ? force_w : 32;
   const long Wu = units / (8L * wg_units);
   if (W > Wu) W = Wu;
@@ -458,8 +473,13 @@ static int plw_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
   const int grid = (int)W * 8;
   if (grid > PL_MAX_WG || (long)grid * PL_SLAB > PL_SLAB_FLOATS_MAX) return 0;
   if (!launch) return 1;
-  if (conv) hipLaunchKernelGGL(gemm_plw_kernel<true>, dim3(grid), dim3(512), 0, st, d, p);
-  else hipLaunchKernelGGL(gemm_plw_kernel<false>, dim3(grid), dim3(512), 0, st, d, p);
+  if (d.bf16_split >= 3) {
+    if (conv) hipLaunchKernelGGL((gemm_plw_kernel<true, 1>), dim3(grid), dim3(512), 0, st, d, p);
+    else hipLaunchKernelGGL((gemm_plw_kernel<false, 1>), dim3(grid), dim3(512), 0, st, d, p);
+  } else {
+    if (conv) hipLaunchKernelGGL((gemm_plw_kernel<true, 6>), dim3(grid), dim3(512), 0, st, d, p);
+    else hipLaunchKernelGGL((gemm_plw_kernel<false, 6>), dim3(grid), dim3(512), 0, st, d, p);
+  }
   CTTS_CHECK_LAUNCH("ctts_gemm(planes, weight gradient)");
   return 1;
 }

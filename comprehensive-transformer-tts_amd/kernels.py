@@ -313,12 +313,23 @@ def gemm_takes_bf16_split(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=Tr
 def gemm_bf16_split_enable(on):
     """Default arithmetic of the descriptors this module builds (ctts_gemm_desc.bf16_split; env CTTS_X6=0 starts with it off): False =
     fp32 MFMA only, True = the large launches may run on the bf16 matrix pipe with the exact six-term operand split, 2 = also launches
-    below the kernels' size thresholds (tests).  Returns the previous setting (pass it back to restore).  The library itself holds no
-    such state any more: the choice travels in every descriptor, so a captured graph keeps the arithmetic it was captured with and two
-    models can differ (`bf16_split=` on a single call overrides the default)."""
+    below the kernels' size thresholds (tests); "amp" (= 3; 4 without the thresholds) = the plane kernels round their operands to bf16
+    and use ONE MFMA term (reference train.py:59,104 `amp.autocast` - reduced precision, never the default: see amp_split).  Returns
+    the previous setting (pass it back to restore).  The library itself holds no such state any more: the choice travels in every
+    descriptor, so a captured graph keeps the arithmetic it was captured with and two models can differ (`bf16_split=` on a single call
+    overrides the default)."""
     global BF16_SPLIT
-    prev, BF16_SPLIT = BF16_SPLIT, (2 if on == 2 else int(bool(on)))
+    prev = BF16_SPLIT
+    BF16_SPLIT = 3 if on == "amp" else (int(on) if on in (2, 3, 4) else int(bool(on)))
     return prev
+
+
+def amp_split():
+    """`bf16_split` for a launch made under torch.amp.autocast (ops._LinearConv asks torch.is_autocast_enabled): the one-term arithmetic
+    with the current setting's thresholds, or None when the bf16 kernels are switched off altogether (CTTS_X6=0 / enable(False))."""
+    if BF16_SPLIT < 1:
+        return None
+    return 4 if BF16_SPLIT in (2, 4) else 3
 
 
 def gemm_takes_planes(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, **kw):
@@ -337,7 +348,7 @@ def plane_shape_ok(M, N, K, conv_cin=None):
     if conv_cin is not None and (conv_cin % 32 or K % conv_cin):
         return False
     tiles = -(-M // 128) * -(-N // 256)
-    return BF16_SPLIT == 2 or (tiles * (K // 32) >= PLANES_MIN_UNITS and tiles >= PLANES_MIN_TILES)
+    return BF16_SPLIT in (2, 4) or (tiles * (K // 32) >= PLANES_MIN_UNITS and tiles >= PLANES_MIN_TILES)
 
 
 def plane_wgrad_shape_ok(Mo, No, Kred, cin=None):
@@ -350,7 +361,7 @@ def plane_wgrad_shape_ok(Mo, No, Kred, cin=None):
     if cin is not None and (cin % 256 or No % cin):
         return False
     tiles = (Mo // 128) * (No // 256)
-    return BF16_SPLIT == 2 or (tiles >= 32 and tiles * (-(-Kred // 32)) >= PLANES_MIN_UNITS)
+    return BF16_SPLIT in (2, 4) or (tiles >= 32 and tiles * (-(-Kred // 32)) >= PLANES_MIN_UNITS)
 
 
 def split_planes(mats):

@@ -292,6 +292,12 @@ class _LinearConv(torch.autograd.Function):
             residual = residual.contiguous()
         gk = dict(conv=conv, alpha=alpha, bias=b, Z=Z, ldz=N, act=act, p_drop=p_drop, seed=seed, drop_offset=drop_offset, R=residual, ldr=N,
                   rowscale=rowscale, row_lens=row_lens, row_T=row_T, row_halo=0)
+        # reference train.py:59,104 `with amp.autocast(args.use_amp)`: honoured by the launches the plane kernels take (the Conv1d layers
+        # with many rows) - operands rounded to bf16, one MFMA term, fp32 accumulate and fp32 tensors everywhere; the backward of the
+        # layer uses the arithmetic its forward ran with.  Everything else stays fp32-class.  Reduced precision: opt-in, own tolerance.
+        ctx.amp = (K.amp_split() if (ksize and x.is_cuda and torch.is_autocast_enabled("cuda")) else None)
+        if ctx.amp is not None:
+            gk["bf16_split"] = ctx.amp
         planes = _operand_planes("fwd", w, x.view(M, Cin), wf, M, N, Kdim, Cin, Kdim, N, out, gk) if ksize else {}
         K.gemm(x, wf, out, M, N, Kdim, Cin, Kdim, N, True, True, tile_map=pr.tile_map(0, M) if (pr is not None and not planes) else None,
                **gk, **planes)
@@ -313,6 +319,8 @@ class _LinearConv(torch.autograd.Function):
         x, w, Z, rowscale, seed, row_lens, b = ctx.saved_tensors
         act, alpha, p_drop, drop_offset, ksize, has_bias, has_res, row_T = ctx.cfg
         rl = dict(row_lens=row_lens, row_T=row_T) if row_lens is not None else {}
+        if getattr(ctx, "amp", None) is not None:
+            rl["bf16_split"] = ctx.amp           # travels with every GEMM of this backward (only the plane kernels act on it)
         pr = ctx.pr
         # weight gradients reduce over the (b,t) rows: the same device-built map, read as a schedule of the active 64-row K-blocks
         kmap = pr.tile_map(0, x.numel() // x.shape[-1]) if (pr is not None and row_lens is not None) else None

@@ -102,7 +102,11 @@ typedef struct ctts_gemm_desc {
    *   0 = fp32 MFMA only (v_mfma_f32_32x32x2_f32: every product an exact fp32 product) - what a zero-initialised descriptor gets;
    *   1 = launches that qualify by shape and size may run on the BF16 matrix pipe with the six-term operand split described at
    *       ctts_gemm_takes_bf16_split below (fp32-class results);
-   *   2 = as 1 without the size thresholds (parity tests of small launches). */
+   *   2 = as 1 without the size thresholds (parity tests of small launches);
+   *   3 = REDUCED precision, opt-in ("amp": reference train.py:59,104 amp.autocast): launches the plane kernels take (A_planes / B_planes
+   *       given and eligible) use the hi pieces only - operands rounded to bf16 (round-to-nearest-even), ONE MFMA term, fp32 accumulate:
+   *       the result equals the product of the bf16-rounded operands up to fp32 summation; every other launch is treated as 1;
+   *   4 = as 3 without the size thresholds. */
   int32_t bf16_split;
   /* Optional PRE-SPLIT operands (ctts_split_planes): A_planes / B_planes hold the exact three-way bf16 split of the SAME fp32 matrices
    * A / B point to, in the K-block-interleaved layout [rows][ld / 32][3][32] (bf16 bit patterns): piece q (0 hi, 1 mid, 2 lo) of element

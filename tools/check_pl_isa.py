@@ -39,7 +39,8 @@ def check(path, which="pl"):
     _, kname, rd, n_rd = KERNELS[which]
     lines = open(path).read().split("\n")
     ok = True
-    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + kname + ".*:", l)]
+    # the six-term instantiations (template argument TERMS = 6: `...ILb?ELi6EE...`); the one-term "amp" variants are not judged here
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*" + kname + r"ILb\dELi6E.*:", l)]
     for st in starts:
         name = lines[st].split(":")[0]
         end = next(i for i in range(st, len(lines)) if ".Lfunc_end" in lines[i])
