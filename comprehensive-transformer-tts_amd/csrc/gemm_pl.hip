@@ -87,6 +87,10 @@ __device__ __forceinline__ void pl_epilogue(const ctts_gemm_desc& d, const float
 #define PL_SGB11() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)
 #define PL_INTERLEAVE_4x1() PL_SGB11(); PL_SGB11(); PL_SGB11(); PL_SGB11()
 
+#ifndef PL_SLAB_BATCH
+#define PL_SLAB_BATCH 8
+#endif
+
 struct PlFrag { pl_u32x4 a[2][3], b[2][3]; };      // one 16-deep k-step: [MFMA row / column tile][plane]
 
 // TERMS = 6: fp32 products from the six cross terms of the three-way split (bf16_split 1 / 2).  TERMS = 1: the "amp" arithmetic
@@ -419,16 +423,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           const unsigned base = (unsigned)src * (PL_SLAB * 4) + (unsigned)(wave * (PL_SLAB / 8) + lane * 4) * 4u;
+          // The loads of a slab in flight in batches of PL_SLAB_BATCH quads, THEN their sums (in the fixed order): written as "load, add" hipcc
+          // reused one register quad and waited for every load - 16 dependent L2 round trips, ~16 us per slab, on the critical path of every
+          // cut tile.  (All 16 at once cost this kernel 59 - 72 spilled VGPRs with reloads inside the K loop; gemm_plw.hip affords it.)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int g = 0; g < 16 / PL_SLAB_BATCH; ++g) {
+            pl_u32x4 sv[PL_SLAB_BATCH];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int e = 0; e < PL_SLAB_BATCH; ++e) sv[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, base + (unsigned)((g * PL_SLAB_BATCH + e) * 1024), 0, 0);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const pl_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_src, base + (unsigned)(((i * 2 + j) * 4 + q) * 1024), 0, 0);
-                acc[i][j][4 * q + 0] += __uint_as_float(v.x); acc[i][j][4 * q + 1] += __uint_as_float(v.y);
-                acc[i][j][4 * q + 2] += __uint_as_float(v.z); acc[i][j][4 * q + 3] += __uint_as_float(v.w);
-              }
+            for (int e = 0; e < PL_SLAB_BATCH; ++e) {
+              const int n = g * PL_SLAB_BATCH + e, i = n >> 3, j = (n >> 2) & 1, q = n & 3;
+              acc[i][j][4 * q + 0] += __uint_as_float(sv[e].x); acc[i][j][4 * q + 1] += __uint_as_float(sv[e].y);
+              acc[i][j][4 * q + 2] += __uint_as_float(sv[e].z); acc[i][j][4 * q + 3] += __uint_as_float(sv[e].w);
+            }
+          }
         }
       }
       if (pad_hi && e_wm0 == 64) {

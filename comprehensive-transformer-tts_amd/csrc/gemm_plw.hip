@@ -366,13 +366,18 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const unsigned base = (unsigned)src * (PL_SLAB * 4) + (unsigned)(wave * (PL_SLAB / 8) + lane * 4) * 4u;
+            // all 16 loads of the slab in flight, THEN the sums (in the fixed order): written as "load, add" hipcc reused one register quad and
+            // waited for every load - 16 dependent L2 round trips, ~16 us per slab, on the critical path of every cut tile
+            pl_u32x4 sv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sv[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, base + (unsigned)(e * 1024), 0, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
               for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                  const pl_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_src, base + (unsigned)(((i * 2 + j) * 4 + q) * 1024), 0, 0);
+                  const pl_u32x4 v = sv[(i * 2 + j) * 4 + q];
                   acc[i][j][4 * q + 0] += __uint_as_float(v.x); acc[i][j][4 * q + 1] += __uint_as_float(v.y);
                   acc[i][j][4 * q + 2] += __uint_as_float(v.z); acc[i][j][4 * q + 3] += __uint_as_float(v.w);
                 }

@@ -401,16 +401,21 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : ((MT * NT >= 2 || STAGES >
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           const unsigned base = (unsigned)src * (SLAB * 4) + (unsigned)(wave * (SLAB / 4) + lane * 4) * 4u;
+          // the four loads of an MFMA tile in flight, then their sums (fixed order): as "load, add" hipcc reused one register quad and
+          // waited for every load - MT * NT * 4 dependent L2 round trips (~1 us each) per slab on the critical path of every cut tile
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NT; ++j) {
+              sk_u32x4 sv[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) sv[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, base + (unsigned)(((i * NT + j) * 4 + q) * 1024), 0, 0);
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const sk_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_src, base + (unsigned)(((i * NT + j) * 4 + q) * 1024), 0, 0);
-                acc[i][j][4 * q + 0] += __uint_as_float(v.x); acc[i][j][4 * q + 1] += __uint_as_float(v.y);
-                acc[i][j][4 * q + 2] += __uint_as_float(v.z); acc[i][j][4 * q + 3] += __uint_as_float(v.w);
+                acc[i][j][4 * q + 0] += __uint_as_float(sv[q].x); acc[i][j][4 * q + 1] += __uint_as_float(sv[q].y);
+                acc[i][j][4 * q + 2] += __uint_as_float(sv[q].z); acc[i][j][4 * q + 3] += __uint_as_float(sv[q].w);
               }
+            }
         }
       }
       if (p.accumulate) {

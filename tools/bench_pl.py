@@ -117,6 +117,17 @@ rs = (torch.arange(T, device=dev)[None, :] < lens[:, None]).float().reshape(-1).
 run("ffn2 fwd step", h, w2, (M, 256), M, 256, 1024, 1024, 2 * nvalid * 256 * 1024,
     dict(bias=torch.zeros(256, device=dev), p_drop=0.1, seed=seed, drop_offset=2, R=R, ldr=256, rowscale=rs, row_lens=lens, row_T=T, row_halo=0),
     tmap=K.row_tile_map(lens, T, 0, M))
+# encoder-sized launches (16 x 128 phoneme rows, about half of them valid): few tiles, every tile cut between many workgroups
+Te = 128
+lens_en = torch.tensor(list(CANONICAL_SRC_LENS), dtype=torch.int32, device=dev)
+nval_e = int(lens_en.sum())
+xe = torch.randn(B, Te, 256, device=dev)
+run("enc ffn1 fwd step", xe, wf, (B, Te, 1024), B * Te, 1024, 2304, 256, 2 * nval_e * 1024 * 2304,
+    dict(conv=(Te, 4, 256), alpha=9 ** -0.5, bias=bias, Z=True, ldz=1024, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1,
+         row_lens=lens_en, row_T=Te, row_halo=0), tmap=K.row_tile_map(lens_en, Te, 0, B * Te))
+dze = torch.randn(B, Te, 1024, device=dev) * (torch.arange(Te, device=dev)[None, :, None] < lens_en[:, None, None])
+run("enc ffn1 dgrad step", dze, wd, (B, Te, 256), B * Te, 256, 9216, 1024, 2 * nval_e * 256 * 9216,
+    dict(conv=(Te, 4, 1024), alpha=9 ** -0.5, row_lens=lens_en, row_T=Te, row_halo=4, split_overwrite=True), tmap=K.row_tile_map(lens_en, Te, 4, B * Te))
 n = 4096
 run("square 4096", torch.randn(n, n, device=dev), torch.randn(n, n, device=dev) * 0.02, (n, n), n, n, n, n, 2 * n ** 3, dict())
 
