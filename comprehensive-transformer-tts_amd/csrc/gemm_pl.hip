@@ -113,14 +113,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_kernel(const ctts_gemm_desc d,
   // ---- schedule of the active m-tiles (ragged rows)
   int n_mt = p.tiles_m;
   if (nutt > 0) {
+    // lengths to LDS first (ONE global load per thread), then the prefix sums from LDS: summing straight from row_lens made thread t wait
+    // for t dependent global loads - ~18 us at the head of every ragged launch (16 utterances), measured on the encoder-sized shapes
+    for (int t = tid; t < nutt; t += 512) s_lenh[t] = d.row_lens[t] + d.row_halo;
+    __syncthreads();
     for (int t = tid; t <= nutt; t += 512) {
       int s = 0;
       for (int b = 0; b < t; ++b) {
-        const int L = d.row_lens[b] + d.row_halo;
+        const int L = s_lenh[b];
         s += L <= 0 ? 0 : min(tpu, (L + PL_BM - 1) / PL_BM);
       }
       s_pref[t] = s;
-      if (t < nutt) s_lenh[t] = d.row_lens[t] + d.row_halo;
     }
     __syncthreads();
     n_mt = s_pref[nutt];
@@ -571,7 +574,10 @@ static int pl_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
   static const int enabled = pl_env("CTTS_PL", 1);
   static const int min_units = pl_env("CTTS_PL_MIN_UNITS", 4096);     // (tile, K-block) units; below this the launch is latency bound either way
   static const int split_from = pl_env("CTTS_PL_SPLIT_NKB", 24);
-  static const int max_split = pl_env("CTTS_PL_MAX_SPLIT", 2);
+  // pieces a tile may be cut into when the tile count alone cannot fill the chip (2,048-row launches: 64 tiles).  2 until the slab
+  // hand-off stopped costing ~16 us per slab (see the owner's loop); with ~4 us per slab: encoder FFN conv forward 93 -> 64 us at 4,
+  // its data gradient (16 tiles x 288 K-blocks) 156 -> 92 us at 8
+  static const int max_split = pl_env("CTTS_PL_MAX_SPLIT", 8);
   static const int wg_units = pl_env("CTTS_PL_WG_UNITS", 16);
   static const int force_w = pl_env("CTTS_PL_W", 0);
   static const int debug = pl_env("CTTS_PL_DEBUG", 0);
@@ -615,7 +621,9 @@ static int pl_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
   long W = force_w > 0 ? force_w : 32;
   const long Wu = units / (8L * wg_units);
   if (W > Wu) W = Wu;
-  const long Wt = d.row_lens ? (tiles * cuts * 3 / 4) / 8 : (tiles * cuts) / 8;      // ragged: expect >= 3/4 of the tiles to be active
+  // ragged rows: expect >= 3/4 of the tiles to be active when an utterance spans several tiles (decoder: T = 1024), all of them when it
+  // spans one (encoder: T = 128 - a tile is inactive only for an empty utterance)
+  const long Wt = (d.row_lens && p.tpu >= 4) ? (tiles * cuts * 3 / 4) / 8 : (tiles * cuts) / 8;
   if (W > Wt) W = Wt;
   if (W < 1) {
     if (!forced) return 0;

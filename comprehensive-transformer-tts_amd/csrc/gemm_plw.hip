@@ -70,14 +70,19 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
 
   int nkb = p.nkb;
   if (nutt > 0) {
-    for (int t = tid; t <= nutt; t += 512) {
-      int s = 0;
-      for (int b = 0; b < t; ++b) {
-        const int L = d.row_lens[b] + d.row_halo;
-        s += L <= 0 ? 0 : min(p.kbu, (L + 31) >> 5);
-      }
-      s_pref[t] = s;
+    // counts to LDS first (one global load per thread), then the prefix sums from LDS (see gemm_pl_kernel: t dependent global loads
+    // per thread cost ~18 us at the head of the launch)
+    for (int t = tid; t < nutt; t += 512) {
+      const int L = d.row_lens[t] + d.row_halo;
+      s_pref[t + 1] = L <= 0 ? 0 : min(p.kbu, (L + 31) >> 5);
     }
+    if (tid == 0) s_pref[0] = 0;
+    __syncthreads();
+    int mine = 0;
+    if (tid <= nutt)
+      for (int b = 0; b <= tid; ++b) mine += s_pref[b];
+    __syncthreads();
+    if (tid <= nutt) s_pref[tid] = mine;
     __syncthreads();
     nkb = s_pref[nutt];
   }
