@@ -171,3 +171,18 @@ def test_weight_gradient_plane_prefilter():
         assert not K.plane_wgrad_shape_ok(1024, 2304, 16384, 256)
     finally:
         K.gemm_bf16_split_enable(prev)
+
+
+def test_arithmetic_switch_values_and_amp_selector():
+    """kernels.gemm_bf16_split_enable: False / True / 2 / "amp" (3) / 4 -> ctts_gemm_desc.bf16_split; amp_split() = what a launch under
+    torch.amp.autocast gets (one-term arithmetic with the current thresholds; None when the bf16 kernels are off)"""
+    from ctts_amd import kernels as K
+    prev = K.gemm_bf16_split_enable(True)
+    try:
+        assert K.BF16_SPLIT == 1 and K.amp_split() == 3
+        assert K.gemm_bf16_split_enable(2) == 1 and K.BF16_SPLIT == 2 and K.amp_split() == 4
+        assert K.gemm_bf16_split_enable("amp") == 2 and K.BF16_SPLIT == 3 and K.amp_split() == 3
+        assert K.gemm_bf16_split_enable(4) == 3 and K.BF16_SPLIT == 4 and K.amp_split() == 4
+        assert K.gemm_bf16_split_enable(False) == 4 and K.BF16_SPLIT == 0 and K.amp_split() is None
+    finally:
+        K.gemm_bf16_split_enable(prev)
