@@ -117,6 +117,18 @@ rs = (torch.arange(T, device=dev)[None, :] < lens[:, None]).float().reshape(-1).
 run("ffn2 fwd step", h, w2, (M, 256), M, 256, 1024, 1024, 2 * nvalid * 256 * 1024,
     dict(bias=torch.zeros(256, device=dev), p_drop=0.1, seed=seed, drop_offset=2, R=R, ldr=256, rowscale=rs, row_lens=lens, row_T=T, row_halo=0),
     tmap=K.row_tile_map(lens, T, 0, M))
+# FFN linear 2 data gradient with the producer's epilogue backward (N = 1024, K = 256: "a2zdB"); in the step it runs NN on the
+# weight-stationary kernel (85 us) - here NT on a transposed weight, to see what the plane kernel would make of it
+dy2 = torch.randn(M, 256, device=dev) * rs[:, None]
+w2t = torch.randn(1024, 256, device=dev) * 0.03
+Zp = torch.randn(M, 1024, device=dev)
+run("ffn2 dgrad step (a2zdB)", dy2, w2t, (M, 1024), M, 1024, 256, 256, 2 * nvalid * 1024 * 256,
+    dict(epi_bwd=True, Z=True, ldz=1024, act=K.ACT_GELU, p_drop=0.1, seed=seed, drop_offset=1, row_lens=lens, row_T=T, row_halo=0),
+    tmap=K.row_tile_map(lens, T, 0, M))
+xq = torch.randn(M, 256, device=dev)
+wq = torch.randn(768, 256, device=dev) * 0.05
+run("qkv fwd step", xq, wq, (M, 768), M, 768, 256, 256, 2 * nvalid * 768 * 256,
+    dict(bias=torch.zeros(768, device=dev), row_lens=lens, row_T=T, row_halo=0), tmap=K.row_tile_map(lens, T, 0, M))
 # encoder-sized launches (16 x 128 phoneme rows, about half of them valid): few tiles, every tile cut between many workgroups
 Te = 128
 lens_en = torch.tensor(list(CANONICAL_SRC_LENS), dtype=torch.int32, device=dev)
