@@ -64,6 +64,16 @@ def test_plain_tn_product_matches_float64(rows, cout, cin):
     close(got, ref_wgrad(dZ, X, 0, 0, 0))
 
 
+@pytest.mark.parametrize("rows,T,ksize,pad", [(1000, 0, 0, 0), (2 * 1000, 1000, 5, 2), (3 * 50, 50, 3, 1)])
+def test_reduction_length_not_a_multiple_of_the_k_block(rows, T, ksize, pad):
+    """the last 32-row K-block is partial (rows beyond the end read the hardware's out-of-range zero); with a conv view and T % 32 != 0
+    every utterance boundary falls inside a K-block (conformer: T = 1000)"""
+    cout, cin = 128, 256
+    dZ, X = rnd(rows, cout, seed=21).to(DEV), rnd(rows, cin, seed=22).to(DEV)
+    got = plane_wgrad(dZ, X, cout, cin, ksize, pad, T, bf16_split=2, split_k=2, split_overwrite=True)
+    close(got, ref_wgrad(dZ, X, ksize, pad, T))
+
+
 def test_transpose_detecting_operands():
     """one-hot operands: every (k, m) x (k, n) pairing lands in exactly one output element (guide rule: symmetric inputs hide transposes)"""
     rows, cout, cin = 256, 128, 256
