@@ -741,7 +741,7 @@ def main():
                        "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
                        "parallelism": f"dp{world}", "final_loss": loss_final,
                        "gemm_arithmetic": ("fp32 storage and accumulation everywhere; the large NT GEMMs (FFN / PostNet Conv1d forward and data gradient: "
-                                           "gemm_pl_kernel on pre-split operand planes) and the weight-gradient GEMMs (TN: gemm_x6tn_kernel) form each fp32 "
+                                           "gemm_pl_kernel on pre-split operand planes) and the weight-gradient GEMMs (TN: gemm_plw_kernel on the same planes for the Conv1d layers, gemm_x6tn_kernel for the k = 1 linears) form each fp32 "
                                            "product from 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands (exact on exactly representable "
                                            "data, dropped cross terms <= one fp32 rounding per product); all other GEMMs on v_mfma_f32_32x32x2_f32"
                                            if _bf16_on() else "v_mfma_f32_32x32x2_f32 (CTTS_X6=0)"),
