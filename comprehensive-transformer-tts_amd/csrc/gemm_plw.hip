@@ -40,6 +40,8 @@ struct PlwArgs {
   int tiles_m, tiles_n;      // 128 x 256 tiles of the [M, N] output
   int nkb;                   // 32-row K-blocks of the reduction (dense; ragged: computed in the kernel from row_lens)
   int nutt, kbu;             // ragged rows: utterances and K-blocks per utterance (row_T / 32); nutt = 0: dense
+  int fold_tt, fold_tiles;   // conv, conv_T % 32 == 0: the first `fold_tiles` n-tiles are FOLDED - 256 columns = fold_tt taps x 256 / fold_tt channels,
+                             // served by ONE B image of 32 + fold_tt - 1 rows (fold_tt = 1: no folding); the remaining taps: one tap per tile
   int accumulate;            // 1: C += alpha * acc
   int debug;                 // CTTS_PL_DEBUG bits of gemm_pl.hip (tools builds)
   unsigned* ws;
@@ -114,21 +116,50 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
     col0 = __builtin_amdgcn_readfirstlane(nt * PL_BN);
   };
 
+  // ---- n-tile -> (first tap, taps in the tile, first channel, channels per tap).  Folded tiles (conv, T % 32 == 0): the taps of a layer
+  //      read the SAME rows of x shifted by one row per tap, so a tile of 8 taps x 32 channels needs a B image of 39 rows x 64 bytes
+  //      (7.5 KB for the three pieces) where 8 one-tap tiles of 256 channels move 8 x 48 KB: the B traffic of the launch falls to a
+  //      sixth (k = 9: 8 folded + 1 one-tap tile per 256 channels), and every K-block comes from the MALL / HBM here.
+  auto tile_kind = [&](int nt, int& tap0, int& tt, int& c0, int& cw) {
+    if (CONV && nt < p.fold_tiles) {
+      tt = p.fold_tt; cw = PL_BN / tt; tap0 = 0; c0 = nt * cw;
+    } else if (CONV) {
+      const int r = nt - p.fold_tiles, cpt = cin / PL_BN;
+      tt = 1; cw = PL_BN; tap0 = (p.fold_tiles > 0 ? p.fold_tt : 0) + r / cpt; c0 = (r % cpt) * PL_BN;
+    } else {
+      tt = 1; cw = PL_BN; tap0 = 0; c0 = nt * PL_BN;
+    }
+  };
+  // 64-byte windows of a B row are XOR-ed with bits of the row index so that the four rows of a half wave's transpose read fall into
+  // different bank groups: rows of 512 / 256 bytes (all four on the same banks): row & 3; 128 bytes (rows 0, 2 collide): (row >> 1) & 1;
+  // 64 bytes (four rows = 256 contiguous bytes): nothing
+  auto b_swz = [](int row, int rs) { return rs >= 256 ? (row & 3) : (rs == 128 ? ((row >> 1) & 1) : 0); };
+
   // ---- loader: wave w moves k-rows 4 w .. 4 w + 3 of the K-block: the three A pieces (one instruction each: 4 rows x 256 bytes) and the
   //      three B pieces (two instructions each: 2 rows x 512 bytes).  LDS position (row, 16-byte chunk c') holds the logical chunk whose
   //      64-byte window index is (c' >> 2) ^ (row & 3).
   const int arow = 4 * wave + (lane >> 4);
   const int achunk = ((((lane & 15) >> 2) ^ (lane >> 4)) << 2) | (lane & 3);
   const unsigned voffA_lane = (unsigned)arow * lda2 + (unsigned)((achunk >> 2) * 192 + (achunk & 3) * 16);
+  // B image: rows of `rs` bytes back to back, instruction n of a piece covers bytes [1024 n, 1024 n + 1024); wave w issues n = w, w + 8
   int brow[2];
   unsigned voffB_lane[2];
+  bool bact[2];
+  int l_ni = 16;                       // DMA instructions that hold rows of the image (regular: 16 per piece)
+  auto loader_b_lanes = [&](int rs, int rows_needed) {
+    const int rs_log = 31 - __builtin_clz(rs);
+    l_ni = (rows_needed * rs + 1023) >> 10;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int sw = 2 * j + (lane >> 5);
-    const int c = ((((lane & 31) >> 2) ^ sw) << 2) | (lane & 3);
-    brow[j] = 4 * wave + sw;
-    voffB_lane[j] = (unsigned)brow[j] * ldb2 + (unsigned)((c >> 2) * 192 + (c & 3) * 16);
-  }
+    for (int j = 0; j < 2; ++j) {
+      const int pos = (wave + 8 * j) * 1024 + lane * 16;
+      const int row = pos >> rs_log, cp = (pos & (rs - 1)) >> 4;
+      const int c = ((((cp >> 2) ^ b_swz(row, rs)) << 2) | (cp & 3));
+      brow[j] = row;
+      bact[j] = row < rows_needed;
+      voffB_lane[j] = (unsigned)row * ldb2 + (unsigned)((c >> 2) * 192 + (c & 3) * 16);
+    }
+  };
+  loader_b_lanes(PL_BN * 2, 32);
   int lu = rg.hi;
   SkPiece lp;
   bool have_l = sk_next_piece(lu, rg.lo, nkb, lp);
@@ -142,9 +173,11 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
     decode(lp, row0, col0);
     l_soffA = (unsigned)(row0 >> 5) * 192u;
     if (CONV) {
-      const int tap = col0 / cin, cb0 = col0 - tap * cin;
-      l_shift = tap - d.conv_pad;
-      l_soffB = (unsigned)(cb0 >> 5) * 192u + (unsigned)tap * ldb2;
+      int tap0, tt, c0, cw;
+      tile_kind(col0 / PL_BN, tap0, tt, c0, cw);
+      l_shift = tap0 - d.conv_pad;
+      l_soffB = (unsigned)(c0 >> 5) * 192u + (unsigned)tap0 * ldb2;
+      if (p.fold_tiles > 0) loader_b_lanes(cw * 2, 32 + tt - 1);
     } else {
       l_soffB = (unsigned)(col0 >> 5) * 192u;
     }
@@ -169,23 +202,25 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
     unsigned vB[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bool ok = brow[j] < rows_left;
+      bool ok = bact[j] && (brow[j] >= 32 || brow[j] < rows_left);       // rows >= 32: the extra rows of a folded image (T % 32 == 0)
       if (CONV) {
         int t = l_tbase + brow[j];
-        t = t >= T ? t - T : t;
+        t = (brow[j] < 32 && t >= T) ? t - T : t;                           // (a K-block may straddle two utterances only unfolded)
         ok = ok && (unsigned)(t + l_shift) < (unsigned)T;
       }
       vB[j] = ok ? voffB_lane[j] + (unsigned)l_row32 * ldb2 : PL_OOB;
     }
     const unsigned sA = smem_addr + (unsigned)(stage * PL_STAGE + wave * 1024);
-    const unsigned sB = smem_addr + (unsigned)(stage * PL_STAGE + 3 * PLW_A_PLANE + wave * 2048);
+    const unsigned sB = smem_addr + (unsigned)(stage * PL_STAGE + 3 * PLW_A_PLANE + wave * 1024);       // instruction n = wave + 8 j
 #pragma unroll
     for (int q = 0; q < NQ; ++q) pl_dma16(ra_src, sA + q * PLW_A_PLANE, vA, l_soffA + q * 64);
     if (!PL_DBG(64)) {                 // tools: 64 = no B DMA after the prologue (what would a smaller B image buy?)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
+      if (wave + 8 * j < l_ni) {         // wave-uniform: a folded image is 3 - 5 instructions per piece, not 16
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) pl_dma16(rb_src, sB + q * PLW_B_PLANE + j * 1024, vB[j], l_soffB + q * 64);
+        for (int q = 0; q < NQ; ++q) pl_dma16(rb_src, sB + q * PLW_B_PLANE + j * 8192, vB[j], l_soffB + q * 64);
+      }
     }
   };
   auto loader_advance = [&]() {
@@ -213,11 +248,25 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
   const int i16 = lane & 15, fsw = i16 >> 2;
   const int fcol2 = 2 * (16 * ((lane >> 4) & 1) + 4 * (i16 & 3));
   int fa_off[2], fb_off[2];
+  int fb_rs = PL_BN * 2;             // row stride of the current piece's B image (bytes)
+  int c_col[2];                      // first output column of the wave's two 32-column MFMA tiles
+  // B fragment base of MFMA column tile j of this wave for an n-tile of kind (tap0, tt, c0, cw): tile jj = 2 (wave & 3) + j of the 8 holds
+  // tap (32 jj) / cw, channels (32 jj) % cw ..+31; its rows sit `tap` rows further down the shared image
+  auto set_b_frag = [&](int nt) {
+    int tap0, tt, c0, cw;
+    tile_kind(nt, tap0, tt, c0, cw);
+    fb_rs = cw * 2;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    fa_off[i] = (8 * h + fsw) * (PL_BM * 2) + ((((wm0 >> 5) + i) ^ fsw) << 6) + fcol2;
-    fb_off[i] = 3 * PLW_A_PLANE + (8 * h + fsw) * (PL_BN * 2) + ((((wn0 >> 5) + i) ^ fsw) << 6) + fcol2;
-  }
+    for (int j = 0; j < 2; ++j) {
+      const int jj = (wn0 >> 5) + j;
+      const int tap_l = (32 * jj) >> (31 - __builtin_clz(cw)), ch_l = (32 * jj) & (cw - 1);
+      const int row = fsw + tap_l;
+      fb_off[j] = 3 * PLW_A_PLANE + (8 * h + row) * fb_rs + ((((ch_l >> 5)) ^ b_swz(row, fb_rs)) << 6) + fcol2;
+      c_col[j] = (CONV ? (tap0 + tap_l) * cin + c0 + ch_l : c0 + 32 * jj);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fa_off[i] = (8 * h + fsw) * (PL_BM * 2) + ((((wm0 >> 5) + i) ^ fsw) << 6) + fcol2;
   auto read_frag = [&](int stage, int ks, PlwFrag& f) {
     const unsigned char* base = smem + stage * PL_STAGE;
 #pragma unroll
@@ -234,9 +283,10 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const unsigned char* pb = base + fb_off[j] + q * PLW_B_PLANE + (16 * ks) * (PL_BN * 2);
+        const int rs = CONV ? fb_rs : PL_BN * 2;             // (compile-time without the conv view: immediates)
+        const unsigned char* pb = base + fb_off[j] + q * PLW_B_PLANE + (16 * ks) * rs;
         const plw_s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plw_lds_s16x4*)(pb));
-        const plw_s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plw_lds_s16x4*)(pb + 4 * (PL_BN * 2)));
+        const plw_s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plw_lds_s16x4*)(pb + 4 * rs));
         const unsigned long long u0 = __builtin_bit_cast(unsigned long long, x0), u1 = __builtin_bit_cast(unsigned long long, x1);
         f.b[j][q] = pl_u32x4{(unsigned)u0, (unsigned)(u0 >> 32), (unsigned)u1, (unsigned)(u1 >> 32)};
       }
@@ -283,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
   SkPiece cp;
   sk_next_piece(cu, rg.lo, nkb, cp);
   int ckb = cp.kb_lo;
+  { int r0_, c0_; decode(cp, r0_, c0_); set_b_frag(c0_ / PL_BN); }
   zero_acc();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   // the K loop in two instruction orders (lower / upper wave group), as in gemm_pl_kernel
@@ -396,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
           const bool accum = p.accumulate != 0;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            float* cj = dc.C + (long)(row0 + e_wm0 + 4 * e_h) * ldc + (col0 + e_wn0 + 32 * j + e_l31);
+            float* cj = dc.C + (long)(row0 + e_wm0 + 4 * e_h) * ldc + (c_col[j] + e_l31);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               float old[16];
@@ -417,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_plw_kernel(const ctts_gemm_desc d
       if (!sk_next_piece(cu, rg.lo, nkb, cp)) break;
       ckb = cp.kb_lo;
       zero_acc();
+      { int r0_, c0_; decode(cp, r0_, c0_); set_b_frag(c0_ / PL_BN); }
       read_frag(stage, 0, f0);            // the next piece's first block landed before the last barrier
     }
   };
@@ -470,6 +522,14 @@ static int plw_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
   p.tiles_m = d.M / PL_BM;
   p.tiles_n = d.N / PL_BN;
   p.accumulate = (d.split_k > 1 && !d.split_overwrite) ? 1 : 0;
+  // tap folding (tile_kind in the kernel): conv view, every 32-row K-block inside one utterance, at least two taps
+  static const int fold = plw_env("CTTS_PLW_FOLD", 1);
+  p.fold_tt = 1; p.fold_tiles = 0;
+  if (fold && conv && d.conv_T % 32 == 0) {
+    const int ntap = d.N / d.conv_cin;
+    const int tt = ntap >= 8 ? 8 : (ntap >= 4 ? 4 : (ntap >= 2 ? 2 : 1));
+    if (tt > 1) { p.fold_tt = tt; p.fold_tiles = d.conv_cin / (PL_BN / tt); }
+  }
   p.debug = debug;
   p.ws = reinterpret_cast<unsigned*>(d.sk_ws);
   const long tiles = (long)p.tiles_m * p.tiles_n;

@@ -86,9 +86,13 @@ def test_transpose_detecting_operands():
 
 
 @pytest.mark.parametrize("T,ksize,pad,cin,cout,nb", [(64, 3, 1, 256, 128, 4), (40, 5, 2, 256, 128, 5), (96, 9, 4, 256, 256, 3), (64, 5, 4, 512, 128, 2),
-                                                      (32, 3, 0, 256, 128, 3)])
+                                                      (32, 3, 0, 256, 128, 3), (64, 9, 4, 512, 128, 2), (64, 8, 3, 256, 128, 2), (64, 2, 0, 256, 128, 3),
+                                                      (64, 12, 5, 256, 128, 2), (32, 4, 1, 256, 128, 4), (64, 1, 0, 256, 128, 2)])
 def test_conv_weight_gradient_dense_rows(T, ksize, pad, cin, cout, nb):
-    """taps shift B by rows; rows shifted across an utterance boundary (also inside a 32-row K-block when T % 32 != 0) contribute zero"""
+    """taps shift B by rows; rows shifted across an utterance boundary (also inside a 32-row K-block when T % 32 != 0) contribute zero.
+    With T % 32 == 0 the n-tiles are FOLDED (8 / 4 / 2 taps x 32 / 64 / 128 channels share one B image of 32 + taps - 1 rows) and the
+    taps beyond the folded ones get one-tap tiles: k = 9 (8 + 1), 5 (4 + 1), 3 (2 + 1), 8, 2, 12 (8 + 4 one-tap), 4, 1 (nothing to fold);
+    cin = 512: two one-tap tiles per tap, 16 folded tiles"""
     rows = nb * T
     dZ, X = rnd(rows, cout, seed=3).to(DEV), rnd(rows, cin, seed=4).to(DEV)
     got = plane_wgrad(dZ, X, cout, cin, ksize, pad, T, bf16_split=2, split_k=2, split_overwrite=True, alpha=0.5)
