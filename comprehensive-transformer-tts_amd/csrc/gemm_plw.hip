@@ -14,8 +14,10 @@
 //     columns 4 (i & 3) ..+3) and lane i receives column i of it - 4 consecutive k of one m, two reads per 8-deep MFMA operand.  A half
 //     wave touches 4 k-rows x 64 bytes; the 64-byte windows of a row are XOR-ed with (k & 3) - on the DMA's SOURCE address - so that the
 //     four rows fall into four different bank groups;
-//   * the conv view is a ROW shift of B (tap - pad rows; one tap per 256-column n-tile, so cin % 256 == 0): it costs nothing but a
-//     per-lane validity test (rows shifted across an utterance boundary read the hardware's out-of-range zero);
+//   * the conv view is a ROW shift of B (tap - pad rows; cin % 256 == 0): it costs nothing but a per-lane validity test (rows shifted
+//     across an utterance boundary read the hardware's out-of-range zero).  One-tap tiles (256 channels of one tap) when a K-block may
+//     straddle two utterances (T % 32 != 0); otherwise the tiles are FOLDED over the taps - 8 / 4 / 2 taps x 32 / 64 / 128 channels
+//     share one B image of 32 + taps - 1 rows (tile_kind below): a sixth of the B traffic at k = 9;
 //   * ragged (b, t) rows: the K-blocks beyond an utterance's length are not part of the unit space at all (their dZ rows are zero by
 //     construction - the rule gemm_x6tn_kernel relies on); every workgroup builds the prefix sums of the active K-blocks from row_lens;
 //   * tile 128 x 256, 8 waves (2 x 4), six cross terms smallest first, two 72 KB stages, the mid-block barrier and the rotated
