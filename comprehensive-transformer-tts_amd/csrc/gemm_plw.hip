@@ -527,7 +527,7 @@ static int plw_try(const ctts_gemm_desc& d, hipStream_t st, bool launch) {
   // tap folding (tile_kind in the kernel): conv view, every 32-row K-block inside one utterance, at least two taps
   static const int fold = plw_env("CTTS_PLW_FOLD", 1);
   p.fold_tt = 1; p.fold_tiles = 0;
-  if (fold && conv && d.conv_T % 32 == 0) {
+  if (fold && conv && d.conv_T % 32 == 0 && d.K % d.conv_T == 0) {       // (whole utterances: the extra rows of a folded image are tested against [0, T) only)
     const int ntap = d.N / d.conv_cin;
     const int tt = ntap >= 8 ? 8 : (ntap >= 4 ? 4 : (ntap >= 2 ? 2 : 1));
     if (tt > 1) { p.fold_tt = tt; p.fold_tiles = d.conv_cin / (PL_BN / tt); }
