@@ -269,19 +269,16 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
         # pipe that bounds them is the bf16 pipe, so the algorithmic fp32 FLOPs are priced against bf16 dense peak / 6; the fraction of
         # the fp32-MFMA peak (what the launch would be bounded by on v_mfma_f32_32x32x2_f32) is reported next to it.
         peak = BF16_MFMA_PEAK_TFLOPS / X6_TERMS
-        kname = ("ctts_gemm conv fwd on gemm_pl_kernel (pre-split bf16 operand planes, persistent stream-K, LDS-DMA; " if planes else
-                 "ctts_gemm conv fwd on gemm_x6_kernel (operands split inside the GEMM; ")
-        extra = {"arithmetic": "fp32 in / out / accumulate; each product = 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands "
-                               "(round-to-nearest pieces: dropped terms <= 2^-24 of a product = one fp32 rounding, 2^-29 in the median; exact on exactly "
-                               "representable data; error vs float64 as the fp32-MFMA kernels' on the same launches: tests/test_planes_gpu.py, "
-                               "tests/test_kernels_gpu.py, tests/test_bf16_split_cpu.py)",
+        kname = "gemm_pl_kernel (bf16 planes, stream-K, LDS-DMA)" if planes else "gemm_x6_kernel (split inside the GEMM)"
+        # strings <= 128 characters: the driver's record truncates longer ones (the long form lives in DESIGN.md section 5)
+        extra = {"arithmetic": "fp32 in/out/accumulate; product = 6 bf16 MFMA terms of the exact hi/mid/lo split (DESIGN.md 3)",
                  "peak_definition": "2500 TFLOP/s dense bf16 MFMA / 6 terms", "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                  "executed_bf16_tflops": ach * X6_TERMS,
-                 "kernel": kname + "decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments incl. padded-row skipping)",
+                 "kernel": kname + ": decoder FFN Conv1d k=9 fwd, train-step arguments, ragged rows",
                  "activation_split_launch_us": split_us}
     else:
         peak = FP32_MFMA_PEAK_TFLOPS
-        extra = {"kernel": "ctts_gemm conv fwd (decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments incl. padded-row skipping)"}
+        extra = {"kernel": "ctts_gemm conv fwd (decoder FFN Conv1d k=9 as implicit GEMM, train-step arguments, ragged rows)"}
 
     def entry(t, kernel):
         a = algo_flops / t / 1e12
@@ -295,6 +292,11 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
                                        ("gemm_x6tn_kernel" if bf16 else "fp32 tile kernels") + f" + ordered split-K sum (split_k = {sk})"),
                         "flops_each": algo_flops, "launches_per_step_each": 6}}
     out.update(extra)
+    # the same three launches once more as flat scalars (the driver's record keeps scalars, not nested objects)
+    out.update({"dgrad_us": dt_d * 1e6, "dgrad_frac": algo_flops / dt_d / 1e12 / peak, "wgrad_us": dt_w * 1e6,
+                "wgrad_frac": algo_flops / dt_w / 1e12 / peak,
+                "traffic_over_algorithmic": (traffic / out["algorithmic_bytes"]) if traffic else None,
+                "traffic_live": bool(traffic_src and "measured" in traffic_src)})
     return out
 
 
@@ -359,11 +361,11 @@ def cpu_baseline(mode="full"):
     phys = _physical_cores()
     runs = []
     # (config, lengths, threads, timed steps, warm-up steps); every run gets a warm-up step (the first step pays allocator / thread-pool
-    # start-up) and reports the MEDIAN of 3 timed steps: ~22 s for C2, ~5 s for C1
+    # start-up) and reports the MEDIAN of 5 timed steps (median of >= 5): ~26 s for C2, ~7 s for C1
     # (median of the timed steps; the n = physical-cores leg of round 4 - one cold step at 128 threads, slower than 8 threads
     #  on every host: oversubscribing the small ops hurts - is dropped)
-    plan = [("C2", None, 8, 3, 1)] if mode == "primary" else \
-           [("C1", C1_SRC_LENS, 8, 3, 1), ("C2", None, 8, 3, 1)]
+    plan = [("C2", None, 8, 5, 1)] if mode == "primary" else \
+           [("C1", C1_SRC_LENS, 8, 5, 1), ("C2", None, 8, 5, 1)]
     for name, lens, nt, n_timed, warm in plan:
         sec, valid = _cpu_train_steps(lens, nt, n_timed, warm)
         runs.append({"config": name, "threads": nt, "valid_frames": valid, "s_per_step": sec, "frames_per_s": valid / sec,
@@ -376,9 +378,9 @@ def cpu_baseline(mode="full"):
         with open(rj) as f:
             ratio = json.load(f).get("speed_ratio_reference_over_oracle")
     return {"value": best["frames_per_s"], "unit": "mel-frames/s", "cores": best["threads"], "kind": "port",
-            "sample": f"C2 = canonical batch B=16 ({best['valid_frames']} valid frames), full train step with dropout, "
-                      f"{best['timed_steps']} timed step(s) after {best['warmup_steps']} warm-up, {best['s_per_step']:.2f} s/step, torch CPU fp32 "
-                      f"{best['threads']} threads ({phys} physical / {os.cpu_count()} logical cores on this host)",
+            "sample": f"C2 B=16 ({best['valid_frames']} frames) full train step, median of {best['timed_steps']} after {best['warmup_steps']} warm-up, "
+                      f"{best['s_per_step']:.2f} s/step, {best['threads']} thr of {phys} phys cores",
+            "s_per_step": best["s_per_step"], "timed_steps": best["timed_steps"], "host_physical_cores": phys,
             "runs": runs, "reference_over_port_time_ratio": ratio}
 
 
@@ -519,7 +521,7 @@ def measure_forward(dev, steps=10, warmup=3):
             torch.cuda.synchronize()
             el = (time.perf_counter() - t0) / steps
             out.append({"config": f"forward only, {block}: teacher-forced eval() forward of the canonical batch (B=16), torch.no_grad()",
-                        "value": valid / el, "unit": "mel-frames/s", "ms_per_step": el * 1e3, "steps": steps, "warmup": warmup,
+                        "key": f"fwd_eval_{'fs2' if block == 'transformer_fs2' else block}", "value": valid / el, "unit": "mel-frames/s", "ms_per_step": el * 1e3, "steps": steps, "warmup": warmup,
                         "valid_frames": valid, "launch_mode": mode, "dtype": "f32",
                         "forward_frac_of_fp32_mfma_peak": valid / el * fl / 1e12 / FP32_MFMA_PEAK_TFLOPS})
             # (b) free-running inference
@@ -541,7 +543,7 @@ def measure_forward(dev, steps=10, warmup=3):
             frames = int(o[9].sum())                          # mel_lens of the synthesised batch
             out.append({"config": f"forward only, {block}: free-running inference (synthesize.py:95-101 call: no targets), B=16, duration-predictor "
                                   "bias = log 9 (~8 frames per phoneme, random-init weights otherwise)",
-                        "value": frames / el, "unit": "mel-frames/s", "ms_per_step": el * 1e3, "steps": steps, "warmup": warmup,
+                        "key": f"fwd_infer_{'fs2' if block == 'transformer_fs2' else block}", "value": frames / el, "unit": "mel-frames/s", "ms_per_step": el * 1e3, "steps": steps, "warmup": warmup,
                         "valid_frames": frames, "launch_mode": "eager (data-dependent output length)", "dtype": "f32",
                         "forward_frac_of_fp32_mfma_peak": frames / el * fl / 1e12 / FP32_MFMA_PEAK_TFLOPS})
             del model
@@ -551,27 +553,62 @@ def measure_forward(dev, steps=10, warmup=3):
     return out
 
 
+def measure_mel_frontend(dev, iters=20, warm=30):
+    """`TacotronSTFT.mel_spectrogram` (audio/stft.py:166-185) on csrc/mel.hip, driver-timed (VERDICT r05 missing #5):
+    y ~ U(-0.5, 0.5) [B, 262144] -> B x 1025 frames, B = 16 (one training batch of audio) and B = 64 (a preprocessing batch); the C entry
+    point alone (`ctts_mel_spectrogram`) and the API call (range assertion deferred = the bulk path), HIP events on the launch stream.
+    HBM-bound: 1 KB in + 324 B out per frame, priced against 8 TB/s.  The mel BASIS is the restated librosa 0.7.2 algorithm - basis
+    parity unpinned (the dependency is absent), STFT arithmetic pinned by golden G8."""
+    import ctts_amd
+    from ctts_amd import kernels as K
+    out = []
+    try:
+        st = ctts_amd.TacotronSTFT(1024, 256, 1024, 80, 22050, 0, 8000).to(dev)
+        g = torch.Generator().manual_seed(1)
+        for B in (16, 64):
+            y = (torch.rand(B, 262144, generator=g) - 0.5).to(dev)
+            for path in ("kernel", "api"):
+                st.use_fft, st.strict_range = True, False
+                if path == "kernel":
+                    ws = st._workspace()
+                    run = lambda: K.mel_spectrogram_fft(y, st._window, ws, 1024, 256, 80, kmax=st._kmax)[:2]      # noqa: E731
+                else:
+                    run = lambda: st.mel_spectrogram(y)                                                         # noqa: E731
+                mel, en = run()
+                dt = _time_launches(run, iters, warm)
+                frames = mel.shape[0] * mel.shape[2]
+                algo = (y.numel() + mel.numel() + en.numel()) * 4
+                out.append({"config": f"mel front end B={B} {path}", "value": frames / dt, "unit": "mel-frames/s", "us_per_call": dt * 1e6,
+                            "frames": frames, "hbm_algorithmic_GBps": algo / dt / 1e9, "frac_of_8TBps": algo / dt / 8e12, "dtype": "f32",
+                            "note": "basis parity unpinned (librosa absent); STFT pinned by G8"})
+            del y
+    except Exception as e:                                    # noqa: BLE001
+        out.append({"config": "mel front end", "error": f"{type(e).__name__}: {e}"})
+    torch.cuda.empty_cache()
+    return out
+
+
 SECONDARY = [   # BASELINE configs[2..4] measured in the same invocation (N = 1 only), so that every claimed configuration is driver-run
-    ("configs[2] LJSpeech conformer batch=16", dict(dataset="LJSpeech", block="conformer", prosody="none", learn_alignment=False), 113.9e6),
-    ("configs[3] VCTK multi-speaker transformer_fs2, per-GPU slice (8 of 64 utterances)",
+    ("configs[2] LJSpeech conformer batch=16", "conformer", dict(dataset="LJSpeech", block="conformer", prosody="none", learn_alignment=False), 113.9e6),
+    ("configs[3] VCTK multi-speaker transformer_fs2, per-GPU slice (8 of 64 utterances)", "vctk_slice",
      dict(dataset="VCTK", block="transformer_fs2", prosody="none", learn_alignment=False), 157.4e6),
-    ("configs[4] LJSpeech transformer_fs2 + liu2021 prosody + learn_alignment batch=16",
+    ("configs[4] LJSpeech transformer_fs2 + liu2021 prosody + learn_alignment batch=16", "c5",
      dict(dataset="LJSpeech", block="transformer_fs2", prosody="liu2021", learn_alignment=True), 157.4e6),
     # the HEADLINE configuration once more with every GEMM on v_mfma_f32_32x32x2_f32 (ctts_gemm_bf16_split_enable(0)): the same-run,
     # same-box figure of the step without the bf16-split kernels
-    ("configs[1] LJSpeech transformer_fs2 batch=16 with fp32 MFMAs only (bf16-split GEMM kernels switched off)",
+    ("configs[1] LJSpeech transformer_fs2 batch=16 with fp32 MFMAs only (bf16-split GEMM kernels switched off)", "fs2_fp32_mfma_only",
      dict(dataset="LJSpeech", block="transformer_fs2", prosody="none", learn_alignment=False, fp32_mfma_only=True), 157.4e6),
     # NOT comparable with the headline: the reference's --use_amp (train.py:59,104 amp.autocast) honoured by the plane-kernel launches -
     # operands rounded to bf16, one MFMA term (reduced precision; tolerance in tests/test_amp_gpu.py)
     ("configs[1] LJSpeech transformer_fs2 batch=16 in the AMP arithmetic (reduced precision: conv-layer GEMM operands rounded to bf16; not the headline)",
-     dict(dataset="LJSpeech", block="transformer_fs2", prosody="none", learn_alignment=False, amp=True), 157.4e6),
+     "fs2_amp_reduced_precision", dict(dataset="LJSpeech", block="transformer_fs2", prosody="none", learn_alignment=False, amp=True), 157.4e6),
 ]
 
 
 def measure_secondary(dev, steps=10, warmup=3):
     """same step definition and timing as the headline (inputs resident, hipGraph replay), fewer steps; FLOP per valid frame from SURVEY 8(d)"""
     out = []
-    for name, cfg, flop_per_frame in SECONDARY:
+    for name, key, cfg, flop_per_frame in SECONDARY:
         prev_split = None
         try:
             if cfg.get("fp32_mfma_only"):
@@ -592,14 +629,14 @@ def measure_secondary(dev, steps=10, warmup=3):
             el = time.perf_counter() - t0
             st.check_kernels()
             v = b["valid_frames"] * steps / el
-            out.append({"config": name, "value": v, "unit": "mel-frames/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
+            out.append({"config": name, "key": key, "value": v, "unit": "mel-frames/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
                         "valid_frames": b["valid_frames"], "padded_frames": b["padded_frames"],
                         "step_frac_of_fp32_mfma_peak": v * flop_per_frame / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                         "final_loss": float(st.loss_val), "launch_mode": b["mode"],
                         "dtype": "bf16 operands / f32 accumulate in the conv-layer GEMMs, f32 elsewhere" if cfg.get("amp") else "f32"})
             del b, st
         except Exception as e:                                # noqa: BLE001
-            out.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+            out.append({"config": name, "key": key, "error": f"{type(e).__name__}: {e}"})
         finally:
             if prev_split is not None:
                 from ctts_amd import kernels as _K
@@ -721,7 +758,22 @@ def main():
                 if (headline and not a.no_roofline) else None)
         # whole-step roofline view: 157.4 (fs2) / 113.9 (conformer) MFLOP per valid frame vs the fp32 MFMA peak
         step_tflops = (value / world) * (157.4e6 if a.block == "transformer_fs2" else 113.9e6) / 1e12
-        secondary = (measure_secondary(dev) + measure_forward(dev)) if (headline and world == 1 and not a.no_secondary) else None
+        secondary = ((measure_secondary(dev) + measure_forward(dev) + measure_mel_frontend(dev))
+                     if (headline and world == 1 and not a.no_secondary) else None)
+        # flat copy of the secondary results (scalars inside `config` survive the driver's record; the full entries stay under `secondary`)
+        flat = {}
+        for e in secondary or []:
+            if "error" in e:
+                flat["sec_error_" + e.get("key", "x")] = e["error"][:120]
+            elif e["config"].startswith("mel front end"):
+                k = e["config"].replace("mel front end ", "mel_").replace("=", "").replace(" ", "_")
+                flat[f"sec_{k}_Mfps"] = round(e["value"] / 1e6, 1)
+                flat[f"sec_{k}_frac_of_8TBps"] = round(e["frac_of_8TBps"], 4)
+            else:
+                flat[f"sec_{e['key']}_ms"] = round(e["ms_per_step"], 3)
+                fr = e.get("step_frac_of_fp32_mfma_peak", e.get("forward_frac_of_fp32_mfma_peak"))
+                if fr is not None:
+                    flat[f"sec_{e['key']}_frac"] = round(fr, 4)
         cpu = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(a.cpu_baseline)      # reported baseline: rank 0 at N = 1 only
         nb = len(batch_cpu["src_lens"])
         what = ("supervised durations, multi-speaker (per-GPU slice of BASELINE configs[3] = 64 utterances over 8 GPUs)"
@@ -734,20 +786,16 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{a.dataset} {a.block} batch={nb}/GPU"
-                                    + (f" (global batch {nb * world}, weak scaling)" if a.scaling == "weak" else
-                                       f" (global batch 16, {a.shard} shard, strong scaling)")
-                                    + f", seq<=128 -> mel<={batch_cpu['mels'].shape[1]}x80, " + what
-                                    + "; full train step fwd+loss+bwd+clip+Adam, dropout on"),
+                                    + (f" (global {nb * world}, weak)" if a.scaling == "weak" else f" (global 16, {a.shard} shard, strong)")
+                                    + f" seq<=128->mel<={batch_cpu['mels'].shape[1]}x80; full train step fwd+loss+bwd+clip+Adam, dropout on"),
+                       "workload_detail": what,
                        "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
                        "parallelism": f"dp{world}", "final_loss": loss_final,
-                       "gemm_arithmetic": ("fp32 storage and accumulation everywhere; the large NT GEMMs (FFN / PostNet Conv1d forward and data gradient: "
-                                           "gemm_pl_kernel on pre-split operand planes) and the weight-gradient GEMMs (TN: gemm_plw_kernel on the same planes for the Conv1d layers, gemm_x6tn_kernel for the k = 1 linears) form each fp32 "
-                                           "product from 6 bf16 MFMA terms of the exact hi/mid/lo split of both operands (exact on exactly representable "
-                                           "data, dropped cross terms <= one fp32 rounding per product); all other GEMMs on v_mfma_f32_32x32x2_f32"
+                       "gemm_arithmetic": ("fp32 storage/accumulate; large GEMMs: 6 bf16 MFMA terms of the exact 3-way split (fp32-class); rest fp32 MFMA"
                                            if _bf16_on() else "v_mfma_f32_32x32x2_f32 (CTTS_X6=0)"),
                        "grad_buckets_bytes": step.reducer.bucket_bytes() if world > 1 else None,
                        "communication": comm,
-                       "strong_scaling_shard": built["shard_balance"]},
+                       "strong_scaling_shard": built["shard_balance"], **flat},
             "roofline": roof, "step_model_tflops_per_gpu": step_tflops,
             "step_frac_of_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
             "pcie_inclusive": pcie,

@@ -141,7 +141,12 @@ _SIGNATURES = {
     "ctts_gru_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_softmax_rect_fwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
     "ctts_softmax_rect_bwd": [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
+    "ctts_comm_unique_id": [_vp],
+    "ctts_comm_create": [C.POINTER(_vp), _i32, _i32, _vp],
+    "ctts_comm_destroy": [_vp],
+    "ctts_allreduce_mean": [_vp, _i64, _vp, _vp],
 }
+COMM_ID_BYTES = 128                   # CTTS_COMM_ID_BYTES of include/ctts.h
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["ctts_last_error", "ctts_version", "ctts_mha_supported", "ctts_relmha_workspace_floats",
                                                "ctts_mel_spectrogram_workspace_bytes", "ctts_gemm_workspace_bytes", "ctts_workspace_bytes",
                                                "ctts_workspace_error_word"])

@@ -8,7 +8,7 @@ SUF=${CTTS_VARIANT:+_$CTTS_VARIANT}
 OUT=libctts_hip${SUF}.so
 OBJ=.obj${SUF}
 mkdir -p $OBJ
-SRCS="gemm.hip gemm_sk.hip gemm_ws.hip gemm_pl.hip gemm_plw.hip attn.hip lr.hip norm.hip elementwise.hip conformer.hip align.hip prosody.hip optim.hip loss.hip mel.hip pitch.hip"
+SRCS="gemm.hip gemm_sk.hip gemm_ws.hip gemm_pl.hip gemm_plw.hip attn.hip lr.hip norm.hip elementwise.hip conformer.hip align.hip prosody.hip optim.hip loss.hip mel.hip pitch.hip comm.hip"
 newest=$(ls -t $SRCS ctts_common.h gemm_common.h gemm_pl_common.h sk_plan.h ../../include/ctts.h build.sh | head -1)
 if [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then echo "$OUT up to date"; exit 0; fi
 objs=""
@@ -20,5 +20,5 @@ for s in $SRCS; do
   objs="$objs $o"
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
+$HIPCC --offload-arch=gfx950 -shared -fPIC $objs -ldl -o $OUT
 echo "built $(pwd)/$OUT"

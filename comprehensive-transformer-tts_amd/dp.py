@@ -136,6 +136,43 @@ def stage_plan(model, n_cuts=3):
     return cut_names, stage_of
 
 
+class AbiCommunicator:
+    """One RCCL communicator per process behind the C ABI (include/ctts.h "Gradient all-reduce"; csrc/comm.hip).  Rank 0 draws the
+    unique id, `torch.distributed` (any backend, or nothing for a single rank) carries its 128 bytes to the other ranks, every rank
+    creates its communicator on ITS device; `allreduce_mean(t)` averages a dense fp32 CUDA tensor over the ranks in place on the
+    current stream (graph-capturable)."""
+
+    def __init__(self, device, group=None):
+        import ctypes
+        from . import _lib
+        self._lib_mod, self._lib = _lib, _lib.load()
+        self.device = torch.device(device)
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        uid = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        if rank == 0:
+            _lib.check(self._lib.ctts_comm_unique_id(uid), "ctts_comm_unique_id")
+        if world > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = ctypes.create_string_buffer(box[0], _lib.COMM_ID_BYTES)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctts_comm_create(ctypes.byref(comm), world, rank, uid), "ctts_comm_create")
+        self.comm, self.world, self.rank = comm, world, rank
+
+    def allreduce_mean(self, t):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self._lib_mod.check(self._lib.ctts_allreduce_mean(t.data_ptr(), t.numel(), self.comm, st), "ctts_allreduce_mean")
+
+    def close(self):
+        if self.comm is not None and self.comm.value:
+            torch.cuda.synchronize(self.device)
+            self._lib.ctts_comm_destroy(self.comm)
+            self.comm = None
+
+
 class BucketedReducer:
     """All-reduce(sum)/world of the arena, one bucket per backward stage, on a side stream (overlaps the following stages).
 
@@ -145,8 +182,12 @@ class BucketedReducer:
     Both calls are capture-safe: under hipGraph capture the side stream forks from and re-joins the capturing stream, so a step
     captured with its collectives inside replays them without any host involvement (trainer.TrainStep graph_collectives)."""
 
-    def __init__(self, arena, stage_of, n_stages, world=None, group=None, always_reduce=False):
+    def __init__(self, arena, stage_of, n_stages, world=None, group=None, always_reduce=False, abi_collective=None):
+        """`abi_collective` (None = env CTTS_ABI_COLLECTIVE, default off): route the bucket all-reduces through the library's own C-ABI
+        collective (include/ctts.h ctts_comm_create / ctts_allreduce_mean: RCCL bound at run time) instead of torch.distributed - the
+        process group is then only the side channel that carries the communicator's unique id.  CUDA arenas only."""
         self.arena, self.group = arena, group
+        self._abi_comm = None
         self.world = (dist.get_world_size(group) if dist.is_initialized() else 1) if world is None else int(world)
         self.active = self.world > 1 or (bool(always_reduce) and dist.is_initialized())
         by_stage = [[] for _ in range(n_stages)]
@@ -156,6 +197,11 @@ class BucketedReducer:
         self.is_cuda = arena.flat.is_cuda
         self.comm = torch.cuda.Stream(device=arena.flat.device) if (self.is_cuda and self.active) else None
         self.launched = 0
+        if abi_collective is None:
+            import os
+            abi_collective = os.environ.get("CTTS_ABI_COLLECTIVE", "0") == "1"
+        if abi_collective and self.active and self.is_cuda:
+            self._abi_comm = AbiCommunicator(arena.flat.device, group)
 
     def bucket_bytes(self):
         return [sum(b - a for a, b in r) * 4 for r in self.ranges]
@@ -163,6 +209,10 @@ class BucketedReducer:
     def _reduce(self, s):
         # one collective per contiguous range (the stage plans of both block types give exactly ONE range per bucket); on RCCL the
         # division by the world size rides inside the collective (ReduceOp.AVG), gloo has no AVG: sum, then scale
+        if self._abi_comm is not None:
+            for a, b in self.ranges[s]:
+                self._abi_comm.allreduce_mean(self.arena.flat[a:b])
+            return
         avg = self.is_cuda and dist.get_backend(self.group) == "nccl"
         inv = 1.0 / self.world
         for a, b in self.ranges[s]:
@@ -269,6 +319,7 @@ class FlatAdam:
         self.state[1] = float(current_step)
 
     def step(self):
+        self._k.WEIGHTS_EPOCH[0] += 1          # the update below bypasses autograd's version counters: weight-derived caches are stale
         self._k.adam_clip_step(self.flat_param, self.arena.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
                                self.weight_decay, self.max_norm, self.state)
 

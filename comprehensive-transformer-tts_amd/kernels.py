@@ -183,6 +183,7 @@ class PartialSink:
         self.tasks = []
         self.keep = []
         self.pending = 0
+        self.streams = []          # streams the pending partials were produced on (a flush must be ordered behind ALL of them)
 
     def add(self, src, count, stride, n, dst, alpha, src_off=0, dst_off=0):
         d0 = dst.data_ptr() + 4 * int(dst_off)
@@ -192,6 +193,10 @@ class PartialSink:
             self.flush()
         self.tasks.append((src.data_ptr() + 4 * int(src_off), d0, int(n), int(stride), int(count), float(alpha)))
         self.keep.append((src, dst))
+        if src.is_cuda:
+            st = torch.cuda.current_stream(src.device)
+            if st not in self.streams:
+                self.streams.append(st)
         self.pending += 4 * int(count) * int(n)
         if self.FLUSH_BYTES and self.pending >= self.FLUSH_BYTES:
             self.flush()
@@ -204,15 +209,27 @@ class PartialSink:
             t.src, t.dst, t.n, t.stride, t.count, t.alpha = src, dst, n, stride, count, alpha
         self.tasks = []
         self.pending = 0
+        producers, self.streams = self.streams, []
         try:
-            _lib.check(_lib.load().ctts_partial_sums(arr, len(arr), _stream()), "ctts_partial_sums")
+            # The partials of a stage are written by whichever stream autograd ran the producing node on (main stream, the side stream
+            # of an input-only branch).  A flush - the mandatory one at the end of the stage, or one triggered inside a node by the byte
+            # threshold / an overlapping destination - reads ALL pending partials: the flushing stream waits for every other producer
+            # stream first (a graph edge under capture), whichever stream it happens to be.
             cur = torch.cuda.current_stream()
+            for st in producers:
+                if st != cur:
+                    cur.wait_stream(st)
+            _lib.check(_lib.load().ctts_partial_sums(arr, len(arr), _stream()), "ctts_partial_sums")
             for src, _ in self.keep:                 # partials a side stream allocated are read by THIS stream's launch: tell the allocator
                 if src.is_cuda:
                     src.record_stream(cur)
         finally:
             self.keep = []
 
+
+# Bumped by every update of the parameters that autograd's version counters cannot see (dp.FlatAdam writes through raw pointers):
+# per-step caches made from the weights (ops._DGRAD_W, ops._PLANES) carry the epoch they were made in.
+WEIGHTS_EPOCH = [0]
 
 _SINK = None
 DEFER_ENABLED = _os.environ.get("CTTS_DEFER_SUMS", "1") != "0"       # A/B switch: 0 = every reduction finishes inside its own call

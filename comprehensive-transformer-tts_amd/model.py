@@ -551,10 +551,12 @@ class VarianceAdaptor(nn.Module):
         self._ref_pending = None
         if self.model_type != "liu2021" or not self.training or mel is None or mel_mask is None:
             return
+        if not mel.is_cuda:
+            return
+        mask_aux(mel_mask)                                    # on the main stream, BEFORE the fork: the branch reads the cached tensors
         side = ops.fork_side(mel)
         if side is None:
             return
-        mask_aux(mel_mask)                                    # on the main stream: other consumers share the cached tensors
         with torch.cuda.stream(side):
             out = self._reference_memories(mel, mel_mask)
         self._ref_pending = (side, out)

@@ -390,13 +390,13 @@ class _LinearConv(torch.autograd.Function):
                 wk = dict(conv=(T, pad, Cin), conv_on_b=True, split_k=max(2, _split_k_for(N, Kd, M)), alpha=alpha, **rl)
                 if gmaj is not None:             # GEMM-major parameter: the split-K partials are added straight into param.grad
                     wp = _wgrad_planes(dZ.view(M, N), x.view(M, Cin), dz_planes, getattr(ctx, "x_planes", None), gmaj, N, Kd, M, Cin, wk)
-                    with _wgrad_scope(True, dZ, x, rows=M):
+                    with _wgrad_scope(True, dZ, x, *wp.values(), rows=M):        # the plane sets too: read on the side stream until the join
                         K.gemm(dZ, x, gmaj, N, Kd, M, N, Cin, Kd, False, False, tile_map=kmap, defer=_WGRAD["stream"] is None, **wk, **wp)
                 else:
                     dwf = torch.empty(N, Kd, dtype=torch.float32, device=x.device)
                     wk["split_overwrite"] = True
                     wp = _wgrad_planes(dZ.view(M, N), x.view(M, Cin), dz_planes, getattr(ctx, "x_planes", None), dwf, N, Kd, M, Cin, wk)
-                    with _wgrad_scope(fused, dZ, x, dwf, rows=M):
+                    with _wgrad_scope(fused, dZ, x, dwf, *wp.values(), rows=M):
                         K.gemm(dZ, x, dwf, N, Kd, M, N, Cin, Kd, False, False, tile_map=kmap, **wk, **wp)
                         if fused:
                             K.conv_weight_repack(dwf, _grad_of(w), N, Cin, ksize, 3)
@@ -440,12 +440,18 @@ class _LinearConv(torch.autograd.Function):
 # Entries carry the weight's autograd version: an in-place update through torch after the preparation invalidates them.
 
 
+def _wstamp(w):
+    """what a weight-derived cache entry is valid for: the tensor's autograd version AND the epoch of raw-pointer updates
+    (dp.FlatAdam.step never bumps `_version`)"""
+    return (w._version, K.WEIGHTS_EPOCH[0])
+
+
 class _DgradCache(dict):
     """data_ptr -> (wd, version of the weight it was made from); pop() hands out only entries that still match the weight"""
 
     def take(self, w, shape):
         ent = dict.pop(self, w.data_ptr(), None)
-        if ent is None or ent[1] != w._version or tuple(ent[0].shape) != tuple(shape):
+        if ent is None or ent[1] != _wstamp(w) or tuple(ent[0].shape) != tuple(shape):
             return None
         return ent[0]
 
@@ -472,7 +478,7 @@ def _operand_planes(kind, w, a_mat, b_mat, M, N, Kdim, lda, ldb, ldc, out, gk):
     if not K.gemm_takes_planes(a_mat, b_mat, out, M, N, Kdim, lda, ldb, ldc, True, True, a_planes=_FakePlanes(a_mat), b_planes=_FakePlanes(b_mat), **gk):
         return {}
     ent = _PLANES[kind].get(w.data_ptr())
-    if ent is not None and ent[1] == w._version and ent[0].numel() == 3 * b_mat.numel():
+    if ent is not None and ent[1] == _wstamp(w) and ent[0].numel() == 3 * b_mat.numel():
         bp = ent[0]
     else:
         _PLANES["want_" + kind].add(w.data_ptr())
@@ -509,6 +515,10 @@ def prepare_dgrad_weights(params):
     once per step, after the optimizer update and before the backward pass (trainer.TrainStep does, in front of the forward).  Builds
     the data-gradient matrices of all layers (one launch) and the bf16 planes of the weights the plane kernel consumes (one launch)."""
     clear_dgrad_weights()
+    params = list(params)
+    live = {w.data_ptr() for w in params}          # addresses announced by tensors that no longer exist (another model) are dropped
+    _PLANES["want_fwd"] &= live
+    _PLANES["want_dgrad"] &= live
     todo = []
     for w in params:
         wm = _gemm_major(w) if w.dim() == 3 else None
@@ -517,13 +527,13 @@ def prepare_dgrad_weights(params):
             todo.append((w, (wm.detach(), N, Cin, k)))
     mats, slots = [], []
     for (w, (wm, _, _, _)), wd in zip(todo, K.conv_dgrad_weights([t for _, t in todo])):
-        _DGRAD_W[w.data_ptr()] = (wd, w._version)
+        _DGRAD_W[w.data_ptr()] = (wd, _wstamp(w))
         if w.data_ptr() in _PLANES["want_fwd"]:
             mats.append(wm.contiguous()); slots.append(("fwd", w))
         if w.data_ptr() in _PLANES["want_dgrad"]:
             mats.append(wd); slots.append(("dgrad", w))
     for (kind, w), pl in zip(slots, K.split_planes(mats)):
-        _PLANES[kind][w.data_ptr()] = (pl, w._version)
+        _PLANES[kind][w.data_ptr()] = (pl, _wstamp(w))
 
 
 def clear_dgrad_weights():

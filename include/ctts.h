@@ -513,6 +513,28 @@ int ctts_mel_l1_fwd(const float* p1, const float* p2, const float* tgt, const ui
 int ctts_mel_l1_bwd(const float* p1, const float* p2, const float* tgt, const float* roww, const float* sums, const float* g, float* d1,
                     float* d2, int64_t rows, int C, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Gradient all-reduce of the data-parallel step (SURVEY.md section 8(b) `ctts_allreduce_*`, 8(e); replaces what
+ * `DistributedDataParallel(model, device_ids=[rank])` does after backward in the reference: train.py:29-35,58,112).
+ *   ctts_comm_unique_id  rank 0 draws CTTS_COMM_ID_BYTES opaque bytes (ncclGetUniqueId) and hands them to every rank by any side
+ *                        channel (the Python host: `torch.distributed.broadcast_object_list`; a C host: its own launcher)
+ *   ctts_comm_create     one communicator per process, bound to the CURRENT HIP device (ncclCommInitRank; collective: every rank calls it)
+ *   ctts_allreduce_mean  buf[i] <- mean over ranks of buf[i], in place, n floats, stream-ordered on `stream` and capturable into a
+ *                        hipGraph (ncclAllReduce, ncclFloat32, ncclAvg: the division by the world size rides inside the collective).
+ *                        The product calls it once per gradient BUCKET (4 contiguous ranges of the flat gradient arena, one per
+ *                        backward stage, 8 - 60 MB each) on a side stream while the next stage runs.
+ *   ctts_comm_destroy    ncclCommDestroy
+ * RCCL (librccl.so.1) is bound at run time by dlopen - libctts_hip.so does not link it, single-GPU use never loads it; when it cannot be
+ * loaded these calls fail with a text, nothing else is affected.  Which collective runs where: `dp.BucketedReducer` uses
+ * `torch.distributed` (backend "nccl" = the same RCCL) by default because the rendezvous, the process group and its watchdog are
+ * already there under a PyTorch host; `CTTS_ABI_COLLECTIVE=1` (or `BucketedReducer(..., abi_collective=True)`) routes the bucket
+ * all-reduces through these entry points instead - same bytes, same stream, bit-identical result (tests/test_dp_gpu.py). */
+#define CTTS_COMM_ID_BYTES 128
+int ctts_comm_unique_id(void* id_out /* CTTS_COMM_ID_BYTES host bytes */);
+int ctts_comm_create(void** comm_out, int32_t nranks, int32_t rank, const void* id /* CTTS_COMM_ID_BYTES host bytes */);
+int ctts_comm_destroy(void* comm);
+int ctts_allreduce_mean(float* buf, int64_t n, void* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 """One rank of the DistributedDataParallel wrap test (tests/test_dropin_gpu.py; not a test module): the reference's train.py:58
 `model = DistributedDataParallel(model, device_ids=[rank])` applied to the product model, whose Conv1d parameters are dense but
-STRIDED (GEMM-major memory).  gloo, every rank on cuda:0.   argv: out_path
+STRIDED (GEMM-major memory).  Backend as tests/dp_worker.py picks it: RCCL with `device_ids=[local_rank]` when the box has a GPU per
+rank, else gloo with every rank on cuda:0.   argv: out_path
 """
 import os
 import sys
@@ -19,15 +20,18 @@ def main():
     from ctts_amd import ops
     from ctts_amd.synthetic import shard, to_device, as_model_args
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend, dev = dp_worker.pick_backend(rank, world)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     ops.set_grad_accumulation_fusion(False)          # plain autograd: DDP's hooks see every parameter gradient
     model, loss_fn, _ = dp_worker.build("transformer_fs2", dev)
     if rank == 1:                                    # DDP must broadcast rank 0's weights at construction
         with torch.no_grad():
             model.mel_linear.weight.add_(1.0)
-    ddp = DistributedDataParallel(model, device_ids=[0])
+    ddp = DistributedDataParallel(model, device_ids=[dev.index])
     args = list(as_model_args(to_device(shard(dp_worker.global_batch(), rank, world), dev)))
     out = ddp(*args, step=50001)
     inputs = [None, None] + args

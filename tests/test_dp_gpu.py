@@ -223,7 +223,10 @@ def test_rccl_one_rank_group_runs_the_collective_path_on_this_gpu():
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "try_rccl_world1.py")], env=env, capture_output=True, text=True, timeout=600)
         print(f"--- attempt {attempt}: rc {r.returncode}\n" + r.stdout[-3000:] + ("\n[stderr]\n" + r.stderr[-2000:] if r.returncode else ""))
-        if r.returncode == 0 or "identical to no-collective run: False" in r.stdout:
+        # retried only when the child died before ANY mode ran (rendezvous / communicator start-up); a mode that reported a mismatch or
+        # raised ("FAILED: ...") is a failure of the path under test and is never retried
+        if r.returncode == 0 or "identical to no-collective run" in r.stdout or "FAILED:" in r.stdout:
             break
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
-    assert "backend=nccl" in r.stdout and r.stdout.count("identical to no-collective run: True") == 3
+    # three torch.distributed modes + the C-ABI collective (include/ctts.h ctts_allreduce_mean) eagerly and inside the whole-step graph
+    assert "backend=nccl" in r.stdout and r.stdout.count("identical to no-collective run: True") == 5

@@ -1,7 +1,8 @@
 """One-rank RCCL on a single GPU: the only way to execute the RCCL code path of the DP step on a 1-GPU box.
 backend "nccl" = RCCL, world_size 1; the bucketed all-reduces (ReduceOp.AVG, side stream) run (a) eagerly between eager stages,
-(b) eagerly between the replays of the 4 stage graphs, (c) captured INSIDE one whole-step hipGraph (TrainStep graph_collectives) -
-and must reproduce the loss trajectory of the step without any collective bit for bit (the average over one rank is the identity).
+(b) eagerly between the replays of the 4 stage graphs, (c) captured INSIDE one whole-step hipGraph (TrainStep graph_collectives), and
+(d, e) the same through the library's own C-ABI collective (ctts_comm_create / ctts_allreduce_mean) eagerly and inside the whole-step
+graph - and must reproduce the loss trajectory of the step without any collective bit for bit (the average over one rank is the identity).
 
     python tools/try_rccl_world1.py            (prints one line per mode; exit code 1 on a mismatch)"""
 import os
@@ -35,12 +36,23 @@ def run(mode, n=4):
         kw.update(use_graph=False, always_reduce=True)
     elif mode == "stage-graphs":
         kw.update(use_graph=True, always_reduce=True, graph_collectives=False)
-    else:
+    elif mode == "whole-step-graph":
         kw.update(use_graph=True, always_reduce=True, graph_collectives=True)
-    step = TrainStep(model, loss_fn, optim, as_model_args(batch), **kw)
+    else:
+        # the library's own C-ABI collective (include/ctts.h ctts_comm_create / ctts_allreduce_mean, csrc/comm.hip) instead of
+        # torch.distributed: eager between eager stages ("abi-eager") and captured inside the whole-step graph ("abi-whole-step-graph")
+        os.environ["CTTS_ABI_COLLECTIVE"] = "1"
+        kw.update(use_graph=mode != "abi-eager", always_reduce=True, graph_collectives=mode != "abi-eager")
+    try:
+        step = TrainStep(model, loss_fn, optim, as_model_args(batch), **kw)
+    finally:
+        os.environ.pop("CTTS_ABI_COLLECTIVE", None)
+    if mode.startswith("abi"):
+        assert step.reducer._abi_comm is not None and step.reducer._abi_comm.world == 1
+
     if kw["use_graph"]:
         step.capture(warmup=2)
-        assert (step.g_all is not None) == (mode == "whole-step-graph")
+        assert (step.g_all is not None) == (mode.endswith("whole-step-graph"))
     else:
         for _ in range(2):
             step.optim.update_learning_rate()
@@ -66,7 +78,7 @@ def main():
     ref = run("none")
     print("no collectives      ", ref[0])
     ok = True
-    for mode in ("eager", "stage-graphs", "whole-step-graph"):
+    for mode in ("eager", "stage-graphs", "whole-step-graph", "abi-eager", "abi-whole-step-graph"):
         try:
             got = run(mode)
             same = got[0] == ref[0] and torch.equal(got[1], ref[1])
