@@ -44,6 +44,7 @@ class GemmDesc(C.Structure):
         ("bf16_split", _i32),
         ("A_planes", _vp),
         ("B_planes", _vp),
+        ("C_planes", _vp),
     ]
 
 
@@ -97,14 +98,14 @@ _SIGNATURES = {
     "ctts_embedding_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "ctts_positions": [_vp, C.c_int, _i64, C.c_int, C.c_int, _vp, _vp],
     "ctts_cwt_pitch": [_vp, _i64, C.c_int, _vp, _vp, _f32, _vp, C.c_int, _f32, _f32, _f32, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp],
-    "ctts_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp, _vp],
+    "ctts_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp, _vp, _vp],
     "ctts_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _vp, _u32, _vp, C.c_int, _vp, _vp, _vp, _vp],
     "ctts_colstats": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],
     "ctts_bn_finalize": [_vp, C.c_int, C.c_int, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "ctts_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp],
+    "ctts_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp, _vp],
     "ctts_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp, _u32, _vp, _vp],
     "ctts_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _vp,
-                          _u32, C.c_int, _vp],
+                          _u32, C.c_int, _vp, _vp],
     "ctts_softmax_fwd": [_vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_softmax_bwd": [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _i64, _vp],
     "ctts_act_dropout_bwd": [_vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, _f32, _vp, _u32, _vp],

@@ -85,6 +85,27 @@ __device__ __forceinline__ void gemm_epilogue(const ctts_gemm_desc& d, floatx16 
 //   RS: the row scale (non-pad mask) exists.  AUX: the gathered operand of the direction exists - the residual R (forward) or the stored pre-activation Z (backward, ACT != 0).
 //   Forward with ACT != 0 stores the pre-activation to Z; without Z (inference) that store runs into an empty descriptor.
 constexpr unsigned GEMM_OOB = 0x80000000u;
+
+// one float -> the bit patterns of its three bf16 pieces: the arithmetic of planes_common.h spl_one / include/ctts.h ctts_split_planes,
+// restated here so that gemm_common.h does not pull the plane headers into every GEMM translation unit
+typedef __bf16 gemm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gemm_floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gemm_split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const gemm_floatx2 v0 = {x, 0.f};
+  unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, gemm_bf16x2)) & 0xFFFFu;
+  const bool x_fin = fabsf(x) < __builtin_inff();
+  if ((hb & 0x7F80u) == 0x7F80u) {
+    if (x_fin) hb = (hb & 0x8000u) | 0x7F7Fu;
+    else { hi = hb; mid = 0u; lo = 0u; return; }
+  }
+  const float r1 = x - __uint_as_float(hb << 16);
+  const gemm_floatx2 v1 = {r1, 0.f};
+  const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, gemm_bf16x2)) & 0xFFFFu;
+  const float r2 = r1 - __uint_as_float(mb << 16);
+  const gemm_floatx2 v2 = {r2, 0.f};
+  const unsigned lb = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, gemm_bf16x2)) & 0xFFFFu;
+  hi = hb; mid = mb; lo = lb;
+}
 __device__ __host__ __forceinline__ bool gemm_fits32(const void* p, long M, long ld, long N);
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const void* p, long bytes) {
@@ -93,10 +114,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const void* p, long 
 
 // Batched / length-limited launches pass their batch base Cb, batch index z and limits Mv x Nv (only the combination without
 // gathered operands is dispatched for them: R, Z and rowscale are not batched).
-template <int MT, int NT, int ACT, bool DROP, bool BWD, bool AUX, bool RS = false>
+// PLANES (round 6; only the weight-stationary kernel's backward instantiations ask for it - the 64-VGPR tile kernels must not carry the
+// code): when d.C_planes is set, the bf16 plane set of the stored values is written too.  A lane owns ONE column and 8 rows of a batch;
+// a 32-bit plane store needs two neighbouring columns of one row: lanes l and l ^ 1 swap halves with one DPP move per piece - the even
+// lane ends up with columns (n, n + 1) of the first row of a row pair, the odd lane with (n - 1, n) of the second.
+template <int MT, int NT, int ACT, bool DROP, bool BWD, bool AUX, bool RS = false, bool PLANES = false>
 __device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, const floatx16 (&acc)[MT][NT], float* Cb, int z, int row0,
                                                    int col0, int wm0, int wn0, int l31, int h, int Mv, int Nv) {
 #pragma clang fp contract(off)
+  const bool planes_on = PLANES && d.C_planes != nullptr;
+  const __amdgpu_buffer_rsrc_t rp = gemm_rsrc(d.C_planes, planes_on ? (long)Mv * d.ldc * 6 : 0);
+  const unsigned p_row = (unsigned)(d.ldc * 6);
+  const unsigned p_sel = (l31 & 1) ? 0x03020706u : 0x05040100u;       // v_perm_b32 selectors: odd lane (nbr.hi16, own.hi16), even lane (own.lo16, nbr.lo16)
   const float alpha = d.alpha;
   uint32_t dkey = 0;
   float inv_keep = 1.f;
@@ -123,6 +152,8 @@ __device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, cons
     const unsigned z_lane = n_ok ? (unsigned)(4 * h) * z_row + (unsigned)n * 4u : GEMM_OOB;
     const float bv = (!BWD && d.bias && n_ok) ? d.bias[n] : 0.f;
     const uint32_t dlane = (zoff + (uint32_t)(4 * h) * (uint32_t)d.N + (uint32_t)n) * CTTS_DROP_G + dkey;
+    // plane byte offset of (row 4h + (lane odd), column pair n & ~1): K-block n / 32 at + 192 bytes each, piece q at + 64 q
+    const unsigned p_lane = n_ok ? (unsigned)(4 * h + (l31 & 1)) * p_row + (unsigned)(n >> 5) * 192u + (unsigned)(n & 30) * 2u : GEMM_OOB;
 #pragma unroll
     for (int ib = 0; ib < 2 * MT; ++ib) {               // batches of 8 rows: 8 gathered values in registers at a time
       const int i = ib >> 1, rb = (ib & 1) * 8;
@@ -159,6 +190,25 @@ __device__ __forceinline__ void gemm_epilogue_lean(const ctts_gemm_desc& d, cons
           if (RS) v *= rs[q];
         }
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, c_lane + (unsigned)mu * c_row, 0, 0);
+        if (PLANES) aux[q] = v;            // the gathered operand is consumed: its registers carry the stored values to the split below
+      }
+      if (PLANES) {
+        if (planes_on) {
+#pragma unroll
+          for (int q = 0; q < 8; q += 2) {         // rows mu, mu + 1 (q even: (r & 3) even, so r + 1 is the next row of the same group of four)
+            const int r = rb + q, mu = row0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2);
+            unsigned ha, ma, la, hb, mb, lb;
+            gemm_split3(aux[q], ha, ma, la);
+            gemm_split3(aux[q + 1], hb, mb, lb);
+            const unsigned own[3] = {ha | (hb << 16), ma | (mb << 16), la | (lb << 16)};
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+              const unsigned nbr = (unsigned)__builtin_amdgcn_mov_dpp((int)own[pc], 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]: lane ^ 1
+              const unsigned out = __builtin_amdgcn_perm(nbr, own[pc], p_sel);
+              __builtin_amdgcn_raw_buffer_store_b32(out, rp, p_lane + (unsigned)mu * p_row + (unsigned)(pc * 64), 0, 0);
+            }
+          }
+        }
       }
     }
   }

@@ -26,6 +26,7 @@
 //     that own a wholly padded upper half of an active tile write zeros instead of their epilogue.
 // Eligibility: pl_try below.  Everything else stays on gemm.hip / gemm_sk.hip / gemm_ws.hip.
 #include "gemm_pl_common.h"
+#include "planes_common.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -480,7 +481,7 @@ int pl_env(const char* name, int dflt) {
 }
 
 // ---------------------------------------------------------------- exact three-way bf16 split of fp32 matrices (many per launch)
-constexpr int SPL_BATCH = 24;
+constexpr int SPL_BATCH = 32;          // all weight sets of an fs2 step (26 matrices) in ONE launch
 struct SplitBatch {
   const float* src[SPL_BATCH];
   uint16_t* dst[SPL_BATCH];
@@ -489,24 +490,6 @@ struct SplitBatch {
   int ntasks;
 };
 constexpr int SPL_PER_BLOCK = 256 * 4;           // 8-element groups per workgroup
-
-// one float -> (hi bits, mid bits, lo bits) with the domain rules of include/ctts.h
-__device__ __forceinline__ void spl_one(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-  const pl_floatx2 v0 = {x, 0.f};
-  unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, pl_bf16x2)) & 0xFFFFu;
-  const bool x_fin = fabsf(x) < __builtin_inff();
-  if ((hb & 0x7F80u) == 0x7F80u) {               // hi is +-inf / NaN
-    if (x_fin) hb = (hb & 0x8000u) | 0x7F7Fu;    // a finite x that would round to infinity: the largest bf16 (the remainder stays exact)
-    else { hi = hb; mid = 0u; lo = 0u; return; }
-  }
-  const float r1 = x - __uint_as_float(hb << 16);
-  const pl_floatx2 v1 = {r1, 0.f};
-  const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, pl_bf16x2)) & 0xFFFFu;
-  const float r2 = r1 - __uint_as_float(mb << 16);
-  const pl_floatx2 v2 = {r2, 0.f};
-  const unsigned lb = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, pl_bf16x2)) & 0xFFFFu;
-  hi = hb; mid = mb; lo = lb;
-}
 
 // dst [rows][ld / 32][3][32] bf16: thread = 8 consecutive k of one row -> three 16-byte stores 64 bytes apart inside the K-block's 192 bytes
 __global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch b) {
@@ -523,20 +506,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch b) {
     const long r = gidx / c8, c = (gidx - r * c8) * 8;
     const float4 x0 = *reinterpret_cast<const float4*>(src + r * ld + c), x1 = *reinterpret_cast<const float4*>(src + r * ld + c + 4);
     const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    unsigned hi[8], mid[8], lo[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) spl_one(xs[e], hi[e], mid[e], lo[e]);
-    pl_u32x4 ph, pm, pq;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ph[e] = hi[2 * e] | (hi[2 * e + 1] << 16);
-      pm[e] = mid[2 * e] | (mid[2 * e + 1] << 16);
-      pq[e] = lo[2 * e] | (lo[2 * e + 1] << 16);
-    }
-    uint16_t* o = dst + r * ld * 3 + (c >> 5) * 96 + (c & 31);
-    *reinterpret_cast<pl_u32x4*>(o) = ph;
-    *reinterpret_cast<pl_u32x4*>(o + 32) = pm;
-    *reinterpret_cast<pl_u32x4*>(o + 64) = pq;
+    spl_store8(dst, r, ld, c, xs);
   }
 }
 

@@ -93,6 +93,13 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const ctts_gemm_desc d,
           if (d.Z && !d.epi_bwd) d.Z[(long)(row0 + r) * d.ldz + c0 + c] = 0.f;
         }
       }
+      if (BWD && d.C_planes) {          // the plane set of a zero tile: 128 columns = 4 K-blocks x 192 bytes per row, as 16-byte stores
+        for (int e = tid; e < nrows * 48; e += 256) {
+          const int r = e / 48, q = e - r * 48;
+          if (q * 8 / 96 * 32 < ncols)
+            *reinterpret_cast<uint4*>(d.C_planes + (long)(row0 + r) * d.ldc * 3 + (long)(c0 >> 5) * 96 + q * 8) = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
     }
   }
   const ws_i32x4 ra_src = ws_make_rsrc(d.A);
@@ -197,7 +204,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(const ctts_gemm_desc d,
     if (next < n_mt && !(p.debug & 4)) issue_half(next, 0);
     if (!(p.debug & 8)) compute_half(std::integral_constant<int, 1>{});
     if (p.debug & 1) { t0 = __builtin_readcyclecounter(); t_c1 += t0 - t1; }
-    if (wave_has_cols && !(p.debug & 2)) gemm_epilogue_lean<2, 1, ACT, DROP, BWD, AUX>(d, acc, d.C, 0, row0, col0, 0, wn0, l31, h, d.M, d.N);
+    // BWD instantiations carry the plane-writing variant (d.C_planes: the dZ handed to the previous layer arrives with its operand planes)
+    if (wave_has_cols && !(p.debug & 2)) gemm_epilogue_lean<2, 1, ACT, DROP, BWD, AUX, false, BWD>(d, acc, d.C, 0, row0, col0, 0, wn0, l31, h, d.M, d.N);
     if (p.debug & 1) { t1 = __builtin_readcyclecounter(); t_epi += t1 - t0; }
     ++n_done;
   }
@@ -270,6 +278,8 @@ static bool ws_plan(const ctts_gemm_desc& d, WsArgs& p) {
   if ((long)(d.M + 64) * d.lda * 4 >= 0x7FFF0000L) return false;
   if (!gemm_fits32(d.C, d.M, d.ldc, d.N) || !gemm_fits32(d.Z, d.M, d.ldz, d.N) || !gemm_fits32(d.R, d.M, d.ldr, d.N)) return false;
   if (d.row_lens && !d.tile_map) return false;           // padded-row zeroing needs the schedule
+  // an output plane set (round 6) is written by the backward epilogue only, for whole 32-column K-blocks
+  if (d.C_planes && (!d.epi_bwd || (d.ldc & 31) || (d.N & 31) || !al16(d.C_planes) || (long)(d.M + 64) * d.ldc * 6 >= 0x7FFF0000L)) return false;
   // combinations no K = 256 launch of the model uses are not compiled in: row scale, tanh, a pre-activation store without activation
   if (d.rowscale || d.act == 3 || (d.Z && !d.act && !d.epi_bwd)) return false;
   if (d.tile_map == reinterpret_cast<const int32_t*>(1)) return false;

@@ -1,6 +1,7 @@
 // LayerNorm / BatchNorm1d (channel-last) / masked softmax kernels.  All HBM-bound: one pass over
 // the activation per direction, row statistics in registers (one wavefront per row).
 #include "ctts_common.h"
+#include "planes_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -13,7 +14,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                              float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                              int rows, int C, float eps, float p_drop,
                                                              const uint64_t* seed, uint32_t drop_offset,
-                                                             const float* __restrict__ rowscale) {
+                                                             const float* __restrict__ rowscale, uint16_t* __restrict__ planes) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
   const bool do_drop = p_drop > 0.f;
@@ -57,6 +58,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
           o[e] *= sc;
         }
         yr[c] = make_float4(o[0], o[1], o[2], o[3]);
+        // the bf16 plane set of y for the plane-kernel GEMM that consumes it (FFN conv): the values are in registers here - a separate
+        // ctts_split_planes launch would read y back (round 6)
+        if (planes) spl_store4(planes, row, C, c * 4, o);
       }
     }
   }
@@ -270,6 +274,99 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
+__device__ __forceinline__ void bn_load8(const float* __restrict__ p, float (&o)[8]) {       // p 16-byte aligned (c % 8 == 0, aligned base)
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void bn_load8d(const double* __restrict__ p, float (&o)[8]) {     // (float) of 8 doubles, 16-byte aligned
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double2 v = *reinterpret_cast<const double2*>(p + 2 * i);
+    o[2 * i] = (float)v.x; o[2 * i + 1] = (float)v.y;
+  }
+}
+
+// the same element-wise map, 8 consecutive channels per thread (C % 8 == 0, 16-byte aligned), with the bf16 plane set of y written next
+// to it: the PostNet convolutions that consume y run on the plane kernel (round 6: no separate ctts_split_planes pass over y)
+__global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ y,
+                                                              uint16_t* __restrict__ planes, long total8, int C, int act, float p_drop,
+                                                              const uint64_t* seed, uint32_t drop_offset) {
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  const int c8n = C >> 3;
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total8; g += (long)gridDim.x * blockDim.x) {
+    const long r = g / c8n;
+    const int c = (int)(g - r * c8n) * 8;
+    const long e0 = r * C + c;
+    const float4 x0 = *reinterpret_cast<const float4*>(x + e0), x1 = *reinterpret_cast<const float4*>(x + e0 + 4);
+    const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    // per-channel vectors as 16-byte loads: with one channel per load instruction the 64 lanes of a wave touch 16 cache lines for 256
+    // useful bytes, 32 times per thread - the first version of this kernel ran 2.8x slower than the scalar one on exactly that
+    float pm[8], pr[8], pg[8], pb[8];
+    bn_load8(mean + c, pm); bn_load8(rstd + c, pr); bn_load8(gamma + c, pg); bn_load8(beta + c, pb);
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = ctts_act((xs[i] - pm[i]) * pr[i] * pg[i] + pb[i], act);
+      if (do_drop) v *= ctts_drop_scale(dkey, (uint32_t)(e0 + i), p_drop, inv_keep);
+      o[i] = v;
+    }
+    *reinterpret_cast<float4*>(y + e0) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(y + e0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    spl_store8(planes, r, C, c, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const double* __restrict__ sums, float* __restrict__ dx,
+                                                                  uint16_t* __restrict__ planes, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, long total8, int rows, int C, int act,
+                                                                  float p_drop, const uint64_t* seed, uint32_t drop_offset, int batch_stats) {
+  const bool do_drop = p_drop > 0.f;
+  uint32_t dkey = 0; float inv_keep = 1.f;
+  if (do_drop) { dkey = ctts_drop_key(seed, drop_offset); inv_keep = 1.f / (1.f - p_drop); }
+  const float invR = 1.f / (float)rows;
+  const bool accumulate = (batch_stats & 2) != 0;
+  batch_stats &= 1;
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      if (accumulate) { dbeta[c] += (float)sums[c]; dgamma[c] += (float)sums[C + c]; }
+      else { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
+    }
+  const int c8n = C >> 3;
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total8; g += (long)gridDim.x * blockDim.x) {
+    const long r = g / c8n;
+    const int c = (int)(g - r * c8n) * 8;
+    const long e0 = r * C + c;
+    const float4 d0 = *reinterpret_cast<const float4*>(dy + e0), d1 = *reinterpret_cast<const float4*>(dy + e0 + 4);
+    const float4 x0 = *reinterpret_cast<const float4*>(x + e0), x1 = *reinterpret_cast<const float4*>(x + e0 + 4);
+    const float ds[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    float pm[8], pr[8], pg[8], pb[8], s0[8], s1[8];
+    bn_load8(mean + c, pm); bn_load8(rstd + c, pr); bn_load8(gamma + c, pg); bn_load8(beta + c, pb);
+    if (batch_stats) { bn_load8d(sums + c, s0); bn_load8d(sums + C + c, s1); }
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float d = ds[i];
+      if (do_drop) d *= ctts_drop_scale(dkey, (uint32_t)(e0 + i), p_drop, inv_keep);
+      const float xh = (xs[i] - pm[i]) * pr[i];
+      d *= ctts_act_grad(xh * pg[i] + pb[i], act);
+      float v = d;
+      if (batch_stats) v = d - s0[i] * invR - xh * s1[i] * invR;
+      o[i] = pg[i] * pr[i] * v;
+    }
+    *reinterpret_cast<float4*>(dx + e0) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(dx + e0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    spl_store8(planes, r, C, c, o);
+  }
+}
+
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const double* __restrict__ sums, float* __restrict__ dx,
@@ -351,13 +448,15 @@ __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ S, con
 
 extern "C" int ctts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                   float* rstd, int rows, int C, float eps, float p_drop, const uint64_t* seed,
-                                  uint32_t drop_offset, const float* rowscale, void* stream) {
+                                  uint32_t drop_offset, const float* rowscale, uint16_t* planes, void* stream) {
   CTTS_REQUIRE(x && gamma && beta && y && mean && rstd, "ctts_layernorm_fwd: null pointer");
   CTTS_REQUIRE((C % 4) == 0 && C <= 1024 && C > 0, "ctts_layernorm_fwd: C=%d must be a multiple of 4 and <= 1024", C);
+  CTTS_REQUIRE(!planes || ((C % 32) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15) == 0),
+               "ctts_layernorm_fwd: a plane set needs C %% 32 == 0 (got %d) and a 16-byte aligned pointer", C);
   if (rows == 0) return 0;
   const int blocks = min((rows + 3) / 4, 2048);
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd,
-                     rows, C, eps, p_drop, seed, drop_offset, rowscale);
+                     rows, C, eps, p_drop, seed, drop_offset, rowscale, planes);
   CTTS_CHECK_LAUNCH("ctts_layernorm_fwd");
   return 0;
 }
@@ -459,10 +558,22 @@ extern "C" int ctts_bn_finalize(const double* sums, int rows, int C, float eps, 
 
 extern "C" int ctts_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                              float* y, int rows, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset,
-                             void* stream) {
+                             uint16_t* planes, void* stream) {
   CTTS_REQUIRE(x && mean && rstd && gamma && beta && y, "ctts_bn_apply: null pointer");
   const long total = (long)rows * C;
   if (total == 0) return 0;
+  if (planes) {
+    CTTS_REQUIRE((C % 32) == 0 && ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                                    reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(gamma) |
+                                    reinterpret_cast<uintptr_t>(beta)) & 15) == 0 && total < (1L << 32),
+                 "ctts_bn_apply: a plane set needs C %% 32 == 0 (got %d), 16-byte aligned pointers (x, y, planes and the per-channel vectors) and < 2^32 elements", C);
+    const long total8 = total / 8;
+    const int pb = (int)min((total8 + 255) / 256, (long)4096);
+    hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(pb), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, planes, total8, C,
+                       act, p_drop, seed, drop_offset);
+    CTTS_CHECK_LAUNCH("ctts_bn_apply");
+    return 0;
+  }
   const int blocks = (int)min((total + 255) / 256, (long)4096);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, total, C,
                      act, p_drop, seed, drop_offset);
@@ -487,10 +598,23 @@ extern "C" int ctts_bn_bwd_reduce(const float* dy, const float* x, const float* 
 extern "C" int ctts_bn_bwd_apply(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                  const float* beta, const double* sums, float* dx, float* dgamma, float* dbeta, int rows,
                                  int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, int batch_stats,
-                                 void* stream) {
+                                 uint16_t* planes, void* stream) {
   CTTS_REQUIRE(dy && x && mean && rstd && gamma && beta && sums && dx && dgamma && dbeta, "ctts_bn_bwd_apply: null pointer");
   const long total = (long)rows * C;
   if (total == 0) return 0;
+  if (planes) {
+    CTTS_REQUIRE((C % 32) == 0 && total < (1L << 32) &&
+                     ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                       reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(gamma) |
+                       reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(sums)) & 15) == 0,
+                 "ctts_bn_bwd_apply: a plane set needs C %% 32 == 0 (got %d), 16-byte aligned pointers (tensors, planes, per-channel vectors) and < 2^32 elements", C);
+    const long total8 = total / 8;
+    const int pb = (int)min((total8 + 255) / 256, (long)4096);
+    hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(pb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, sums, dx,
+                       planes, dgamma, dbeta, total8, rows, C, act, p_drop, seed, drop_offset, batch_stats);
+    CTTS_CHECK_LAUNCH("ctts_bn_bwd_apply");
+    return 0;
+  }
   const int blocks = (int)min((total + 255) / 256, (long)4096);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, sums,
                      dx, dgamma, dbeta, total, rows, C, act, p_drop, seed, drop_offset, batch_stats);

@@ -253,8 +253,10 @@ def _gemm_desc(A, B, Cout, M, N, K, lda, ldb, ldc, a_kc=True, b_kc=True, a_off=0
                sA=(0, 0), sB=(0, 0), sC=(0, 0), lens=None, lim=(0, 0, 0), conv=None, conv_on_b=False, split_k=1, alpha=1.0,
                bias=None, Z=None, ldz=0, act=ACT_NONE, p_drop=0.0, seed=None, drop_offset=0, R=None, ldr=0, rowscale=None,
                row_lens=None, row_T=0, row_halo=0, tile_map=None, E=None, rowsub=None, use_sk=None, epi_bwd=False, split_overwrite=False,
-               bf16_split=None, a_planes=None, b_planes=None):
+               bf16_split=None, a_planes=None, b_planes=None, c_planes=None):
     d = GemmDesc()
+    if c_planes is not None:
+        d.C_planes = c_planes.data_ptr()
     d.bf16_split = int(BF16_SPLIT if bf16_split is None else bf16_split)
     if a_planes is not None and b_planes is not None:
         d.A_planes, d.B_planes = a_planes.data_ptr(), b_planes.data_ptr()
@@ -382,7 +384,7 @@ def plane_wgrad_shape_ok(Mo, No, Kred, cin=None):
 
 
 def split_planes(mats):
-    """Exact three-way bf16 split of fp32 matrices in one launch per 24 (include/ctts.h ctts_split_planes): `mats` = list of dense 2-D
+    """Exact three-way bf16 split of fp32 matrices in one launch per 32 (include/ctts.h ctts_split_planes): `mats` = list of dense 2-D
     float32 tensors [rows, cols] (cols % 32 == 0) -> list of bf16 tensors [rows, cols / 32, 3, 32]: pieces hi | mid | lo of every 32-deep
     K-block of a row side by side (the layout the plane kernel's DMA reads; `planes_piece` gives a piece back as [rows, cols])."""
     if not mats:
@@ -399,6 +401,38 @@ def split_planes(mats):
         t.src, t.dst, t.rows, t.cols, t.ld = _p(m), o.data_ptr(), int(rows), int(cols), int(cols)
     _lib.check(_lib.load().ctts_split_planes(arr, len(arr), _stream()), "ctts_split_planes")
     return outs
+
+
+# ---- plane sets written by PRODUCERS (round 6) ------------------------------------------------------------------------------------------
+# A kernel that holds an activation in registers (LayerNorm forward, BatchNorm apply / backward, the producer-epilogue backward of the
+# K = 256 GEMM) can write the activation's bf16 plane set in the same launch; the set travels WITH the fp32 tensor as a Python attribute
+# (autograd keeps the Python object of a tensor alive across Function boundaries, forward and backward), validated against the tensor's
+# address, size and version when a GEMM asks for it.  CTTS_PRODUCER_PLANES=0: every consumer splits its own operand again (A/B switch).
+PRODUCER_PLANES = _os.environ.get("CTTS_PRODUCER_PLANES", "1") != "0"
+
+
+def _al16(*ts):
+    return all(t.data_ptr() % 16 == 0 for t in ts)
+
+
+def new_planes(rows, cols, device):
+    return torch.empty(rows, cols // 32, 3, 32, dtype=torch.bfloat16, device=device)
+
+
+def attach_planes(t, pl):
+    t._ctts_planes = (pl, t.data_ptr(), t._version, t.numel())
+    return t
+
+
+def planes_of(t):
+    """the plane set a producer attached to `t`, or None (never attached / `t` was written since / another tensor)"""
+    ent = getattr(t, "_ctts_planes", None)
+    if ent is None:
+        return None
+    pl, ptr, ver, n = ent
+    if ptr != t.data_ptr() or ver != t._version or n != t.numel() or pl.numel() != 3 * n:
+        return None
+    return pl
 
 
 def planes_piece(pl, q):
@@ -510,15 +544,19 @@ def cwt_pitch(spec, f0_mean, f0_std, std_scale, eps, mel_min, mel_max, f0_bin, u
     return f0, den, ids
 
 
-def layernorm_fwd(x, gamma, beta, eps, p_drop=0.0, seed=None, drop_offset=0, rowscale=None):
+def layernorm_fwd(x, gamma, beta, eps, p_drop=0.0, seed=None, drop_offset=0, rowscale=None, want_planes=False):
+    """want_planes: also write the bf16 plane set of y (same launch) and attach it to y (`planes_of(y)`)"""
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    pl = new_planes(rows, Cc, x.device) if (want_planes and PRODUCER_PLANES and Cc % 32 == 0 and x.is_cuda) else None
     lib = _lib.load()
     _lib.check(lib.ctts_layernorm_fwd(_p(_f32c(x, "x")), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, Cc, eps,
-                                      p_drop, _p(seed), drop_offset, _p(rowscale), _stream()), "ctts_layernorm_fwd")
+                                      p_drop, _p(seed), drop_offset, _p(rowscale), _p(pl), _stream()), "ctts_layernorm_fwd")
+    if pl is not None:
+        attach_planes(y, pl)
     return y, mean, rstd
 
 
@@ -568,18 +606,24 @@ def bn_batch_stats(x2d, eps, momentum, running_mean, running_var, num_batches):
     return mean, rstd
 
 
-def bn_apply(x2d, mean, rstd, gamma, beta, act, p_drop=0.0, seed=None, drop_offset=0):
+def bn_apply(x2d, mean, rstd, gamma, beta, act, p_drop=0.0, seed=None, drop_offset=0, want_planes=False):
+    """-> y, or (y, planes of y) with want_planes (None when the shape has no plane layout)"""
     rows, Cc = x2d.shape
     y = torch.empty_like(x2d)
+    pl = (new_planes(rows, Cc, x2d.device) if (want_planes and PRODUCER_PLANES and Cc % 32 == 0 and x2d.is_cuda and rows > 0
+                                               and _al16(x2d, mean, rstd, gamma, beta)) else None)
     lib = _lib.load()
     _lib.check(lib.ctts_bn_apply(_p(_f32c(x2d, "x")), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), rows, Cc, act, p_drop,
-                                 _p(seed), drop_offset, _stream()), "ctts_bn_apply")
-    return y
+                                 _p(seed), drop_offset, _p(pl), _stream()), "ctts_bn_apply")
+    return (y, pl) if want_planes else y
 
 
-def bn_bwd(dy, x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats, acc_into=None):
-    """acc_into = (dgamma, dbeta): existing float32 [C] buffers the parameter gradients are ADDED to (param.grad); returns (dx, None, None)"""
+def bn_bwd(dy, x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats, acc_into=None, want_planes=False):
+    """acc_into = (dgamma, dbeta): existing float32 [C] buffers the parameter gradients are ADDED to (param.grad); returns (dx, None, None).
+    want_planes: the bf16 plane set of dx is written by the apply launch and attached to dx (`planes_of(dx)`)."""
     rows, Cc = x2d.shape
+    pl = (new_planes(rows, Cc, x2d.device) if (want_planes and PRODUCER_PLANES and Cc % 32 == 0 and x2d.is_cuda and rows > 0
+                                               and _al16(dy, x2d, mean, rstd, gamma, beta)) else None)
     sums = torch.empty(2 * Cc, dtype=torch.float64, device=x2d.device)
     dx = torch.empty_like(x2d)
     if acc_into is not None:
@@ -592,8 +636,10 @@ def bn_bwd(dy, x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, bat
     _lib.check(lib.ctts_bn_bwd_reduce(_p(_f32c(dy, "dy")), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), rows,
                                       Cc, act, p_drop, _p(seed), drop_offset, _ws(dy), _stream()), "ctts_bn_bwd_reduce")
     _lib.check(lib.ctts_bn_bwd_apply(_p(dy), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), _p(dx), _p(dgamma),
-                                     _p(dbeta), rows, Cc, act, p_drop, _p(seed), drop_offset, int(batch_stats), _stream()),
+                                     _p(dbeta), rows, Cc, act, p_drop, _p(seed), drop_offset, int(batch_stats), _p(pl), _stream()),
                "ctts_bn_bwd_apply")
+    if pl is not None:
+        attach_planes(dx, pl)
     return (dx, None, None) if acc_into is not None else (dx, dgamma, dbeta)
 
 

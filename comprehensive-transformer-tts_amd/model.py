@@ -200,7 +200,9 @@ class FFTBlocks(nn.Module):
             qkv = ops.linear(h, op.self_attn.in_proj_weight, pad_rows=pr)
             a = ops.self_attention(qkv, lens, self.num_heads)
             x = ops.linear(a, op.self_attn.out_proj.weight, None, residual=xr, rowscale=nonpad, p_drop=p, drop=drop, pad_rows=pr)
-            h, xr = ops.layer_norm_res(x, op.layer_norm2.weight, op.layer_norm2.bias, 1e-12)
+            # the FFN convolution runs on the plane kernel at the decoder's size: LN2 writes its operand planes in the same launch
+            h, xr = ops.layer_norm_res(x, op.layer_norm2.weight, op.layer_norm2.bias, 1e-12,
+                                       planes_for=(op.ffn.conv1.weight.shape[0], self.ksize))
             # g feeds ffn_2 only: its epilogue backward (GELU', dropout mask) rides in the epilogue of ffn_2's data-gradient GEMM
             link = ops.EpiLink()
             g = ops.conv1d(h, op.ffn.conv1.weight, op.ffn.conv1.bias, act=self.ffn_act, alpha=alpha, p_drop=p, drop=drop,
@@ -743,11 +745,20 @@ class PostNet(nn.Module):
         n = len(self.convolutions)
         p = self.dropout if self.training else 0.0
         drop = self.drop_ctx if p > 0 else None
+        convs = [getattr(seq, "0").conv for seq in self.convolutions]
         for i, seq in enumerate(self.convolutions):
-            cv, bn = getattr(seq, "0").conv, getattr(seq, "1")
+            cv, bn = convs[i], getattr(seq, "1")
+            cin_i, k_i = cv.weight.shape[1], cv.weight.shape[2]
             x = ops.conv1d(x, cv.weight, cv.bias)
+            # operand planes from the producers (round 6): this layer's output is the A operand of the NEXT convolution's forward, and the
+            # gradient BatchNorm's backward returns is the dZ operand of THIS convolution's data / weight gradient - when those launches
+            # run on the plane kernel, the BatchNorm launches write the bf16 plane sets next to the fp32 tensors
+            fwd_pl = i + 1 < n and ops.consumer_takes_planes(x, convs[i + 1].weight.shape[0], convs[i + 1].weight.shape[2])
+            dz_pl = (self.training and i > 0 and x.is_cuda
+                     and ops.consumer_takes_planes(x, cin_i, k_i))          # data gradient: [M, cout] x [cin, k * cout]^T
             x = ops.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                   self.training, act=ops.ACT_TANH if i < n - 1 else ops.ACT_NONE, p_drop=p, drop=drop)
+                                   self.training, act=ops.ACT_TANH if i < n - 1 else ops.ACT_NONE, p_drop=p, drop=drop,
+                                   planes=fwd_pl, dx_planes=dz_pl)
         return x
 
 

@@ -244,12 +244,14 @@ class EpiLink:
     def __init__(self):
         self.Z = self.seed = None
         self.act, self.p_drop, self.drop_offset = ACT_NONE, 0.0, 0
+        self.conv_dims = None       # (cin, ksize) of a Conv1d producer: lets the consumer's backward decide whether the producer's dZ is wanted as planes
         self.armed = False          # producer forward has run with this link and no consumer has taken it yet
         self.gen = 0                # every producer forward is a new generation: a link object reused across forwards (or re-armed before
         self.done = set()           # backward) pairs each consumer backward with ITS producer; `done`: generations whose dZ was delivered
 
-    def arm(self, Z, act, p_drop, seed, drop_offset):
+    def arm(self, Z, act, p_drop, seed, drop_offset, conv_dims=None):
         self.Z, self.act, self.p_drop, self.seed, self.drop_offset = Z, act, p_drop, seed, drop_offset
+        self.conv_dims = conv_dims
         self.gen += 1
         self.armed = True
         return self.gen
@@ -258,7 +260,7 @@ class EpiLink:
         """consumer forward: snapshot of the producer's epilogue (the consumer's backward must not read the mutable link: ADVICE r03) -
         one consumer per producer forward"""
         self.armed = False
-        return (self.Z, self.act, self.p_drop, self.seed, self.drop_offset, self.gen)
+        return (self.Z, self.act, self.p_drop, self.seed, self.drop_offset, self.gen, self.conv_dims)
 
 
 class _LinearConv(torch.autograd.Function):
@@ -298,7 +300,7 @@ class _LinearConv(torch.autograd.Function):
         ctx.amp = (K.amp_split() if (ksize and x.is_cuda and torch.is_autocast_enabled("cuda")) else None)
         if ctx.amp is not None:
             gk["bf16_split"] = ctx.amp
-        planes = _operand_planes("fwd", w, x.view(M, Cin), wf, M, N, Kdim, Cin, Kdim, N, out, gk) if ksize else {}
+        planes = _operand_planes("fwd", w, x.view(M, Cin), wf, M, N, Kdim, Cin, Kdim, N, out, gk, a_given=K.planes_of(x)) if ksize else {}
         K.gemm(x, wf, out, M, N, Kdim, Cin, Kdim, N, True, True, tile_map=pr.tile_map(0, M) if (pr is not None and not planes) else None,
                **gk, **planes)
         ctx.x_planes = planes.get("a_planes")        # the weight-gradient launch reads the same plane set (gemm_plw.hip)
@@ -308,7 +310,7 @@ class _LinearConv(torch.autograd.Function):
         ctx.link, ctx.link_role, ctx.link_snap = None, 0, None
         if link is not None and _FUSE_EPILOGUE_BWD:
             if link_role == 1 and rowscale is None and residual is None and (act != ACT_NONE or p_drop > 0):
-                ctx.link_gen = link.arm(Z, act, p_drop, seed, drop_offset)
+                ctx.link_gen = link.arm(Z, act, p_drop, seed, drop_offset, conv_dims=(Cin, ksize) if ksize else None)
                 ctx.link, ctx.link_role = link, 1
             elif link_role == 2 and link.armed and not ksize:
                 ctx.link, ctx.link_role, ctx.link_snap = link, 2, link.take()
@@ -354,7 +356,7 @@ class _LinearConv(torch.autograd.Function):
             d_res = (gm if rowscale is not None else dY) if has_res else None
             if want_bias and not fuse_bias:
                 dB = dBn
-        dz_planes = None
+        dz_planes = K.planes_of(dZ) if ksize else None          # written by dZ's producer (BatchNorm backward, the EpiLink GEMM epilogue)
         if ksize:
             T = x.shape[-2]
             pad = ctx.pad_left                   # forward / weight-gradient view
@@ -374,7 +376,8 @@ class _LinearConv(torch.autograd.Function):
                 sk = min(4, max(2, -(-2304 // tiles))) if (_DGRAD_SPLIT_K and tiles < 1536 and ksize * N >= 4096) else 1
                 dX = torch.empty_like(x)             # split: the ordered reduce launch writes every element (zeros in padded tiles)
                 dg0 = dict(conv=(T, pad_d, N), alpha=alpha, row_halo=pad_d, **rl)
-                planes = _operand_planes("dgrad", w, dZ.view(M, N), wd, M, Cin, ksize * N, N, ksize * N, Cin, dX, dict(split_overwrite=True, **dg0))
+                planes = _operand_planes("dgrad", w, dZ.view(M, N), wd, M, Cin, ksize * N, N, ksize * N, Cin, dX, dict(split_overwrite=True, **dg0),
+                                         a_given=dz_planes)
                 if planes:          # pre-split operands on the persistent plane kernel: balances the reduction itself, writes every element
                     dz_planes = planes["a_planes"]
                     K.gemm(dZ, wd, dX, M, Cin, ksize * N, N, ksize * N, Cin, True, True, split_k=1, split_overwrite=True, **dg0, **planes)
@@ -409,10 +412,21 @@ class _LinearConv(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dX = torch.empty_like(x)
                 if ctx.link_role == 2:   # hand the producer its dZ: mask / (1-p) * act'(Z_producer) applied in this GEMM's epilogue
-                    lZ, lact, lp, lseed, loff, lgen = ctx.link_snap           # the producer's epilogue as it was at THIS forward
-                    K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha, epi_bwd=True, Z=lZ, ldz=Cin, act=lact,
-                           p_drop=lp, seed=lseed, drop_offset=loff,
-                           tile_map=pr.tile_map(0, M) if pr is not None else None, **rl)
+                    lZ, lact, lp, lseed, loff, lgen, lconv = ctx.link_snap     # the producer's epilogue as it was at THIS forward
+                    gk = dict(alpha=alpha, epi_bwd=True, Z=lZ, ldz=Cin, act=lact, p_drop=lp, seed=lseed, drop_offset=loff,
+                              tile_map=pr.tile_map(0, M) if pr is not None else None, **rl)
+                    # dX IS the producer convolution's dZ: when that layer's data gradient runs on the plane kernel and this launch runs on
+                    # the weight-stationary kernel (the only one whose epilogue writes planes), dZ arrives with its operand planes - no
+                    # ctts_split_planes pass over the [M, 4C] gradient (round 6)
+                    cpl = None
+                    if (lconv is not None and K.PRODUCER_PLANES and dZ.is_cuda and Cin % 32 == 0
+                            and K.plane_shape_ok(M, lconv[0], lconv[1] * Cin, Cin)):
+                        cand = K.new_planes(M, Cin, dZ.device)
+                        if K.gemm_takes_weight_stationary(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, c_planes=cand, **gk):
+                            cpl = cand
+                    K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, c_planes=cpl, **gk)
+                    if cpl is not None:
+                        K.attach_planes(dX, cpl)
                     ctx.link.done.add(lgen)
                 else:
                     K.gemm(dZ, w, dX, M, Cin, N, N, Cin, Cin, True, False, alpha=alpha,
@@ -466,7 +480,7 @@ _DGRAD_W = _DgradCache()
 _PLANES = {"fwd": {}, "dgrad": {}, "want_fwd": set(), "want_dgrad": set()}
 
 
-def _operand_planes(kind, w, a_mat, b_mat, M, N, Kdim, lda, ldb, ldc, out, gk):
+def _operand_planes(kind, w, a_mat, b_mat, M, N, Kdim, lda, ldb, ldc, out, gk, a_given=None):
     """{} or dict(a_planes=, b_planes=) for K.gemm: the three-way bf16 split of the activation-side matrix `a_mat` [M, lda] (made here:
     one streaming launch) and of the weight-side matrix `b_mat` [N, Kdim] (from the step's cache) - when the library would run this
     launch on the plane kernel (asked with placeholder planes: no device work)."""
@@ -483,7 +497,8 @@ def _operand_planes(kind, w, a_mat, b_mat, M, N, Kdim, lda, ldb, ldc, out, gk):
     else:
         _PLANES["want_" + kind].add(w.data_ptr())
         bp = K.split_planes([b_mat])[0]
-    return dict(a_planes=K.split_planes([a_mat])[0], b_planes=bp)
+    # `a_given`: the set the activation's PRODUCER wrote next to the fp32 tensor (kernels.planes_of) - no split launch for it
+    return dict(a_planes=a_given if a_given is not None else K.split_planes([a_mat])[0], b_planes=bp)
 
 
 def _wgrad_planes(dz_mat, x_mat, dz_pl, x_pl, out, Mo, No, Kred, cin, kw):
@@ -680,9 +695,9 @@ class _LayerNormRes(torch.autograd.Function):
     gradient paths then arrive HERE, and the LN backward kernel adds the residual one while it writes dx - no separate autograd add."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, want_planes=False):
         x = x.contiguous()
-        y, mean, rstd = K.layernorm_fwd(x, gamma, beta, eps, 0.0, None, 0, None)
+        y, mean, rstd = K.layernorm_fwd(x, gamma, beta, eps, 0.0, None, 0, None, want_planes=want_planes)
         ctx.save_for_backward(x, gamma, mean, rstd, beta)
         return y, x.view_as(x)
 
@@ -690,18 +705,28 @@ class _LayerNormRes(torch.autograd.Function):
     def backward(ctx, dy, dres):
         x, gamma, mean, rstd, beta = ctx.saved_tensors
         if dy is None:
-            return dres, None, None, None
+            return dres, None, None, None, None
         dres = dres.contiguous() if dres is not None else None
         if _fusable(gamma) and _fusable(beta):
             dx, _, _ = K.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, acc_into=(gamma.grad, beta.grad), dres=dres)
-            return dx, None, None, None
+            return dx, None, None, None, None
         dx, dg, db = K.layernorm_bwd(dy.contiguous(), x, gamma, mean, rstd, dres=dres)
-        return dx, dg, db, None
+        return dx, dg, db, None, None
 
 
-def layer_norm_res(x, gamma, beta, eps):
-    """-> (LayerNorm(x), x_res): use x_res as the `residual=` of the GEMM that closes the pre-LN sub-layer (transformer_fs2.py:186-199)."""
-    return _LayerNormRes.apply(x, gamma, beta, eps)
+def consumer_takes_planes(x, cout, ksize):
+    """would the Conv1d (cout, k = ksize) that consumes the activation x [B, T, C] run on the plane kernel?  Then x's producer writes the
+    bf16 plane set next to x (kernels.attach_planes) instead of leaving a ctts_split_planes pass over x to the consumer."""
+    Cc = x.shape[-1]
+    return bool(x.is_cuda and K.PRODUCER_PLANES and K.plane_shape_ok(x.numel() // Cc, int(cout), int(ksize) * Cc, Cc))
+
+
+def layer_norm_res(x, gamma, beta, eps, planes_for=None):
+    """-> (LayerNorm(x), x_res): use x_res as the `residual=` of the GEMM that closes the pre-LN sub-layer (transformer_fs2.py:186-199).
+    planes_for = (cout, ksize) of the Conv1d that consumes the normalised tensor: when that launch runs on the plane kernel the LN launch
+    writes the operand's bf16 plane set as well."""
+    want = planes_for is not None and consumer_takes_planes(x, *planes_for)
+    return _LayerNormRes.apply(x, gamma, beta, eps, want)
 
 
 def layer_norm(x, gamma, beta, eps, rowscale=None, p_drop=0.0, drop=None):
@@ -863,30 +888,47 @@ def dur_to_mel2ph(dur, dur_padding=None):
 
 
 class _BatchNormAct(torch.autograd.Function):
+    """x [..., C] -> drop(act(BN(x))) with the flattening to [rows, C] INSIDE the Function, so that the tensors that cross its boundary
+    are the ones the neighbouring convolutions see: a plane set attached to the output (forward) / the input gradient (backward) by the
+    kernels reaches the consuming GEMM with the tensor (kernels.attach_planes)."""
+
     @staticmethod
-    def forward(ctx, x2d, gamma, beta, mean, rstd, act, p_drop, seed, drop_offset, batch_stats):
-        y = K.bn_apply(x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset)
+    def forward(ctx, x, gamma, beta, mean, rstd, act, p_drop, seed, drop_offset, batch_stats, want_planes, want_dx_planes):
+        x2d = x.contiguous().view(-1, x.shape[-1])
+        if want_planes:
+            y2d, pl = K.bn_apply(x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, want_planes=True)
+        else:
+            y2d, pl = K.bn_apply(x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset), None
         ctx.save_for_backward(x2d, gamma, beta, mean, rstd, seed)
-        ctx.cfg = (act, p_drop, drop_offset, batch_stats)
+        ctx.cfg = (act, p_drop, drop_offset, batch_stats, bool(want_dx_planes), x.shape)
+        y = y2d.view(x.shape)
+        if pl is not None:
+            K.attach_planes(y, pl)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x2d, gamma, beta, mean, rstd, seed = ctx.saved_tensors
-        act, p_drop, drop_offset, batch_stats = ctx.cfg
+        act, p_drop, drop_offset, batch_stats, want_dx_planes, shape = ctx.cfg
         gg, gb = _grad_of(gamma), _grad_of(beta)
         acc = (gg, gb) if (gg is not None and gb is not None and gg.is_contiguous() and gb.is_contiguous()) else None
-        dx, dg, db = K.bn_bwd(dy.contiguous(), x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats, acc_into=acc)
-        return dx, dg, db, None, None, None, None, None, None, None
+        dx2d, dg, db = K.bn_bwd(dy.contiguous().view(-1, x2d.shape[-1]), x2d, mean, rstd, gamma, beta, act, p_drop, seed, drop_offset, batch_stats,
+                                acc_into=acc, want_planes=want_dx_planes)
+        dx = dx2d.view(shape)
+        pl = K.planes_of(dx2d)
+        if pl is not None:
+            K.attach_planes(dx, pl)
+        return dx, dg, db, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked, training, act=ACT_NONE, p_drop=0.0,
-                   drop=None, eps=1e-5, momentum=0.1):
+                   drop=None, eps=1e-5, momentum=0.1, planes=False, dx_planes=False):
     """drop(act(BatchNorm1d(x))) on channel-last x [B,T,C]; statistics over all B*T rows,
-    pads included, exactly as nn.BatchNorm1d sees them in modules.py:140-148."""
+    pads included, exactly as nn.BatchNorm1d sees them in modules.py:140-148.
+    planes / dx_planes: the launch that writes the output / the input gradient also writes its bf16 plane set (the neighbouring
+    convolution consumes it on the plane kernel: ops.consumer_takes_planes)."""
     C = x.shape[-1]
     x2d = x.contiguous().view(-1, C)
-    rows = x2d.shape[0]
     if training:
         with torch.no_grad():
             mean, rstd = K.bn_batch_stats(x2d, eps, momentum, running_mean, running_var, num_batches_tracked)
@@ -894,8 +936,8 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracke
         mean = running_mean
         rstd = torch.rsqrt(running_var + eps)
     seed, off = (drop.seed, drop.next_offset()) if (drop is not None and p_drop > 0) else (None, 0)
-    y = _BatchNormAct.apply(x2d, gamma, beta, mean, rstd, act, p_drop if seed is not None else 0.0, seed, off, bool(training))
-    return y.view(x.shape)
+    return _BatchNormAct.apply(x, gamma, beta, mean, rstd, act, p_drop if seed is not None else 0.0, seed, off, bool(training),
+                               bool(planes), bool(dx_planes))
 
 
 def sinusoid_table(n_pos, dim, device):

@@ -121,6 +121,12 @@ typedef struct ctts_gemm_desc {
    * A / B must stay valid: descriptors the plane kernels do not take (ctts_gemm_takes_planes) run on the other kernels from A / B. */
   const uint16_t* A_planes;
   const uint16_t* B_planes;
+  /* Optional plane set of the OUTPUT (round 6): with epi_bwd != 0 on the weight-stationary K = 256 kernel (ctts_gemm_takes_weight_stationary)
+   * the epilogue writes the exact three-way bf16 split of every C element it stores into C_planes as well ([M][ldc / 32][3][32], ldc % 32
+   * == 0, N % 32 == 0, 16-byte aligned; zeros in wholly padded tiles like C itself) - bit-identical to ctts_split_planes(C).  The dZ a
+   * data-gradient GEMM hands the previous layer then arrives with the operand planes that layer's own data- and weight-gradient launches
+   * read (transformer_fs2.py:220-239: ffn_2 -> ffn_1).  Launches on any other kernel IGNORE the field: ask first. */
+  uint16_t* C_planes;
 } ctts_gemm_desc;
 
 int ctts_gemm(const ctts_gemm_desc* d, void* stream);
@@ -255,10 +261,14 @@ int ctts_positions(const void* src, int src_is_float, int64_t stride, int B, int
 
 /* ---------------------------------------------------------------------------------------
  * LayerNorm over the last dim (blocks.py:137-156 eps 1e-12; nn.LayerNorm eps 1e-5), fused with
- * inverted dropout and the non-pad row mask:  y = rowscale * drop(LN(x)).                    */
+ * inverted dropout and the non-pad row mask:  y = rowscale * drop(LN(x)).
+ * planes (optional, round 6): the bf16 plane set of y in the layout of ctts_split_planes ([rows][C / 32][3][32], C % 32 == 0),
+ * written by the same launch from the registers that hold y - bit-identical to ctts_split_planes(y), for the plane-kernel GEMM that
+ * consumes y (FFN Conv1d, transformer_fs2.py:220-239) without a second pass over y.  The same optional argument on ctts_bn_apply (the
+ * PostNet convolutions' inputs, modules.py:140-148) and ctts_bn_bwd_apply (their output gradients dZ).                               */
 int ctts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        int rows, int C, float eps, float p_drop, const uint64_t* seed, uint32_t drop_offset,
-                       const float* rowscale, void* stream);
+                       const float* rowscale, uint16_t* planes, void* stream);
 int ctts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        float* dx, float* dgamma, float* dbeta, int rows, int C, float p_drop, const uint64_t* seed,
                        uint32_t drop_offset, const float* rowscale, int accumulate, const float* dres, void* ws, float* parts,
@@ -281,13 +291,14 @@ int ctts_bn_finalize(const double* sums, int rows, int C, float eps, float momen
                      float* running_var, int64_t* num_batches, void* stream);
 int ctts_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   float* y, int rows, int C, int act, float p_drop, const uint64_t* seed, uint32_t drop_offset,
-                  void* stream);
+                  uint16_t* planes /* optional plane set of y, see ctts_layernorm_fwd */, void* stream);
 int ctts_bn_bwd_reduce(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        const float* beta, double* sums, int rows, int C, int act, float p_drop, const uint64_t* seed,
                        uint32_t drop_offset, void* ws, void* stream);
 int ctts_bn_bwd_apply(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const double* sums, float* dx, float* dgamma, float* dbeta, int rows, int C,
-                      int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, int batch_stats, void* stream);
+                      int act, float p_drop, const uint64_t* seed, uint32_t drop_offset, int batch_stats,
+                      uint16_t* planes /* optional plane set of dx */, void* stream);
 
 /* Masked row softmax for attention scores S[nbatch, T, T] (in place), keys >= lens[z/nb1] get 0
  * and query rows >= len are left untouched (F.multi_head_attention_forward key_padding_mask).
