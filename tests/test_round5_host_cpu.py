@@ -75,13 +75,14 @@ def test_dgrad_cache_hands_out_only_entries_made_from_the_current_weight_version
     w = torch.nn.Parameter(torch.zeros(4, 3, 5))
     cache = ops._DgradCache()
     wd = torch.zeros(3, 20)
-    cache[w.data_ptr()] = (wd, w._version)
+    # entries carry ops._wstamp(w) = (autograd version, epoch of raw-pointer updates: dp.FlatAdam) since round 6 - tests/test_round6_host_cpu.py
+    cache[w.data_ptr()] = (wd, ops._wstamp(w))
     assert cache.take(w, (3, 20)) is wd and cache.take(w, (3, 20)) is None          # popped
-    cache[w.data_ptr()] = (wd, w._version)
+    cache[w.data_ptr()] = (wd, ops._wstamp(w))
     with torch.no_grad():
         w.add_(1.0)                                                                  # an in-place update after the preparation
     assert cache.take(w, (3, 20)) is None
-    cache[w.data_ptr()] = (wd, w._version)
+    cache[w.data_ptr()] = (wd, ops._wstamp(w))
     assert cache.take(w, (4, 20)) is None                                            # wrong shape
 
 
