@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void bn_apply_planes_kernel(const float* __res
     }
     *reinterpret_cast<float4*>(y + e0) = make_float4(o[0], o[1], o[2], o[3]);
     *reinterpret_cast<float4*>(y + e0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
-    spl_store8(planes, r, C, c, o);
+    if (planes) spl_store8(planes, r, C, c, o);
   }
 }
 
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float* _
     }
     *reinterpret_cast<float4*>(dx + e0) = make_float4(o[0], o[1], o[2], o[3]);
     *reinterpret_cast<float4*>(dx + e0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
-    spl_store8(planes, r, C, c, o);
+    if (planes) spl_store8(planes, r, C, c, o);
   }
 }
 
@@ -562,11 +562,14 @@ extern "C" int ctts_bn_apply(const float* x, const float* mean, const float* rst
   CTTS_REQUIRE(x && mean && rstd && gamma && beta && y, "ctts_bn_apply: null pointer");
   const long total = (long)rows * C;
   if (total == 0) return 0;
-  if (planes) {
-    CTTS_REQUIRE((C % 32) == 0 && ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
-                                    reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(gamma) |
-                                    reinterpret_cast<uintptr_t>(beta)) & 15) == 0 && total < (1L << 32),
-                 "ctts_bn_apply: a plane set needs C %% 32 == 0 (got %d), 16-byte aligned pointers (x, y, planes and the per-channel vectors) and < 2^32 elements", C);
+  const bool wide_ok = (C % 8) == 0 && total < (1L << 32) &&
+                       ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                         reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(gamma) |
+                         reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+  CTTS_REQUIRE(!planes || (wide_ok && (C % 32) == 0),
+               "ctts_bn_apply: a plane set needs C %% 32 == 0 (got %d), 16-byte aligned pointers (x, y, planes and the per-channel vectors) and < 2^32 elements", C);
+  static const bool wide_on = !(getenv("CTTS_BN_WIDE") && atoi(getenv("CTTS_BN_WIDE")) == 0);      // A/B switch: 0 = the scalar kernel unless planes are asked for
+  if (planes || (wide_ok && wide_on)) {      // 8 channels per thread, 16-byte accesses (same arithmetic, element for element)
     const long total8 = total / 8;
     const int pb = (int)min((total8 + 255) / 256, (long)4096);
     hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(pb), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, y, planes, total8, C,
@@ -602,12 +605,14 @@ extern "C" int ctts_bn_bwd_apply(const float* dy, const float* x, const float* m
   CTTS_REQUIRE(dy && x && mean && rstd && gamma && beta && sums && dx && dgamma && dbeta, "ctts_bn_bwd_apply: null pointer");
   const long total = (long)rows * C;
   if (total == 0) return 0;
-  if (planes) {
-    CTTS_REQUIRE((C % 32) == 0 && total < (1L << 32) &&
-                     ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
-                       reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(gamma) |
-                       reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(sums)) & 15) == 0,
-                 "ctts_bn_bwd_apply: a plane set needs C %% 32 == 0 (got %d), 16-byte aligned pointers (tensors, planes, per-channel vectors) and < 2^32 elements", C);
+  const bool wide_ok = (C % 8) == 0 && total < (1L << 32) &&
+                       ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                         reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(gamma) |
+                         reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(sums)) & 15) == 0;
+  CTTS_REQUIRE(!planes || (wide_ok && (C % 32) == 0),
+               "ctts_bn_bwd_apply: a plane set needs C %% 32 == 0 (got %d), 16-byte aligned pointers (tensors, planes, per-channel vectors) and < 2^32 elements", C);
+  static const bool wide_on = !(getenv("CTTS_BN_WIDE") && atoi(getenv("CTTS_BN_WIDE")) == 0);
+  if (planes || (wide_ok && wide_on)) {
     const long total8 = total / 8;
     const int pb = (int)min((total8 + 255) / 256, (long)4096);
     hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(pb), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, beta, sums, dx,

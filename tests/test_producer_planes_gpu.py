@@ -60,6 +60,29 @@ def test_layernorm_planes_are_refused_without_the_layout():
     assert rc != 0 and b"C % 32" in lib.ctts_last_error()
 
 
+def test_batchnorm_wide_kernels_equal_the_scalar_kernels_element_for_element():
+    """the 8-channels-per-thread kernels (every launch with C % 8 == 0 and 16-byte aligned operands since round 6) against the scalar
+    kernels they replace, reached through a misaligned view (C % 8 != 0 is the other way in): same arithmetic, same bits"""
+    rows, C = 777, 40
+    x = _nasty(rows, C, 9)
+    gamma, beta = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+    mean, rstd = x.mean(0), torch.rsqrt(x.var(0, unbiased=False) + 1e-5)
+    seed = torch.full((1,), 17, dtype=torch.int64, device=DEV)
+    dy = _nasty(rows, C, 10)
+    wide = (K.bn_apply(x, mean, rstd, gamma, beta, K.ACT_TANH, 0.5, seed, 3),) + tuple(K.bn_bwd(dy, x, mean, rstd, gamma, beta, K.ACT_TANH, 0.5, seed, 3, True))
+    # the same operands 4 bytes off a 16-byte boundary: the library falls back to the scalar kernels
+    def off(t):
+        buf = torch.empty(t.numel() + 1, device=DEV)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        return v
+    g2, b2, m2, r2 = off(gamma), off(beta), off(mean), off(rstd)
+    assert g2.data_ptr() % 16 != 0
+    scalar = (K.bn_apply(x, m2, r2, g2, b2, K.ACT_TANH, 0.5, seed, 3),) + tuple(K.bn_bwd(dy, x, m2, r2, g2, b2, K.ACT_TANH, 0.5, seed, 3, True))
+    for a, b in zip(wide, scalar):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("rows,C,act,p_drop", [(16384, 512, K.ACT_TANH, 0.5), (1000, 512, K.ACT_NONE, 0.0), (333, 64, K.ACT_TANH, 0.5)])
 def test_batchnorm_apply_and_backward_write_plane_sets(rows, C, act, p_drop):
     x = _nasty(rows, C, 2)
@@ -68,7 +91,7 @@ def test_batchnorm_apply_and_backward_write_plane_sets(rows, C, act, p_drop):
     seed = torch.full((1,), 99, dtype=torch.int64, device=DEV) if p_drop > 0 else None
     y0 = K.bn_apply(x, mean, rstd, gamma, beta, act, p_drop, seed, 3)
     y1, pl = K.bn_apply(x, mean, rstd, gamma, beta, act, p_drop, seed, 3, want_planes=True)
-    assert torch.equal(y0, y1)                        # the 8-wide kernel computes what the scalar kernel computes, element for element
+    assert torch.equal(y0, y1)
     _same_planes(pl, y1)
     dy = _nasty(rows, C, 3)
     for batch_stats in (True, False):
