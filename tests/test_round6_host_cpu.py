@@ -100,3 +100,63 @@ def test_partial_sink_remembers_producer_streams_only_for_device_partials():
     sink.tasks.append((src.data_ptr(), dst.data_ptr(), 8, 8, 2, 1.0))      # as add() would, minus the launch at flush
     sink.keep.append((src, dst))
     assert sink.streams == []
+
+
+def test_attached_planes_are_validated_against_the_tensor_they_were_made_for():
+    """kernels.attach_planes / planes_of (the producers' side channel): the set is handed out only for the SAME storage address, element
+    count and autograd version; it survives the trip through autograd.Function boundaries in both directions (the property the whole
+    scheme rests on: autograd keeps a tensor's Python object)."""
+    t = torch.zeros(4, 64)
+    pl = torch.zeros(4, 2, 3, 32, dtype=torch.bfloat16)
+    assert K.planes_of(t) is None
+    K.attach_planes(t, pl)
+    assert K.planes_of(t) is pl
+    v = t.view(2, 2, 64)                                # another Python object over the same memory: nothing attached
+    assert K.planes_of(v) is None
+    K.attach_planes(v, pl)                              # what _BatchNormAct does for the reshaped tensor it returns
+    assert K.planes_of(v) is pl
+    t.add_(1.0)                                         # written since: void (the view shares the version counter)
+    assert K.planes_of(t) is None and K.planes_of(v) is None
+    t2 = torch.zeros(4, 64)
+    t2._ctts_planes = (torch.zeros(3, dtype=torch.bfloat16), t2.data_ptr(), t2._version, t2.numel())      # wrong size
+    assert K.planes_of(t2) is None
+
+    class Producer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            y = x * 2
+            K.attach_planes(y, torch.zeros(y.numel() * 3, dtype=torch.bfloat16))
+            return y
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(("producer.backward", K.planes_of(g) is not None))
+            return g * 2
+
+    class Consumer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, y):
+            seen.append(("consumer.forward", K.planes_of(y) is not None))
+            return y + 1
+
+        @staticmethod
+        def backward(ctx, g):
+            out = g.clone()
+            K.attach_planes(out, torch.zeros(out.numel() * 3, dtype=torch.bfloat16))
+            return out
+
+    seen = []
+    x = torch.randn(2, 32, requires_grad=True)
+    Consumer.apply(Producer.apply(x)).sum().backward()
+    assert seen == [("consumer.forward", True), ("producer.backward", True)], seen
+
+
+def test_consumer_takes_planes_needs_a_device_tensor_and_the_plane_kernel_shape():
+    x = torch.zeros(16, 1024, 256)
+    assert not ops.consumer_takes_planes(x, 1024, 9)            # host tensor: the product has no CPU path
+    prev = K.PRODUCER_PLANES
+    try:
+        K.PRODUCER_PLANES = False
+        assert not ops.consumer_takes_planes(x, 1024, 9)
+    finally:
+        K.PRODUCER_PLANES = prev
