@@ -183,6 +183,35 @@ def _time_launches(launch, iters, warm):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def _time_launches_graph(launch, n=20, reps=3):
+    """the same launch `n` times inside ONE hipGraph, replayed `reps` times between two HIP events: the kernel's duration without the host's
+    launch path between two launches (what it costs inside the replayed train step); None when capture is not possible"""
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            launch()                          # the stream's workspace (zero-filled once) must exist BEFORE the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            for _ in range(n):
+                launch()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            g.replay()
+        e1.record(st)
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / (n * reps)
+    except Exception as e:                                    # noqa: BLE001
+        print(f"[bench] graph-timed launch skipped ({type(e).__name__}: {e})", file=sys.stderr)
+        torch.cuda.synchronize()
+        return None
+
+
 def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
     """HIP-event timing (on the launch stream) of the three GEMMs of the decoder FFN Conv1d(256->1024, k=9) at their train-step
     arguments (M = B*Tm rows of which `valid` are not padding, N = 1024, K = 2304): forward (implicit GEMM on the activation),
@@ -219,6 +248,7 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
     # `warm` launches first: after the host-side pause between the timed loops and this measurement the first ~30 launches run 15 %
     # slower (594 vs 511 us, tools/dbg_dom.py) while the clocks come back up; inside the train step the GPU never idles
     dt = _time_launches(fwd, iters, warm)
+    dt_graph = _time_launches_graph(fwd)      # reported next to `launch_us` (never instead of it): rounds 1 - 5 priced the eager-launch timing
     algo_flops = 2.0 * cout * ks * cin * valid          # 4,718,592 FLOP per valid frame per layer
     padded_flops = 2.0 * cout * ks * cin * M
     # ---- data gradient and weight gradient of the same layer, as ops._LinearConv.backward launches them
@@ -296,7 +326,9 @@ def measure_dominant_kernel(dev, batch, iters=50, warm=30, live_traffic=True):
     out.update({"dgrad_us": dt_d * 1e6, "dgrad_frac": algo_flops / dt_d / 1e12 / peak, "wgrad_us": dt_w * 1e6,
                 "wgrad_frac": algo_flops / dt_w / 1e12 / peak,
                 "traffic_over_algorithmic": (traffic / out["algorithmic_bytes"]) if traffic else None,
-                "traffic_live": bool(traffic_src and "measured" in traffic_src)})
+                "traffic_live": bool(traffic_src and "measured" in traffic_src),
+                "launch_us_in_graph": (dt_graph * 1e6) if dt_graph else None,
+                "frac_in_graph": (algo_flops / dt_graph / 1e12 / peak) if dt_graph else None})
     return out
 
 
