@@ -54,6 +54,8 @@ canon = [8 * s for s in CANONICAL_SRC_LENS]
 v2 = sum(l * l for l in canon)
 uni = int(round((v2 / B) ** 0.5 / 8)) * 8
 run("canonical ragged", canon)
+if "--only-canonical" in sys.argv:
+    sys.exit(0)
 run("dense", [T] * B)
 run(f"uniform {uni}", [uni] * B)
 run("uniform 512", [512] * B)
