@@ -817,10 +817,11 @@ def main():
             "metric": "mel-frames/sec (train step) LJSpeech batch=16, 1/2/4/8 MI355X", "value": value, "unit": "mel-frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{a.dataset} {a.block} batch={nb}/GPU"
-                                    + (f" (global {nb * world}, weak)" if a.scaling == "weak" else f" (global 16, {a.shard} shard, strong)")
-                                    + f" seq<=128->mel<={batch_cpu['mels'].shape[1]}x80; full train step fwd+loss+bwd+clip+Adam, dropout on"),
+            "config": {"workload": (f"{a.dataset} {a.block} batch={nb}/GPU seq<=128->mel<={batch_cpu['mels'].shape[1]}x80; "
+                                    "full train step fwd+loss+bwd+clip+Adam, dropout on"),
                        "workload_detail": what,
+                       "global_batch": nb * world if a.scaling == "weak" else 16,
+                       "shard": None if a.scaling == "weak" else a.shard,
                        "valid_frames_per_gpu": valid_frames, "padded_frames_per_gpu": padded_frames, "launch_mode": mode,
                        "parallelism": f"dp{world}", "final_loss": loss_final,
                        "gemm_arithmetic": ("fp32 storage/accumulate; large GEMMs: 6 bf16 MFMA terms of the exact 3-way split (fp32-class); rest fp32 MFMA"

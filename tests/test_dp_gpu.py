@@ -204,9 +204,20 @@ def test_bench_rejects_gpus_world_mismatch():
 
 
 def test_single_gpu_bench_line_has_roofline_and_pcie_rates():
-    d = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline"], {})
+    d = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic"], {})
     assert d["n_gpus"] == 1 and d["roofline"]["frac"] > 0.3 and d["roofline"]["bound"] == "mfma"
     assert d["pcie_inclusive"]["value"] > 0.8 * d["value"]                  # one 8 MB H2D per step hides behind the previous step
+    # round 6: what the driver's record keeps are scalars - the three FFN-conv launches flat inside `roofline`, every secondary result flat
+    # inside `config` (train steps of configs[2..4], forward-only lines, the mel front end), all strings at most 128 characters
+    r, c = d["roofline"], d["config"]
+    for k in ("dgrad_us", "wgrad_us", "dgrad_frac", "wgrad_frac", "launch_us_in_graph", "traffic_over_algorithmic"):
+        assert k in r, k
+    assert 0.3 < r["dgrad_frac"] < 1.0 and 0.3 < r["wgrad_frac"] < 1.0 and abs(r["launch_us_in_graph"] / r["launch_us"] - 1.0) < 0.15
+    for k in ("sec_conformer_ms", "sec_vctk_slice_ms", "sec_c5_ms", "sec_fwd_eval_fs2_ms", "sec_mel_B16_kernel_Mfps", "sec_mel_B64_api_Mfps"):
+        assert k in c and c[k] > 0, (k, {q: v for q, v in c.items() if q.startswith("sec_error")})
+    assert not [k for k in c if k.startswith("sec_error")]
+    too_long = [k for blk in (c, r, d["cpu_baseline"] or {}) for k, v in blk.items() if isinstance(v, str) and len(v) > 128]
+    assert not too_long, too_long
 
 
 def test_rccl_one_rank_group_runs_the_collective_path_on_this_gpu():
