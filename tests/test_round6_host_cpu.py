@@ -160,3 +160,19 @@ def test_consumer_takes_planes_needs_a_device_tensor_and_the_plane_kernel_shape(
         assert not ops.consumer_takes_planes(x, 1024, 9)
     finally:
         K.PRODUCER_PLANES = prev
+
+
+def test_a_plain_c_host_binds_the_abi(tmp_path):
+    """include/ctts.h is a C header (`gcc -std=c99`) and libctts_hip.so a plain C-ABI library: a C program with no Python and no torch in
+    it links the library and calls it (tests/native/c_host_abi.c: version, the collective's argument checks, the error text)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "c_host_abi")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "c_host_abi.c"),
+                    "-o", exe, "-L", libdir, "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c host ok" in r.stdout, (r.stdout, r.stderr)
